@@ -1,0 +1,188 @@
+/*
+ * smr_hip.h -- C ABI of libsmr_hip.so: the MI355X (gfx950) engine for SortMeRNA's per-read hot path.
+ *
+ * This is the drop-in boundary.  The reference is one C++17 executable with no plugin
+ * API; the seam is the per-read call  traverse(opts, index, refs, readstats, refstats, read, isLastStrand)
+ * made from align2()  (/root/reference/src/sortmerna/processor.cpp:85,104-161), once per
+ * read x strand x index part, by the thread pool of align() (processor.cpp:173-285).  A maintainer
+ * replaces that loop by batch calls into this library (binding sketch: INTEGRATION.md).
+ *
+ * Everything here is plain C: pointers, sizes, int error codes (0 = ok, <0 = error, message via
+ * smr_last_error).  No exceptions, no C++ or torch types cross the ABI.
+ *
+ * What each entry point replaces in the reference:
+ *   smr_index_*      Index::load + References::load          index.cpp:143-357, references.cpp:55-159
+ *                    (+ our own builder = build_index()       indexdb.cpp:1119-2095)
+ *   smr_reads_*      Readfeed::next -> Read(readstr).init()   readfeed.hpp:124, read.cpp:264-347
+ *   smr_refstats_*   Refstats::load (.stats + minimal_score)  refstats.cpp:103-265  (Gumbel lambda,K are INPUTS:
+ *                    the reference gets them from the vendored NCBI ALP library, refstats.cpp:194-233)
+ *   smr_align_part   the N x align2() threads for one (index, part): traverse() -> traversetrie_align()
+ *                    -> compute_lis_alignment() -> ssw_align()   paralleltraversal.cpp:81-298,
+ *                    traverse_bursttrie.cpp:100-298, alignment.cpp:100-509, ssw.c:834-941
+ *   smr_result_*     Read::toBinString() / kvdb.put()         read.cpp:429-462, processor.cpp:150-155
+ *   smr_counters     Readstats atomics                        readstats.hpp:77-85
+ */
+#ifndef SMR_HIP_H
+#define SMR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMR_OK 0
+#define SMR_ERR_ARG (-1)        /* bad argument / unsupported option value */
+#define SMR_ERR_IO (-2)         /* file missing or malformed */
+#define SMR_ERR_DEVICE (-3)     /* HIP error (no GPU, out of memory, kernel fault) */
+#define SMR_ERR_CAPACITY (-4)   /* a device pool overflowed after automatic regrow attempts */
+#define SMR_ERR_STATE (-5)      /* call order violated */
+
+typedef struct smr_ctx smr_ctx;          /* one GPU: stream, resident index parts, resident read batch */
+typedef struct smr_index smr_index;      /* HOST: one flattened index part + its reference sequences */
+typedef struct smr_reads smr_reads;      /* HOST: a packed read batch */
+
+/* Options of Runopts that reach the hot path (include/options.hpp:495-608; defaults options.cpp:1566-1758). */
+typedef struct {
+  uint32_t skiplengths[3];   /* -passes      pass strides; {0,0,0} => {L, L/2, 3}     refstats.cpp:159-166 */
+  int32_t  num_seeds;        /* -num_seeds   2 */
+  int32_t  min_lis;          /* -min_lis     2 */
+  int32_t  edges;            /* -edges       4 */
+  int32_t  is_as_percent;    /* -edges N%    0 */
+  int32_t  match;            /* -match       2 */
+  int32_t  mismatch;         /* -mismatch   -3 */
+  int32_t  score_N;          /* -N           = mismatch */
+  int32_t  gap_open;         /* -gap_open    5 */
+  int32_t  gap_ext;          /* -gap_ext     2 */
+  uint32_t num_alignments;   /* -num_alignments 1 (0 = all) */
+  int32_t  is_best;          /* 1 unless -no-best */
+  int32_t  is_full_search;   /* -full_search 0 */
+  int32_t  is_forward;       /* -F */
+  int32_t  is_reverse;       /* -R  (both 1 when neither given) */
+  uint32_t minoccur;         /* 0 */
+  /* per call of smr_align_part: */
+  uint32_t minimal_score;    /* Refstats::minimal_score[index_num]            refstats.cpp:261-265 */
+  uint32_t index_num;        /* position of the DB in --ref order */
+  uint32_t part;             /* index part number */
+  int32_t  is_last_index_part; /* last part of the last index                 paralleltraversal.cpp:294 */
+} smr_params;
+
+void smr_params_default(smr_params* p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index (host side).  An smr_index is one (index, part): 9-mer lookup, mini burst tries in a compact
+ * word arena, positions CSR, reference sequences (0..4, 1 byte/nt).
+ * ---------------------------------------------------------------------------------------------- */
+/* Load a part written by the reference's indexer: <prefix>.kmer_P.dat / .bursttrie_P.dat / .pos_P.dat
+ * (+ <prefix>.stats for the part's byte range in the FASTA).  Replaces Index::load + References::load. */
+int smr_index_load_files(const char* prefix, uint32_t part, const char* ref_fasta, smr_index** out, char* err, size_t errcap);
+
+/* Build ALL parts of the index of one FASTA ourselves (replaces build_index(), indexdb.cpp:1119-2095):
+ * same 19-mer geometry, same forward/reverse mini-trie contents, ids = rank of the unique 18-mer
+ * (any bijection is equivalent: ids are opaque keys into the positions table), positions in file
+ * order truncated at max_pos.  n_parts_out parts are returned in parts_out[0..n_parts_out).
+ * max_file_size_mb = the reference's -m (3072), seed_win_len = -L (18), max_pos = -max_pos (10000). */
+int smr_index_build(const char* ref_fasta, uint32_t seed_win_len, double max_file_size_mb, uint32_t max_pos,
+                    uint32_t threads, smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out,
+                    char* err, size_t errcap);
+/* Write one part in the REFERENCE's on-disk format (so the reference binary can consume our index). */
+int smr_index_write_files(const smr_index* const* parts, uint32_t n_parts, const char* ref_fasta, const char* prefix,
+                          char* err, size_t errcap);
+void smr_index_free(smr_index*);
+
+typedef struct {
+  uint32_t lnwin;            /* L */
+  uint32_t n_kmers;          /* 4^(L/2) */
+  uint64_t trie_words;       /* u32 words in the mini-trie arena */
+  uint32_t n_ids;            /* unique 18-mers */
+  uint64_t n_pos;            /* total positions */
+  uint32_t n_refs;           /* sequences in this part */
+  uint64_t ref_bytes;        /* total nt in this part */
+  uint64_t n_nodes, n_buckets, n_entries;
+  double   bg[4];            /* A,C,G,T background frequencies of the whole DB (from .stats / builder) */
+  uint64_t full_len;         /* total nt of the whole DB */
+  uint64_t numseq;           /* total sequences of the whole DB */
+  uint32_t n_parts;
+} smr_index_info;
+int smr_index_get_info(const smr_index*, smr_index_info* out);
+
+/* Refstats::load arithmetic (refstats.cpp:238-265): minimal SW score for E-value `evalue` given the
+ * Gumbel parameters of the (scoring scheme, background) pair and the GLOBAL read totals
+ * (all_reads_count / all_reads_len are sums over every rank when reads are sharded). */
+uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq,
+                           uint64_t all_reads_count, uint64_t all_reads_len, double evalue);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reads (host side): 2-bit packed + ambiguity mask (Read::seqToIntStr: ACGT(U) -> 0..3, other -> 0
+ * and the position is remembered, read.cpp:334-347).
+ * ---------------------------------------------------------------------------------------------- */
+/* seqs: concatenated ASCII sequences, offs[n+1] byte offsets. */
+int smr_reads_pack(const char* seqs, const uint64_t* offs, uint32_t n_reads, smr_reads** out);
+/* FASTA/FASTQ (optionally multi-line FASTA), plain text; [first, first+count) selects a record range
+ * (count = 0 => to the end): the host-side read shard of one rank. */
+int smr_reads_load_fastx(const char* path, uint64_t first, uint64_t count, smr_reads** out, char* err, size_t errcap);
+void smr_reads_free(smr_reads*);
+uint32_t smr_reads_count(const smr_reads*);
+uint64_t smr_reads_total_len(const smr_reads*);
+uint32_t smr_reads_min_len(const smr_reads*);
+uint32_t smr_reads_max_len(const smr_reads*);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device context
+ * ---------------------------------------------------------------------------------------------- */
+int  smr_create(int device, smr_ctx** out, char* err, size_t errcap);
+void smr_destroy(smr_ctx*);
+const char* smr_last_error(const smr_ctx*);
+
+/* Copy an index part to HBM; it stays resident under `slot` (0..63) until freed. */
+int smr_index_upload(smr_ctx*, const smr_index*, int slot);
+int smr_index_unload(smr_ctx*, int slot);
+
+/* Copy a read batch to HBM and allocate its persistent per-read state (what the reference keeps in
+ * the KVDB between index parts, read.cpp:429-539).  Resets all state and counters. */
+int smr_reads_upload(smr_ctx*, const smr_reads*, uint32_t max_alignments_per_read);
+/* Forget all per-read results/counters of the resident batch (reads stay resident). */
+int smr_state_reset(smr_ctx*);
+
+/* The hot path for ONE (index, part) over the resident batch: both strands, all passes, LIS chaining,
+ * Smith-Waterman scoring; commits per-read state exactly like processor.cpp:104-161 + kvdb.put.
+ * Synchronous (returns after the GPU finished). */
+int smr_align_part(smr_ctx*, int slot, const smr_params*);
+/* Banded traceback -> CIGAR for every stored alignment that does not have one yet and whose
+ * (index_num, part) is resident in `slot` (ssw.c:577-773).  Call after smr_align_part of that slot. */
+int smr_traceback(smr_ctx*, int slot, const smr_params*);
+
+/* Readstats counters (readstats.hpp:77-85): out[0]=num_aligned, out[1]=num_short (of the last part),
+ * out[2+i]=reads_matched_per_db[i], i < n_db.  These are what the RCCL all-reduce sums across ranks. */
+int smr_counters(smr_ctx*, uint64_t* out, uint32_t n_db);
+/* Device pointer + count of the u64 counters block (for an in-place RCCL all-reduce by the caller). */
+int smr_counters_device(smr_ctx*, void** dptr, uint32_t* n_u64);
+
+/* Results.  smr_result_record writes Read::toBinString() bytes of read i (the KVDB value,
+ * read.cpp:429-462; 0 bytes when the read has no alignment) and returns the size needed. */
+int    smr_results_fetch(smr_ctx*);                       /* device -> host copy of all per-read results */
+size_t smr_result_record(const smr_ctx*, uint32_t read_idx, uint8_t* buf, size_t cap);
+int    smr_result_is_hit(const smr_ctx*, uint32_t read_idx);
+
+/* Seed hits of the last smr_seed_scan call (kernel-level parity + roofline bench of the seed-scan kernel).
+ * Runs ONLY the window-scan/burst-trie kernel for (strand, pass) over every read of the resident batch. */
+int smr_seed_scan(smr_ctx*, int slot, const smr_params*, int strand, int pass, uint64_t* n_hits_out);
+/* hits as (read_idx, id, win) triples in unspecified order */
+int smr_seed_hits_fetch(smr_ctx*, uint32_t* triples, uint64_t cap_triples, uint64_t* n_out);
+
+/* Timing/work counters accumulated since the last smr_prof_reset (HIP events on the engine's stream). */
+typedef struct {
+  double   seed_ms;  uint64_t seed_launches;   /* window-scan + burst-trie kernel */
+  double   chain_ms; uint64_t chain_launches;  /* LIS chaining + SW scoring kernel */
+  double   trace_ms; uint64_t trace_launches;  /* banded traceback kernel */
+  /* exact work counters of the seed-scan kernel (SURVEY.md 8d byte formula) */
+  uint64_t n_windows, n_lookup, n_node, n_entry, n_hit, n_read_bytes;
+  uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;
+} smr_prof;
+int smr_prof_reset(smr_ctx*);
+int smr_prof_get(smr_ctx*, smr_prof* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""ctypes binding of include/smr_hip.h (the C ABI of libsmr_hip.so)."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("skiplengths", C.c_uint32 * 3), ("num_seeds", C.c_int32), ("min_lis", C.c_int32), ("edges", C.c_int32),
+        ("is_as_percent", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32), ("score_N", C.c_int32),
+        ("gap_open", C.c_int32), ("gap_ext", C.c_int32), ("num_alignments", C.c_uint32), ("is_best", C.c_int32),
+        ("is_full_search", C.c_int32), ("is_forward", C.c_int32), ("is_reverse", C.c_int32), ("minoccur", C.c_uint32),
+        ("minimal_score", C.c_uint32), ("index_num", C.c_uint32), ("part", C.c_uint32),
+        ("is_last_index_part", C.c_int32),
+    ]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [
+        ("lnwin", C.c_uint32), ("n_kmers", C.c_uint32), ("trie_words", C.c_uint64), ("n_ids", C.c_uint32),
+        ("n_pos", C.c_uint64), ("n_refs", C.c_uint32), ("ref_bytes", C.c_uint64), ("n_nodes", C.c_uint64),
+        ("n_buckets", C.c_uint64), ("n_entries", C.c_uint64), ("bg", C.c_double * 4), ("full_len", C.c_uint64),
+        ("numseq", C.c_uint64), ("n_parts", C.c_uint32),
+    ]
+
+
+class Prof(C.Structure):
+    _fields_ = [
+        ("seed_ms", C.c_double), ("seed_launches", C.c_uint64), ("chain_ms", C.c_double), ("chain_launches", C.c_uint64),
+        ("trace_ms", C.c_double), ("trace_launches", C.c_uint64), ("n_windows", C.c_uint64), ("n_lookup", C.c_uint64),
+        ("n_node", C.c_uint64), ("n_entry", C.c_uint64), ("n_hit", C.c_uint64), ("n_read_bytes", C.c_uint64),
+        ("n_sw_fwd", C.c_uint64), ("n_sw_rev", C.c_uint64), ("n_sw_cells", C.c_uint64),
+    ]
+
+
+EXPORTS = [
+    "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_write_files", "smr_index_free",
+    "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_free",
+    "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
+    "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_reads_upload", "smr_state_reset", "smr_align_part",
+    "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
+    "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_prof_reset", "smr_prof_get",
+]
+
+_lib = None
+
+
+def load(rebuild_if_stale=True):
+    """Load libsmr_hip.so (building it with hipcc when missing/stale).  Raises if it cannot be built:
+    there is no CPU fallback for the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if rebuild_if_stale and _build.is_stale():
+        path = _build.build_library()
+    if not os.path.isfile(path):
+        raise RuntimeError("libsmr_hip.so is missing; run sortmerna_amd/build.py (needs hipcc)")
+    L = C.CDLL(path)
+    vp, cp, u32, u64, i32 = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_int
+    L.smr_params_default.argtypes = [C.POINTER(Params)]
+    L.smr_index_load_files.restype = i32
+    L.smr_index_load_files.argtypes = [cp, u32, cp, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_index_build.restype = i32
+    L.smr_index_build.argtypes = [cp, u32, C.c_double, u32, u32, C.POINTER(vp), u32, C.POINTER(u32), cp, C.c_size_t]
+    L.smr_index_write_files.restype = i32
+    L.smr_index_write_files.argtypes = [C.POINTER(vp), u32, cp, cp, cp, C.c_size_t]
+    L.smr_index_free.argtypes = [vp]
+    L.smr_index_get_info.restype = i32
+    L.smr_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
+    L.smr_minimal_score.restype = u32
+    L.smr_minimal_score.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), u64, u64, u64, u64, C.c_double]
+    L.smr_reads_pack.restype = i32
+    L.smr_reads_pack.argtypes = [cp, vp, u32, C.POINTER(vp)]
+    L.smr_reads_load_fastx.restype = i32
+    L.smr_reads_load_fastx.argtypes = [cp, u64, u64, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_reads_free.argtypes = [vp]
+    for f in ("smr_reads_count", "smr_reads_min_len", "smr_reads_max_len"):
+        getattr(L, f).restype = u32
+        getattr(L, f).argtypes = [vp]
+    L.smr_reads_total_len.restype = u64
+    L.smr_reads_total_len.argtypes = [vp]
+    L.smr_create.restype = i32
+    L.smr_create.argtypes = [i32, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_destroy.argtypes = [vp]
+    L.smr_last_error.restype = cp
+    L.smr_last_error.argtypes = [vp]
+    L.smr_index_upload.restype = i32
+    L.smr_index_upload.argtypes = [vp, vp, i32]
+    L.smr_index_unload.restype = i32
+    L.smr_index_unload.argtypes = [vp, i32]
+    L.smr_reads_upload.restype = i32
+    L.smr_reads_upload.argtypes = [vp, vp, u32]
+    L.smr_state_reset.restype = i32
+    L.smr_state_reset.argtypes = [vp]
+    L.smr_align_part.restype = i32
+    L.smr_align_part.argtypes = [vp, i32, C.POINTER(Params)]
+    L.smr_traceback.restype = i32
+    L.smr_traceback.argtypes = [vp, i32, C.POINTER(Params)]
+    L.smr_counters.restype = i32
+    L.smr_counters.argtypes = [vp, C.POINTER(u64), u32]
+    L.smr_counters_device.restype = i32
+    L.smr_counters_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u32)]
+    L.smr_results_fetch.restype = i32
+    L.smr_results_fetch.argtypes = [vp]
+    L.smr_result_record.restype = C.c_size_t
+    L.smr_result_record.argtypes = [vp, u32, vp, C.c_size_t]
+    L.smr_result_is_hit.restype = i32
+    L.smr_result_is_hit.argtypes = [vp, u32]
+    L.smr_seed_scan.restype = i32
+    L.smr_seed_scan.argtypes = [vp, i32, C.POINTER(Params), i32, i32, C.POINTER(u64)]
+    L.smr_seed_hits_fetch.restype = i32
+    L.smr_seed_hits_fetch.argtypes = [vp, vp, u64, C.POINTER(u64)]
+    L.smr_prof_reset.restype = i32
+    L.smr_prof_reset.argtypes = [vp]
+    L.smr_prof_get.restype = i32
+    L.smr_prof_get.argtypes = [vp, C.POINTER(Prof)]
+    _lib = L
+    return L

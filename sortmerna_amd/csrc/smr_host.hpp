@@ -1,0 +1,68 @@
+// smr_host.hpp -- host-side data model of libsmr_hip (index part, read batch).  Internal header.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/smr_hip.h"
+
+namespace smr {
+
+// 9-mer lookup entry.  Replaces struct kmer {trie_F, trie_R, count}  (include/indexdb.hpp:98-103):
+// pointers become word offsets of the mini-trie root node in the trie arena (NONE if absent).
+struct Lookup {
+  uint32_t count;
+  uint32_t rootF;
+  uint32_t rootR;
+};
+static constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// Mini burst trie arena (u32 words).  Replaces NodeElement[4] nodes + malloc'd buckets
+// (include/indexdb.hpp:67-84).  A node is 4 words, one element per nucleotide A,C,G,T:
+//   bits 31..30 flag   0 empty, 1 child node, 2 bucket
+//   bits 29..22 nent   number of bucket entries (flag 2)
+//   bits 21..0  off    word offset RELATIVE to the mini-trie's root node
+// A bucket is nent x {u32 tail (2 bit/nt, first nt in the low bits), u32 id} -- the reference's
+// 8-byte ENTRYSIZE entries unchanged (indexdb.hpp:57).
+static constexpr uint32_t ELEM_FLAG_SHIFT = 30;
+static constexpr uint32_t ELEM_NENT_SHIFT = 22;
+static constexpr uint32_t ELEM_OFF_MASK = (1u << 22) - 1;
+static constexpr uint32_t ELEM_NENT_MAX = 255;
+
+struct PartStats {
+  uint64_t start_part = 0, seq_part_size = 0;
+  uint32_t numseq_part = 0;
+};
+
+}  // namespace smr
+
+struct smr_index {
+  uint32_t lnwin = 18;
+  uint32_t part = 0, n_parts = 1;
+  std::vector<smr::Lookup> lookup;      // 4^(L/2)
+  std::vector<uint32_t> trie;           // arena
+  std::vector<uint32_t> pos_off;        // n_ids + 1
+  std::vector<uint32_t> pos_arr;        // 2 * n_pos : {pos, seq}   (struct seq_pos, indexdb.hpp:87-91)
+  std::vector<uint8_t> ref_seq;         // 0..4 per nt (References::convert_fix, references.cpp:162-169)
+  std::vector<uint64_t> ref_off;        // n_refs + 1
+  uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
+  // whole-DB statistics (.stats)
+  double bg[4] = {0.25, 0.25, 0.25, 0.25};
+  uint64_t full_len = 0, numseq = 0, filesize = 0;
+  std::vector<smr::PartStats> parts;                          // all parts of the DB
+  std::vector<std::pair<std::string, uint32_t>> sq_header;    // (id, len) of every sequence of the DB
+  uint32_t n_ids() const { return pos_off.empty() ? 0 : (uint32_t)pos_off.size() - 1; }
+  uint32_t n_refs() const { return ref_off.empty() ? 0 : (uint32_t)ref_off.size() - 1; }
+};
+
+// Packed read batch.  Record i = ceil(len/16) words of 2-bit codes (nt k in bits 2*(k%16) of word k/16)
+// followed by ceil(len/32) words of ambiguity mask (bit k%32 of word k/32 set when the input letter
+// was not ACGTU: Read::seqToIntStr stores 0 there and remembers the position, read.cpp:334-347).
+struct smr_reads {
+  uint32_t n = 0;
+  std::vector<uint32_t> words;
+  std::vector<uint64_t> rec_off;   // n + 1, in words
+  std::vector<uint32_t> len;       // n
+  uint64_t total_len = 0;
+  uint32_t min_len = 0, max_len = 0;
+};

@@ -1,0 +1,636 @@
+// smr_index.cpp -- host side of the index: loader for reference-built index files, our own builder,
+// writer of the reference's on-disk format, .stats handling and the minimal-score arithmetic.
+//
+// Reference behaviour restated here (paths under /root/reference):
+//   on-disk format      writer src/sortmerna/indexdb.cpp:730-865,1930-2080 ; reader index.cpp:143-357
+//   19-mer geometry     indexdb.cpp:1434-1550 (forward tail under 9-mer prefix, reversed head under 9-mer suffix)
+//   burst rule          indexdb.cpp:225-228 (bucket > 128 B bursts while depth < L+1 - L/2 - 3)
+//   nucleotide maps     index: map_nt indexdb.cpp:83-109 ; SW refs: nt_table include/common.hpp:68-77
+//   part split          indexdb.cpp:1384-1420 (9.5e-6 MB per (L+1)-mer, -m limit)
+//   positions           indexdb.cpp:318-349,1716-1723 (file order, truncated at max_pos)
+//   minimal score       refstats.cpp:238-265
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "smr_host.hpp"
+
+using namespace smr;
+
+namespace {
+
+void set_err(char* err, size_t cap, const std::string& m) {
+  if (err && cap) { snprintf(err, cap, "%s", m.c_str()); }
+}
+
+bool slurp(const std::string& path, std::vector<uint8_t>& out) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize((size_t)sz);
+  bool ok = sz == 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+  fclose(f);
+  return ok;
+}
+
+// include/common.hpp:68-77 nt_table
+inline uint8_t nt_sw(int c) {
+  switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return 4;
+  }
+}
+// indexdb.cpp:83-109 map_nt (values of the table, not of its comment): everything else -> 0
+inline uint8_t nt_index(int c) {
+  switch (c) {
+    case 'B': case 'C': case 'D': case 'W': case 'Y': case 'b': case 'c': case 'w': case 'y': return 1;
+    case 'G': case 'K': case 'S': case 'X': case 'g': case 'k': case 's': case 'x': return 2;
+    case 'T': case 'U': case 't': case 'u': return 3;
+    default: return 0;
+  }
+}
+
+struct Stats {
+  uint64_t filesize = 0;
+  std::string fasta_name;
+  double bg[4] = {0, 0, 0, 0};
+  uint64_t full_len = 0;
+  uint32_t lnwin = 0;
+  uint64_t numseq = 0;
+  uint16_t nparts = 0;
+  std::vector<PartStats> parts;
+  std::vector<std::pair<std::string, uint32_t>> sq;
+};
+
+bool load_stats(const std::string& prefix, Stats& st) {
+  std::vector<uint8_t> b;
+  if (!slurp(prefix + ".stats", b)) return false;
+  size_t o = 0;
+  auto rd = [&](void* dst, size_t n) { if (o + n > b.size()) { o = b.size() + 1; return; } memcpy(dst, b.data() + o, n); o += n; };
+  rd(&st.filesize, 8);
+  uint32_t nl = 0; rd(&nl, 4);
+  if (o + nl <= b.size()) st.fasta_name.assign((const char*)b.data() + o, nl ? nl - 1 : 0);
+  o += nl;
+  rd(st.bg, 32); rd(&st.full_len, 8); rd(&st.lnwin, 4); rd(&st.numseq, 8); rd(&st.nparts, 2);
+  for (uint16_t j = 0; j < st.nparts; j++) {
+    uint8_t raw[24] = {0}; rd(raw, 24);     // struct index_parts_stats {ulong, ulong, u32 + pad}
+    PartStats p; memcpy(&p.start_part, raw, 8); memcpy(&p.seq_part_size, raw + 8, 8); memcpy(&p.numseq_part, raw + 16, 4);
+    st.parts.push_back(p);
+  }
+  uint32_t nsq = 0; rd(&nsq, 4);
+  for (uint32_t i = 0; i < nsq && o <= b.size(); i++) {
+    uint32_t li = 0; rd(&li, 4);
+    std::string id; if (o + li <= b.size()) id.assign((const char*)b.data() + o, li); o += li;
+    uint32_t ls = 0; rd(&ls, 4);
+    st.sq.emplace_back(id, ls);
+  }
+  return o <= b.size();
+}
+
+// References::load (references.cpp:55-159), FASTA: numseq records starting at byte `start`.
+bool load_refs(const std::string& fasta, uint64_t start, uint32_t numseq, smr_index& ix) {
+  std::vector<uint8_t> b;
+  if (!slurp(fasta, b)) return false;
+  ix.ref_seq.clear(); ix.ref_off.assign(1, 0);
+  size_t o = (size_t)start, n = b.size();
+  bool have = false; uint32_t done = 0;
+  while (o < n && done < numseq) {
+    size_t e = o;
+    while (e < n && b[e] != '\n') e++;
+    size_t le = e;
+    while (le > o && (b[le - 1] == ' ' || b[le - 1] == '\r' || b[le - 1] == '\t' || b[le - 1] == '\f' || b[le - 1] == '\v')) le--;
+    if (le > o) {
+      if (b[o] == '>') {
+        if (have) { ix.ref_off.push_back(ix.ref_seq.size()); done++; }
+        have = true;
+      } else if (have) {
+        for (size_t k = o; k < le; k++) ix.ref_seq.push_back(b[k] != 32 ? nt_sw(b[k]) : (uint8_t)32);
+      }
+    }
+    o = e + 1;
+  }
+  if (have && done < numseq) { ix.ref_off.push_back(ix.ref_seq.size()); done++; }
+  return done == numseq;
+}
+
+// ---- compact arena construction from an explicit node list -------------------------------------
+struct TmpElem { uint8_t flag = 0; uint32_t child = 0; uint32_t ent_begin = 0, ent_count = 0; };
+struct TmpNode { TmpElem e[4]; };
+
+// lays out one mini-trie (nodes[0] = root) in DFS order; entries = {tail,id} pairs in `ents`
+bool emit_minitrie(const std::vector<TmpNode>& nodes, const std::vector<uint32_t>& ents, std::vector<uint32_t>& arena,
+                   uint32_t& root_off, smr_index& ix, std::string& why) {
+  size_t base = arena.size();
+  if (base > 0xFFFFFFF0ull) { why = "trie arena exceeds 2^32 words"; return false; }
+  root_off = (uint32_t)base;
+  // DFS with explicit stack; a node's 4 words are reserved when it is first visited
+  std::vector<uint32_t> node_at(nodes.size(), 0);
+  struct Fr { uint32_t node; int next; };
+  std::vector<Fr> st;
+  arena.resize(base + 4, 0);
+  node_at[0] = 0;
+  st.push_back({0, 0});
+  ix.n_nodes++;
+  while (!st.empty()) {
+    Fr& f = st.back();
+    if (f.next == 4) { st.pop_back(); continue; }
+    int k = f.next++;
+    uint32_t nd = f.node;
+    const TmpElem& el = nodes[nd].e[k];
+    size_t word = base + node_at[nd] + k;
+    if (el.flag == 0) { arena[word] = 0; continue; }
+    size_t rel = arena.size() - base;
+    if (rel > ELEM_OFF_MASK) { why = "mini-trie larger than 2^22 words"; return false; }
+    if (el.flag == 2) {
+      if (el.ent_count > ELEM_NENT_MAX) { why = "bucket with more than 255 entries"; return false; }
+      arena[word] = (2u << ELEM_FLAG_SHIFT) | (el.ent_count << ELEM_NENT_SHIFT) | (uint32_t)rel;
+      arena.insert(arena.end(), ents.begin() + (size_t)el.ent_begin * 2, ents.begin() + ((size_t)el.ent_begin + el.ent_count) * 2);
+      ix.n_buckets++; ix.n_entries += el.ent_count;
+    } else {
+      arena[word] = (1u << ELEM_FLAG_SHIFT) | (uint32_t)rel;
+      node_at[el.child] = (uint32_t)rel;
+      arena.resize(arena.size() + 4, 0);
+      ix.n_nodes++;
+      st.push_back({el.child, 0});   // note: invalidates f
+    }
+  }
+  return true;
+}
+
+// BFS stream of one mini-trie (index.cpp:176-316) -> TmpNode list
+bool parse_bfs(const std::vector<uint8_t>& b, size_t& o, std::vector<TmpNode>& nodes, std::vector<uint32_t>& ents) {
+  nodes.clear(); ents.clear();
+  std::vector<uint8_t> flags;
+  size_t hf = 0;
+  auto rd8 = [&]() -> uint8_t { return o < b.size() ? b[o++] : (o++, (uint8_t)0); };
+  nodes.emplace_back();
+  for (int i = 0; i < 4; i++) flags.push_back(rd8());
+  for (size_t head = 0; head < nodes.size(); head++) {
+    for (int i = 0; i < 4; i++) {
+      uint8_t fl = flags[hf++];
+      TmpElem el;
+      el.flag = fl;
+      if (fl == 1) {
+        for (int k = 0; k < 4; k++) flags.push_back(rd8());
+        el.child = (uint32_t)nodes.size();
+        nodes.emplace_back();
+      } else if (fl == 2) {
+        uint32_t sz = 0;
+        if (o + 4 <= b.size()) memcpy(&sz, b.data() + o, 4);
+        o += 4;
+        if (o + sz > b.size()) return false;
+        el.ent_begin = (uint32_t)(ents.size() / 2); el.ent_count = sz / 8;
+        size_t old = ents.size(); ents.resize(old + sz / 4);
+        memcpy(ents.data() + old, b.data() + o, sz);
+        o += sz;
+      } else if (fl != 0) {
+        return false;
+      }
+      nodes[head].e[i] = el;
+    }
+  }
+  return o <= b.size();
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const char* ref_fasta, smr_index** out, char* err, size_t errcap) {
+  if (!prefix || !ref_fasta || !out) return SMR_ERR_ARG;
+  Stats st;
+  if (!load_stats(prefix, st)) { set_err(err, errcap, std::string("cannot read ") + prefix + ".stats"); return SMR_ERR_IO; }
+  if (part >= st.nparts) { set_err(err, errcap, "part out of range"); return SMR_ERR_ARG; }
+  if (st.lnwin < 8 || st.lnwin > 20 || (st.lnwin & 1)) { set_err(err, errcap, "seed length L must be even, 8..20"); return SMR_ERR_ARG; }
+  auto ix = new smr_index();
+  ix->lnwin = st.lnwin; ix->part = part; ix->n_parts = st.nparts;
+  memcpy(ix->bg, st.bg, sizeof st.bg); ix->full_len = st.full_len; ix->numseq = st.numseq; ix->filesize = st.filesize;
+  ix->parts = st.parts; ix->sq_header = st.sq;
+  std::string p = std::to_string(part);
+  uint32_t nk = 1u << st.lnwin;
+  std::vector<uint8_t> kb, tb, pb;
+  if (!slurp(std::string(prefix) + ".kmer_" + p + ".dat", kb) || !slurp(std::string(prefix) + ".bursttrie_" + p + ".dat", tb) ||
+      !slurp(std::string(prefix) + ".pos_" + p + ".dat", pb)) {
+    delete ix; set_err(err, errcap, "cannot read index part files"); return SMR_ERR_IO;
+  }
+  ix->lookup.assign(nk, Lookup{0, NONE, NONE});
+  for (uint32_t i = 0; i < nk && (size_t)(i + 1) * 4 <= kb.size(); i++) memcpy(&ix->lookup[i].count, kb.data() + (size_t)i * 4, 4);
+  size_t o = 0;
+  std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::string why;
+  for (uint32_t i = 0; i < nk && o < tb.size(); i++) {
+    uint32_t sz[2] = {0, 0};
+    if (o + 8 <= tb.size()) memcpy(sz, tb.data() + o, 8);
+    o += 8;
+    if (ix->lookup[i].count == 0) continue;       // index.cpp:190: tries are only read when count != 0
+    for (int j = 0; j < 2; j++) {
+      if (sz[j] == 0) continue;
+      uint32_t root = NONE;
+      if (!parse_bfs(tb, o, nodes, ents) || !emit_minitrie(nodes, ents, ix->trie, root, *ix, why)) {
+        delete ix; set_err(err, errcap, "malformed burst trie file: " + why); return SMR_ERR_IO;
+      }
+      if (j == 0) ix->lookup[i].rootF = root; else ix->lookup[i].rootR = root;
+    }
+  }
+  // positions (index.cpp:322-352) -> CSR; keep file order (sorted by seq, then pos, by construction)
+  o = 0;
+  uint32_t nid = 0;
+  if (pb.size() >= 4) memcpy(&nid, pb.data(), 4);
+  o = 4;
+  ix->pos_off.assign((size_t)nid + 1, 0);
+  for (uint32_t i = 0; i < nid; i++) {
+    uint32_t sz = 0;
+    if (o + 4 <= pb.size()) memcpy(&sz, pb.data() + o, 4);
+    o += 4;
+    if (o + (size_t)sz * 8 > pb.size()) { delete ix; set_err(err, errcap, "malformed pos file"); return SMR_ERR_IO; }
+    size_t old = ix->pos_arr.size();
+    if (old / 2 + sz > 0xFFFFFFFFull) { delete ix; set_err(err, errcap, "more than 2^32 positions"); return SMR_ERR_IO; }
+    ix->pos_arr.resize(old + (size_t)sz * 2);
+    memcpy(ix->pos_arr.data() + old, pb.data() + o, (size_t)sz * 8);
+    o += (size_t)sz * 8;
+    ix->pos_off[i + 1] = (uint32_t)(ix->pos_arr.size() / 2);
+    // the device code binary-searches each list by seq: enforce (seq,pos) order
+    bool sorted = true;
+    for (uint32_t k = 1; k < sz && sorted; k++) {
+      const uint32_t* a = ix->pos_arr.data() + old + (size_t)(k - 1) * 2;
+      if (a[1] > a[3] || (a[1] == a[3] && a[0] > a[2])) sorted = false;
+    }
+    if (!sorted) {
+      std::vector<std::pair<uint32_t, uint32_t>> v(sz);
+      for (uint32_t k = 0; k < sz; k++) v[k] = {ix->pos_arr[old + 2 * k + 1], ix->pos_arr[old + 2 * k]};
+      std::sort(v.begin(), v.end());
+      for (uint32_t k = 0; k < sz; k++) { ix->pos_arr[old + 2 * k] = v[k].second; ix->pos_arr[old + 2 * k + 1] = v[k].first; }
+    }
+  }
+  if (!load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix)) {
+    delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO;
+  }
+  *out = ix;
+  return SMR_OK;
+}
+
+extern "C" void smr_index_free(smr_index* ix) { delete ix; }
+
+extern "C" int smr_index_get_info(const smr_index* ix, smr_index_info* o) {
+  if (!ix || !o) return SMR_ERR_ARG;
+  o->lnwin = ix->lnwin; o->n_kmers = (uint32_t)ix->lookup.size(); o->trie_words = ix->trie.size();
+  o->n_ids = ix->n_ids(); o->n_pos = ix->pos_arr.size() / 2; o->n_refs = ix->n_refs(); o->ref_bytes = ix->ref_seq.size();
+  o->n_nodes = ix->n_nodes; o->n_buckets = ix->n_buckets; o->n_entries = ix->n_entries;
+  memcpy(o->bg, ix->bg, sizeof o->bg); o->full_len = ix->full_len; o->numseq = ix->numseq; o->n_parts = ix->n_parts;
+  return SMR_OK;
+}
+
+// refstats.cpp:238-265
+extern "C" uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref, uint64_t numseq,
+                                      uint64_t all_reads_count, uint64_t all_reads_len, double evalue) {
+  double H = -(bg[0] * std::log2(bg[0]) + bg[1] * std::log2(bg[1]) + bg[2] * std::log2(bg[2]) + bg[3] * std::log2(bg[3]));
+  uint64_t full_read = all_reads_len;
+  uint64_t expect_L = static_cast<uint64_t>(std::log(K * full_ref * full_read / 1) / H);
+  if (full_ref > expect_L * numseq) full_ref -= expect_L * numseq;
+  full_read -= expect_L * all_reads_count / 1;
+  return static_cast<uint32_t>(std::log(evalue / ((double)K * full_ref * full_read / 1)) / -lambda);
+}
+
+// =================================================================================================
+// Our own builder.
+// =================================================================================================
+namespace {
+
+struct SeqRec { uint64_t file_start; uint64_t file_end; uint64_t seq_begin; uint32_t len; std::string id; };
+
+// parse the FASTA like build_index() does (indexdb.cpp:1198-1260): header up to '\n', sequence = every
+// char except '\n' and ' '
+bool parse_fasta(const std::vector<uint8_t>& b, std::vector<SeqRec>& recs, std::vector<uint8_t>& raw, std::string& why) {
+  size_t o = 0, n = b.size();
+  while (o < n) {
+    if (b[o] != '>') { why = "each reference header must begin with '>'"; return false; }
+    SeqRec r; r.file_start = o;
+    size_t e = o + 1; bool stop = false;
+    while (e < n && b[e] != '\n') {
+      if (b[e] != ' ' && b[e] != '\t' && !stop) r.id.push_back((char)b[e]); else stop = true;
+      e++;
+    }
+    o = e + 1;
+    r.seq_begin = raw.size();
+    while (o < n && b[o] != '>') { if (b[o] != '\n' && b[o] != ' ') raw.push_back(b[o]); o++; }
+    r.len = (uint32_t)(raw.size() - r.seq_begin);
+    r.file_end = o;
+    recs.push_back(std::move(r));
+  }
+  return true;
+}
+
+template <class F> void parallel_for(uint32_t threads, size_t n, F f) {
+  if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
+  std::vector<std::thread> th;
+  size_t chunk = (n + threads - 1) / threads;
+  for (uint32_t t = 0; t < threads; t++) {
+    size_t lo = (size_t)t * chunk, hi = std::min(n, lo + chunk);
+    if (lo >= hi) break;
+    th.emplace_back([=]() { f(lo, hi, t); });
+  }
+  for (auto& x : th) x.join();
+}
+
+// sort u64 keys: partition by the top `topbits` bits (counting), then std::sort every bucket in parallel
+void bucket_sort_u64(std::vector<uint64_t>& a, int keybits, uint32_t threads) {
+  size_t n = a.size();
+  if (n < (1u << 16) || threads <= 1) { std::sort(a.begin(), a.end()); return; }
+  const int topbits = 12; const uint32_t nb = 1u << topbits; const int sh = keybits - topbits;
+  std::vector<std::vector<size_t>> hist(threads, std::vector<size_t>(nb, 0));
+  parallel_for(threads, n, [&](size_t lo, size_t hi, uint32_t t) { for (size_t i = lo; i < hi; i++) hist[t][a[i] >> sh]++; });
+  std::vector<size_t> start(nb + 1, 0);
+  std::vector<std::vector<size_t>> off(threads, std::vector<size_t>(nb, 0));
+  size_t acc = 0;
+  for (uint32_t b = 0; b < nb; b++) { start[b] = acc; for (uint32_t t = 0; t < threads; t++) { off[t][b] = acc; acc += hist[t][b]; } }
+  start[nb] = acc;
+  std::vector<uint64_t> tmp(n);
+  parallel_for(threads, n, [&](size_t lo, size_t hi, uint32_t t) { for (size_t i = lo; i < hi; i++) tmp[off[t][a[i] >> sh]++] = a[i]; });
+  a.swap(tmp);
+  std::atomic<uint32_t> next(0);
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < threads; t++) th.emplace_back([&]() {
+    for (;;) { uint32_t b = next.fetch_add(1); if (b >= nb) break; std::sort(a.begin() + start[b], a.begin() + start[b + 1]); }
+  });
+  for (auto& x : th) x.join();
+}
+
+// build one mini-trie from entries sorted by tail (tails given MSB-first in `tailbits` = 2*T bits).
+// ent[i] = (tail << 32) | id ; T = L/2 + 1 characters.
+struct TrieBuilder {
+  int T;                 // tail length in nt
+  int burst_depth;       // elements with (0-based node depth + 1) < burst_depth may burst   (indexdb.cpp:225)
+  std::vector<TmpNode> nodes;
+  std::vector<uint32_t> ents;
+  const uint64_t* e = nullptr;
+  static inline uint32_t nt_at(uint64_t tail, int T, int k) { return (uint32_t)(tail >> (2 * (T - 1 - k))) & 3u; }
+  void build_node(uint32_t node, size_t lo, size_t hi, int depth) {
+    size_t p = lo;
+    for (uint32_t c = 0; c < 4; c++) {
+      size_t q = p;
+      while (q < hi && nt_at(e[q] >> 32, T, depth) == c) q++;
+      TmpElem el;
+      if (q > p) {
+        size_t cnt = q - p;
+        if (cnt > 16 && depth + 1 < burst_depth) {
+          el.flag = 1; el.child = (uint32_t)nodes.size();
+          nodes.emplace_back();
+          nodes[node].e[c] = el;
+          build_node(el.child, p, q, depth + 1);
+          p = q;
+          continue;
+        }
+        el.flag = 2; el.ent_begin = (uint32_t)(ents.size() / 2); el.ent_count = (uint32_t)cnt;
+        int s = T - 1 - depth;                       // remaining characters per entry
+        for (size_t i = p; i < q; i++) {
+          uint64_t tail = e[i] >> 32; uint32_t enc = 0;
+          for (int k = 0; k < s; k++) enc |= nt_at(tail, T, depth + 1 + k) << (2 * k);   // first nt in the low bits
+          ents.push_back(enc); ents.push_back((uint32_t)e[i]);
+        }
+      }
+      nodes[node].e[c] = el;
+      p = q;
+    }
+  }
+  void build(const uint64_t* ent, size_t n) {
+    nodes.clear(); ents.clear(); e = ent;
+    nodes.emplace_back();
+    build_node(0, 0, n, 0);
+  }
+};
+
+}  // namespace
+
+extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads,
+                               smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
+  if (!ref_fasta || !parts_out || !n_parts_out) return SMR_ERR_ARG;
+  if (L < 8 || L > 18 || (L & 1)) { set_err(err, errcap, "builder supports even seed lengths 8..18"); return SMR_ERR_ARG; }
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  std::vector<uint8_t> file;
+  if (!slurp(ref_fasta, file)) { set_err(err, errcap, std::string("cannot read ") + ref_fasta); return SMR_ERR_IO; }
+  std::vector<SeqRec> recs; std::vector<uint8_t> raw; std::string why;
+  if (!parse_fasta(file, recs, raw, why)) { set_err(err, errcap, why); return SMR_ERR_IO; }
+  const uint32_t P = L / 2, W = L + 1, T = P + 1;
+  // STEP 1 statistics (indexdb.cpp:1198-1268)
+  double bgc[4] = {0, 0, 0, 0}; uint64_t full_len = 0;
+  for (auto& r : recs) {
+    if (r.len < W) { set_err(err, errcap, "at least one sequence is shorter than the seed length " + std::to_string(W)); return SMR_ERR_IO; }
+    full_len += r.len;
+    for (uint32_t k = 0; k < r.len; k++) { int c = raw[r.seq_begin + k]; if (c != 'N') bgc[nt_index(c)]++; }
+  }
+  double tot = bgc[0] + bgc[1] + bgc[2] + bgc[3];
+  // part split (indexdb.cpp:1384-1420)
+  struct PartRange { size_t s0, s1; };
+  std::vector<PartRange> pr; std::vector<PartStats> pstats;
+  {
+    size_t i = 0;
+    while (i < recs.size()) {
+      double idx_size = 0; size_t s0 = i; PartStats ps; ps.start_part = recs[i].file_start; bool any = false;
+      while (i < recs.size()) {
+        double est = (double)(recs[i].len - W + 1) * 9.5e-6;
+        if (est > max_mb) { i++; continue; }              // sequence alone too large: skipped by the reference
+        if (idx_size + est > max_mb) break;
+        idx_size += est; ps.numseq_part++; ps.seq_part_size = recs[i].file_end - ps.start_part; any = true; i++;
+      }
+      if (!any) break;
+      pr.push_back({s0, i}); pstats.push_back(ps);
+    }
+  }
+  if (pr.empty()) { set_err(err, errcap, "no index could be created with this memory limit"); return SMR_ERR_ARG; }
+  if (pr.size() > cap_parts) { set_err(err, errcap, "too many index parts for the caller's array"); return SMR_ERR_ARG; }
+  std::vector<std::pair<std::string, uint32_t>> sq;
+  for (auto& r : recs) sq.emplace_back(r.id, r.len);
+
+  for (size_t pi = 0; pi < pr.size(); pi++) {
+    auto ix = new smr_index();
+    ix->lnwin = L; ix->part = (uint32_t)pi; ix->n_parts = (uint32_t)pr.size();
+    for (int k = 0; k < 4; k++) ix->bg[k] = bgc[k] / tot;
+    ix->full_len = full_len; ix->numseq = recs.size(); ix->filesize = file.size(); ix->parts = pstats; ix->sq_header = sq;
+    // sequences of this part (those skipped for size are not part of it); seq number = rank within the part
+    std::vector<size_t> members;
+    for (size_t s = pr[pi].s0; s < pr[pi].s1; s++) if ((double)(recs[s].len - W + 1) * 9.5e-6 <= max_mb) members.push_back(s);
+    // reference sequences for SW (nt_table)
+    ix->ref_off.assign(1, 0);
+    for (size_t s : members) {
+      for (uint32_t k = 0; k < recs[s].len; k++) ix->ref_seq.push_back(nt_sw(raw[recs[s].seq_begin + k]));
+      ix->ref_off.push_back(ix->ref_seq.size());
+    }
+    // occurrences: key = (18-mer prefix, 2L bits) << occbits | occurrence number (scan order)
+    std::vector<uint64_t> occ_start(members.size() + 1, 0);
+    for (size_t m = 0; m < members.size(); m++) occ_start[m + 1] = occ_start[m] + (recs[members[m]].len - W + 1);
+    uint64_t N = occ_start.back();
+    int occbits = 1; while ((1ull << occbits) < N) occbits++;
+    if ((int)(2 * L) + occbits > 64) { delete ix; set_err(err, errcap, "part too large for the builder (reduce -m)"); return SMR_ERR_ARG; }
+    std::vector<uint64_t> keys(N);
+    std::vector<uint8_t> last_nt(N);     // nt at position p+L of occurrence (the 19th)
+    parallel_for(threads, members.size(), [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t m = lo; m < hi; m++) {
+        const SeqRec& r = recs[members[m]];
+        const uint8_t* s = raw.data() + r.seq_begin;
+        uint64_t code = 0, mask = (L == 32) ? ~0ull : ((1ull << (2 * L)) - 1);
+        for (uint32_t k = 0; k < L; k++) code = (code << 2) | nt_index(s[k]);
+        uint64_t o = occ_start[m];
+        for (uint32_t p = 0; p + W <= r.len; p++) {
+          keys[o + p] = (code << occbits) | (o + p);
+          last_nt[o + p] = nt_index(s[p + L]);
+          if (p + W < r.len) code = ((code << 2) | nt_index(s[p + L])) & mask;
+        }
+      }
+    });
+    bucket_sort_u64(keys, 2 * (int)L + occbits, threads);
+    // ids, positions CSR, unique 19-mers
+    const uint64_t occmask = (1ull << occbits) - 1;
+    auto occ_to_seqpos = [&](uint64_t occ, uint32_t& seq, uint32_t& pos) {
+      size_t m = std::upper_bound(occ_start.begin(), occ_start.end(), occ) - occ_start.begin() - 1;
+      seq = (uint32_t)m; pos = (uint32_t)(occ - occ_start[m]);
+    };
+    // F entries (keyF, tail, id) come out already sorted; R entries need regrouping by keyR
+    std::vector<uint64_t> fent;                       // (prefix19 code) kept implicit: we store key|tail|id in parallel arrays
+    std::vector<uint32_t> f_key; std::vector<uint64_t> f_tail_id;
+    std::vector<uint32_t> r_key; std::vector<uint64_t> r_tail_id;
+    ix->pos_off.assign(1, 0);
+    uint32_t id = 0;
+    for (uint64_t i = 0; i < N;) {
+      uint64_t pre = keys[i] >> occbits;
+      uint64_t j = i; uint32_t present = 0;
+      uint32_t stored = 0;
+      while (j < N && (keys[j] >> occbits) == pre) {
+        uint64_t occ = keys[j] & occmask;
+        present |= 1u << last_nt[occ];
+        if (max_pos == 0 || stored == 0 || stored < max_pos) {      // indexdb.cpp:318-349
+          uint32_t sq_, ps_; occ_to_seqpos(occ, sq_, ps_);
+          ix->pos_arr.push_back(ps_); ix->pos_arr.push_back(sq_); stored++;
+        }
+        j++;
+      }
+      ix->pos_off.push_back((uint32_t)(ix->pos_arr.size() / 2));
+      for (uint32_t c = 0; c < 4; c++) if (present & (1u << c)) {
+        uint64_t code19 = (pre << 2) | c;                         // 2W bits
+        uint32_t keyF = (uint32_t)(code19 >> (2 * T));            // first P nt
+        uint64_t tailF = code19 & ((1ull << (2 * T)) - 1);        // last T nt, MSB-first
+        f_key.push_back(keyF); f_tail_id.push_back((tailF << 32) | id);
+        uint32_t keyR = (uint32_t)(code19 & ((1ull << (2 * P)) - 1));   // last P nt
+        uint64_t head = code19 >> (2 * P);                        // first T nt, MSB-first
+        uint64_t tailR = 0;                                        // reversed head (indexdb.cpp:1441-1444)
+        for (uint32_t k = 0; k < T; k++) tailR = (tailR << 2) | ((head >> (2 * k)) & 3);
+        r_key.push_back(keyR); r_tail_id.push_back((tailR << 32) | id);
+      }
+      id++;
+      i = j;
+    }
+    keys.clear(); keys.shrink_to_fit(); last_nt.clear(); last_nt.shrink_to_fit();
+    const uint32_t NK = 1u << L;
+    ix->lookup.assign(NK, Lookup{0, NONE, NONE});
+    // group R by key (counting sort), sort each group by tail
+    size_t M = f_key.size();
+    std::vector<size_t> rstart((size_t)NK + 1, 0);
+    for (size_t i = 0; i < M; i++) rstart[r_key[i] + 1]++;
+    for (uint32_t k = 0; k < NK; k++) rstart[k + 1] += rstart[k];
+    std::vector<uint64_t> rsorted(M);
+    { std::vector<size_t> cur(rstart.begin(), rstart.end() - 1); for (size_t i = 0; i < M; i++) rsorted[cur[r_key[i]]++] = r_tail_id[i]; }
+    r_tail_id.clear(); r_tail_id.shrink_to_fit(); r_key.clear(); r_key.shrink_to_fit();
+    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) { for (size_t k = lo; k < hi; k++) std::sort(rsorted.begin() + rstart[k], rsorted.begin() + rstart[k + 1]); });
+    std::vector<size_t> fstart((size_t)NK + 1, 0);
+    for (size_t i = 0; i < M; i++) fstart[f_key[i] + 1]++;
+    for (uint32_t k = 0; k < NK; k++) fstart[k + 1] += fstart[k];
+    // emit tries
+    TrieBuilder tb; tb.T = (int)T; tb.burst_depth = (int)(W - P - 3);
+    for (uint32_t k = 0; k < NK; k++) {
+      size_t nf = fstart[k + 1] - fstart[k], nr = rstart[k + 1] - rstart[k];
+      ix->lookup[k].count = (uint32_t)(nf + nr);             // only tested as `count > minoccur`
+      for (int j = 0; j < 2; j++) {
+        size_t cnt = j == 0 ? nf : nr;
+        if (!cnt) continue;
+        tb.build(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], cnt);
+        uint32_t root = NONE;
+        if (!emit_minitrie(tb.nodes, tb.ents, ix->trie, root, *ix, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_IO; }
+        if (j == 0) ix->lookup[k].rootF = root; else ix->lookup[k].rootR = root;
+      }
+    }
+    parts_out[pi] = ix;
+  }
+  *n_parts_out = (uint32_t)pr.size();
+  return SMR_OK;
+}
+
+// =================================================================================================
+// Writer of the reference's on-disk format (so `sortmerna` itself and the test oracle can consume our index)
+// =================================================================================================
+namespace {
+void write_bfs(const smr_index& ix, uint32_t root, std::vector<uint8_t>& out, uint32_t& mem_size) {
+  // BFS over the compact arena; mem_size = nodes*64 + bucket bytes (indexdb.cpp:730-748)
+  std::vector<uint32_t> q{0};
+  mem_size = 0;
+  auto put_flags = [&](uint32_t rel) { for (int k = 0; k < 4; k++) out.push_back((uint8_t)(ix.trie[root + rel + k] >> ELEM_FLAG_SHIFT)); };
+  put_flags(0);
+  for (size_t h = 0; h < q.size(); h++) {
+    mem_size += 64;
+    for (int k = 0; k < 4; k++) {
+      uint32_t e = ix.trie[root + q[h] + k]; uint32_t fl = e >> ELEM_FLAG_SHIFT;
+      if (fl == 1) { uint32_t rel = e & ELEM_OFF_MASK; put_flags(rel); q.push_back(rel); }
+      else if (fl == 2) {
+        uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFF, rel = e & ELEM_OFF_MASK, bytes = n * 8;
+        size_t old = out.size(); out.resize(old + 4 + bytes);
+        memcpy(out.data() + old, &bytes, 4); memcpy(out.data() + old + 4, &ix.trie[root + rel], bytes);
+        mem_size += bytes;
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int smr_index_write_files(const smr_index* const* parts, uint32_t n_parts, const char* ref_fasta, const char* prefix, char* err, size_t errcap) {
+  if (!parts || !n_parts || !prefix || !ref_fasta) return SMR_ERR_ARG;
+  for (uint32_t p = 0; p < n_parts; p++) {
+    const smr_index& ix = *parts[p];
+    std::string ps = std::to_string(p);
+    { std::ofstream f(std::string(prefix) + ".kmer_" + ps + ".dat", std::ios::binary);
+      if (!f) { set_err(err, errcap, "cannot write kmer file"); return SMR_ERR_IO; }
+      for (auto& l : ix.lookup) f.write((const char*)&l.count, 4); }
+    { std::ofstream f(std::string(prefix) + ".bursttrie_" + ps + ".dat", std::ios::binary);
+      if (!f) { set_err(err, errcap, "cannot write bursttrie file"); return SMR_ERR_IO; }
+      std::vector<uint8_t> sf, sr;
+      for (auto& l : ix.lookup) {
+        uint32_t sz[2] = {0, 0}; sf.clear(); sr.clear();
+        if (l.rootF != NONE) write_bfs(ix, l.rootF, sf, sz[0]);
+        if (l.rootR != NONE) write_bfs(ix, l.rootR, sr, sz[1]);
+        f.write((const char*)sz, 8);
+        if (l.count != 0) { f.write((const char*)sf.data(), (std::streamsize)sf.size()); f.write((const char*)sr.data(), (std::streamsize)sr.size()); }
+      } }
+    { std::ofstream f(std::string(prefix) + ".pos_" + ps + ".dat", std::ios::binary);
+      if (!f) { set_err(err, errcap, "cannot write pos file"); return SMR_ERR_IO; }
+      uint32_t nid = ix.n_ids(); f.write((const char*)&nid, 4);
+      for (uint32_t i = 0; i < nid; i++) {
+        uint32_t sz = ix.pos_off[i + 1] - ix.pos_off[i];
+        f.write((const char*)&sz, 4);
+        f.write((const char*)(ix.pos_arr.data() + (size_t)ix.pos_off[i] * 2), (std::streamsize)sz * 8);
+      } }
+  }
+  const smr_index& ix0 = *parts[0];
+  std::ofstream st(std::string(prefix) + ".stats", std::ios::binary);
+  if (!st) { set_err(err, errcap, "cannot write stats file"); return SMR_ERR_IO; }
+  uint64_t fs = ix0.filesize; st.write((const char*)&fs, 8);
+  std::string fn(ref_fasta); uint32_t fl = (uint32_t)fn.size() + 1; st.write((const char*)&fl, 4); st.write(fn.c_str(), fl);
+  st.write((const char*)ix0.bg, 32); st.write((const char*)&ix0.full_len, 8); st.write((const char*)&ix0.lnwin, 4);
+  st.write((const char*)&ix0.numseq, 8);
+  uint16_t np = (uint16_t)n_parts; st.write((const char*)&np, 2);
+  for (uint32_t p = 0; p < n_parts; p++) {
+    uint8_t raw[24] = {0};
+    memcpy(raw, &ix0.parts[p].start_part, 8); memcpy(raw + 8, &ix0.parts[p].seq_part_size, 8); memcpy(raw + 16, &ix0.parts[p].numseq_part, 4);
+    st.write((const char*)raw, 24);
+  }
+  uint32_t nsq = (uint32_t)ix0.sq_header.size(); st.write((const char*)&nsq, 4);
+  for (auto& s : ix0.sq_header) {
+    uint32_t li = (uint32_t)s.first.size(); st.write((const char*)&li, 4); st.write(s.first.data(), li); st.write((const char*)&s.second, 4);
+  }
+  return SMR_OK;
+}

@@ -1,0 +1,244 @@
+"""Host-side mirror of the reference's alignment driver for the hot path.
+
+`align()` below has the shape of processor.cpp:align() (/root/reference/src/sortmerna/processor.cpp:173-285):
+for every index and every part: load index + references, run the per-read path over all reads, keep per-read
+state between parts -- except that the inner N x align2() thread loop is one call into libsmr_hip (GPU).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class SmrError(RuntimeError):
+    pass
+
+
+def default_params(**kw):
+    p = capi.Params()
+    capi.load().smr_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == "skiplengths":
+            for i in range(3):
+                p.skiplengths[i] = v[i]
+        else:
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+    return p
+
+
+class Index:
+    """One (index, part) on the host: flattened lookup / mini-trie arena / positions CSR / reference bytes."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def load_files(prefix, part, ref_fasta):
+        L = capi.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.smr_index_load_files(prefix.encode(), part, ref_fasta.encode(), C.byref(h), err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_load_files: %s (rc=%d)" % (err.value.decode(), rc))
+        return Index(h)
+
+    @staticmethod
+    def build(ref_fasta, seed_win_len=18, max_file_size_mb=3072.0, max_pos=10000, threads=0):
+        """-> list of Index (one per part)"""
+        L = capi.load()
+        cap = 256
+        arr = (C.c_void_p * cap)()
+        n = C.c_uint32()
+        err = C.create_string_buffer(512)
+        rc = L.smr_index_build(ref_fasta.encode(), seed_win_len, max_file_size_mb, max_pos, threads,
+                               C.cast(arr, C.POINTER(C.c_void_p)), cap, C.byref(n), err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_build: %s (rc=%d)" % (err.value.decode(), rc))
+        return [Index(C.c_void_p(arr[i])) for i in range(n.value)]
+
+    @staticmethod
+    def write_files(parts, ref_fasta, prefix):
+        L = capi.load()
+        arr = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        err = C.create_string_buffer(512)
+        rc = L.smr_index_write_files(C.cast(arr, C.POINTER(C.c_void_p)), len(parts), ref_fasta.encode(), prefix.encode(), err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_write_files: %s (rc=%d)" % (err.value.decode(), rc))
+
+    def info(self):
+        i = capi.IndexInfo()
+        capi.load().smr_index_get_info(self.h, C.byref(i))
+        return i
+
+    def free(self):
+        if self.h:
+            capi.load().smr_index_free(self.h)
+            self.h = None
+
+
+class Reads:
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def from_seqs(seqs):
+        L = capi.load()
+        blob = "".join(seqs).encode("latin-1")
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        if seqs:
+            offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+        h = C.c_void_p()
+        rc = L.smr_reads_pack(blob, offs.ctypes.data, len(seqs), C.byref(h))
+        if rc != 0:
+            raise SmrError("smr_reads_pack rc=%d" % rc)
+        return Reads(h)
+
+    @staticmethod
+    def from_fastx(path, first=0, count=0):
+        L = capi.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.smr_reads_load_fastx(path.encode(), first, count, C.byref(h), err, 512)
+        if rc != 0:
+            raise SmrError("smr_reads_load_fastx: %s (rc=%d)" % (err.value.decode(), rc))
+        return Reads(h)
+
+    @property
+    def count(self):
+        return capi.load().smr_reads_count(self.h)
+
+    @property
+    def total_len(self):
+        return capi.load().smr_reads_total_len(self.h)
+
+    @property
+    def min_len(self):
+        return capi.load().smr_reads_min_len(self.h)
+
+    @property
+    def max_len(self):
+        return capi.load().smr_reads_max_len(self.h)
+
+    def free(self):
+        if self.h:
+            capi.load().smr_reads_free(self.h)
+            self.h = None
+
+
+def minimal_score(lam, K, info, all_reads_count, all_reads_len, evalue=1.0):
+    """Refstats arithmetic (refstats.cpp:238-265) from Gumbel (lambda, K) + DB statistics + GLOBAL read totals."""
+    return capi.load().smr_minimal_score(lam, K, info.bg, info.full_len, info.numseq, all_reads_count, all_reads_len, evalue)
+
+
+class Engine:
+    """One GPU.  Fails loudly when no HIP device / library is available (no CPU fallback)."""
+
+    def __init__(self, device=0):
+        self.L = capi.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self.L.smr_create(device, C.byref(h), err, 512)
+        if rc != 0:
+            raise SmrError("smr_create: %s (rc=%d)" % (err.value.decode(), rc))
+        self.h = h
+        self.n_reads = 0
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise SmrError("%s: %s (rc=%d)" % (what, self.L.smr_last_error(self.h).decode(), rc))
+
+    def upload_index(self, index, slot=0):
+        self._chk(self.L.smr_index_upload(self.h, index.h, slot), "smr_index_upload")
+
+    def unload_index(self, slot=0):
+        self._chk(self.L.smr_index_unload(self.h, slot), "smr_index_unload")
+
+    def upload_reads(self, reads, max_alignments_per_read=1):
+        self._chk(self.L.smr_reads_upload(self.h, reads.h, max_alignments_per_read), "smr_reads_upload")
+        self.n_reads = reads.count
+
+    def reset_state(self):
+        self._chk(self.L.smr_state_reset(self.h), "smr_state_reset")
+
+    def align_part(self, slot, params):
+        self._chk(self.L.smr_align_part(self.h, slot, C.byref(params)), "smr_align_part")
+
+    def traceback(self, slot, params):
+        self._chk(self.L.smr_traceback(self.h, slot, C.byref(params)), "smr_traceback")
+
+    def counters(self, n_db=1):
+        out = (C.c_uint64 * (2 + n_db))()
+        self._chk(self.L.smr_counters(self.h, out, n_db), "smr_counters")
+        return dict(num_aligned=out[0], num_short=out[1], reads_matched_per_db=[out[2 + i] for i in range(n_db)])
+
+    def counters_device(self):
+        p = C.c_void_p()
+        n = C.c_uint32()
+        self._chk(self.L.smr_counters_device(self.h, C.byref(p), C.byref(n)), "smr_counters_device")
+        return p.value, n.value
+
+    def fetch(self):
+        self._chk(self.L.smr_results_fetch(self.h), "smr_results_fetch")
+
+    def record(self, i):
+        n = self.L.smr_result_record(self.h, i, None, 0)
+        if n == 0:
+            return b""
+        buf = C.create_string_buffer(n)
+        self.L.smr_result_record(self.h, i, buf, n)
+        return buf.raw
+
+    def records(self):
+        return [self.record(i) for i in range(self.n_reads)]
+
+    def is_hit(self, i):
+        return bool(self.L.smr_result_is_hit(self.h, i))
+
+    def seed_scan(self, slot, params, strand, pass_):
+        n = C.c_uint64()
+        self._chk(self.L.smr_seed_scan(self.h, slot, C.byref(params), strand, pass_, C.byref(n)), "smr_seed_scan")
+        return n.value
+
+    def seed_hits(self):
+        n = C.c_uint64()
+        self._chk(self.L.smr_seed_hits_fetch(self.h, None, 0, C.byref(n)), "smr_seed_hits_fetch")
+        arr = np.zeros((max(n.value, 1), 3), dtype=np.uint32)
+        self._chk(self.L.smr_seed_hits_fetch(self.h, arr.ctypes.data, n.value, C.byref(n)), "smr_seed_hits_fetch")
+        return arr[: n.value]
+
+    def prof_reset(self):
+        self._chk(self.L.smr_prof_reset(self.h), "smr_prof_reset")
+
+    def prof(self):
+        p = capi.Prof()
+        self._chk(self.L.smr_prof_get(self.h, C.byref(p)), "smr_prof_get")
+        return p
+
+    def close(self):
+        if self.h:
+            self.L.smr_destroy(self.h)
+            self.h = None
+
+
+def align(engine, reads, index_parts, params_per_index, with_cigar=True, max_alignments_per_read=None):
+    """processor.cpp:align(): index_parts = [[Index part0, part1, ...] per --ref], params_per_index = [Params per --ref]
+    (each carrying that DB's minimal_score).  Returns nothing; results stay in `engine` (fetch()/record())."""
+    p0 = params_per_index[0]
+    slots = max_alignments_per_read or (p0.num_alignments if p0.num_alignments > 0 else 32)
+    engine.upload_reads(reads, slots)
+    n_idx = len(index_parts)
+    for idx_num, parts in enumerate(index_parts):
+        for part, ix in enumerate(parts):
+            p = params_per_index[idx_num]
+            p.index_num = idx_num
+            p.part = part
+            p.is_last_index_part = int(idx_num == n_idx - 1 and part == len(parts) - 1)
+            engine.upload_index(ix, 0)
+            engine.align_part(0, p)
+            if with_cigar:
+                engine.traceback(0, p)
+            engine.unload_index(0)
+    engine.fetch()
