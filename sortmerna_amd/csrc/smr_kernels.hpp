@@ -563,7 +563,6 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
   extern __shared__ __align__(16) unsigned char lds_raw[];
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
-  __shared__ uint32_t s_np;
   const int lane = lane_id();
   uint8_t* rdq = lds_raw;
   uint8_t* rfq = rdq + lds_ml;
@@ -956,7 +955,9 @@ __global__ void __launch_bounds__(64) k_trace(DReads rd, DIndex ix, DParams P, c
       // trace back (ssw.c:674-747); dl points at the last row
       i = readLen - 1; j = refLen - 1; e = 0; l = 0; f = 0; mx = 0; temp2 = 2;
       while (i > 0) {
+        if (j < 0) { fail = true; break; }
         TR_SET_D(temp1, band_width, i, j, temp2);
+        if (temp1 < 0 || temp1 >= width_d * 3) { fail = true; break; }
         int dv = DIRX(dl + temp1);
         switch (dv) {
           case 1: --i; --j; temp2 = 2; dl -= (size_t)width_d * 3; f = 0; break;
