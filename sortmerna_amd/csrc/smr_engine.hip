@@ -330,6 +330,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   const int num_strands = single ? 1 : 2;
   for (int attempt = 0; attempt < 8; attempt++) {
     if ((rc = ensure_chain_scratch(c, di))) return rc;
+    const double t_seed0 = c->seed_ms, t_chain0 = c->chain_ms; const uint64_t l_seed0 = c->seed_l, l_chain0 = c->chain_l;
     // restore counters (retry) and clear the per-part ones (processor.cpp:230 resets num_short per part)
     std::vector<unsigned long long> init = snap;
     init[C_NUM_SHORT] = 0;
@@ -346,7 +347,6 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
         if ((rc = launch_chain(c, di, P, pass, single || count == 1))) return rc;
       }
     }
-    hipLaunchKernelGGL(k_commit_part, dim3(nb), dim3(tb), 0, c->stream, c->n, P, c->d_saved, c->d_saved_aln, c->d_work, c->d_work_aln, c->d_rw);
     HIPCHK(c, hipGetLastError());
     if ((rc = read_ctr(c, h))) return rc;
     ev_collect(c);
@@ -362,7 +362,14 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       retry = true;
     }
     if (h[C_ERR_SLOTS]) { c->err = "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"; return SMR_ERR_CAPACITY; }
-    if (!retry) return SMR_OK;
+    if (retry) { c->seed_ms = t_seed0; c->chain_ms = t_chain0; c->seed_l = l_seed0; c->chain_l = l_chain0; }   // timings of a discarded attempt
+    if (!retry) {
+      // only a clean attempt is committed to the persistent per-read state (kvdb.put, processor.cpp:150-155)
+      hipLaunchKernelGGL(k_commit_part, dim3(nb), dim3(tb), 0, c->stream, c->n, P, c->d_saved, c->d_saved_aln, c->d_work, c->d_work_aln, c->d_rw);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      return SMR_OK;
+    }
   }
   c->err = "capacity retries exhausted";
   return SMR_ERR_CAPACITY;
