@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/sec of the MI355X hot path (libsmr_hip) on BASELINE.json's headline workload.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2]): synthetic 150-nt Illumina-like reads (10 % sampled from
+the DB with sequencing errors, 90 % random background) against an rRNA-like reference DB of the size of
+smr_v4.3_default_db.fasta (140 Mnt; the real file is a release download that is not available offline, so a seeded
+synthetic DB of families of mutated copies stands in -- `config.workload` says so).  A "step" is one pass of the
+whole hot path -- both strands, all three seed passes, LIS chaining, Smith-Waterman, banded traceback, result fetch --
+over ONE batch of `--batch-reads` reads that is already resident in HBM; every step uses a different batch.
+The 10 M read job of the config is `10 M / batch` such steps; reads/s does not depend on how many of them are timed.
+
+Reads shard across GPUs (one rank per GPU, each with a full index replica, no data-path collective); the only
+collectives are the two tiny all-reduces the reference's semantics need: global read totals before (they define
+minimal_score, refstats.cpp:247-265) and the Readstats counters after (RCCL).
+
+The JSON line also carries
+  roofline      seed-scan kernel (k_seed): algorithmic bytes (SURVEY.md 8d formula, from exact device work counters)
+                / HIP-event time of its launches, against the 8 TB/s HBM3E peak
+  kernels       HIP-event time and launch count of each kernel family in the timed region
+  cpu_baseline  the UNMODIFIED reference (oracle/_ref/sortmerna_ref) timed on this host's cores on a bounded sample of
+                the same reads with the same index files (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+# Gumbel (lambda, K) of the scoring scheme 2/-3/5/2 for a near-uniform background, as the reference's vendored ALP
+# computes them (refstats.cpp:194-233); inputs of smr_minimal_score.
+GUMBEL = (0.618874, 0.343238)
+HBM_PEAK_GBS = 8000.0
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def make_batch(synth, codes, offs, n, read_len, seed):
+    return synth.make_reads(codes, offs, n, read_len=read_len, frac_db=0.10, seed=seed, sub=0.005, indel=0.0001, n_rate=0.001)
+
+
+def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_slots):
+    """Time the unmodified reference on a bounded sample; also compare its hit count with the GPU path's."""
+    ref_bin = os.path.join(HERE, "oracle", "_ref", "sortmerna_ref")
+    strhash = os.path.join(HERE, "oracle", "_ref", "strhash")
+    cores = os.cpu_count() or 1
+    if not (os.path.isfile(ref_bin) and os.path.isfile(strhash)):
+        return {"value": None, "unit": "reads/s", "cores": cores, "kind": "reference", "sample": "oracle/_ref/sortmerna_ref not built"}
+    from sortmerna_amd import synth
+    n = min(len(letters), args.cpu_sample_reads)
+    wd = tempfile.mkdtemp(prefix="smr_cpu_")
+    try:
+        reads = os.path.join(wd, "sample.fastq")
+        synth.write_fastq(reads, letters[:n])
+        idx = os.path.join(wd, "idx")
+        os.makedirs(idx)
+        h = subprocess.check_output([strhash, os.path.basename(db)]).decode().strip()
+        t0 = time.time()
+        smr.Index.write_files(parts, db, os.path.join(idx, h))
+        log("index files for the reference written in %.1fs" % (time.time() - t0))
+        threads = min(cores, 64)
+        cmd = [ref_bin, "-ref", db, "-reads", reads, "-workdir", os.path.join(wd, "run"), "-idx-dir", idx, "-threads", str(threads), "-fastx", "-v"]
+        t0 = time.time()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+        out = p.stdout.decode("latin-1")
+        wall = time.time() - t0
+        m = re.findall(r"done index: \d+ part: \d+ in ([0-9.eE+-]+) sec", out)
+        if p.returncode != 0 or not m:
+            return {"value": None, "unit": "reads/s", "cores": threads, "kind": "reference", "sample": "reference run failed rc=%d: %s" % (p.returncode, out[-300:])}
+        align_s = sum(float(x) for x in m)
+        res = {"value": n / align_s, "unit": "reads/s", "cores": threads, "kind": "reference",
+               "sample": "first %d reads of batch 0, same index files, alignment stage only (%.2f s; whole process %.1f s incl. index load)" % (n, align_s, wall)}
+        logp = os.path.join(wd, "run", "out", "aligned.log")
+        if os.path.isfile(logp):
+            t = open(logp).read()
+            ms = re.search(r"Minimal SW score based on E-value = (\d+)", t)
+            na = re.search(r"Total reads passing E-value threshold = (\d+)", t)
+            if ms and na:
+                # same sample through the GPU path with the reference's own minimal_score: hit counts must be equal
+                r = smr.Reads.from_seqs([bytes(x).decode() for x in letters[:n]])
+                eng.select_batch(15)
+                eng.upload_reads(r, 1)
+                p2 = smr.default_params(minimal_score=int(ms.group(1)))
+                smr.align_resident(eng, idx_slots, [p2], with_cigar=False)
+                res["parity"] = {"reference_aligned": int(na.group(1)), "gpu_aligned": int(eng.counters(1)["num_aligned"]),
+                                 "minimal_score": int(ms.group(1))}
+                r.free()
+        return res
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--db-nt", type=int, default=140_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cigar", action="store_true", help="skip the banded traceback (not the reference's behaviour)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    if args.warmup + args.steps > 15:
+        sys.exit("warmup + steps must be <= 15 (resident batches)")
+
+    import numpy as np
+    import torch
+    import sortmerna_amd as smr
+    from sortmerna_amd import shard, synth
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    # ---------------- workload: DB + index (rank 0 builds, the others load its files) ----------------
+    cache = os.path.join(tempfile.gettempdir(), "smr_bench_%d" % args.db_nt)
+    os.makedirs(cache, exist_ok=True)
+    db = os.path.join(cache, "synth_rrna_db_%d.fasta" % args.db_nt)
+    prefix = os.path.join(cache, "index")
+    t0 = time.time()
+    if rank == 0 and not os.path.isfile(db):
+        synth.make_db(db + ".tmp", args.db_nt, seed=42)
+        os.replace(db + ".tmp", db)
+    log("DB ready (%.1fs)" % (time.time() - t0))
+    t0 = time.time()
+    if rank == 0:
+        parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+        if world > 1:
+            smr.Index.write_files(parts, db, prefix)
+    barrier()
+    if rank != 0:
+        parts = []
+        k = 0
+        while os.path.isfile("%s.kmer_%d.dat" % (prefix, k)):
+            parts.append(smr.Index.load_files(prefix, k, db))
+            k += 1
+    info = parts[0].info()
+    log("index ready: %d part(s), trie %.0f MB, positions %.0f MB, %d refs (%.1fs)" % (
+        len(parts), sum(p.info().trie_words for p in parts) * 4 / 1e6, sum(p.info().n_pos for p in parts) * 8 / 1e6,
+        info.numseq, time.time() - t0))
+
+    eng = smr.Engine(local)
+    idx_slots = list(range(len(parts)))
+    for s, ix in zip(idx_slots, parts):
+        eng.upload_index(ix, s)
+
+    # ---------------- reads: W + K different batches per rank, resident in HBM ----------------
+    t0 = time.time()
+    codes, offs = synth.load_db_codes(db)
+    nb = args.warmup + args.steps
+    batch0 = None
+    tot_reads = 0
+    tot_len = 0
+    for b in range(nb):
+        letters = make_batch(synth, codes, offs, args.batch_reads, args.read_len, 1234 + 1000 * rank + b)
+        if b == 0:
+            batch0 = letters
+        blob = letters.tobytes()
+        o = (np.arange(args.batch_reads + 1, dtype=np.uint64) * np.uint64(args.read_len))
+        import ctypes as C
+        h = C.c_void_p()
+        rc = eng.L.smr_reads_pack(blob, o.ctypes.data, args.batch_reads, C.byref(h))
+        assert rc == 0
+        r = smr.Reads(h)
+        eng.select_batch(b)
+        eng.upload_reads(r, 1)
+        tot_reads += r.count
+        tot_len += r.total_len
+        r.free()
+    del codes, offs
+    log("%d batches of %d reads resident (%.1fs)" % (nb, args.batch_reads, time.time() - t0))
+
+    # C1: global read totals -> the same minimal_score on every rank (refstats.cpp:247-265)
+    g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, args.read_len, args.read_len, device="cuda")
+    ms = smr.minimal_score(GUMBEL[0], GUMBEL[1], info, g_reads, g_len)
+    params = smr.default_params(minimal_score=ms)
+
+    def step(b):
+        eng.select_batch(b)
+        eng.reset_state()
+        smr.align_resident(eng, idx_slots, [params], with_cigar=not args.no_cigar)
+
+    for b in range(args.warmup):
+        step(b)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for b in range(args.warmup, nb):
+        step(b)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt = shard.time_max(dt, device="cuda")
+
+    # C2: Readstats counters of the timed batches, summed over ranks (RCCL)
+    ctr = np.zeros(3, dtype=np.int64)
+    for b in range(args.warmup, nb):
+        eng.select_batch(b)
+        c = eng.counters(1)
+        ctr += np.array([c["num_aligned"], c["num_short"], c["reads_matched_per_db"][0]], dtype=np.int64)
+    ctr_t = shard.reduce_counters(ctr.tolist(), device="cuda")
+    pr = eng.prof()
+    prof = torch.tensor([pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.seed_launches, pr.chain_launches, pr.trace_launches,
+                         pr.n_windows, pr.n_lookup, pr.n_node, pr.n_entry, pr.n_hit, pr.n_read_bytes, pr.n_sw_fwd, pr.n_sw_rev,
+                         pr.n_sw_cells], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(prof)
+    prof = [float(x) for x in prof.cpu()]
+
+    if rank == 0:
+        reads_timed = args.gpus * args.steps * args.batch_reads
+        seed_ms, chain_ms, trace_ms, seed_l, chain_l, trace_l = prof[0:6]
+        n_lookup, n_node, n_entry, n_hit, n_read_bytes = prof[7], prof[8], prof[9], prof[10], prof[11]
+        b_seed = n_read_bytes + 12 * n_lookup + 16 * n_node + 8 * n_entry + 8 * n_hit
+        # per-rank kernel time: ranks run concurrently, the sums above are over ranks
+        ach = (b_seed / args.gpus) / (seed_ms / args.gpus * 1e-3) / 1e9 if seed_ms > 0 else 0.0
+        out = {
+            "metric": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "value": reads_timed / dt, "unit": "reads/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32", "data": "synthetic",
+            "config": {"workload": "synthetic 150-nt Illumina-like reads (10% from DB, 90% background) vs seeded synthetic rRNA-like DB "
+                                   "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); default options (--fastx, best 1)" % args.db_nt,
+                       "batch_reads": args.batch_reads, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
+                       "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
+                       "cigar": not args.no_cigar},
+            "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
+            "roofline": {"kernel": "k_seed", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": b_seed / max(seed_l, 1), "avg_launch_ms": seed_ms / max(seed_l, 1),
+                         "bytes_per_read": b_seed / reads_timed},
+            "kernels": {"k_seed": {"ms": seed_ms / args.gpus, "launches": seed_l / args.gpus},
+                        "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
+                                    "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6},
+                        "k_trace": {"ms": trace_ms / args.gpus, "launches": trace_l / args.gpus}},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, db, parts, batch0, smr, None, eng, idx_slots)
+            except Exception as e:  # the baseline must never lose the measured GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,7 +138,13 @@ const char* smr_last_error(const smr_ctx*);
 int smr_index_upload(smr_ctx*, const smr_index*, int slot);
 int smr_index_unload(smr_ctx*, int slot);
 
-/* Copy a read batch to HBM and allocate its persistent per-read state (what the reference keeps in
+/* Several read batches (0..15) can be resident at once, so the host can upload batch k+1 while batch k is being
+ * aligned (the reference's Readfeed hands reads to align2() one at a time, processor.cpp:104; here the unit is a
+ * batch).  smr_batch_select picks the batch every later call acts on (default 0).  Each batch owns its per-read
+ * state, its Readstats counter block and its CIGAR pool; the caller sums the counters of its batches. */
+int smr_batch_select(smr_ctx*, int batch);
+
+/* Copy a read batch to HBM (into the selected batch) and allocate its persistent per-read state (what the reference keeps in
  * the KVDB between index parts, read.cpp:429-539).  Resets all state and counters. */
 int smr_reads_upload(smr_ctx*, const smr_reads*, uint32_t max_alignments_per_read);
 /* Forget all per-read results/counters of the resident batch (reads stay resident). */

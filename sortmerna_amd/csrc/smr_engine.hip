@@ -27,20 +27,34 @@ struct EvPair { hipEvent_t a, b; int kind; };
 
 }  // namespace
 
+#define SMR_MAX_BATCHES 16
+
+// One resident read batch: packed reads + everything the reference keeps per read in the KVDB (read.cpp:429-539)
+// + its Readstats counter block + its CIGAR pool.  Several batches can be resident at once (the host uploads
+// batch k+1 while batch k is being aligned); smr_batch_select picks the one the other calls act on.
+struct Batch {
+  bool used = false;
+  uint32_t n = 0, max_len = 0, slots = 1;
+  uint32_t* d_words = nullptr; uint64_t* d_rec_off = nullptr; uint32_t* d_len = nullptr;
+  RState* d_saved = nullptr; RState* d_work = nullptr; RWork* d_rw = nullptr;
+  AlignRec* d_saved_aln = nullptr; AlignRec* d_work_aln = nullptr;
+  unsigned long long* d_ctr = nullptr;
+  uint32_t* d_cigar = nullptr; uint64_t cigar_words = 0;
+  // host copies of results
+  std::vector<RState> h_state; std::vector<AlignRec> h_aln; std::vector<uint32_t> h_cigar;
+  uint32_t last_num_alignments = 1;
+  bool fetched = false;
+};
+
 struct smr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
   int n_cu = 256;
   DevIndex idx[64];
-  // reads
-  uint32_t n = 0, max_len = 0, slots = 1;
-  uint32_t* d_words = nullptr; uint64_t* d_rec_off = nullptr; uint32_t* d_len = nullptr;
-  // state
-  RState* d_saved = nullptr; RState* d_work = nullptr; RWork* d_rw = nullptr;
-  AlignRec* d_saved_aln = nullptr; AlignRec* d_work_aln = nullptr;
-  unsigned long long* d_ctr = nullptr;
-  // pools / scratch
+  Batch bt[SMR_MAX_BATCHES];
+  Batch* b = &bt[0];
+  // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 16;
   uint32_t chain_blocks = 0;
@@ -48,14 +62,10 @@ struct smr_ctx {
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
-  uint32_t* d_cigar = nullptr; uint64_t cigar_words = 0;
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   int8_t* d_dir = nullptr; int* d_hbuf = nullptr; uint32_t* d_cig = nullptr;
   uint64_t tr_dir_cap = 0; uint32_t tr_wcap = 0, tr_cig_cap = 0, tr_blocks = 0;
-  // host copies of results
-  std::vector<RState> h_state; std::vector<AlignRec> h_aln; std::vector<uint32_t> h_cigar;
-  uint32_t last_num_alignments = 1;
-  bool fetched = false;
+  uint32_t tr_max_len = 0;
   // profiling
   std::vector<EvPair> events;
   double seed_ms = 0, chain_ms = 0, trace_ms = 0; uint64_t seed_l = 0, chain_l = 0, trace_l = 0;
@@ -94,7 +104,7 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
   P.minimal_score = p->minimal_score; P.num_alignments = p->num_alignments;
   P.is_best = p->is_best; P.is_full_search = p->is_full_search; P.is_forward = p->is_forward; P.is_reverse = p->is_reverse;
   P.minoccur = p->minoccur; P.index_num = p->index_num; P.part = p->part; P.is_last_index_part = p->is_last_index_part;
-  P.slots = c->slots;
+  P.slots = c->b->slots;
   return P;
 }
 
@@ -107,7 +117,7 @@ int check_params(smr_ctx* c, const smr_params* p) {
   // such paths are never optimal and the standard affine recurrence computed here is cell-for-cell identical.
   int mm = std::max(-p->mismatch, -std::min(p->score_N, 0));
   if (2 * p->gap_open < mm || 2 * p->gap_ext < mm) { c->err = "scoring scheme outside the supported range (2*gap_open and 2*gap_ext must be >= |mismatch|)"; return SMR_ERR_ARG; }
-  if (p->num_alignments > 0 && p->num_alignments > c->slots) { c->err = "num_alignments exceeds max_alignments_per_read given to smr_reads_upload"; return SMR_ERR_ARG; }
+  if (p->num_alignments > 0 && p->num_alignments > c->b->slots) { c->err = "num_alignments exceeds max_alignments_per_read given to smr_reads_upload"; return SMR_ERR_ARG; }
   return SMR_OK;
 }
 
@@ -116,7 +126,7 @@ DIndex dindex(const DevIndex& d) {
   x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2;
   return x;
 }
-DReads dreads(const smr_ctx* c) { DReads r; r.words = c->d_words; r.rec_off = c->d_rec_off; r.len = c->d_len; r.n = c->n; r.max_len = c->max_len; return r; }
+DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off = c->b->d_rec_off; r.len = c->b->d_len; r.n = c->b->n; r.max_len = c->b->max_len; return r; }
 
 int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
   if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * 8;
@@ -160,33 +170,33 @@ uint32_t group_width(uint32_t max_len, uint32_t L, uint32_t stride) {
 
 // launches k_seed for one pass
 int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
-  uint32_t gw = group_width(c->max_len, P.lnwin, P.skip[pass]);
+  uint32_t gw = group_width(c->b->max_len, P.lnwin, P.skip[pass]);
   uint32_t reads_per_block = 4 * (64 / gw);
-  uint32_t blocks = (c->n + reads_per_block - 1) / reads_per_block;
+  uint32_t blocks = (c->b->n + reads_per_block - 1) / reads_per_block;
   size_t lds = (size_t)4 * 64 * c->hcap * 4;
   ev_begin(c, 0);
-  hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), lds, c->stream, dreads(c), dindex(di), P, pass, gw, c->hcap, c->d_work, c->d_rw,
-                     c->d_pool, (uint32_t)std::min<uint64_t>(c->pool_words, 0xFFFFFFF0ull), c->d_ctr);
+  hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), lds, c->stream, dreads(c), dindex(di), P, pass, gw, c->hcap, c->b->d_work, c->b->d_rw,
+                     c->d_pool, (uint32_t)std::min<uint64_t>(c->pool_words, 0xFFFFFFF0ull), c->b->d_ctr);
   ev_end(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
 }
 
 void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, size_t& bytes) {
-  uint32_t edges = P.is_as_percent ? (uint32_t)((P.edges / 100.0) * c->max_len) + 1 : (uint32_t)std::max(P.edges, 0);
-  ml = (c->max_len + 15) & ~15u;
-  rf = (c->max_len + 2 * edges + 16 + 15) & ~15u;
+  uint32_t edges = P.is_as_percent ? (uint32_t)((P.edges / 100.0) * c->b->max_len) + 1 : (uint32_t)std::max(P.edges, 0);
+  ml = (c->b->max_len + 15) & ~15u;
+  rf = (c->b->max_len + 2 * edges + 16 + 15) & ~15u;
   bytes = (size_t)ml + rf + (size_t)2 * rf * 4 + (size_t)CH_KEYS_LDS * 8 + (size_t)CH_PAIRS_LDS * 8 + (size_t)2 * CH_PAIRS_LDS * 4 + (size_t)CH_HITS_LDS * 8;
 }
 
 int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int is_last_strand) {
   uint32_t ml, rf; size_t lds;
   chain_lds(c, P, ml, rf, lds);
-  HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
-  uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->n, 1u));
+  HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
+  uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
   ev_begin(c, 1);
-  hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->d_work, c->d_work_aln,
-                     c->d_rw, c->d_pool, c->d_ctr, c->d_cnt, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf);
+  hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
+                     c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_cnt, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf);
   ev_end(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
@@ -194,7 +204,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
 
 int read_ctr(smr_ctx* c, std::vector<unsigned long long>& h) {
   h.resize(C_COUNT);
-  HIPCHK(c, hipMemcpyAsync(h.data(), c->d_ctr, C_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->b->d_ctr, C_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SMR_OK;
 }
@@ -219,8 +229,9 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-  if (hipMalloc((void**)&c->d_ctr, C_COUNT * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
-  (void)hipMemset(c->d_ctr, 0, C_COUNT * 8);
+  if (hipMalloc((void**)&c->b->d_ctr, C_COUNT * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
+  (void)hipMemset(c->b->d_ctr, 0, C_COUNT * 8);
+  c->b->used = true;
   *out = c;
   return SMR_OK;
 }
@@ -230,10 +241,14 @@ extern "C" void smr_destroy(smr_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int s = 0; s < 64; s++) if (c->idx[s].used) smr_index_unload(c, s);
-  dev_free(&c->d_words); dev_free(&c->d_rec_off); dev_free(&c->d_len);
-  dev_free(&c->d_saved); dev_free(&c->d_work); dev_free(&c->d_rw); dev_free(&c->d_saved_aln); dev_free(&c->d_work_aln); dev_free(&c->d_ctr);
+  for (int k = 0; k < SMR_MAX_BATCHES; k++) {
+    Batch& B = c->bt[k];
+    dev_free(&B.d_words); dev_free(&B.d_rec_off); dev_free(&B.d_len);
+    dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
+    dev_free(&B.d_cigar);
+  }
   dev_free(&c->d_pool); dev_free(&c->d_cnt); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
-  dev_free(&c->d_cigar); dev_free(&c->d_tasks); dev_free(&c->d_dir); dev_free(&c->d_hbuf); dev_free(&c->d_cig);
+  dev_free(&c->d_tasks); dev_free(&c->d_dir); dev_free(&c->d_hbuf); dev_free(&c->d_cig);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -272,14 +287,27 @@ extern "C" int smr_index_unload(smr_ctx* c, int slot) {
   return SMR_OK;
 }
 
-extern "C" int smr_state_reset(smr_ctx* c) {
-  if (!c || !c->d_saved) return SMR_ERR_STATE;
+extern "C" int smr_batch_select(smr_ctx* c, int batch) {
+  if (!c || batch < 0 || batch >= SMR_MAX_BATCHES) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemsetAsync(c->d_saved, 0, (size_t)c->n * sizeof(RState), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_saved_aln, 0, (size_t)c->n * c->slots * sizeof(AlignRec), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_ctr, 0, C_COUNT * 8, c->stream));
+  Batch& B = c->bt[batch];
+  if (!B.d_ctr) {
+    HIPCHK(c, hipMalloc((void**)&B.d_ctr, C_COUNT * 8));
+    HIPCHK(c, hipMemset(B.d_ctr, 0, C_COUNT * 8));
+  }
+  B.used = true;
+  c->b = &B;
+  return SMR_OK;
+}
+
+extern "C" int smr_state_reset(smr_ctx* c) {
+  if (!c || !c->b->d_saved) return SMR_ERR_STATE;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemsetAsync(c->b->d_saved, 0, (size_t)c->b->n * sizeof(RState), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->b->d_saved_aln, 0, (size_t)c->b->n * c->b->slots * sizeof(AlignRec), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->b->d_ctr, 0, C_COUNT * 8, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->fetched = false;
+  c->b->fetched = false;
   return SMR_OK;
 }
 
@@ -287,32 +315,30 @@ extern "C" int smr_reads_upload(smr_ctx* c, const smr_reads* r, uint32_t max_aln
   if (!c || !r) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   if (max_aln == 0) max_aln = 1;
-  c->n = r->n; c->max_len = r->max_len; c->slots = max_aln;
+  c->b->n = r->n; c->b->max_len = r->max_len; c->b->slots = max_aln;
   int rc;
-  if ((rc = dev_alloc(c, &c->d_words, r->words.size()))) return rc;
-  if ((rc = dev_alloc(c, &c->d_rec_off, r->rec_off.size()))) return rc;
-  if ((rc = dev_alloc(c, &c->d_len, r->len.size()))) return rc;
-  if ((rc = dev_alloc(c, &c->d_saved, (size_t)c->n))) return rc;
-  if ((rc = dev_alloc(c, &c->d_work, (size_t)c->n))) return rc;
-  if ((rc = dev_alloc(c, &c->d_rw, (size_t)c->n))) return rc;
-  if ((rc = dev_alloc(c, &c->d_saved_aln, (size_t)c->n * c->slots))) return rc;
-  if ((rc = dev_alloc(c, &c->d_work_aln, (size_t)c->n * c->slots))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_words, r->words.data(), r->words.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_rec_off, r->rec_off.data(), r->rec_off.size() * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_len, r->len.data(), r->len.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_rw, 0, (size_t)c->n * sizeof(RWork), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->d_work, 0, (size_t)c->n * sizeof(RState), c->stream));
-  uint64_t want_pool = std::max<uint64_t>((uint64_t)c->n * 64 + (1u << 20), 1u << 22);
+  if ((rc = dev_alloc(c, &c->b->d_words, r->words.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_rec_off, r->rec_off.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_len, r->len.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_saved, (size_t)c->b->n))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_work, (size_t)c->b->n))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_rw, (size_t)c->b->n))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_saved_aln, (size_t)c->b->n * c->b->slots))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_work_aln, (size_t)c->b->n * c->b->slots))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->b->d_words, r->words.data(), r->words.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->b->d_rec_off, r->rec_off.data(), r->rec_off.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->b->d_len, r->len.data(), r->len.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->b->d_rw, 0, (size_t)c->b->n * sizeof(RWork), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->b->d_work, 0, (size_t)c->b->n * sizeof(RState), c->stream));
+  uint64_t want_pool = std::max<uint64_t>((uint64_t)c->b->n * 64 + (1u << 20), 1u << 22);
   if (c->pool_words < want_pool) { if ((rc = dev_alloc(c, &c->d_pool, want_pool))) return rc; c->pool_words = want_pool; }
-  // trace scratch depends on max_len: drop it
-  dev_free(&c->d_dir); dev_free(&c->d_hbuf); dev_free(&c->d_cig); c->tr_dir_cap = 0;
-  c->cigar_words = 0; dev_free(&c->d_cigar);
+  c->b->cigar_words = 0; dev_free(&c->b->d_cigar);
   return smr_state_reset(c);
 }
 
 extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
+  if (!c->idx[slot].used || !c->b->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_params(c, p); if (rc) return rc;
   const DevIndex& di = c->idx[slot];
@@ -320,12 +346,12 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   DParams P = make_dparams(c, di, p);
   uint32_t ml, rf; size_t lds; chain_lds(c, P, ml, rf, lds);
   if (lds > 150 * 1024) { c->err = "reads too long for this build of the SW kernel (LDS)"; return SMR_ERR_CAPACITY; }
-  c->last_num_alignments = p->num_alignments;
-  c->fetched = false;
-  if (c->n == 0) return SMR_OK;
+  c->b->last_num_alignments = p->num_alignments;
+  c->b->fetched = false;
+  if (c->b->n == 0) return SMR_OK;
   std::vector<unsigned long long> snap, h;
   if ((rc = read_ctr(c, snap))) return rc;
-  const uint32_t tb = 256, nb = (c->n + tb - 1) / tb;
+  const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   const int single = (p->is_forward != 0) ^ (p->is_reverse != 0);
   const int num_strands = single ? 1 : 2;
   for (int attempt = 0; attempt < 8; attempt++) {
@@ -336,11 +362,11 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     init[C_NUM_SHORT] = 0;
     for (int k = C_ERR_HITCAP; k <= C_ERR_TRACE; k++) init[k] = 0;
     init[C_POOL_CURSOR] = 0; init[C_WORK_NEXT] = 0;
-    HIPCHK(c, hipMemcpyAsync(c->d_ctr, init.data(), C_COUNT * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->d_saved, c->d_saved_aln, c->d_work, c->d_work_aln, c->d_rw, c->d_ctr);
+    HIPCHK(c, hipMemcpyAsync(c->b->d_ctr, init.data(), C_COUNT * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     for (int count = 0; count < num_strands; count++) {
-      hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->n, P, count, c->d_work, c->d_rw);
-      HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_POOL_CURSOR], 0, 8, c->stream));
+      hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, count, c->b->d_work, c->b->d_rw);
+      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_POOL_CURSOR], 0, 8, c->stream));
       for (int pass = 0; pass < 3; pass++) {
         if (pass > 0 && P.skip[pass] == P.skip[pass - 1]) continue;     // equal strides are skipped (paralleltraversal.cpp:269-272)
         if ((rc = launch_seed(c, di, P, pass))) return rc;
@@ -365,7 +391,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if (retry) { c->seed_ms = t_seed0; c->chain_ms = t_chain0; c->seed_l = l_seed0; c->chain_l = l_chain0; }   // timings of a discarded attempt
     if (!retry) {
       // only a clean attempt is committed to the persistent per-read state (kvdb.put, processor.cpp:150-155)
-      hipLaunchKernelGGL(k_commit_part, dim3(nb), dim3(tb), 0, c->stream, c->n, P, c->d_saved, c->d_saved_aln, c->d_work, c->d_work_aln, c->d_rw);
+      hipLaunchKernelGGL(k_commit_part, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));
       return SMR_OK;
@@ -390,27 +416,27 @@ __global__ void k_trace_collect(uint32_t n, uint32_t slots, const RState* __rest
 
 extern "C" int smr_traceback(smr_ctx* c, int slot, const smr_params* p) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
+  if (!c->idx[slot].used || !c->b->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_params(c, p); if (rc) return rc;
-  if (c->n == 0) return SMR_OK;
+  if (c->b->n == 0) return SMR_OK;
   const DevIndex& di = c->idx[slot];
   DParams P = make_dparams(c, di, p);
-  c->fetched = false;
-  uint64_t ntot = (uint64_t)c->n * c->slots;
+  c->b->fetched = false;
+  uint64_t ntot = (uint64_t)c->b->n * c->b->slots;
   if (c->tasks_cap < ntot) { if ((rc = dev_alloc(c, &c->d_tasks, ntot))) return rc; c->tasks_cap = ntot; }
-  if (c->cigar_words == 0) {
-    c->cigar_words = std::max<uint64_t>(ntot * 16, 1u << 20);
-    if ((rc = dev_alloc(c, &c->d_cigar, c->cigar_words))) return rc;
+  if (c->b->cigar_words == 0) {
+    c->b->cigar_words = std::max<uint64_t>(ntot * 16, 1u << 20);
+    if ((rc = dev_alloc(c, &c->b->d_cigar, c->b->cigar_words))) return rc;
   }
   std::vector<unsigned long long> h;
-  const uint32_t maxL = c->max_len + 2 * (uint32_t)std::max(P.edges, 0) + 16;
+  const uint32_t maxL = c->b->max_len + 2 * (uint32_t)std::max(P.edges, 0) + 16;
   // level 0: band <= 32 ; level 1: worst case (band < 2*maxL)
   for (int level = 0; level < 2; level++) {
     for (int grow = 0; grow < 6; grow++) {
-      HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_TRACE_NEXT], 0, 8, c->stream));
-      HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_ERR_CIGAR], 0, 16, c->stream));     // C_ERR_CIGAR, C_ERR_TRACE
-      hipLaunchKernelGGL(k_trace_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->n, c->slots, c->d_saved, c->d_saved_aln, P.index_num, P.part, c->d_tasks, c->d_ctr);
+      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_TRACE_NEXT], 0, 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_CIGAR], 0, 16, c->stream));     // C_ERR_CIGAR, C_ERR_TRACE
+      hipLaunchKernelGGL(k_trace_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->b->n, c->b->slots, c->b->d_saved, c->b->d_saved_aln, P.index_num, P.part, c->d_tasks, c->b->d_ctr);
       if ((rc = read_ctr(c, h))) return rc;
       uint32_t n_tasks = (uint32_t)h[C_TRACE_NEXT];
       if (n_tasks == 0) return SMR_OK;
@@ -428,21 +454,21 @@ extern "C" int smr_traceback(smr_ctx* c, int slot, const smr_params* p) {
         c->tr_dir_cap = dir_cap; c->tr_wcap = wcap; c->tr_blocks = blocks; c->tr_cig_cap = cig_cap;
       }
       ev_begin(c, 2);
-      hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(64), 0, c->stream, dreads(c), dindex(di), P, c->d_tasks, n_tasks, c->d_saved_aln, c->d_cigar,
-                         (uint32_t)std::min<uint64_t>(c->cigar_words, 0xFFFFFFF0ull), c->d_ctr, c->d_dir, c->d_hbuf, c->d_cig, dir_cap, wcap, cig_cap);
+      hipLaunchKernelGGL(k_trace, dim3(blocks), dim3(64), 0, c->stream, dreads(c), dindex(di), P, c->d_tasks, n_tasks, c->b->d_saved_aln, c->b->d_cigar,
+                         (uint32_t)std::min<uint64_t>(c->b->cigar_words, 0xFFFFFFF0ull), c->b->d_ctr, c->d_dir, c->d_hbuf, c->d_cig, dir_cap, wcap, cig_cap);
       ev_end(c);
       HIPCHK(c, hipGetLastError());
       if ((rc = read_ctr(c, h))) return rc;
       ev_collect(c);
       if (h[C_ERR_CIGAR]) {
         // grow the CIGAR pool, keeping what is already there
-        uint64_t w = c->cigar_words * 2; uint32_t* nw = nullptr;
+        uint64_t w = c->b->cigar_words * 2; uint32_t* nw = nullptr;
         HIPCHK(c, hipMalloc((void**)&nw, w * 4));
-        HIPCHK(c, hipMemcpy(nw, c->d_cigar, c->cigar_words * 4, hipMemcpyDeviceToDevice));
-        (void)hipFree(c->d_cigar); c->d_cigar = nw; c->cigar_words = w;
+        HIPCHK(c, hipMemcpy(nw, c->b->d_cigar, c->b->cigar_words * 4, hipMemcpyDeviceToDevice));
+        (void)hipFree(c->b->d_cigar); c->b->d_cigar = nw; c->b->cigar_words = w;
         // the failed atomics moved the cursor past the end: put it back to the last good value
-        unsigned long long cur = std::min<unsigned long long>(h[C_CIGAR_CURSOR], c->cigar_words / 2);
-        HIPCHK(c, hipMemcpy(&c->d_ctr[C_CIGAR_CURSOR], &cur, 8, hipMemcpyHostToDevice));
+        unsigned long long cur = std::min<unsigned long long>(h[C_CIGAR_CURSOR], c->b->cigar_words / 2);
+        HIPCHK(c, hipMemcpy(&c->b->d_ctr[C_CIGAR_CURSOR], &cur, 8, hipMemcpyHostToDevice));
         continue;
       }
       break;
@@ -464,34 +490,34 @@ extern "C" int smr_counters(smr_ctx* c, uint64_t* out, uint32_t n_db) {
 }
 extern "C" int smr_counters_device(smr_ctx* c, void** dptr, uint32_t* n_u64) {
   if (!c || !dptr || !n_u64) return SMR_ERR_ARG;
-  *dptr = c->d_ctr; *n_u64 = C_PER_DB + 64;
+  *dptr = c->b->d_ctr; *n_u64 = C_PER_DB + 64;
   return SMR_OK;
 }
 
 extern "C" int smr_results_fetch(smr_ctx* c) {
-  if (!c || !c->d_saved) return SMR_ERR_STATE;
+  if (!c || !c->b->d_saved) return SMR_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
-  c->h_state.resize(c->n); c->h_aln.resize((size_t)c->n * c->slots);
+  c->b->h_state.resize(c->b->n); c->b->h_aln.resize((size_t)c->b->n * c->b->slots);
   std::vector<unsigned long long> h;
   int rc = read_ctr(c, h); if (rc) return rc;
-  uint64_t cw = std::min<uint64_t>(h[C_CIGAR_CURSOR], c->cigar_words);
-  c->h_cigar.resize(cw);
-  if (c->n) {
-    HIPCHK(c, hipMemcpyAsync(c->h_state.data(), c->d_saved, (size_t)c->n * sizeof(RState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_aln.data(), c->d_saved_aln, (size_t)c->n * c->slots * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  uint64_t cw = std::min<uint64_t>(h[C_CIGAR_CURSOR], c->b->cigar_words);
+  c->b->h_cigar.resize(cw);
+  if (c->b->n) {
+    HIPCHK(c, hipMemcpyAsync(c->b->h_state.data(), c->b->d_saved, (size_t)c->b->n * sizeof(RState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->b->h_aln.data(), c->b->d_saved_aln, (size_t)c->b->n * c->b->slots * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
   }
-  if (cw) HIPCHK(c, hipMemcpyAsync(c->h_cigar.data(), c->d_cigar, cw * 4, hipMemcpyDeviceToHost, c->stream));
+  if (cw) HIPCHK(c, hipMemcpyAsync(c->b->h_cigar.data(), c->b->d_cigar, cw * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->fetched = true;
+  c->b->fetched = true;
   return SMR_OK;
 }
 
 // Read::toBinString read.cpp:429-462 (+ alignment_struct2::toString, s_align2::toString ssw.hpp:106-140)
 extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, size_t cap) {
-  if (!c || !c->fetched || i >= c->n) return 0;
-  const RState& s = c->h_state[i];
+  if (!c || !c->b->fetched || i >= c->b->n) return 0;
+  const RState& s = c->b->h_state[i];
   if (s.n_align == 0) return 0;
-  const AlignRec* al = c->h_aln.data() + (size_t)i * c->slots;
+  const AlignRec* al = c->b->h_aln.data() + (size_t)i * c->b->slots;
   size_t need = 24 + 3 + 2 + 4 + 4 + 8 + 4 + 4 + 8;
   for (uint32_t k = 0; k < s.n_align; k++) need += 8 + 8 + (size_t)(al[k].has_cigar ? al[k].cigar_len : 0) * 4 + 24 + 6 + 1;
   if (!buf || cap < need) return need;
@@ -501,7 +527,7 @@ extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, 
   put(&s.lastIndex, 4); put(&s.lastPart, 4); put(&z32, 4); put(&z32, 4); put(&z32, 4); put(&z32, 4);
   put(&s.is_done, 1); put(&s.is_hit, 1); put(&z8, 1);
   put(&s.max_SW_count, 2);
-  int32_t na = (int32_t)c->last_num_alignments; put(&na, 4);      // Read::init: num_alignments = opts.num_alignments (if > 0)
+  int32_t na = (int32_t)c->b->last_num_alignments; put(&na, 4);      // Read::init: num_alignments = opts.num_alignments (if > 0)
   put(&s.hit_seeds, 4);
   uint64_t asz = 16;
   for (uint32_t k = 0; k < s.n_align; k++) asz += 8 + 8 + (uint64_t)(al[k].has_cigar ? al[k].cigar_len : 0) * 4 + 24 + 6 + 1;
@@ -511,13 +537,13 @@ extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, 
     const AlignRec& a = al[k];
     uint64_t cl = a.has_cigar ? a.cigar_len : 0;
     uint64_t rl = 8 + cl * 4 + 24 + 6 + 1; put(&rl, 8); put(&cl, 8);
-    if (cl) put(c->h_cigar.data() + a.cigar_off, cl * 4);
+    if (cl) put(c->b->h_cigar.data() + a.cigar_off, cl * 4);
     put(&a.ref_num, 4); put(&a.ref_begin1, 4); put(&a.ref_end1, 4); put(&a.read_begin1, 4); put(&a.read_end1, 4); put(&a.readlen, 4);
     put(&a.score1, 2); put(&a.part, 2); put(&a.index_num, 2); put(&a.strand, 1);
   }
   return (size_t)(p - buf);
 }
-extern "C" int smr_result_is_hit(const smr_ctx* c, uint32_t i) { return (c && c->fetched && i < c->n) ? c->h_state[i].is_hit : 0; }
+extern "C" int smr_result_is_hit(const smr_ctx* c, uint32_t i) { return (c && c->b->fetched && i < c->b->n) ? c->b->h_state[i].is_hit : 0; }
 
 // ---- standalone seed scan (kernel-level parity and the seed-scan roofline bench) ------------------
 __global__ void k_force_pass(uint32_t n, DParams P, int pass, const uint32_t* __restrict__ len, RWork* __restrict__ rw) {
@@ -531,22 +557,22 @@ __global__ void k_force_pass(uint32_t n, DParams P, int pass, const uint32_t* __
 
 extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int strand, int pass, uint64_t* n_hits_out) {
   if (!c || slot < 0 || slot >= 64 || pass < 0 || pass > 2) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
+  if (!c->idx[slot].used || !c->b->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_params(c, p); if (rc) return rc;
   const DevIndex& di = c->idx[slot];
   DParams P = make_dparams(c, di, p);
-  const uint32_t tb = 256, nb = (c->n + tb - 1) / tb;
+  const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   std::vector<unsigned long long> h;
   for (int attempt = 0; attempt < 8; attempt++) {
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_ERR_HITCAP], 0, 16, c->stream));          // HITCAP, POOL
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_POOL_CURSOR], 0, 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_HIT], 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_HITCAP], 0, 16, c->stream));          // HITCAP, POOL
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_POOL_CURSOR], 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_HIT], 0, 8, c->stream));
     // fresh per-part/strand state: forward, or reverse-complement with ambiguous letters complemented (aval 0 -> 3)
-    hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->d_saved, c->d_saved_aln, c->d_work, c->d_work_aln, c->d_rw, c->d_ctr);
+    hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     DParams Q = P; Q.is_forward = 1; Q.is_reverse = 1;
-    hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->n, Q, strand ? 1 : 0, c->d_work, c->d_rw);
-    hipLaunchKernelGGL(k_force_pass, dim3(nb), dim3(tb), 0, c->stream, c->n, P, pass, c->d_len, c->d_rw);
+    hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->b->n, Q, strand ? 1 : 0, c->b->d_work, c->b->d_rw);
+    hipLaunchKernelGGL(k_force_pass, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, pass, c->b->d_len, c->b->d_rw);
     if ((rc = launch_seed(c, di, P, pass))) return rc;
     if ((rc = read_ctr(c, h))) return rc;
     ev_collect(c);
@@ -566,11 +592,11 @@ extern "C" int smr_seed_hits_fetch(smr_ctx* c, uint32_t* triples, uint64_t cap_t
   int rc = read_ctr(c, h); if (rc) return rc;
   uint64_t words = std::min<uint64_t>(h[C_POOL_CURSOR], c->pool_words);
   std::vector<uint32_t> pool(words);
-  std::vector<RWork> rw(c->n);
+  std::vector<RWork> rw(c->b->n);
   if (words) HIPCHK(c, hipMemcpy(pool.data(), c->d_pool, words * 4, hipMemcpyDeviceToHost));
-  if (c->n) HIPCHK(c, hipMemcpy(rw.data(), c->d_rw, (size_t)c->n * sizeof(RWork), hipMemcpyDeviceToHost));
+  if (c->b->n) HIPCHK(c, hipMemcpy(rw.data(), c->b->d_rw, (size_t)c->b->n * sizeof(RWork), hipMemcpyDeviceToHost));
   uint64_t o = 0;
-  for (uint32_t r = 0; r < c->n; r++) {
+  for (uint32_t r = 0; r < c->b->n; r++) {
     for (uint32_t seg = rw[r].hit_head; seg != NONE && seg + 1 < words;) {
       uint32_t nxt = pool[seg], cnt = pool[seg + 1];
       for (uint32_t q = 0; q < cnt; q++) {
@@ -588,15 +614,21 @@ extern "C" int smr_prof_reset(smr_ctx* c) {
   if (!c) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   c->seed_ms = c->chain_ms = c->trace_ms = 0; c->seed_l = c->chain_l = c->trace_l = 0;
-  HIPCHK(c, hipMemsetAsync(&c->d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
+  for (int k = 0; k < SMR_MAX_BATCHES; k++)
+    if (c->bt[k].d_ctr) HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SMR_OK;
 }
 extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
   if (!c || !o) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  std::vector<unsigned long long> h;
-  int rc = read_ctr(c, h); if (rc) return rc;
+  std::vector<unsigned long long> h(C_COUNT, 0), t(C_COUNT);
+  for (int k = 0; k < SMR_MAX_BATCHES; k++) {
+    if (!c->bt[k].d_ctr) continue;
+    HIPCHK(c, hipMemcpyAsync(t.data(), c->bt[k].d_ctr, C_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
+  }
   o->seed_ms = c->seed_ms; o->seed_launches = c->seed_l; o->chain_ms = c->chain_ms; o->chain_launches = c->chain_l; o->trace_ms = c->trace_ms; o->trace_launches = c->trace_l;
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];

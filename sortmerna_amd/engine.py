@@ -145,6 +145,8 @@ class Engine:
             raise SmrError("smr_create: %s (rc=%d)" % (err.value.decode(), rc))
         self.h = h
         self.n_reads = 0
+        self._batch_n = {}
+        self._cur = 0
 
     def _chk(self, rc, what):
         if rc != 0:
@@ -156,9 +158,15 @@ class Engine:
     def unload_index(self, slot=0):
         self._chk(self.L.smr_index_unload(self.h, slot), "smr_index_unload")
 
+    def select_batch(self, batch):
+        self._chk(self.L.smr_batch_select(self.h, batch), "smr_batch_select")
+        self.n_reads = self._batch_n.get(batch, 0)
+        self._cur = batch
+
     def upload_reads(self, reads, max_alignments_per_read=1):
         self._chk(self.L.smr_reads_upload(self.h, reads.h, max_alignments_per_read), "smr_reads_upload")
         self.n_reads = reads.count
+        self._batch_n[self._cur] = reads.count
 
     def reset_state(self):
         self._chk(self.L.smr_state_reset(self.h), "smr_state_reset")
@@ -241,4 +249,23 @@ def align(engine, reads, index_parts, params_per_index, with_cigar=True, max_ali
             if with_cigar:
                 engine.traceback(0, p)
             engine.unload_index(0)
+    engine.fetch()
+
+
+def align_resident(engine, index_slots, params_per_index, with_cigar=True):
+    """Same loop over (index, part) for reads AND index parts that are already resident in HBM: index_slots is either a
+    flat list of slots (one --ref, its parts in order) or a list of such lists (one per --ref).  Acts on the selected
+    batch; the caller resets its state first when the batch is reused."""
+    if index_slots and not isinstance(index_slots[0], (list, tuple)):
+        index_slots = [index_slots]
+    n_idx = len(index_slots)
+    for idx_num, slots in enumerate(index_slots):
+        for part, slot in enumerate(slots):
+            p = params_per_index[idx_num]
+            p.index_num = idx_num
+            p.part = part
+            p.is_last_index_part = int(idx_num == n_idx - 1 and part == len(slots) - 1)
+            engine.align_part(slot, p)
+            if with_cigar:
+                engine.traceback(slot, p)
     engine.fetch()
