@@ -171,11 +171,11 @@ uint32_t group_width(uint32_t max_len, uint32_t L, uint32_t stride) {
 // launches k_seed for one pass
 int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   uint32_t gw = group_width(c->b->max_len, P.lnwin, P.skip[pass]);
-  uint32_t reads_per_block = 4 * (64 / gw);
+  uint32_t reads_per_block = 64 / gw;                      // one wave per block
   uint32_t blocks = (c->b->n + reads_per_block - 1) / reads_per_block;
-  size_t lds = (size_t)4 * 64 * c->hcap * 4;
+  size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4;
   ev_begin(c, 0);
-  hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(256), lds, c->stream, dreads(c), dindex(di), P, pass, gw, c->hcap, c->b->d_work, c->b->d_rw,
+  hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, gw, c->hcap, c->b->d_work, c->b->d_rw,
                      c->d_pool, (uint32_t)std::min<uint64_t>(c->pool_words, 0xFFFFFFF0ull), c->b->d_ctr);
   ev_end(c);
   HIPCHK(c, hipGetLastError());

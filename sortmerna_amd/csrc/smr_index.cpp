@@ -131,6 +131,9 @@ struct TmpNode { TmpElem e[4]; };
 // lays out one mini-trie (nodes[0] = root) in DFS order; entries = {tail,id} pairs in `ents`
 bool emit_minitrie(const std::vector<TmpNode>& nodes, const std::vector<uint32_t>& ents, std::vector<uint32_t>& arena,
                    uint32_t& root_off, smr_index& ix, std::string& why) {
+  // every node (4 words) and bucket starts on a 16-byte boundary so that the kernels can fetch a node with one
+  // 128-bit load and a bucket entry with one 64-bit load: buckets with an odd entry count are padded by 2 zero words
+  arena.resize((arena.size() + 3) & ~(size_t)3, 0);
   size_t base = arena.size();
   if (base > 0xFFFFFFF0ull) { why = "trie arena exceeds 2^32 words"; return false; }
   root_off = (uint32_t)base;
@@ -156,6 +159,7 @@ bool emit_minitrie(const std::vector<TmpNode>& nodes, const std::vector<uint32_t
       if (el.ent_count > ELEM_NENT_MAX) { why = "bucket with more than 255 entries"; return false; }
       arena[word] = (2u << ELEM_FLAG_SHIFT) | (el.ent_count << ELEM_NENT_SHIFT) | (uint32_t)rel;
       arena.insert(arena.end(), ents.begin() + (size_t)el.ent_begin * 2, ents.begin() + ((size_t)el.ent_begin + el.ent_count) * 2);
+      arena.resize((arena.size() + 3) & ~(size_t)3, 0);
       ix.n_buckets++; ix.n_entries += el.ent_count;
     } else {
       arena[word] = (1u << ELEM_FLAG_SHIFT) | (uint32_t)rel;
