@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,8 @@ struct smr_ctx {
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 16;
+  SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
+  uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t chain_blocks = 0;
   uint32_t* d_cnt = nullptr; uint32_t cnt_refs = 0;
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
@@ -162,21 +165,57 @@ void ev_collect(smr_ctx* c) {
   c->events.clear();
 }
 
-uint32_t group_width(uint32_t max_len, uint32_t L, uint32_t stride) {
-  uint32_t numwin = max_len >= L ? (max_len - L + stride) / stride : 1;
-  uint32_t g = pow2ceil(std::max(numwin, 1u));
-  return std::min(g, 64u);
+uint32_t num_windows(uint32_t max_len, uint32_t L, uint32_t stride) {
+  return max_len >= L ? (max_len - L + stride) / stride : 1;
 }
 
-// launches k_seed for one pass
+int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
+  uint32_t mw = 1;
+  for (int p = 0; p < 3; p++) mw = std::max(mw, num_windows(c->b->max_len, P.lnwin, P.skip[p]));
+  const uint64_t slots = (uint64_t)std::max(c->b->n, 1u) * mw;
+  const uint32_t nk = 1u << P.lnwin;                      // 4^(L/2)
+  if (slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^32): use smaller batches"; return SMR_ERR_CAPACITY; }
+  int rc;
+  if (c->sb_nk < nk) {
+    if ((rc = dev_alloc(c, &c->sb.hist, nk))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.bin_off, (size_t)nk + 1))) return rc;
+    if (!c->sb.sn && (rc = dev_alloc(c, &c->sb.sn, SN_COUNT))) return rc;
+    c->sb_nk = nk;
+  }
+  if (c->sb_slots < slots) {
+    if ((rc = dev_alloc(c, &c->sb.tmp, slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.tup, slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.tkey, slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.wseg, slots))) return rc;
+    c->sb_slots = slots;
+  }
+  c->sb.nk = nk;
+  return SMR_OK;
+}
+
+// the seed stage of one (strand, pass): forward searches of all windows, then reverse searches (smr_seed.hpp)
 int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
-  uint32_t gw = group_width(c->b->max_len, P.lnwin, P.skip[pass]);
-  uint32_t reads_per_block = 64 / gw;                      // one wave per block
-  uint32_t blocks = (c->b->n + reads_per_block - 1) / reads_per_block;
-  size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4;
+  int rc = ensure_seed_bufs(c, P); if (rc) return rc;
+  if (c->b->n > 0xFFFFFFu || c->b->max_len > 0xFFFFu) { c->err = "seed stage limits: <= 16M reads per batch, reads <= 65535 nt"; return SMR_ERR_CAPACITY; }
+  SeedBufs sb = c->sb;
+  sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
+  const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
+  sb.cap_tuples = (uint32_t)slots;
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4;
+  const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
+  const uint32_t gk = (uint32_t)((slots + 255) / 256), gw = (uint32_t)((slots + 63) / 64);
   ev_begin(c, 0);
-  hipLaunchKernelGGL(k_seed, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, gw, c->hcap, c->b->d_work, c->b->d_rw,
-                     c->d_pool, (uint32_t)std::min<uint64_t>(c->pool_words, 0xFFFFFFF0ull), c->b->d_ctr);
+  for (int dir = 0; dir < 2; dir++) {
+    HIPCHK(c, hipMemsetAsync(sb.hist, 0, (size_t)sb.nk * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
+    if (dir == 0) hipLaunchKernelGGL(k_seed_keys<0>, dim3(gk), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
+    else hipLaunchKernelGGL(k_seed_keys<1>, dim3(gk), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
+    hipLaunchKernelGGL(k_seed_scan, dim3(1), dim3(1024), 0, c->stream, sb);
+    hipLaunchKernelGGL(k_seed_scatter, dim3(gk), dim3(256), 0, c->stream, sb);
+    if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+    else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+  }
+  hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, c->b->d_ctr);
   ev_end(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
@@ -247,6 +286,8 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
+  dev_free(&c->sb.hist); dev_free(&c->sb.bin_off); dev_free(&c->sb.tmp);
+  dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_cnt); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_dir); dev_free(&c->d_hbuf); dev_free(&c->d_cig);
   (void)hipStreamDestroy(c->stream);
@@ -317,7 +358,7 @@ extern "C" int smr_reads_upload(smr_ctx* c, const smr_reads* r, uint32_t max_aln
   if (max_aln == 0) max_aln = 1;
   c->b->n = r->n; c->b->max_len = r->max_len; c->b->slots = max_aln;
   int rc;
-  if ((rc = dev_alloc(c, &c->b->d_words, r->words.size()))) return rc;
+  if ((rc = dev_alloc(c, &c->b->d_words, r->words.size() + 4))) return rc;     // + slack: window extraction reads 2 words ahead
   if ((rc = dev_alloc(c, &c->b->d_rec_off, r->rec_off.size()))) return rc;
   if ((rc = dev_alloc(c, &c->b->d_len, r->len.size()))) return rc;
   if ((rc = dev_alloc(c, &c->b->d_saved, (size_t)c->b->n))) return rc;
@@ -378,7 +419,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     ev_collect(c);
     bool retry = false;
     if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { c->err = "more than 128 distinct seed hits in one window"; return SMR_ERR_CAPACITY; } }
-    if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0xFFFFFFF0ull) { c->err = "seed-hit pool exceeds 16 GiB"; return SMR_ERR_CAPACITY; }
+    if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0x7FFFFFF0ull) { c->err = "seed-hit pool exceeds 8 GiB"; return SMR_ERR_CAPACITY; }
       if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (h[C_ERR_PAIRS]) {
       c->pairs_cap *= 4; c->hits_cap *= 4; dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);

@@ -14,6 +14,8 @@ struct Lookup {
   uint32_t count;
   uint32_t rootF;
   uint32_t rootR;
+  uint32_t wordsF;   // size of the forward / reverse mini-trie in arena words (multiple of 4), for LDS staging
+  uint32_t wordsR;
 };
 static constexpr uint32_t NONE = 0xFFFFFFFFu;
 

@@ -227,7 +227,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       !slurp(std::string(prefix) + ".pos_" + p + ".dat", pb)) {
     delete ix; set_err(err, errcap, "cannot read index part files"); return SMR_ERR_IO;
   }
-  ix->lookup.assign(nk, Lookup{0, NONE, NONE});
+  ix->lookup.assign(nk, Lookup{0, NONE, NONE, 0, 0});
   for (uint32_t i = 0; i < nk && (size_t)(i + 1) * 4 <= kb.size(); i++) memcpy(&ix->lookup[i].count, kb.data() + (size_t)i * 4, 4);
   size_t o = 0;
   std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::string why;
@@ -242,7 +242,8 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       if (!parse_bfs(tb, o, nodes, ents) || !emit_minitrie(nodes, ents, ix->trie, root, *ix, why)) {
         delete ix; set_err(err, errcap, "malformed burst trie file: " + why); return SMR_ERR_IO;
       }
-      if (j == 0) ix->lookup[i].rootF = root; else ix->lookup[i].rootR = root;
+      if (j == 0) { ix->lookup[i].rootF = root; ix->lookup[i].wordsF = (uint32_t)(ix->trie.size() - root); }
+      else { ix->lookup[i].rootR = root; ix->lookup[i].wordsR = (uint32_t)(ix->trie.size() - root); }
     }
   }
   // positions (index.cpp:322-352) -> CSR; keep file order (sorted by seq, then pos, by construction)
@@ -533,7 +534,7 @@ extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb,
     }
     keys.clear(); keys.shrink_to_fit(); last_nt.clear(); last_nt.shrink_to_fit();
     const uint32_t NK = 1u << L;
-    ix->lookup.assign(NK, Lookup{0, NONE, NONE});
+    ix->lookup.assign(NK, Lookup{0, NONE, NONE, 0, 0});
     // group R by key (counting sort), sort each group by tail
     size_t M = f_key.size();
     std::vector<size_t> rstart((size_t)NK + 1, 0);
@@ -557,7 +558,8 @@ extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb,
         tb.build(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], cnt);
         uint32_t root = NONE;
         if (!emit_minitrie(tb.nodes, tb.ents, ix->trie, root, *ix, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_IO; }
-        if (j == 0) ix->lookup[k].rootF = root; else ix->lookup[k].rootR = root;
+        if (j == 0) { ix->lookup[k].rootF = root; ix->lookup[k].wordsF = (uint32_t)(ix->trie.size() - root); }
+        else { ix->lookup[k].rootR = root; ix->lookup[k].wordsR = (uint32_t)(ix->trie.size() - root); }
       }
     }
     parts_out[pi] = ix;

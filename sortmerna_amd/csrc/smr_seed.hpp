@@ -40,193 +40,367 @@ __device__ __forceinline__ BitVec make_bitvec(uint32_t chars /*2 bits per char, 
   return b;
 }
 
-struct SeedCounters { uint32_t lookup, node, entry; };
+// The LEV(1) tables as 64-bit rows: row r holds the next state of every state s in nibble s, so a transition is one
+// shift once the row is known -- and the row only depends on (depth, nucleotide, the window's bit-vectors), not on the
+// state, so all rows of an entry can be fetched up front and the state chain runs in registers.
+// rows 0..15 = t0[bit-vector], 16..23 = t1, 24..27 = t2, 28..29 = t3; nibble 14 (dead) maps to 14.
+#define LEV_ROWS 30
+__device__ __forceinline__ void build_lev_rows(unsigned long long* s_row) {
+  const uint32_t i = threadIdx.x;
+  if (i < LEV_ROWS) {
+    unsigned long long r = (14ull << 56) | (14ull << 60);
+    for (uint32_t st = 0; st < 14; st++) r |= (unsigned long long)c_lev[i * 14 + st] << (4 * st);
+    s_row[i] = r;
+  }
+}
+__device__ __forceinline__ uint32_t lev_row_index(const BitVec& bv, uint32_t depth, uint32_t nt, uint32_t pw) {
+  if (depth < pw - 2) return bv.get(depth, nt);                 // traverse_bursttrie.cpp:131-135
+  const uint32_t t = 3 - pw + depth;                            // 1,2,3 (:136-139)
+  const uint32_t v = bv.get(pw - 3, nt) & ((2u << (pw - depth)) - 1u);
+  return (t == 1 ? 16u : (t == 2 ? 24u : 28u)) + v;
+}
+__device__ __forceinline__ uint32_t lev_next(unsigned long long row, uint32_t state) { return (uint32_t)(row >> (4 * state)) & 15u; }
 
 // ------------------------------------------------------------------------------------------------
-// k_seed: window scan + burst-trie descent, one wave per block.
+// The seed stage of one (strand, pass): window scan + burst-trie descent, organised as a sort-merge join.
 //
-// The wave is split into groups of `gw` lanes (gw = pow2 >= windows per read in this pass); each group owns one
-// read, each lane one window.  A lane walks its two mini-tries (forward, then reverse unless the forward search
-// ended with a 0-error match) exactly in the reference's DFS order (A<C<G<T, traverse_bursttrie.cpp:117), but the
-// walk is cut into ROUNDS: in a round every lane advances over trie NODES only, until it stands in front of its
-// next bucket; then the whole wave scans the entries of all 64 pending buckets together, one lane per ENTRY
-// (prefix sum over the bucket sizes, owner found by binary search), so the dominant work -- the LEV(1) automaton
-// over bucket entries -- runs with full lanes and contiguous 8-byte loads instead of one divergent lane per window.
-// Accepted entries ("candidates", rare) are handed back to the owning lane in entry order, which applies the
-// reference's sequential rules to its lane-local hit list in LDS:
+// The reference probes, per window, lookup_tbl[9-mer] and walks that mini burst trie (paralleltraversal.cpp:124-249,
+// traverse_bursttrie.cpp:100-298): a hash-scatter into a structure of GBs.  Here the windows of the WHOLE batch are
+// first binned by their 9-mer key (counting sort: histogram with rank -> scan -> scatter), and the searches run in
+// key order, 64 consecutive tuples per wave: neighbouring lanes walk the same or adjacent mini-tries, so their node
+// and bucket loads hit the same cache lines.  The forward half-seed searches of all windows run first (phase F), then
+// the reverse searches of the windows whose forward search did not end with a 0-error match (phase R,
+// paralleltraversal.cpp:188), seeded with the forward hit list so that the reference's in-order de-duplication rules
+// are applied exactly.
+//
+//   k_seed_keys<DIR>    window -> (key, rank in bin, payload)            [9-mer hash, lookup probe, Read::flip34 view]
+//   k_seed_scan         exclusive scan of the bin counts
+//   k_seed_scatter      tuples to bin order
+//   k_seed_search<DIR>  the searches (below)
+//   k_seed_finish       per read: link the windows' hit segments, hit_seeds / hit_total (paralleltraversal.cpp:242-249)
+//
+// k_seed_search, one wave per 64 tuples: lane = one window's search.  A lane walks its mini-trie exactly in the
+// reference's DFS order (A<C<G<T, traverse_bursttrie.cpp:117), but the walk is cut into ROUNDS: in a round every lane
+// advances over trie NODES only and collects its next few buckets; then the whole wave scans the entries of all
+// collected buckets together, one lane per ENTRY, so the dominant work -- the LEV(1) automaton over bucket entries --
+// runs with full lanes.  Accepted entries ("candidates", rare) are handed back to the owning lane in entry order,
+// which applies the reference's sequential rules to its lane-local hit list in LDS:
 //   entry accepted at t_a = first step with depth_b >= pw-2 and state >= 8   (traverse_bursttrie.cpp:229-235)
 //   UNCOND  state 9 at depth_b == pw-1 in the accepting step itself  -> 0-error hit: list = {id}, search over (:256-262)
 //   COND    accepted at pw-2 and state 9 one step later: the reference reaches that step only if the id was NOT
 //           already in the list when it was accepted (otherwise the duplicate check `break`s first, :265-277)
 //   PLAIN   1-error hit: appended unless the id is already present
-// LDS per wave: hit lists hl[hcap][64], node-offset stacks stk[12][64], pref/bdesc/bmeta[64], bit-vectors bvw[4][64].
 // ------------------------------------------------------------------------------------------------
-#define SEED_STK 12
-#define SEED_LDS_WORDS(hcap) (64u * (hcap) + SEED_STK * 64u + 3u * 64u + 4u * 64u)
+#define SEED_STK 10                                    // trie depth < partialwin - 1 <= 9
+#define SEED_OWN_CAP 4096u                             // entries of one round that get a direct entry -> bucket byte map
+#define SEED_MAXPW 10u
+#define SEED_K 4                                       // buckets a lane may collect per round
+#define SEED_GATHER 48u                                // ... or until it holds this many entries
+// dynamic LDS words of k_seed_search: hit lists, node stacks (offsets + level state), row-index table, pref/pb/nat, FIFO, owner map
+#define SEED_LDS_WORDS(hcap) (64u * (hcap) + 2u * SEED_STK * 64u + (SEED_MAXPW + 1u) * 64u + 3u * 64u * SEED_K + 3u * 128u + SEED_OWN_CAP / 4u)
+#define SEED_ZERO_BIT 0x80000000u
 
-enum { PH_F_INIT = 0, PH_F = 1, PH_R_INIT = 2, PH_R = 3, PH_DONE = 4 };
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
+enum { SN_TUPLES = 0, SN_COUNT = 4 };                  // device counters of the seed stage (u32)
 
-__global__ void __launch_bounds__(64) k_seed(DReads rd, DIndex ix, DParams P, int pass, uint32_t gw, uint32_t hcap,
-                                             RState* __restrict__ work, RWork* __restrict__ rw, uint32_t* __restrict__ pool,
-                                             uint32_t pool_words, unsigned long long* __restrict__ ctr) {
-  extern __shared__ uint32_t lds_dyn[];
-  uint32_t* hl = lds_dyn;
-  uint32_t* stk = hl + 64 * hcap;
-  uint32_t* pref = stk + SEED_STK * 64;
-  uint32_t* bdesc = pref + 64;
-  uint32_t* bmeta = bdesc + 64;
-  uint32_t* bvw = bmeta + 64;
-  __shared__ uint8_t s_lev[LEV_SIZE];
-  for (uint32_t i = threadIdx.x; i < LEV_SIZE; i += blockDim.x) s_lev[i] = c_lev[i];
-  __syncthreads();
+struct SeedTmp { uint32_t key, rank; unsigned long long payload; };   // payload: read | win_pos << 24 | chars << 40
+
+struct SeedBufs {
+  uint32_t* hist;            // [NK] tuples per key (phase-local)
+  uint32_t* bin_off;         // [NK + 1]
+  SeedTmp* tmp;              // unsorted tuples
+  unsigned long long* tup;   // payloads in key order
+  uint32_t* tkey;            // keys in key order
+  uint32_t* wseg;            // [n * maxwin] pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
+  uint32_t* sn;              // SN_* counters
+  uint32_t nk, maxwin, cap_tuples;
+};
+
+// nbits <= 40 bits starting at bit `bit0` of a little-endian word stream (reads up to 2 words past the first)
+__device__ __forceinline__ unsigned long long extract_bits(const uint32_t* w, uint32_t bit0, uint32_t nbits) {
+  const uint32_t i = bit0 >> 5, s = bit0 & 31u;
+  unsigned long long v = ((unsigned long long)w[i] | ((unsigned long long)w[i + 1] << 32)) >> s;
+  if (s) v |= (unsigned long long)w[i + 2] << (64 - s);
+  return v & ((1ull << nbits) - 1ull);
+}
+
+// window content of a read in the CURRENT strand/encoding state: 2 bits per nt, char i at bits 2i.
+// Fast path: one 2L-bit extraction from the packed record (reverse strand: 2-bit groups reversed and complemented,
+// Read::revIntStr read.cpp:350-357); windows touching an ambiguous letter take the per-letter path.
+__device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, uint32_t len, uint32_t win_pos, uint32_t L,
+                                                           uint32_t reversed, uint32_t aval) {
+  const uint32_t cw = (len + 15) >> 4;
+  const uint32_t j0 = reversed ? (len - win_pos - L) : win_pos;           // first read position covered, ascending
+  if (extract_bits(rec + cw, j0, L) == 0ull) {
+    unsigned long long x = extract_bits(rec, 2 * j0, 2 * L);
+    if (reversed) {
+      x = __brevll(x) >> (64 - 2 * L);                                      // reverse the bit order ...
+      x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);   // ... and restore each 2-bit group
+      x = ~x & ((1ull << (2 * L)) - 1ull);                                   // complement: 3 - code
+    }
+    return x;
+  }
+  unsigned long long wchars = 0;
+  for (uint32_t i = 0; i < L; i++) wchars |= (unsigned long long)read_nt(rec, len, win_pos + i, reversed, aval) << (2 * i);
+  return wchars;
+}
+
+// DIR 0: forward half-seed (key = first 9-mer, automaton fed by chars [pw, 2pw): init_win_f bitvector.cpp:57-91)
+// DIR 1: reverse half-seed (key = second 9-mer, automaton fed by chars pw-1 .. 0: init_win_r :99-132)
+template <int DIR>
+__global__ void __launch_bounds__(256) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
+                                                   const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
   const int lane = lane_id();
-  const uint32_t gpw = 64 / gw;                                   // groups (reads) per wave
-  const uint32_t g = lane / gw, wl = lane % gw;
-  const uint32_t r = blockIdx.x * gpw + g;
   const uint32_t pw = P.partialwin, L = P.lnwin;
-  const uint32_t last_row = pw - 3;
-  const bool full = P.is_full_search != 0;
-
-  bool active = false;
-  RWork w;
-  uint32_t len = 0;
-  const uint32_t* rec = nullptr;
+  bool emit = false;
+  uint32_t key = 0, is_win = 0, is_lookup = 0;
+  unsigned long long payload = 0;
   if (r < rd.n) {
-    w = rw[r];
-    active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
-    len = rd.len[r];
-    rec = rd.words + rd.rec_off[r];
-  }
-  uint32_t aval = 0, reversed = 0;
-  if (active) {
-    // traverse(): `if (read.is04) read.flip34()` before every window (paralleltraversal.cpp:126)
-    aval = w.is04 ? 0 : w.aval;
-    reversed = w.reversed;
-  }
-  const uint32_t stride = P.skip[pass];
-  const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // :118-120
-
-  SeedCounters sc; sc.lookup = 0; sc.node = 0; sc.entry = 0;
-  uint32_t n_win_searched = 0, grp_hits_total = 0, grp_seeds = 0;
-  bool overflow = false;
-  uint32_t seg_head = active ? w.hit_head : NONE;
-
-  for (uint32_t wbase = 0; __any(wbase < numwin); wbase += gw) {
-    uint32_t k = wbase + wl;
-    uint32_t nh = 0;
-    bool mine = active && k < numwin;
-    uint32_t win_pos = k * stride;
-    if (mine) {                                        // read_pos_searched (paralleltraversal.cpp:128-131)
-      for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;
-    }
-    uint32_t keyf = 0, keyr = 0, fchars = 0, rchars = 0;
+    const RWork w = rw[r];
+    const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
+    const uint32_t len = rd.len[r];
+    const uint32_t stride = P.skip[pass];
+    const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
+    bool mine = k < numwin;
+    const uint32_t win_pos = k * stride;
+    if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
+    const size_t slot = (size_t)r * sb.maxwin + k;
+    if (DIR == 0) { if (active) sb.wseg[slot] = NONE; }
+    else if (mine) { const uint32_t s = sb.wseg[slot]; if (s != NONE && (s & SEED_ZERO_BIT)) mine = false; }   // accept_zero_kmer (:188)
     if (mine) {
-      n_win_searched++;
-      // window content, char i at bits 2i
-      unsigned long long wchars = 0;
-      for (uint32_t i = 0; i < L; i++) wchars |= (unsigned long long)read_nt(rec, len, win_pos + i, reversed, aval) << (2 * i);
-      // forward half: key = first partialwin chars (MSB first, Read::hashKmer read.cpp:601-611), bit-vectors from
-      // chars [pw .. 2pw) (init_win_f); reverse half: key = chars [pw .. 2pw), bit-vectors from chars pw-1 .. 0 (init_win_r)
-      for (uint32_t i = 0; i < pw; i++) {
-        keyf = (keyf << 2) | (uint32_t)((wchars >> (2 * i)) & 3);
-        keyr = (keyr << 2) | (uint32_t)((wchars >> (2 * (pw + i))) & 3);
-        fchars |= (uint32_t)((wchars >> (2 * (pw + i))) & 3) << (2 * i);
-        rchars |= (uint32_t)((wchars >> (2 * (pw - 1 - i))) & 3) << (2 * i);
+      // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
+      const uint32_t aval = w.is04 ? 0 : w.aval;
+      const unsigned long long wc = window_chars(rd.words + rd.rec_off[r], len, win_pos, L, w.reversed, aval);
+      const unsigned long long half = (1ull << (2 * pw)) - 1ull;
+      // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
+      const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
+      const uint32_t sel = DIR == 0 ? a : b;
+      uint32_t rv = __brev(sel) >> (32 - 2 * pw);
+      rv = ((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u);
+      key = rv;
+      // DIR 0: automaton chars = second half in order; DIR 1: first half walked backwards (chars pw-1 .. 0)
+      uint32_t chars;
+      if (DIR == 0) chars = b;
+      else { uint32_t ra = __brev(a) >> (32 - 2 * pw); chars = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u); }
+      is_win = DIR == 0 ? 1 : 0; is_lookup = 1;
+      const Lookup lk = ix.lookup[key];
+      emit = lk.count > P.minoccur && (DIR == 0 ? lk.rootF : lk.rootR) != NONE;
+      payload = (unsigned long long)r | ((unsigned long long)win_pos << 24) | ((unsigned long long)chars << 40);
+    }
+  }
+  // wave-aggregated slot allocation in the unsorted tuple array
+  const unsigned long long em = __ballot(emit);
+  uint32_t base = 0;
+  if (em) {
+    if (lane == __ffsll((long long)em) - 1) base = atomicAdd(&sb.sn[SN_TUPLES], (uint32_t)__popcll(em));
+    base = __shfl(base, __ffsll((long long)em) - 1, 64);
+  }
+  if (emit) {
+    const uint32_t idx = base + (uint32_t)__popcll(em & ((1ull << lane) - 1));
+    if (idx < sb.cap_tuples) {
+      SeedTmp t; t.key = key; t.rank = atomicAdd(&sb.hist[key], 1u); t.payload = payload;
+      sb.tmp[idx] = t;
+    }
+  }
+  const unsigned long long wm = __ballot(is_win), lm = __ballot(is_lookup);
+  if (lane == 0) {
+    if (wm) atomicAdd(&ctr[C_WINDOWS], (unsigned long long)__popcll(wm));
+    if (lm) atomicAdd(&ctr[C_LOOKUP], (unsigned long long)__popcll(lm));
+  }
+}
+
+// one block of 1024 threads: exclusive scan of hist (tuple offsets of the bins)
+__global__ void __launch_bounds__(1024) k_seed_scan(SeedBufs sb) {
+  __shared__ uint32_t s_a[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (sb.nk + 1023) / 1024;
+  const uint32_t lo = t * per, hi = min(lo + per, sb.nk);
+  uint32_t a = 0;
+  for (uint32_t i = lo; i < hi; i++) a += sb.hist[i];
+  s_a[t] = a;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t va = 0;
+    if (t >= d) va = s_a[t - d];
+    __syncthreads();
+    s_a[t] += va;
+    __syncthreads();
+  }
+  uint32_t oa = s_a[t] - a;
+  for (uint32_t i = lo; i < hi; i++) { sb.bin_off[i] = oa; oa += sb.hist[i]; }
+  if (t == 1023) sb.bin_off[sb.nk] = s_a[1023];
+}
+
+__global__ void __launch_bounds__(256) k_seed_scatter(SeedBufs sb) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = min(sb.sn[SN_TUPLES], sb.cap_tuples);
+  if (i < n) { const SeedTmp t = sb.tmp[i]; const uint32_t p = sb.bin_off[t.key] + t.rank; sb.tup[p] = t.payload; sb.tkey[p] = t.key; }
+}
+
+struct SeedLane {           // per-lane search result
+  uint32_t nh; bool zero, overflow; uint32_t n_node, n_entry;
+};
+
+// LDS of one search wave (32-bit words unless noted)
+struct SeedLds {
+  uint32_t* hl;        // [hcap][64]   lane-local hit lists (ids), element k of lane l at k*64+l
+  uint32_t* stk;       // [SEED_STK][64] node offsets of the DFS stack
+  uint32_t* lvl;       // [SEED_STK][64] per level: pending-element mask (4 bits) | the 4 elements' states << 4
+  uint32_t* rt;        // [SEED_MAXPW+1][64] per depth: the 4 LEV row indices (5 bits each) of the lane's window
+  uint32_t* pref;      // [64*SEED_K]  first flattened entry of bucket (lane*K+slot) in this round
+  uint32_t* pb;        // [64*SEED_K]  bucket offset | depth << 22 | state << 26
+  uint32_t* nat;       // [64*SEED_K]  nodes visited when the bucket was reached << 8 | entries
+  uint32_t* sq;        // [3][128]     survivor FIFO: id, remaining tail, (bucket | state<<8 | depth<<12 | q<<16)
+  uint8_t* own;        // [SEED_OWN_CAP] flattened entry -> bucket (lane*K+slot)
+};
+
+// state of the 4 elements of a node given the state `piv` it was entered with: pending mask | states << 4
+__device__ __forceinline__ uint32_t node_states(const uint4 nd, uint32_t rtw, uint32_t piv, const unsigned long long* s_row) {
+  const uint32_t l0 = lev_next(s_row[rtw & 31u], piv), l1 = lev_next(s_row[(rtw >> 5) & 31u], piv);
+  const uint32_t l2 = lev_next(s_row[(rtw >> 10) & 31u], piv), l3 = lev_next(s_row[(rtw >> 15) & 31u], piv);
+  uint32_t m = 0;
+  if ((nd.x >> ELEM_FLAG_SHIFT) && l0 != 14) m |= 1u;
+  if ((nd.y >> ELEM_FLAG_SHIFT) && l1 != 14) m |= 2u;
+  if ((nd.z >> ELEM_FLAG_SHIFT) && l2 != 14) m |= 4u;
+  if ((nd.w >> ELEM_FLAG_SHIFT) && l3 != 14) m |= 8u;
+  return m | (l0 << 4) | (l1 << 8) | (l2 << 12) | (l3 << 16);
+}
+
+// All searches of one wave; lane-varying mini-trie root `trie` (offsets inside are relative to it).  hl holds the
+// lane-local hit lists (nh entries already present for DIR 1: the forward search's hits).
+//
+// Round = (1) every lane walks trie nodes in DFS order and collects its next <= SEED_K buckets; (2) the entries of all
+// collected buckets are flattened lane-major (so one window's entries stay in DFS order) and scanned one lane per
+// entry in two stages: stage A runs the first <= 2 automaton steps (never an accepting depth) and drops the dead
+// entries -- most of them --, the survivors are compacted through a FIFO in LDS and stage B finishes them 64 at a
+// time; (3) accepted entries go back to the owning lane in entry order.  Work counters follow the reference's
+// sequential scan: nothing after a 0-error match is counted.
+__device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ trie, bool mine, uint32_t chars, uint32_t pw, bool full,
+                                                 const unsigned long long* s_row, const SeedLds L, uint32_t hcap, SeedLane& out) {
+  const int lane = lane_id();
+  uint32_t nh = out.nh;
+  bool zero = false, overflow = false;
+  uint32_t n_node = 0, n_entry = 0;
+  int sp = -1;
+  uint32_t st = 0;                                      // pending mask | states of the node on top of the stack
+  uint4 cur = make_uint4(0, 0, 0, 0);                   // its 4 elements
+  if (mine) {
+    const BitVec bv = make_bitvec(chars, pw);
+    for (uint32_t d = 0; d <= pw; d++) {
+      uint32_t w = 0;
+      for (uint32_t nt = 0; nt < 4; nt++) w |= lev_row_index(bv, d, nt, pw) << (5 * nt);
+      L.rt[d * 64 + lane] = w;
+    }
+    sp = 0; L.stk[lane] = 0; cur = *reinterpret_cast<const uint4*>(trie); n_node = 1;
+    st = node_states(cur, L.rt[lane], 0, s_row);
+  }
+  for (;;) {
+    // ---------- (1) node walk: collect this lane's next buckets ----------
+    uint32_t nb = 0, my_total = 0;
+    while (sp >= 0 && nb < SEED_K && my_total < SEED_GATHER) {
+      if ((st & 15u) == 0) {                               // node exhausted: back to the parent
+        sp--;
+        if (sp >= 0) { cur = *reinterpret_cast<const uint4*>(trie + L.stk[sp * 64 + lane]); st = L.lvl[sp * 64 + lane]; }
+        continue;
+      }
+      const uint32_t ne = (uint32_t)__ffs((int)(st & 15u)) - 1;
+      st &= ~(1u << ne);
+      const uint32_t e = ne == 0 ? cur.x : (ne == 1 ? cur.y : (ne == 2 ? cur.z : cur.w));
+      const uint32_t lev_t = (st >> (4 + 4 * ne)) & 15u;
+      if ((e >> ELEM_FLAG_SHIFT) == 1) {                    // child node
+        L.lvl[sp * 64 + lane] = st;
+        sp++;
+        L.stk[sp * 64 + lane] = e & ELEM_OFF_MASK;
+        cur = *reinterpret_cast<const uint4*>(trie + (e & ELEM_OFF_MASK)); n_node++;
+        st = node_states(cur, L.rt[sp * 64 + lane], lev_t, s_row);
+        continue;
+      }
+      const uint32_t nent = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+      L.pb[lane * SEED_K + nb] = (e & ELEM_OFF_MASK) | ((uint32_t)sp << 22) | (lev_t << 26);
+      L.nat[lane * SEED_K + nb] = (n_node << 8) | nent;
+      L.pref[lane * SEED_K + nb] = my_total;                 // lane-relative for now
+      my_total += nent; nb++;
+    }
+    if (!__any(nb > 0)) break;
+    // ---------- (2) flatten: lane-major prefix, entry -> bucket map ----------
+    uint32_t incl = my_total;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    const uint32_t T = __shfl(incl, 63, 64);
+    const uint32_t my_first = incl - my_total;
+    for (uint32_t k = 0; k < SEED_K; k++) L.pref[lane * SEED_K + k] = k < nb ? L.pref[lane * SEED_K + k] + my_first : my_first + my_total;
+    const bool direct = T <= SEED_OWN_CAP;
+    if (direct) {
+      for (uint32_t k = 0; k < nb; k++) {
+        const uint32_t f = L.pref[lane * SEED_K + k], c = L.nat[lane * SEED_K + k] & 0xFFu;
+        for (uint32_t q = 0; q < c; q++) L.own[f + q] = (uint8_t)(lane * SEED_K + k);
       }
     }
-    // ---- lane-local DFS state ----
-    int phase = mine ? PH_F_INIT : PH_DONE;
-    bool zero = false;
-    uint32_t root = 0;
-    int sp = -1;
-    unsigned long long cur_bits = 0, piv_bits = 0;        // 3-bit element cursors / 4-bit pivot states per level
-    uint4 cur = make_uint4(0, 0, 0, 0);                   // the 4 elements of the node on top of the stack
-    BitVec bv; bv.lo = 0; bv.hi = 0;
-
-    for (;;) {
-      // ---------- node walk: advance to this lane's next bucket ----------
-      bool has = false;
-      uint32_t b_off = 0, b_nent = 0, b_depth = 0, b_lev = 0;
-      while (phase != PH_DONE && !has) {
-        if (phase == PH_F_INIT || phase == PH_R_INIT) {
-          const bool fwd = phase == PH_F_INIT;
-          const Lookup lk = ix.lookup[fwd ? keyf : keyr]; sc.lookup++;
-          const uint32_t rt = fwd ? lk.rootF : lk.rootR;
-          if (lk.count > P.minoccur && rt != NONE) {
-            root = rt; bv = make_bitvec(fwd ? fchars : rchars, pw);
-            sp = 0; cur_bits = 0; piv_bits = 0; stk[lane] = 0;
-            cur = *reinterpret_cast<const uint4*>(ix.trie + root); sc.node++;
-            bvw[lane] = (uint32_t)bv.lo; bvw[64 + lane] = (uint32_t)(bv.lo >> 32);
-            bvw[128 + lane] = (uint32_t)bv.hi; bvw[192 + lane] = (uint32_t)(bv.hi >> 32);
-            phase = fwd ? PH_F : PH_R;
-          } else phase = fwd ? PH_R_INIT : PH_DONE;
-          continue;
-        }
-        if (sp < 0) { phase = (phase == PH_F) ? PH_R_INIT : PH_DONE; continue; }
-        const uint32_t ne = (uint32_t)(cur_bits >> (3 * sp)) & 7u;
-        if (ne == 4) {
-          sp--;
-          if (sp >= 0) cur = *reinterpret_cast<const uint4*>(ix.trie + root + stk[sp * 64 + lane]);
-          continue;
-        }
-        cur_bits += 1ull << (3 * sp);
-        const uint32_t e = ne == 0 ? cur.x : (ne == 1 ? cur.y : (ne == 2 ? cur.z : cur.w));
-        const uint32_t flag = e >> ELEM_FLAG_SHIFT;
-        if (flag == 0) continue;
-        const uint32_t depth = (uint32_t)sp;
-        const uint32_t piv = (uint32_t)(piv_bits >> (4 * sp)) & 15u;
-        const uint32_t lev_t = lev_step(s_lev, depth, pw, depth < pw - 2 ? bv.get(depth, ne) : 0, bv.get(last_row, ne), piv);
-        if (lev_t == 14) continue;
-        if (flag == 1) {
-          sp++;
-          stk[sp * 64 + lane] = e & ELEM_OFF_MASK;
-          cur_bits &= ~(7ull << (3 * sp));
-          piv_bits = (piv_bits & ~(15ull << (4 * sp))) | ((unsigned long long)lev_t << (4 * sp));
-          cur = *reinterpret_cast<const uint4*>(ix.trie + root + (e & ELEM_OFF_MASK)); sc.node++;
-          continue;
-        }
-        has = true; b_off = root + (e & ELEM_OFF_MASK); b_nent = (e >> ELEM_NENT_SHIFT) & 0xFFu; b_depth = depth; b_lev = lev_t;
-      }
-      if (!__any(has)) break;
-      // ---------- entry scan: one lane per entry of the 64 pending buckets ----------
-      const uint32_t my_n = has ? b_nent : 0;
-      sc.entry += my_n;
-      uint32_t incl = my_n;
-      for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-      const uint32_t T = __shfl(incl, 63, 64);
-      pref[lane] = incl - my_n; bdesc[lane] = b_off; bmeta[lane] = b_depth | (b_lev << 4);
-      __syncthreads();
-      for (uint32_t base = 0; base < T; base += 64) {
+    __syncthreads();
+    bool zero_round = false;                               // a 0-error match was found in this round (owner lane)
+    uint32_t qn = 0;                                       // survivors waiting in the FIFO (wave-uniform)
+    for (uint32_t base = 0; base < T || qn > 0; base += 64) {
+      // ----- stage A: up to 2 automaton steps at non-accepting depths for 64 fresh entries -----
+      if (base < T) {
         const uint32_t e = base + lane;
         const bool v = e < T;
-        uint32_t owner = 0;
-        if (v) {                                           // largest o with pref[o] <= e
-          for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = owner + step; if (t < 64 && pref[t] <= e) owner = t; }
+        uint32_t bk = 0;
+        if (v) {
+          if (direct) bk = L.own[e];
+          else for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t t = bk + step; if (t < 64 * SEED_K && L.pref[t] <= e) bk = t; }
         }
-        const uint32_t q = e - pref[owner];
-        const uint32_t meta = bmeta[owner];
-        uint32_t depth_b = meta & 15u, lv = meta >> 4;
+        const uint32_t q = e - L.pref[bk];
+        const uint32_t pbv = L.pb[bk];
+        uint32_t db = ((pbv >> 22) & 15u) + 1, lv = pbv >> 26;
+        const uint32_t olane = bk / SEED_K;
         uint32_t str = 0, id = 0;
-        if (v) { const uint2 en = *reinterpret_cast<const uint2*>(ix.trie + bdesc[owner] + 2 * q); str = en.x; id = en.y; }
-        BitVec obv;
-        obv.lo = (unsigned long long)bvw[owner] | ((unsigned long long)bvw[64 + owner] << 32);
-        obv.hi = (unsigned long long)bvw[128 + owner] | ((unsigned long long)bvw[192 + owner] << 32);
+        // (shuffle outside the branch: a bpermute reads 0 from lanes that are masked off)
+        const uint32_t* otrie = reinterpret_cast<const uint32_t*>(__shfl((unsigned long long)trie, olane, 64));
+        if (v) { const uint2 en = *reinterpret_cast<const uint2*>(otrie + (pbv & ELEM_OFF_MASK) + 2 * q); str = en.x; id = en.y; }
+        bool alive = v;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          if (alive && db + 3 <= pw) {                       // db <= pw-3: no accept / 0-error decision at this depth
+            lv = lev_next(s_row[(L.rt[db * 64 + olane] >> (5 * (str & 3u))) & 31u], lv);
+            str >>= 2; db++;
+            if (lv == 14) alive = false;
+          }
+        }
+        const unsigned long long am = __ballot(alive);
+        if (alive) {
+          const uint32_t pos = qn + (uint32_t)__popcll(am & ((1ull << lane) - 1));
+          L.sq[pos] = id; L.sq[128 + pos] = str; L.sq[256 + pos] = bk | (lv << 8) | (db << 12) | (q << 16);
+        }
+        qn += (uint32_t)__popcll(am);
+        __syncthreads();
+      }
+      // ----- stage B: finish 64 survivors (or the rest at the end of the round) -----
+      if (qn >= 64 || (base + 64 >= T && qn > 0)) {
+        const uint32_t cnt = min(qn, 64u);
+        const bool v = (uint32_t)lane < cnt;
+        uint32_t id = 0, str = 0, meta = 0;
+        if (v) { id = L.sq[lane]; str = L.sq[128 + lane]; meta = L.sq[256 + lane]; }
+        uint32_t mv_id = 0, mv_str = 0, mv_meta = 0;
+        const bool mv = 64u + lane < qn;
+        if (mv) { mv_id = L.sq[64 + lane]; mv_str = L.sq[192 + lane]; mv_meta = L.sq[320 + lane]; }
+        const uint32_t bk = meta & 0xFFu, olane = bk / SEED_K, q = meta >> 16;
+        uint32_t lv = (meta >> 8) & 15u, db = (meta >> 12) & 15u;
         bool alive = v, acc = false;
         uint32_t kind = CK_PLAIN;
-        for (uint32_t j = 0; j < pw; j++) {
-          if (!__any(alive)) break;
+        while (__any(alive)) {                              // traverse_bursttrie.cpp:200-287 for one entry
           if (alive) {
-            const uint32_t nt = str & 3u; str >>= 2; depth_b++;
-            lv = lev_step(s_lev, depth_b, pw, depth_b < pw - 2 ? obv.get(depth_b, nt) : 0, obv.get(last_row, nt), lv);
-            if (lv == 14) alive = false;
+            if (db > pw) alive = false;
             else {
-              if (depth_b >= pw - 2) {
-                const bool z = (depth_b == pw - 1 && lv == 9 && !full);
+              lv = lev_next(s_row[(L.rt[db * 64 + olane] >> (5 * (str & 3u))) & 31u], lv);
+              str >>= 2;
+              if (lv == 14) alive = false;
+              else if (db + 2 >= pw) {
+                const bool z = (db + 1 == pw && lv == 9 && !full);
                 if (!acc) { if (lv >= 8) { acc = true; if (z) kind = CK_UNCOND; } }
                 else { if (z) kind = CK_COND; alive = false; }
               }
-              if (depth_b >= pw) alive = false;
+              db++;
             }
           }
         }
@@ -234,56 +408,135 @@ __global__ void __launch_bounds__(64) k_seed(DReads rd, DIndex ix, DParams P, in
         unsigned long long cm = __ballot(acc);
         while (cm) {
           const int c = __ffsll((long long)cm) - 1; cm &= cm - 1;
-          const uint32_t o = __shfl(owner, c, 64), idc = __shfl(id, c, 64), kc = __shfl(kind, c, 64), qc = __shfl(q, c, 64);
+          const uint32_t o = __shfl(olane, c, 64), idc = __shfl(id, c, 64), kc = __shfl(kind, c, 64), qc = __shfl(q, c, 64), bc = __shfl(bk, c, 64);
           if ((uint32_t)lane == o && !zero) {
             bool present = false;
-            for (uint32_t f = 0; f < nh; f++) if (hl[f * 64 + lane] == idc) { present = true; break; }
+            for (uint32_t f = 0; f < nh; f++) if (L.hl[f * 64 + lane] == idc) { present = true; break; }
             if (kc == CK_UNCOND || (kc == CK_COND && !present)) {
-              hl[lane] = idc; nh = 1; zero = true;
-              sc.entry -= b_nent - (qc + 1);               // the reference stops scanning at the 0-error entry
+              L.hl[lane] = idc; nh = 1; zero = true; zero_round = true;
+              // the reference stops at the 0-error entry: count the buckets before it, this one up to the entry, no later node
+              const uint32_t zs = bc % SEED_K;
+              for (uint32_t k = 0; k < zs; k++) n_entry += L.nat[lane * SEED_K + k] & 0xFFu;
+              n_entry += qc + 1;
+              n_node = L.nat[lane * SEED_K + zs] >> 8;
             } else if (!present) {
-              if (nh < hcap) { hl[nh * 64 + lane] = idc; nh++; } else overflow = true;
+              if (nh < hcap) { L.hl[nh * 64 + lane] = idc; nh++; } else overflow = true;
             }
           }
         }
+        __syncthreads();
+        if (mv) { L.sq[lane] = mv_id; L.sq[128 + lane] = mv_str; L.sq[256 + lane] = mv_meta; }
+        qn -= cnt;
+        __syncthreads();
       }
-      if (zero) phase = PH_DONE;                           // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
-      __syncthreads();
     }
-    // segmented (width gw) inclusive scan of nh
-    uint32_t incl = nh;
-    for (uint32_t d = 1; d < gw; d <<= 1) { uint32_t t = __shfl_up(incl, d, gw); if (wl >= d) incl += t; }
-    uint32_t total = __shfl(incl, gw - 1, gw);
-    uint32_t seeds = __popcll(__ballot(nh > 0) & (gw == 64 ? ~0ull : (((1ull << gw) - 1) << (g * gw))));
-    uint32_t base = 0;
-    if (wl == 0 && total > 0) {
-      unsigned long long old = atomicAdd(&ctr[C_POOL_CURSOR], (unsigned long long)(2 + 2 * total));
-      if (old + 2 + 2 * (unsigned long long)total > pool_words) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; }
-      else { base = (uint32_t)old; pool[base] = seg_head; pool[base + 1] = total; seg_head = base; }
-    }
-    base = __shfl(base, 0, gw);
-    if (total > 0 && base != NONE) {
-      uint32_t o = base + 2 + 2 * (incl - nh);
-      for (uint32_t q = 0; q < nh; q++) { pool[o + 2 * q] = hl[q * 64 + lane]; pool[o + 2 * q + 1] = win_pos; }
-    }
-    grp_hits_total += total; grp_seeds += seeds;
+    if (!zero_round) n_entry += my_total;
+    if (zero) sp = -1;                                   // 0-error match: the reference unwinds the recursion (:167,256-262)
+    __syncthreads();
   }
-  if (overflow) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
-  if (active && wl == 0) {
-    w.is04 = 0; w.aval = (uint8_t)aval;                     // the flip back to 0..3 is persistent
-    w.hit_head = seg_head; w.hit_total += grp_hits_total;
-    rw[r] = w;
-    work[r].hit_seeds += grp_seeds;                          // ++read.hit_seeds per window with hits (:242-249)
+  out.nh = nh; out.zero = zero; out.overflow = overflow; out.n_node = n_node; out.n_entry = n_entry;
+}
+
+template <int DIR>
+__global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
+                                                    uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
+  const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples);
+  if (blockIdx.x * 64u >= n_tup) return;
+  extern __shared__ __align__(16) uint32_t lds_dyn[];
+  SeedLds L;
+  L.hl = lds_dyn;
+  L.stk = L.hl + 64 * hcap;
+  L.lvl = L.stk + SEED_STK * 64;
+  L.rt = L.lvl + SEED_STK * 64;
+  L.pref = L.rt + (SEED_MAXPW + 1) * 64;
+  L.pb = L.pref + 64 * SEED_K;
+  L.nat = L.pb + 64 * SEED_K;
+  L.sq = L.nat + 64 * SEED_K;
+  L.own = reinterpret_cast<uint8_t*>(L.sq + 3 * 128);
+  uint32_t* hl = L.hl;
+  __shared__ unsigned long long s_row[LEV_ROWS];
+  const int lane = lane_id();
+  build_lev_rows(s_row);
+  const uint32_t pos = blockIdx.x * 64u + lane;
+  const bool mine = pos < n_tup;
+  uint32_t r = 0, win_pos = 0, chars = 0;
+  const uint32_t* trie = ix.trie;
+  size_t slot = 0;
+  SeedLane sl; sl.nh = 0; sl.zero = false; sl.overflow = false; sl.n_node = 0; sl.n_entry = 0;
+  uint32_t n_prev = 0;
+  if (mine) {
+    const unsigned long long pl = sb.tup[pos];
+    const Lookup lk = ix.lookup[sb.tkey[pos]];
+    trie = ix.trie + (DIR == 0 ? lk.rootF : lk.rootR);
+    r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
+    slot = (size_t)r * sb.maxwin + win_pos / P.skip[pass];
+    if (DIR == 1) {                                      // the window's list so far = the forward search's hits
+      const uint32_t seg = sb.wseg[slot];
+      if (seg != NONE) {
+        n_prev = pool[seg + 1];
+        for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
+        if (n_prev > hcap) { sl.overflow = true; n_prev = hcap; }
+        sl.nh = n_prev;
+      }
+    }
   }
-  // work counters
-  unsigned long long v[6];
-  v[0] = n_win_searched; v[1] = sc.lookup; v[2] = sc.node; v[3] = sc.entry; v[4] = (wl == 0) ? grp_hits_total : 0;
-  v[5] = (active && wl == 0) ? ((len + 3) / 4) : 0;
-  for (int c = 0; c < 6; c++) {
+  __syncthreads();
+  seed_search_wave(trie, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
+  // ---- write the windows' hit segments: [next (linked by k_seed_finish), count, (id, win_pos) x count] ----
+  const bool wr = mine && (DIR == 0 ? sl.nh > 0 : (sl.zero || sl.nh > n_prev));
+  const uint32_t need = wr ? 2 + 2 * sl.nh : 0;
+  uint32_t incl = need;
+  for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+  const uint32_t total = __shfl(incl, 63, 64);
+  uint32_t base = 0;
+  if (total) {
+    if (lane == 0) {
+      const unsigned long long old = atomicAdd(&ctr[C_POOL_CURSOR], (unsigned long long)total);
+      if (old + total > pool_words) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = (uint32_t)old;
+    }
+    base = __shfl(base, 0, 64);
+  }
+  if (wr && base != NONE) {
+    const uint32_t o = base + incl - need;
+    pool[o] = NONE; pool[o + 1] = sl.nh;
+    for (uint32_t q = 0; q < sl.nh; q++) { pool[o + 2 + 2 * q] = hl[q * 64 + lane]; pool[o + 3 + 2 * q] = win_pos; }
+    sb.wseg[slot] = o | (sl.zero ? SEED_ZERO_BIT : 0u);
+  }
+  if (__any(sl.overflow) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
+  unsigned long long v[2] = {sl.n_node, sl.n_entry};
+  for (int c = 0; c < 2; c++) {
     unsigned long long x = v[c];
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    if (lane == 0 && x) atomicAdd(&ctr[C_WINDOWS + c], x);
+    if (lane == 0 && x) atomicAdd(&ctr[C_NODE + c], x);
   }
+}
+
+// per read: link the hit segments of this pass in front of the read's list, count seeds/hits, make the 0..3 view persistent
+__global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
+                                                     RWork* __restrict__ rw, uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long hits = 0, bytes = 0;
+  if (r < rd.n) {
+    RWork w = rw[r];
+    if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
+      const uint32_t len = rd.len[r], stride = P.skip[pass];
+      const uint32_t numwin = (len - P.lnwin + stride) / stride;
+      uint32_t head = w.hit_head, seeds = 0, total = 0;
+      for (uint32_t k = 0; k < numwin; k++) {
+        const uint32_t s = sb.wseg[(size_t)r * sb.maxwin + k];
+        if (s == NONE) continue;
+        const uint32_t o = s & ~SEED_ZERO_BIT;
+        pool[o] = head; head = o; seeds++; total += pool[o + 1];
+      }
+      w.aval = w.is04 ? 0 : w.aval; w.is04 = 0;            // the flip back to 0..3 is persistent (read.cpp:379-401)
+      w.hit_head = head; w.hit_total += total;
+      rw[r] = w;
+      work[r].hit_seeds += seeds;                          // ++read.hit_seeds per window with hits (:242-249)
+      hits = total; bytes = (len + 3) / 4;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); }
+  if (lane_id() == 0) { if (hits) atomicAdd(&ctr[C_HIT], hits); if (bytes) atomicAdd(&ctr[C_READ_BYTES], bytes); }
 }
 
 }  // namespace smr
