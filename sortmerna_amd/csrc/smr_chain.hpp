@@ -165,12 +165,18 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
   uint32_t* gl = g_lis + (size_t)blockIdx.x * 2 * pairs_cap;
   uint2* gh = g_hits + (size_t)blockIdx.x * hits_cap;
 
+  unsigned long long n_fwd = 0, n_rev = 0, n_cells = 0;   // flushed once per block (lane 0)
+  uint32_t chunk_next = 0, chunk_end = 0;                 // reads are claimed 16 at a time (one atomic per chunk)
   for (;;) {
+    if (chunk_next == chunk_end) {
+      __syncthreads();
+      if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 16ull);
+      __syncthreads();
+      chunk_next = s_next; chunk_end = min(chunk_next + 16u, rd.n);
+      if (chunk_next >= rd.n) break;
+    }
     __syncthreads();
-    if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 1ull);
-    __syncthreads();
-    const uint32_t r = s_next;
-    if (r >= rd.n) break;
+    const uint32_t r = chunk_next++;
     RWork w = rw[r];
     if (!(w.strand_active && w.search && w.pass_n == (uint32_t)pass)) continue;
     RState st = work[r];
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
                   for (int q = lane; q < nref; q += 64) rfq[q] = ix.ref_seq[rf_start + q];
                   __syncthreads();
                   fw = sw_wave(rdq, m, 0, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
-                  if (lane == 0) { atomicAdd(&ctr[C_SW_FWD], 1ull); atomicAdd(&ctr[C_SW_CELLS], (unsigned long long)m * nref); }
+                  n_fwd++; n_cells += (unsigned long long)m * nref;
                 }
                 int score1 = fw.score > 65535 ? 65535 : fw.score;
                 int ref_begin1 = -1, read_begin1 = -1;
@@ -362,7 +368,7 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
                                      P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
                   ref_begin1 = ref_end1 - bw.end_ref;
                   read_begin1 = read_end1 - bw.end_read;
-                  if (lane == 0) { atomicAdd(&ctr[C_SW_REV], 1ull); atomicAdd(&ctr[C_SW_CELLS], (unsigned long long)(read_end1 + 1) * (ref_end1 + 1)); }
+                  n_rev++; n_cells += (unsigned long long)(read_end1 + 1) * (ref_end1 + 1);
                 }
                 is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
                 if (is_aligned) {
@@ -448,6 +454,11 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
       w.strand_active = 0;
     }
     if (lane == 0) { work[r] = st; rw[r] = w; }
+  }
+  if (lane == 0) {
+    if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
+    if (n_rev) ctr_add(ctr, C_SW_REV, n_rev);
+    if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
   }
 }
 

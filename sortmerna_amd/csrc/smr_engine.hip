@@ -203,13 +203,13 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.cap_tuples = (uint32_t)slots;
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gk = (uint32_t)((slots + 255) / 256), gw = (uint32_t)((slots + 63) / 64);
+  const uint32_t gk = (uint32_t)((slots + 255) / 256), gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024);
   ev_begin(c, 0);
   for (int dir = 0; dir < 2; dir++) {
     HIPCHK(c, hipMemsetAsync(sb.hist, 0, (size_t)sb.nk * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
-    if (dir == 0) hipLaunchKernelGGL(k_seed_keys<0>, dim3(gk), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
-    else hipLaunchKernelGGL(k_seed_keys<1>, dim3(gk), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
+    if (dir == 0) hipLaunchKernelGGL(k_seed_keys<0>, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
+    else hipLaunchKernelGGL(k_seed_keys<1>, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
     hipLaunchKernelGGL(k_seed_scan, dim3(1), dim3(1024), 0, c->stream, sb);
     hipLaunchKernelGGL(k_seed_scatter, dim3(gk), dim3(256), 0, c->stream, sb);
     if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
@@ -241,10 +241,24 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   return SMR_OK;
 }
 
+// fold the sharded work counters into their base slots (and clear the shards, so the vector can be written back);
+// C_POOL_CURSOR becomes the largest shard cursor
+void fold_shards(std::vector<unsigned long long>& h) {
+  for (int s = 0; s < C_NSHARD; s++)
+    for (int k = 0; k < 16; k++) {
+      if (k < 9) h[C_WINDOWS + k] += h[C_SHARDS + 16 * s + k];
+      h[C_SHARDS + 16 * s + k] = 0;
+    }
+  unsigned long long mx = 0;
+  for (int s = 0; s < C_NSHARD; s++) mx = std::max(mx, h[C_PCUR + s]);
+  h[C_POOL_CURSOR] = mx;
+}
+
 int read_ctr(smr_ctx* c, std::vector<unsigned long long>& h) {
-  h.resize(C_COUNT);
-  HIPCHK(c, hipMemcpyAsync(h.data(), c->b->d_ctr, C_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+  h.resize(C_TOTAL);
+  HIPCHK(c, hipMemcpyAsync(h.data(), c->b->d_ctr, C_TOTAL * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  fold_shards(h);
   return SMR_OK;
 }
 
@@ -268,8 +282,8 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-  if (hipMalloc((void**)&c->b->d_ctr, C_COUNT * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
-  (void)hipMemset(c->b->d_ctr, 0, C_COUNT * 8);
+  if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
+  (void)hipMemset(c->b->d_ctr, 0, C_TOTAL * 8);
   c->b->used = true;
   *out = c;
   return SMR_OK;
@@ -333,8 +347,8 @@ extern "C" int smr_batch_select(smr_ctx* c, int batch) {
   HIPCHK(c, hipSetDevice(c->device));
   Batch& B = c->bt[batch];
   if (!B.d_ctr) {
-    HIPCHK(c, hipMalloc((void**)&B.d_ctr, C_COUNT * 8));
-    HIPCHK(c, hipMemset(B.d_ctr, 0, C_COUNT * 8));
+    HIPCHK(c, hipMalloc((void**)&B.d_ctr, C_TOTAL * 8));
+    HIPCHK(c, hipMemset(B.d_ctr, 0, C_TOTAL * 8));
   }
   B.used = true;
   c->b = &B;
@@ -346,7 +360,7 @@ extern "C" int smr_state_reset(smr_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemsetAsync(c->b->d_saved, 0, (size_t)c->b->n * sizeof(RState), c->stream));
   HIPCHK(c, hipMemsetAsync(c->b->d_saved_aln, 0, (size_t)c->b->n * c->b->slots * sizeof(AlignRec), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->b->d_ctr, 0, C_COUNT * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->b->d_ctr, 0, C_TOTAL * 8, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->b->fetched = false;
   return SMR_OK;
@@ -403,11 +417,12 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     init[C_NUM_SHORT] = 0;
     for (int k = C_ERR_HITCAP; k <= C_ERR_TRACE; k++) init[k] = 0;
     init[C_POOL_CURSOR] = 0; init[C_WORK_NEXT] = 0;
-    HIPCHK(c, hipMemcpyAsync(c->b->d_ctr, init.data(), C_COUNT * 8, hipMemcpyHostToDevice, c->stream));
+    for (int q = 0; q < C_NSHARD; q++) init[C_PCUR + q] = 0;
+    HIPCHK(c, hipMemcpyAsync(c->b->d_ctr, init.data(), C_TOTAL * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     for (int count = 0; count < num_strands; count++) {
       hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, count, c->b->d_work, c->b->d_rw);
-      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_POOL_CURSOR], 0, 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * 8, c->stream));
       for (int pass = 0; pass < 3; pass++) {
         if (pass > 0 && P.skip[pass] == P.skip[pass - 1]) continue;     // equal strides are skipped (paralleltraversal.cpp:269-272)
         if ((rc = launch_seed(c, di, P, pass))) return rc;
@@ -607,8 +622,9 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
   std::vector<unsigned long long> h;
   for (int attempt = 0; attempt < 8; attempt++) {
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_HITCAP], 0, 16, c->stream));          // HITCAP, POOL
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_POOL_CURSOR], 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_HIT], 0, 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_SHARDS], 0, 16 * C_NSHARD * 8, c->stream));
     // fresh per-part/strand state: forward, or reverse-complement with ambiguous letters complemented (aval 0 -> 3)
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     DParams Q = P; Q.is_forward = 1; Q.is_reverse = 1;
@@ -631,7 +647,7 @@ extern "C" int smr_seed_hits_fetch(smr_ctx* c, uint32_t* triples, uint64_t cap_t
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<unsigned long long> h;
   int rc = read_ctr(c, h); if (rc) return rc;
-  uint64_t words = std::min<uint64_t>(h[C_POOL_CURSOR], c->pool_words);
+  uint64_t words = h[C_POOL_CURSOR] ? std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull) : 0;   // sharded pool: fetch all regions
   std::vector<uint32_t> pool(words);
   std::vector<RWork> rw(c->b->n);
   if (words) HIPCHK(c, hipMemcpy(pool.data(), c->d_pool, words * 4, hipMemcpyDeviceToHost));
@@ -656,18 +672,22 @@ extern "C" int smr_prof_reset(smr_ctx* c) {
   HIPCHK(c, hipSetDevice(c->device));
   c->seed_ms = c->chain_ms = c->trace_ms = 0; c->seed_l = c->chain_l = c->trace_l = 0;
   for (int k = 0; k < SMR_MAX_BATCHES; k++)
-    if (c->bt[k].d_ctr) HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
+    if (c->bt[k].d_ctr) {
+      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SHARDS], 0, 16 * C_NSHARD * 8, c->stream));
+    }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SMR_OK;
 }
 extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
   if (!c || !o) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  std::vector<unsigned long long> h(C_COUNT, 0), t(C_COUNT);
+  std::vector<unsigned long long> h(C_TOTAL, 0), t(C_TOTAL);
   for (int k = 0; k < SMR_MAX_BATCHES; k++) {
     if (!c->bt[k].d_ctr) continue;
-    HIPCHK(c, hipMemcpyAsync(t.data(), c->bt[k].d_ctr, C_COUNT * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(t.data(), c->bt[k].d_ctr, C_TOTAL * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
   o->seed_ms = c->seed_ms; o->seed_launches = c->seed_l; o->chain_ms = c->chain_ms; o->chain_launches = c->chain_l; o->trace_ms = c->trace_ms; o->trace_launches = c->trace_l;

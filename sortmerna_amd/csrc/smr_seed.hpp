@@ -148,7 +148,7 @@ __device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, 
 // DIR 0: forward half-seed (key = first 9-mer, automaton fed by chars [pw, 2pw): init_win_f bitvector.cpp:57-91)
 // DIR 1: reverse half-seed (key = second 9-mer, automaton fed by chars pw-1 .. 0: init_win_r :99-132)
 template <int DIR>
-__global__ void __launch_bounds__(256) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
+__global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
                                                    const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
@@ -190,24 +190,28 @@ __global__ void __launch_bounds__(256) k_seed_keys(DReads rd, DIndex ix, DParams
       payload = (unsigned long long)r | ((unsigned long long)win_pos << 24) | ((unsigned long long)chars << 40);
     }
   }
-  // wave-aggregated slot allocation in the unsorted tuple array
-  const unsigned long long em = __ballot(emit);
-  uint32_t base = 0;
-  if (em) {
-    if (lane == __ffsll((long long)em) - 1) base = atomicAdd(&sb.sn[SN_TUPLES], (uint32_t)__popcll(em));
-    base = __shfl(base, __ffsll((long long)em) - 1, 64);
+  // block-aggregated slot allocation in the unsorted tuple array (one atomic per 1024 slots)
+  __shared__ uint32_t s_cnt[16], s_win[16], s_lk[16], s_base;
+  const uint32_t wv = threadIdx.x >> 6;
+  const unsigned long long em = __ballot(emit), wm = __ballot(is_win), lm = __ballot(is_lookup);
+  if (lane == 0) { s_cnt[wv] = (uint32_t)__popcll(em); s_win[wv] = (uint32_t)__popcll(wm); s_lk[wv] = (uint32_t)__popcll(lm); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tc = 0, tw = 0, tl = 0;
+    for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { tc += s_cnt[q]; tw += s_win[q]; tl += s_lk[q]; }
+    s_base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
+    if (tw) ctr_add(ctr, C_WINDOWS, tw);
+    if (tl) ctr_add(ctr, C_LOOKUP, tl);
   }
+  __syncthreads();
   if (emit) {
+    uint32_t base = s_base;
+    for (uint32_t q = 0; q < wv; q++) base += s_cnt[q];
     const uint32_t idx = base + (uint32_t)__popcll(em & ((1ull << lane) - 1));
     if (idx < sb.cap_tuples) {
       SeedTmp t; t.key = key; t.rank = atomicAdd(&sb.hist[key], 1u); t.payload = payload;
       sb.tmp[idx] = t;
     }
-  }
-  const unsigned long long wm = __ballot(is_win), lm = __ballot(is_lookup);
-  if (lane == 0) {
-    if (wm) atomicAdd(&ctr[C_WINDOWS], (unsigned long long)__popcll(wm));
-    if (lm) atomicAdd(&ctr[C_LOOKUP], (unsigned long long)__popcll(lm));
   }
 }
 
@@ -490,9 +494,10 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   const uint32_t total = __shfl(incl, 63, 64);
   uint32_t base = 0;
   if (total) {
-    if (lane == 0) {
-      const unsigned long long old = atomicAdd(&ctr[C_POOL_CURSOR], (unsigned long long)total);
-      if (old + total > pool_words) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = (uint32_t)old;
+    if (lane == 0) {                                     // the pool is split into C_NSHARD regions, each with its own cursor
+      const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
+      const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], (unsigned long long)total);
+      if (old + total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = shard * region + (uint32_t)old;
     }
     base = __shfl(base, 0, 64);
   }
@@ -507,7 +512,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   for (int c = 0; c < 2; c++) {
     unsigned long long x = v[c];
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    if (lane == 0 && x) atomicAdd(&ctr[C_NODE + c], x);
+    if (lane == 0 && x) ctr_add(ctr, C_NODE + c, x);
   }
 }
 
@@ -536,7 +541,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
     }
   }
   for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); }
-  if (lane_id() == 0) { if (hits) atomicAdd(&ctr[C_HIT], hits); if (bytes) atomicAdd(&ctr[C_READ_BYTES], bytes); }
+  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); }
 }
 
 }  // namespace smr
