@@ -194,10 +194,10 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
       if (cap_err) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); }
       else {
         uint32_t o = 0;
-        for (uint32_t seg = w.hit_head; seg != NONE;) {
-          uint32_t nxt = pool[seg], c = pool[seg + 1];
-          for (uint32_t q = lane; q < c; q += 64) hits[o + q] = make_uint2(pool[seg + 2 + 2 * q], pool[seg + 3 + 2 * q]);
-          o += c; seg = nxt;
+        for (uint32_t pp = 0; pp < 3; pp++) {              // one contiguous block per pass run so far on this strand
+          const uint32_t c = w.blk_cnt[pp], bo = w.blk_off[pp];
+          for (uint32_t q = lane; q < c; q += 64) hits[o + q] = make_uint2(pool[bo + 2 * q], pool[bo + 2 * q + 1]);
+          o += c;
         }
         __syncthreads();
         // 1. per-reference histogram of seed hits (:117-130) with device atomics on this slot's private counters

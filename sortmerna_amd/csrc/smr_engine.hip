@@ -132,7 +132,7 @@ DIndex dindex(const DevIndex& d) {
 DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off = c->b->d_rec_off; r.len = c->b->d_len; r.n = c->b->n; r.max_len = c->b->max_len; return r; }
 
 int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
-  if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * 8;
+  if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * 12;    // 3 waves per SIMD (134 VGPRs)
   uint32_t need_keys = std::max(pow2ceil(di.n_refs), 1024u);
   if (c->cnt_refs < di.n_refs) {
     int rc = dev_alloc(c, &c->d_cnt, (size_t)c->chain_blocks * di.n_refs); if (rc) return rc;
@@ -215,7 +215,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
     if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
     else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
   }
-  hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, c->b->d_ctr);
+  hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, pool_words, c->b->d_ctr);
   ev_end(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
@@ -607,7 +607,8 @@ __global__ void k_force_pass(uint32_t n, DParams P, int pass, const uint32_t* __
   if (i >= n) return;
   RWork w = rw[i];
   w.strand_active = len[i] >= P.lnwin ? 1 : 0; w.search = 1; w.pass_n = (uint8_t)pass; w.win_shift = P.skip[pass];
-  w.hit_head = NONE; w.hit_total = 0; w.valid = w.strand_active;
+  for (int q = 0; q < 3; q++) w.blk_cnt[q] = 0;
+  w.hit_total = 0; w.valid = w.strand_active;
   rw[i] = w;
 }
 
@@ -654,13 +655,12 @@ extern "C" int smr_seed_hits_fetch(smr_ctx* c, uint32_t* triples, uint64_t cap_t
   if (c->b->n) HIPCHK(c, hipMemcpy(rw.data(), c->b->d_rw, (size_t)c->b->n * sizeof(RWork), hipMemcpyDeviceToHost));
   uint64_t o = 0;
   for (uint32_t r = 0; r < c->b->n; r++) {
-    for (uint32_t seg = rw[r].hit_head; seg != NONE && seg + 1 < words;) {
-      uint32_t nxt = pool[seg], cnt = pool[seg + 1];
-      for (uint32_t q = 0; q < cnt; q++) {
-        if (triples && o < cap_triples) { triples[3 * o] = r; triples[3 * o + 1] = pool[seg + 2 + 2 * q]; triples[3 * o + 2] = pool[seg + 3 + 2 * q]; }
+    for (int pp = 0; pp < 3; pp++) {
+      const uint32_t cnt = rw[r].blk_cnt[pp], bo = rw[r].blk_off[pp];
+      for (uint32_t q = 0; q < cnt && (uint64_t)bo + 2 * q + 1 < words; q++) {
+        if (triples && o < cap_triples) { triples[3 * o] = r; triples[3 * o + 1] = pool[bo + 2 * q]; triples[3 * o + 2] = pool[bo + 2 * q + 1]; }
         o++;
       }
-      seg = nxt;
     }
   }
   *n_out = o;

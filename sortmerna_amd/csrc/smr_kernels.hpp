@@ -54,7 +54,8 @@ struct RState {                 // what round-trips through the reference's KVDB
 
 struct RWork {                  // per (read, index part) transient state
   int32_t best;                 // Read::best (not stored in the KVDB, read.hpp:122)
-  uint32_t hit_head;            // head of this strand's hit-segment list in the pool (NONE = empty)
+  uint32_t blk_off[3];          // per pass: pool offset of this strand's contiguous (id, win_pos) pairs
+  uint32_t blk_cnt[3];          // ... and their number
   uint32_t hit_total;           // number of (id,win) hits of this strand so far
   uint32_t win_shift;
   uint8_t is_new_hit;
@@ -159,7 +160,8 @@ __global__ void k_begin_part(DReads rd, DParams P, const RState* __restrict__ sa
     for (uint32_t k = 0; k < s.n_align; k++) work_aln[(size_t)i * P.slots + k] = saved_aln[(size_t)i * P.slots + k];
     RWork w;
     w.best = P.min_lis > 0 ? P.min_lis : 0;          // Read::init read.cpp:264-271
-    w.hit_head = NONE; w.hit_total = 0; w.win_shift = P.skip[0];
+    for (int q = 0; q < 3; q++) { w.blk_off[q] = 0; w.blk_cnt[q] = 0; }
+    w.hit_total = 0; w.win_shift = P.skip[0];
     w.is_new_hit = 0; w.is04 = 0; w.aval = 0; w.reversed = 0;
     is_short = rd.len[i] < P.lnwin;                   // processor.cpp:109-114
     w.valid = (!is_short && !s.is_done) ? 1 : 0;      // :120-126
@@ -191,7 +193,8 @@ __global__ void k_begin_strand(uint32_t n, DParams P, int count, const RState* _
       }
     }
     w.strand_active = 1; w.search = 1; w.pass_n = 0; w.win_shift = P.skip[0];
-    w.hit_head = NONE; w.hit_total = 0;                 // read.id_win_hits.clear()
+    for (int q = 0; q < 3; q++) w.blk_cnt[q] = 0;       // read.id_win_hits.clear()
+    w.hit_total = 0;
   }
   rw[i] = w;
 }

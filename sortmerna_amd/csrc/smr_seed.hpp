@@ -77,7 +77,7 @@ __device__ __forceinline__ uint32_t lev_next(unsigned long long row, uint32_t st
 //   k_seed_scan         exclusive scan of the bin counts
 //   k_seed_scatter      tuples to bin order
 //   k_seed_search<DIR>  the searches (below)
-//   k_seed_finish       per read: link the windows' hit segments, hit_seeds / hit_total (paralleltraversal.cpp:242-249)
+//   k_seed_finish       per read: gather the windows' hits into one block, hit_seeds / hit_total (paralleltraversal.cpp:242-249)
 //
 // k_seed_search, one wave per 64 tuples: lane = one window's search.  A lane walks its mini-trie exactly in the
 // reference's DFS order (A<C<G<T, traverse_bursttrie.cpp:117), but the walk is cut into ROUNDS: in a round every lane
@@ -486,7 +486,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   }
   __syncthreads();
   seed_search_wave(trie, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
-  // ---- write the windows' hit segments: [next (linked by k_seed_finish), count, (id, win_pos) x count] ----
+  // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
   const bool wr = mine && (DIR == 0 ? sl.nh > 0 : (sl.zero || sl.nh > n_prev));
   const uint32_t need = wr ? 2 + 2 * sl.nh : 0;
   uint32_t incl = need;
@@ -516,9 +516,12 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   }
 }
 
-// per read: link the hit segments of this pass in front of the read's list, count seeds/hits, make the 0..3 view persistent
+// per read: copy the hit segments of this pass's windows into ONE contiguous block (k_chain then reads a strand's
+// cumulative hits with coalesced loads instead of chasing a list), count seeds/hits (++read.hit_seeds per window with
+// hits, paralleltraversal.cpp:242-249), make the 0..3 view persistent (Read::flip34, read.cpp:379-401)
 __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
-                                                     RWork* __restrict__ rw, uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr) {
+                                                     RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
+                                                     unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long hits = 0, bytes = 0;
   if (r < rd.n) {
@@ -526,17 +529,31 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
     if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
       const uint32_t len = rd.len[r], stride = P.skip[pass];
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
-      uint32_t head = w.hit_head, seeds = 0, total = 0;
+      uint32_t seeds = 0, total = 0;
       for (uint32_t k = 0; k < numwin; k++) {
         const uint32_t s = sb.wseg[(size_t)r * sb.maxwin + k];
         if (s == NONE) continue;
-        const uint32_t o = s & ~SEED_ZERO_BIT;
-        pool[o] = head; head = o; seeds++; total += pool[o + 1];
+        seeds++; total += pool[(s & ~SEED_ZERO_BIT) + 1];
       }
-      w.aval = w.is04 ? 0 : w.aval; w.is04 = 0;            // the flip back to 0..3 is persistent (read.cpp:379-401)
-      w.hit_head = head; w.hit_total += total;
+      uint32_t base = 0;
+      if (total) {
+        const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
+        const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], 2ull * total);
+        if (old + 2ull * total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); total = 0; seeds = 0; }
+        else base = shard * region + (uint32_t)old;
+      }
+      uint32_t o = base;
+      if (total) for (uint32_t k = 0; k < numwin; k++) {
+        const uint32_t s = sb.wseg[(size_t)r * sb.maxwin + k];
+        if (s == NONE) continue;
+        const uint32_t sg = s & ~SEED_ZERO_BIT, c = pool[sg + 1];
+        for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
+        o += 2 * c;
+      }
+      w.aval = w.is04 ? 0 : w.aval; w.is04 = 0;
+      w.blk_off[pass] = base; w.blk_cnt[pass] = total; w.hit_total += total;
       rw[r] = w;
-      work[r].hit_seeds += seeds;                          // ++read.hit_seeds per window with hits (:242-249)
+      work[r].hit_seeds += seeds;
       hits = total; bytes = (len + 3) / 4;
     }
   }
