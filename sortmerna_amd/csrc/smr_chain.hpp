@@ -42,55 +42,69 @@ __device__ void wave_sort_u64(unsigned long long* keys, uint32_t n) {
   }
 }
 
+__device__ __forceinline__ uint32_t pow2_floor(uint32_t v) { return v ? 1u << (31 - __clz((int)v)) : 0u; }
+
 struct SwRes { int score, end_ref, end_read; };
 
-// Smith-Waterman score + end cell as an anti-diagonal systolic array: lane = read row within a strip of 64 rows,
-// step t computes column t-lane.  Same H as the reference's striped SSE2 kernels (ssw.c:150-575) under the
-// affine model H = max(0, diag+s, E, F), first gap base costs gap_open, further bases gap_ext; end cell =
-// first column (in processing order) where the maximum is first reached, smallest row in that column
-// (ssw.c:305-336).  dir = +1 forward, -1 reverse (the reverse pass ssw.c:900-918 runs the same recurrence on the
-// reversed prefixes; since its maximum equals the forward score, stopping at `terminate` selects the same cell).
-// rdq: read in 0..4 alphabet (LDS), rfq: reference window (LDS).  bound: 2*n ints of LDS.
-__device__ SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
-                         int* bound, int match, int mismatch, int scoreN, int go, int ge) {
+// Smith-Waterman score + end cell as an anti-diagonal systolic array over the wave.  Lane i owns R consecutive read
+// rows (R = ceil(m/64) <= 4: a 150-nt read is ONE strip of 64 x 3 rows; longer reads take several strips with an LDS
+// boundary row in between); at step t lane i computes its R cells of reference column t - i.  Everything that moves
+// between lanes -- the last row's H and F and the column's nucleotide -- moves by one lane per step with a DPP
+// wave_shr:1 (a register move, no LDS round trip); lane 0's inputs (boundary H/F of the previous strip, next
+// reference nucleotide) are injected by the same instruction and prefetched one step ahead.
+// Same H as the reference's striped SSE2 kernels (ssw.c:150-575) under the affine model H = max(0, diag+s, E, F),
+// first gap base costs gap_open, further bases gap_ext; end cell = first column (in processing order) where the
+// maximum is first reached, smallest row in that column (ssw.c:305-336).  The reverse pass (ssw.c:900-918) runs the
+// same recurrence on the reversed prefixes (strides -1); since its maximum equals the forward score, stopping at
+// `terminate` selects the same cell.  rdq: read in 0..4 alphabet (LDS), rfq: reference window (LDS), bound: 2*n ints.
+__device__ __forceinline__ int dpp_shr1(int inject_lane0, int v) {
+  return __builtin_amdgcn_update_dpp(inject_lane0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
+template <int R>
+__device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                           int* bound, int match, int mismatch, int scoreN, int go, int ge) {
   const int lane = lane_id();
-  int bestH = 0, bestcol = 0x7fffffff, bestrow = 0x7fffffff;
-  const int nstrips = (m + 63) >> 6;
+  int bestH = 0, bestcol = 0x1FFFFF, bestrow = 0x1FFFFF;
+  const int rps = 64 * R;
+  const int nstrips = (m + rps - 1) / rps;
   for (int s = 0; s < nstrips; s++) {
-    const int row = s * 64 + lane;
-    const bool vrow = row < m;
-    const int rnt = vrow ? rdq[rd0 + rdstep * row] : 4;
-    int Hcur = 0, Fcur = 0, Ecur = 0, Hdiag = 0;
+    const int row0 = s * rps + lane * R;
+    int rnt[R], H[R], E[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { rnt[r] = (row0 + r < m) ? rdq[rd0 + rdstep * (row0 + r)] : 5; H[r] = 0; E[r] = 0; }   // 5 = row beyond the read
+    int lastH = 0, lastF = 0, Hdiag0 = 0, fnt = 4;
+    const bool has_prev = s > 0, has_next = s + 1 < nstrips;
+    int inH = has_prev ? bound[0] : 0, inF = has_prev ? bound[1] : 0, cin = n > 0 ? rfq[rf0] : 4;
     const int steps = n + 63;
     for (int t = 0; t < steps; t++) {
-      int upH = __shfl_up(Hcur, 1, 64);
-      int upF = __shfl_up(Fcur, 1, 64);
-      if (lane == 0) {
-        if (s == 0 || t >= n) { upH = 0; upF = 0; }
-        else { upH = bound[2 * t]; upF = bound[2 * t + 1]; }
-      }
+      const int cH = inH, cF = inF, cc = cin;
+      const int tn = t + 1;                                // prefetch lane 0's inputs of the next step
+      cin = tn < n ? rfq[rf0 + rfstep * tn] : 4;
+      inH = (has_prev && tn < n) ? bound[2 * tn] : 0;
+      inF = (has_prev && tn < n) ? bound[2 * tn + 1] : 0;
+      const int upH = dpp_shr1(cH, lastH), upF = dpp_shr1(cF, lastF);
+      fnt = dpp_shr1(cc, fnt);
       const int col = t - lane;
-      const bool act = vrow && col >= 0 && col < n;
-      int Hn = Hcur, Fn = Fcur, En = Ecur;
-      if (act) {
-        const int fnt = rfq[rf0 + rfstep * col];
-        const int sc = (fnt == 4 || rnt == 4) ? scoreN : (fnt == rnt ? match : mismatch);
-        const int Hleft = (col == 0) ? 0 : Hcur;
-        const int Eleft = (col == 0) ? 0 : Ecur;
-        int e = max(Eleft - ge, Hleft - go);
-        int f = max(upF - ge, upH - go);
-        int h = Hdiag + sc;
-        h = max(h, e); h = max(h, f); h = max(h, 0);
+      const bool colok = col >= 0 && col < n;
+      int diag = Hdiag0, uh = upH, uf = upF, fl = 0;
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const int sc = (fnt == 4 || rnt[r] == 4) ? scoreN : (fnt == rnt[r] ? match : mismatch);
+        int e = max(E[r] - ge, H[r] - go);
+        int f = max(uf - ge, uh - go);
+        int h = max(max(diag + sc, e), max(f, 0));
         e = max(e, 0); f = max(f, 0);
-        Hn = h; Fn = f; En = e;
-        if (h > bestH || (h == bestH && (col < bestcol || (col == bestcol && row < bestrow)))) {
-          if (h > 0) { bestH = h; bestcol = col; bestrow = row; }
+        diag = H[r];                                         // H(row, col-1) is the diagonal of the next row
+        if (colok && rnt[r] != 5) {
+          H[r] = h; E[r] = e;
+          if (h > bestH || (h == bestH && h > 0 && col < bestcol)) { bestH = h; bestcol = col; bestrow = row0 + r; }
         }
+        uh = h; uf = f; fl = f;
       }
-      // diag for the next step is the up value of this step (H(row-1, col))
-      Hdiag = (col >= 0) ? upH : 0;
-      Hcur = Hn; Fcur = Fn; Ecur = En;
-      if (lane == 63 && act && s + 1 < nstrips) { bound[2 * col] = Hn; bound[2 * col + 1] = Fn; }
+      Hdiag0 = col >= 0 ? upH : 0;                           // H(row0-1, col): diagonal of row0 at the next column
+      if (colok) { lastH = H[R - 1]; lastF = fl; }
+      if (has_next && lane == 63 && colok) { bound[2 * col] = lastH; bound[2 * col + 1] = lastF; }
     }
     __syncthreads();
   }
@@ -98,12 +112,20 @@ __device__ SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const u
   unsigned long long key = bestH > 0 ? (((unsigned long long)bestH << 42) | ((unsigned long long)(0x1FFFFF - bestcol) << 21) |
                                         (unsigned long long)(0x1FFFFF - bestrow)) : 0ull;
   key = wave_max_u64(key);
-  SwRes r;
-  if (key == 0) { r.score = 0; r.end_ref = -1; r.end_read = m - 1; return r; }
-  r.score = (int)(key >> 42);
-  r.end_ref = 0x1FFFFF - (int)((key >> 21) & 0x1FFFFF);
-  r.end_read = 0x1FFFFF - (int)(key & 0x1FFFFF);
-  return r;
+  SwRes rr;
+  if (key == 0) { rr.score = 0; rr.end_ref = -1; rr.end_read = m - 1; return rr; }
+  rr.score = (int)(key >> 42);
+  rr.end_ref = 0x1FFFFF - (int)((key >> 21) & 0x1FFFFF);
+  rr.end_read = 0x1FFFFF - (int)(key & 0x1FFFFF);
+  return rr;
+}
+
+__device__ __noinline__ SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                         int* bound, int match, int mismatch, int scoreN, int go, int ge) {
+  if (m <= 64) return sw_wave_r<1>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  if (m <= 128) return sw_wave_r<2>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  if (m <= 192) return sw_wave_r<3>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  return sw_wave_r<4>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
 }
 
 // per-block (= per persistent wave slot) scratch in global memory
@@ -116,7 +138,7 @@ struct ChainScratch {
   uint32_t keys_cap, pairs_cap, hits_cap;
 };
 
-#define CH_KEYS_LDS 512
+#define CH_KEYS_LDS 256
 #define CH_PAIRS_LDS 256
 #define CH_HITS_LDS 256
 
@@ -140,13 +162,20 @@ __device__ uint32_t find_lis_dev(const unsigned long long* a, uint32_t n, uint32
 
 // One block (64 threads = one wave) per read, persistent.  Dynamic LDS layout (bytes), ML = max_len rounded:
 //   rdq[ML] | rfq[ML+2*edges_max+64] | bound[2*(ML+...)] ints | keys[CH_KEYS_LDS] u64 | pairs[CH_PAIRS_LDS] u64 |
-//   lis[2*CH_PAIRS_LDS] u32 | hits[CH_HITS_LDS] uint2
-__global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
+//   lis[2*CH_PAIRS_LDS] u32 | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS+8] u32 | bloom[s_cap] u32 | skey[s_cap] u32 | scnt[s_cap] u32
+//
+// Candidate references (alignment.cpp:117-148) without a per-reference counter array: the position lists of all hits
+// are walked twice with one lane per POSITION (prefix sum over the list lengths).  Walk 1 sets one bit per reference
+// in a Bloom bitmap in LDS; a reference seen with its bit already set may occur twice and goes into a small
+// open-addressing set S.  Most background reads leave S empty and are done.  Walk 2 counts exactly, for the
+// references in S only, and records their (pos, win) tuples; candidates are the members of S with count >= num_seeds,
+// and each candidate's (ref_pos, read_pos) pairs are a filter over the tuples instead of per-hit binary searches.
+__global__ void __launch_bounds__(64, 3) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
                                               RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
-                                              uint32_t* g_cnt, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
+                                              unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
-                                              uint32_t lds_ml, uint32_t lds_rf) {
+                                              uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
@@ -155,17 +184,31 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
   uint8_t* rfq = rdq + lds_ml;
   int* bound = (int*)(rfq + lds_rf);
   unsigned long long* l_keys = (unsigned long long*)(bound + 2 * lds_rf);
+  // region R: [pairs | lis] during the candidate loop, [bloom | scnt] while the candidate set is built (dead afterwards)
   unsigned long long* l_pairs = l_keys + CH_KEYS_LDS;
   uint32_t* l_lis = (uint32_t*)(l_pairs + CH_PAIRS_LDS);
-  uint2* l_hits = (uint2*)(l_lis + 2 * CH_PAIRS_LDS);
+  uint32_t* bloom = (uint32_t*)l_pairs;
+  uint32_t* scnt = bloom + s_cap;
+  const uint32_t r_words = max(4u * CH_PAIRS_LDS, 2u * s_cap);
+  uint2* l_hits = (uint2*)((uint32_t*)l_pairs + r_words);
+  uint32_t* l_hp = (uint32_t*)(l_hits + CH_HITS_LDS);
+  uint32_t* skey = l_hp + CH_HITS_LDS + 8;
+  __shared__ uint32_t s_ns, s_nt;
+  const uint32_t s_mask = s_cap - 1, bloom_shift = 32 - (5 + __ffs((int)s_cap) - 1);     // 32 * s_cap bits
 
-  uint32_t* cnt = g_cnt + (size_t)blockIdx.x * ix.n_refs;
+  unsigned long long* gt = g_tuples + (size_t)blockIdx.x * pairs_cap;
   unsigned long long* gk = g_keys + (size_t)blockIdx.x * keys_cap;
   unsigned long long* gp = g_pairs + (size_t)blockIdx.x * pairs_cap;
   uint32_t* gl = g_lis + (size_t)blockIdx.x * 2 * pairs_cap;
   uint2* gh = g_hits + (size_t)blockIdx.x * hits_cap;
 
   unsigned long long n_fwd = 0, n_rev = 0, n_cells = 0;   // flushed once per block (lane 0)
+#ifdef SMR_CHAIN_PHASES                                   // per-phase cycle accounting (build with -DSMR_CHAIN_PHASES, run with SMR_DEBUG_PHASES=1)
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define TPH(i) { const unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; }
+#else
+#define TPH(i)
+#endif
   uint32_t chunk_next = 0, chunk_end = 0;                 // reads are claimed 16 at a time (one atomic per chunk)
   for (;;) {
     if (chunk_next == chunk_end) {
@@ -187,6 +230,7 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
 
     if (st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0) {
       // ---------------- compute_lis_alignment (alignment.cpp:100-509) ----------------
+      TPH(0)
       // gather this strand's hits (all passes so far) into a flat array
       const uint32_t nh = w.hit_total;
       uint2* hits = nh <= CH_HITS_LDS ? l_hits : gh;
@@ -200,62 +244,93 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
           o += c;
         }
         __syncthreads();
-        // 1. per-reference histogram of seed hits (:117-130) with device atomics on this slot's private counters
-        if (lane == 0) s_ncand = 0;
-        __syncthreads();
+        // 1. per-reference counts of seed hits (:117-130)
+        // prefix over the position-list lengths; hits[h].x becomes the list start
+        uint32_t* hp = nh <= CH_HITS_LDS ? l_hp : gl;
+        uint32_t npos = 0;
         for (uint32_t hb = 0; hb < nh; hb += 64) {
-          uint32_t h = hb + lane;
-          uint32_t lo = 0, hi = 0;
-          if (h < nh) { uint32_t id = hits[h].x; lo = ix.pos_off[id]; hi = ix.pos_off[id + 1]; }
-          // short lists: lane-serial; long lists: the whole wave walks them together
-          bool lng = (hi - lo) > 32;
-          if (!lng) {
-            for (uint32_t k = lo; k < hi; k++) {
-              uint32_t seq = ix.pos_arr[k].y;
-              uint32_t old = atomicAdd(&cnt[seq], 1u);
-              if (old + 1 == (uint32_t)P.num_seeds) { uint32_t sl = atomicAdd(&s_ncand, 1u); if (sl < keys_cap) gk[sl] = seq; }
+          const uint32_t h = hb + lane;
+          uint32_t lo = 0, ln = 0;
+          if (h < nh) { const uint32_t id = hits[h].x; lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo; }
+          uint32_t tot; const uint32_t ex = wave_excl_scan_u32(ln, tot);
+          if (h < nh) { hp[h] = npos + ex; hits[h].x = lo; }
+          npos += tot;
+        }
+        if (lane == 0) { hp[nh] = npos; s_ns = 0; s_nt = 0; s_ncand = 0; }
+        for (uint32_t q = lane; q < s_cap; q += 64) { bloom[q] = 0; skey[q] = 0; scnt[q] = 0; }
+        __syncthreads();
+        TPH(1)
+        // walk 1: Bloom bitmap -> set S of references that may occur more than once
+        bool s_over = false;
+        for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
+          const uint32_t p = p0 + lane;
+          if (p < npos) {
+            uint32_t h = 0;
+            for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp[t] <= p) h = t; }
+            const uint32_t seq = ix.pos_arr[hits[h].x + (p - hp[h])].y;
+            const uint32_t hb = (seq * 2654435761u) >> bloom_shift;
+            const uint32_t old = atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
+            if (((old >> (hb & 31u)) & 1u) || P.num_seeds < 2) {
+              uint32_t sl = (seq * 0x9E3779B1u >> 7) & s_mask;
+              for (uint32_t tries = 0; tries < s_cap; tries++) {
+                const uint32_t o = atomicCAS(&skey[sl], 0u, seq + 1);
+                if (o == 0) { if (atomicAdd(&s_ns, 1u) + 1 > (s_cap * 3) / 4) s_over = true; break; }
+                if (o == seq + 1) break;
+                sl = (sl + 1) & s_mask;
+              }
             }
           }
-          unsigned long long lm = __ballot(lng);
-          while (lm) {
-            int src = __ffsll((long long)lm) - 1; lm &= lm - 1;
-            uint32_t llo = __shfl(lo, src, 64), lhi = __shfl(hi, src, 64);
-            for (uint32_t k = llo + lane; k < lhi; k += 64) {
-              uint32_t seq = ix.pos_arr[k].y;
-              uint32_t old = atomicAdd(&cnt[seq], 1u);
-              if (old + 1 == (uint32_t)P.num_seeds) { uint32_t sl = atomicAdd(&s_ncand, 1u); if (sl < keys_cap) gk[sl] = seq; }
+        }
+        __syncthreads();
+        if (__any(s_over)) { if (lane == 0) atomicAdd(&ctr[C_ERR_SCAP], 1ull); cap_err = true; }
+        uint32_t ncand = 0;
+        unsigned long long* keys = l_keys;
+        if (s_ns > 0 && !cap_err) {
+          TPH(2)
+          // walk 2: exact counts for the members of S, and their (pos, win) tuples
+          for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            if (p < npos) {
+              uint32_t h = 0;
+              for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp[t] <= p) h = t; }
+              const uint2 pa = ix.pos_arr[hits[h].x + (p - hp[h])];
+              uint32_t sl = (pa.y * 0x9E3779B1u >> 7) & s_mask;
+              for (;;) {
+                const uint32_t o = skey[sl];
+                if (o == pa.y + 1) {
+                  atomicAdd(&scnt[sl], 1u);
+                  const uint32_t t = atomicAdd(&s_nt, 1u);
+                  if (t < pairs_cap) gt[t] = ((unsigned long long)pa.x << 32) | ((unsigned long long)sl << 16) | hits[h].y;
+                  break;
+                }
+                if (o == 0) break;
+                sl = (sl + 1) & s_mask;
+              }
             }
           }
-        }
-        __threadfence_block();
-        __syncthreads();
-        uint32_t ncand = s_ncand;
-        if (ncand > keys_cap) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); ncand = 0; cap_err = true; }
-        unsigned long long* keys = ncand <= CH_KEYS_LDS ? l_keys : gk;
-        // key = (~count, ref): ascending order == count desc, ref asc (:134-148)
-        for (uint32_t c = lane; c < ncand; c += 64) {
-          uint32_t ref = (uint32_t)gk[c];
-          uint32_t count = __hip_atomic_load(&cnt[ref], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          keys[c] = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | ref;
-        }
-        __syncthreads();
-        // clear the counters (walk again)
-        for (uint32_t hb = 0; hb < nh; hb += 64) {
-          uint32_t h = hb + lane;
-          uint32_t lo = 0, hi = 0;
-          if (h < nh) { uint32_t id = hits[h].x; lo = ix.pos_off[id]; hi = ix.pos_off[id + 1]; }
-          bool lng = (hi - lo) > 32;
-          if (!lng) for (uint32_t k = lo; k < hi; k++) cnt[ix.pos_arr[k].y] = 0;
-          unsigned long long lm = __ballot(lng);
-          while (lm) {
-            int src = __ffsll((long long)lm) - 1; lm &= lm - 1;
-            uint32_t llo = __shfl(lo, src, 64), lhi = __shfl(hi, src, 64);
-            for (uint32_t k = llo + lane; k < lhi; k += 64) cnt[ix.pos_arr[k].y] = 0;
+          __threadfence_block();
+          __syncthreads();
+          if (s_nt > pairs_cap) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
+          // candidates: members of S with count >= num_seeds; key = (~count, ref): ascending == count desc, ref asc (:134-148)
+          for (uint32_t q0 = 0; q0 < s_cap; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            ncand += (uint32_t)__popcll(__ballot(skey[q] != 0 && scnt[q] >= (uint32_t)P.num_seeds));
           }
+          if (ncand > keys_cap) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); ncand = 0; cap_err = true; }
+          keys = ncand <= CH_KEYS_LDS ? l_keys : gk;
+          if (!cap_err) for (uint32_t q0 = 0; q0 < s_cap; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            if (skey[q] != 0 && scnt[q] >= (uint32_t)P.num_seeds) {
+              const uint32_t c = atomicAdd(&s_ncand, 1u);
+              keys[c] = ((unsigned long long)(0xFFFFFFFFu - scnt[q]) << 32) | (skey[q] - 1);
+            }
+          }
+          __syncthreads();
+          if (ncand > 1) wave_sort_u64(keys, ncand);
+          __syncthreads();
         }
-        __syncthreads();
-        if (ncand > 1) wave_sort_u64(keys, ncand);
-        __syncthreads();
+        TPH(3)
+        const uint32_t ntup = min(s_nt, pairs_cap);
 
         // 2. candidate loop (:150-508)
         int is_aligned = 0;
@@ -269,30 +344,27 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
             --w.best;
             if (w.best < 1) break;
           }
-          // 3. hits on this reference (:181-201): each lane binary-searches one hit's (seq-sorted) position list
+          // 3. hits on this reference (:181-201): the tuples recorded for its slot in S
+          uint32_t cslot = (max_ref * 0x9E3779B1u >> 7) & s_mask;
+          while (skey[cslot] != max_ref + 1) cslot = (cslot + 1) & s_mask;
           uint32_t np = 0;
-          for (int phase = 0; phase < 2; phase++) {
-            // phase 0 counts, phase 1 writes at deterministic offsets
+          for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            np += (uint32_t)__popcll(__ballot(t < ntup && (uint32_t)((gt[t] >> 16) & 0xFFFFu) == cslot));
+          }
+          if (np > pairs_cap && np > CH_PAIRS_LDS) cap_err = true;
+          if (!cap_err) {
+            unsigned long long* pw_ = np <= CH_PAIRS_LDS ? l_pairs : gp;
             uint32_t run = 0;
-            unsigned long long* pairs = np <= CH_PAIRS_LDS ? l_pairs : gp;
-            for (uint32_t hb = 0; hb < nh; hb += 64) {
-              uint32_t h = hb + lane;
-              uint32_t first = 0, cntm = 0, win = 0;
-              if (h < nh) {
-                uint32_t id = hits[h].x; win = hits[h].y;
-                uint32_t lo = ix.pos_off[id], hi = ix.pos_off[id + 1];
-                uint32_t a = lo, b = hi;
-                while (a < b) { uint32_t mid = (a + b) >> 1; if (ix.pos_arr[mid].y < max_ref) a = mid + 1; else b = mid; }
-                first = a;
-                uint32_t c2 = a, d2 = hi;
-                while (c2 < d2) { uint32_t mid = (c2 + d2) >> 1; if (ix.pos_arr[mid].y <= max_ref) c2 = mid + 1; else d2 = mid; }
-                cntm = c2 - a;
-              }
-              uint32_t tot; uint32_t ex = wave_excl_scan_u32(cntm, tot);
-              if (phase == 1) for (uint32_t q = 0; q < cntm; q++) pairs[run + ex + q] = ((unsigned long long)ix.pos_arr[first + q].x << 32) | win;
-              run += tot;
+            for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
+              const uint32_t t = t0 + lane;
+              unsigned long long tv = 0;
+              bool mt = false;
+              if (t < ntup) { tv = gt[t]; mt = (uint32_t)((tv >> 16) & 0xFFFFu) == cslot; }
+              const unsigned long long mm = __ballot(mt);
+              if (mt) pw_[run + (uint32_t)__popcll(mm & ((1ull << lane) - 1))] = (tv & 0xFFFFFFFF00000000ull) | (tv & 0xFFFFull);
+              run += (uint32_t)__popcll(mm);
             }
-            if (phase == 0) { np = run; if (np > pairs_cap && np > CH_PAIRS_LDS) { cap_err = true; break; } }
           }
           if (cap_err) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); break; }
           unsigned long long* pairs = np <= CH_PAIRS_LDS ? l_pairs : gp;
@@ -301,6 +373,7 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
           __syncthreads();
           if (np > 1) wave_sort_u64(pairs, np);
           __syncthreads();
+          TPH(4)
           // 4. sliding window of read length along the reference (:203-506)
           uint32_t it = 0, ms_lo = 0, ms_hi = 0;
           uint32_t begin_ref = (uint32_t)(pairs[0] >> 32), begin_read = (uint32_t)pairs[0];
@@ -356,7 +429,9 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
                   for (int q = lane; q < m; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, (uint32_t)align_que_start + q, w.reversed, w.aval);
                   for (int q = lane; q < nref; q += 64) rfq[q] = ix.ref_seq[rf_start + q];
                   __syncthreads();
+                  TPH(5)
                   fw = sw_wave(rdq, m, 0, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
+                  TPH(6)
                   n_fwd++; n_cells += (unsigned long long)m * nref;
                 }
                 int score1 = fw.score > 65535 ? 65535 : fw.score;
@@ -364,10 +439,12 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
                 const int ref_end1 = fw.end_ref, read_end1 = fw.end_read;
                 if (sw_ok && (uint32_t)score1 >= (P.minimal_score & 0xFFFFu)) {   // ssw_align: flag==2 && score1 < filters -> no begin
                   // reverse pass (ssw.c:900-918) on the prefixes ending at (read_end1, ref_end1)
+                  TPH(5)
                   SwRes bw = sw_wave(rdq, read_end1 + 1, read_end1, -1, rfq, ref_end1 + 1, ref_end1, -1, bound,
                                      P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
                   ref_begin1 = ref_end1 - bw.end_ref;
                   read_begin1 = read_end1 - bw.end_read;
+                  TPH(6)
                   n_rev++; n_cells += (unsigned long long)(read_end1 + 1) * (ref_end1 + 1);
                 }
                 is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
@@ -434,6 +511,7 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
         }
       }
     }
+    TPH(5)
     // ---------------- pass control (paralleltraversal.cpp:253-277) ----------------
     uint32_t pass_n = w.pass_n;
     if (search) {
@@ -459,6 +537,9 @@ __global__ void __launch_bounds__(64) k_chain(DReads rd, DIndex ix, DParams P, i
     if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
     if (n_rev) ctr_add(ctr, C_SW_REV, n_rev);
     if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
+#ifdef SMR_CHAIN_PHASES
+    for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
+#endif
   }
 }
 

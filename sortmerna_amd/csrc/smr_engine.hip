@@ -61,7 +61,7 @@ struct smr_ctx {
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t chain_blocks = 0;
-  uint32_t* d_cnt = nullptr; uint32_t cnt_refs = 0;
+  unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
@@ -133,15 +133,15 @@ DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off =
 
 int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
   if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * 12;    // 3 waves per SIMD (134 VGPRs)
-  uint32_t need_keys = std::max(pow2ceil(di.n_refs), 1024u);
-  if (c->cnt_refs < di.n_refs) {
-    int rc = dev_alloc(c, &c->d_cnt, (size_t)c->chain_blocks * di.n_refs); if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, (size_t)c->chain_blocks * di.n_refs * 4, c->stream));
-    c->cnt_refs = di.n_refs;
-  }
+  (void)di;
+  uint32_t need_keys = std::max(c->chain_scap, 1024u);
   if (c->keys_cap < need_keys) { int rc = dev_alloc(c, &c->d_keys, (size_t)c->chain_blocks * need_keys); if (rc) return rc; c->keys_cap = need_keys; }
   if (c->pairs_cap == 0) c->pairs_cap = 4096;
-  if (!c->d_pairs) { int rc = dev_alloc(c, &c->d_pairs, (size_t)c->chain_blocks * c->pairs_cap); if (rc) return rc; rc = dev_alloc(c, &c->d_lis, (size_t)c->chain_blocks * 2 * c->pairs_cap); if (rc) return rc; }
+  if (!c->d_pairs) {
+    int rc = dev_alloc(c, &c->d_pairs, (size_t)c->chain_blocks * c->pairs_cap); if (rc) return rc;
+    rc = dev_alloc(c, &c->d_lis, (size_t)c->chain_blocks * 2 * c->pairs_cap); if (rc) return rc;
+    rc = dev_alloc(c, &c->d_tuples, (size_t)c->chain_blocks * c->pairs_cap); if (rc) return rc;
+  }
   if (c->hits_cap == 0) c->hits_cap = 4096;
   if (!c->d_hits) { int rc = dev_alloc(c, &c->d_hits, (size_t)c->chain_blocks * c->hits_cap); if (rc) return rc; }
   return SMR_OK;
@@ -225,7 +225,8 @@ void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, s
   uint32_t edges = P.is_as_percent ? (uint32_t)((P.edges / 100.0) * c->b->max_len) + 1 : (uint32_t)std::max(P.edges, 0);
   ml = (c->b->max_len + 15) & ~15u;
   rf = (c->b->max_len + 2 * edges + 16 + 15) & ~15u;
-  bytes = (size_t)ml + rf + (size_t)2 * rf * 4 + (size_t)CH_KEYS_LDS * 8 + (size_t)CH_PAIRS_LDS * 8 + (size_t)2 * CH_PAIRS_LDS * 4 + (size_t)CH_HITS_LDS * 8;
+  bytes = (size_t)ml + rf + (size_t)2 * rf * 4 + (size_t)CH_KEYS_LDS * 8 + (size_t)std::max<uint32_t>(4u * CH_PAIRS_LDS, 2u * c->chain_scap) * 4 +
+          (size_t)CH_HITS_LDS * 8 + (size_t)(CH_HITS_LDS + 8) * 4 + (size_t)c->chain_scap * 4;
 }
 
 int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int is_last_strand) {
@@ -235,7 +236,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
   ev_begin(c, 1);
   hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
-                     c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_cnt, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf);
+                     c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap);
   ev_end(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
@@ -302,7 +303,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   }
   dev_free(&c->sb.hist); dev_free(&c->sb.bin_off); dev_free(&c->sb.tmp);
   dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
-  dev_free(&c->d_pool); dev_free(&c->d_cnt); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
+  dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_dir); dev_free(&c->d_hbuf); dev_free(&c->d_cig);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -416,6 +417,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     std::vector<unsigned long long> init = snap;
     init[C_NUM_SHORT] = 0;
     for (int k = C_ERR_HITCAP; k <= C_ERR_TRACE; k++) init[k] = 0;
+    init[C_ERR_SCAP] = 0;
     init[C_POOL_CURSOR] = 0; init[C_WORK_NEXT] = 0;
     for (int q = 0; q < C_NSHARD; q++) init[C_PCUR + q] = 0;
     HIPCHK(c, hipMemcpyAsync(c->b->d_ctr, init.data(), C_TOTAL * 8, hipMemcpyHostToDevice, c->stream));
@@ -437,11 +439,13 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0x7FFFFFF0ull) { c->err = "seed-hit pool exceeds 8 GiB"; return SMR_ERR_CAPACITY; }
       if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (h[C_ERR_PAIRS]) {
-      c->pairs_cap *= 4; c->hits_cap *= 4; dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
+      c->pairs_cap *= 4; c->hits_cap *= 4; dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits); dev_free(&c->d_tuples);
       if (c->pairs_cap > (1u << 22)) { c->err = "per-read candidate scratch exceeds capacity"; return SMR_ERR_CAPACITY; }
-      // the failed attempt may have left non-zero counters in the histogram scratch
-      HIPCHK(c, hipMemsetAsync(c->d_cnt, 0, (size_t)c->chain_blocks * c->cnt_refs * 4, c->stream));
       retry = true;
+    }
+    if (h[C_ERR_SCAP]) {
+      c->chain_scap *= 4; retry = true;
+      if (c->chain_scap > 4096) { c->err = "more than 3072 references share seeds with one read (candidate set capacity)"; return SMR_ERR_CAPACITY; }
     }
     if (h[C_ERR_SLOTS]) { c->err = "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"; return SMR_ERR_CAPACITY; }
     if (retry) { c->seed_ms = t_seed0; c->chain_ms = t_chain0; c->seed_l = l_seed0; c->chain_l = l_chain0; }   // timings of a discarded attempt
@@ -687,6 +691,12 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
     if (!c->bt[k].d_ctr) continue;
     HIPCHK(c, hipMemcpyAsync(t.data(), c->bt[k].d_ctr, C_TOTAL * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (getenv("SMR_DEBUG_PHASES")) {
+      unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int s2 = 0; s2 < C_NSHARD; s2++) for (int q = 0; q < 7; q++) ph[q] += t[C_SHARDS + 16 * s2 + 9 + q];
+      fprintf(stderr, "[smr] k_chain phase cycles (batch %d): other/claim %llu gather+prefix %llu walk1 %llu walk2+cands %llu pairs+sort %llu window/lis/book %llu sw %llu\n",
+              k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+    }
     fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
