@@ -31,6 +31,7 @@ def build_library(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
+    cmd += os.environ.get("SMR_EXTRA_HIPCC_FLAGS", "").split()          # e.g. -DSMR_CHAIN_PHASES (debug instrumentation)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread"]
     if verbose:
         print(" ".join(cmd))

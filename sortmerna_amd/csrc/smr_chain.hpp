@@ -61,7 +61,9 @@ __device__ __forceinline__ int dpp_shr1(int inject_lane0, int v) {
   return __builtin_amdgcn_update_dpp(inject_lane0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
 
-template <int R>
+// PACKED: scores fit 14 bits and columns 16 bits -> the per-lane running maximum is one v_max_u32 over
+// (h << 18 | (0xFFFF - col) << 2 | (3 - r)) per cell (max h, then first column, then smallest row), merged per strip.
+template <int R, bool PACKED>
 __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                            int* bound, int match, int mismatch, int scoreN, int go, int ge) {
   const int lane = lane_id();
@@ -70,9 +72,19 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
   const int nstrips = (m + rps - 1) / rps;
   for (int s = 0; s < nstrips; s++) {
     const int row0 = s * rps + lane * R;
-    int rnt[R], H[R], E[R];
+    // per row: its score against reference nucleotides 0..3 as 4 signed bytes (N in the reference is handled per step)
+    int H[R], E[R];
+    uint32_t sct[R];
+    bool vr[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { rnt[r] = (row0 + r < m) ? rdq[rd0 + rdstep * (row0 + r)] : 5; H[r] = 0; E[r] = 0; }   // 5 = row beyond the read
+    for (int r = 0; r < R; r++) {
+      vr[r] = row0 + r < m;
+      const int c = vr[r] ? rdq[rd0 + rdstep * (row0 + r)] : 4;
+      uint32_t t = 0;
+      for (int b = 0; b < 4; b++) t |= (uint32_t)((c == 4 ? scoreN : (c == b ? match : mismatch)) & 0xFF) << (8 * b);
+      sct[r] = t; H[r] = 0; E[r] = 0;
+    }
+    uint32_t bkey = 0;
     int lastH = 0, lastF = 0, Hdiag0 = 0, fnt = 4;
     const bool has_prev = s > 0, has_next = s + 1 < nstrips;
     int inH = has_prev ? bound[0] : 0, inF = has_prev ? bound[1] : 0, cin = n > 0 ? rfq[rf0] : 4;
@@ -87,24 +99,31 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
       fnt = dpp_shr1(cc, fnt);
       const int col = t - lane;
       const bool colok = col >= 0 && col < n;
-      int diag = Hdiag0, uh = upH, uf = upF, fl = 0;
+      const bool refN = fnt == 4;
+      const int sh = (fnt & 3) * 8;
+      const uint32_t colkey = (uint32_t)(0xFFFF - col) << 2;
+      int diag = Hdiag0, uh = upH, uf = upF;
 #pragma unroll
       for (int r = 0; r < R; r++) {
-        const int sc = (fnt == 4 || rnt[r] == 4) ? scoreN : (fnt == rnt[r] ? match : mismatch);
-        int e = max(E[r] - ge, H[r] - go);
-        int f = max(uf - ge, uh - go);
-        int h = max(max(diag + sc, e), max(f, 0));
-        e = max(e, 0); f = max(f, 0);
+        const int sc = refN ? scoreN : (int)__builtin_amdgcn_sbfe(sct[r], sh, 8);
+        const int e = max(E[r] - ge, H[r] - go);
+        const int f = max(uf - ge, uh - go);
+        const int h = max(max(diag + sc, e), max(f, 0));
         diag = H[r];                                         // H(row, col-1) is the diagonal of the next row
-        if (colok && rnt[r] != 5) {
+        if (colok && vr[r]) {
           H[r] = h; E[r] = e;
-          if (h > bestH || (h == bestH && h > 0 && col < bestcol)) { bestH = h; bestcol = col; bestrow = row0 + r; }
+          if (PACKED) bkey = max(bkey, ((uint32_t)h << 18) | colkey | (uint32_t)(3 - r));
+          else if (h > bestH || (h == bestH && h > 0 && col < bestcol)) { bestH = h; bestcol = col; bestrow = row0 + r; }
         }
-        uh = h; uf = f; fl = f;
+        uh = h; uf = f;
       }
       Hdiag0 = col >= 0 ? upH : 0;                           // H(row0-1, col): diagonal of row0 at the next column
-      if (colok) { lastH = H[R - 1]; lastF = fl; }
+      if (colok) { lastH = H[R - 1]; lastF = uf; }
       if (has_next && lane == 63 && colok) { bound[2 * col] = lastH; bound[2 * col + 1] = lastF; }
+    }
+    if (PACKED) {
+      const int h = (int)(bkey >> 18), col = 0xFFFF - (int)((bkey >> 2) & 0xFFFF), row = row0 + 3 - (int)(bkey & 3);
+      if (h > bestH || (h == bestH && h > 0 && col < bestcol)) { bestH = h; bestcol = col; bestrow = row; }
     }
     __syncthreads();
   }
@@ -122,10 +141,16 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
 
 __device__ __noinline__ SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                          int* bound, int match, int mismatch, int scoreN, int go, int ge) {
-  if (m <= 64) return sw_wave_r<1>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
-  if (m <= 128) return sw_wave_r<2>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
-  if (m <= 192) return sw_wave_r<3>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
-  return sw_wave_r<4>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  const bool small = (long long)m * match < 16384 && n < 65535 && match < 128 && mismatch > -128 && scoreN > -128 && scoreN < 128;
+#define SW_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge
+  if (small) {
+    if (m <= 64) return sw_wave_r<1, true>(SW_ARGS);
+    if (m <= 128) return sw_wave_r<2, true>(SW_ARGS);
+    if (m <= 192) return sw_wave_r<3, true>(SW_ARGS);
+    return sw_wave_r<4, true>(SW_ARGS);
+  }
+  return sw_wave_r<4, false>(SW_ARGS);
+#undef SW_ARGS
 }
 
 // per-block (= per persistent wave slot) scratch in global memory

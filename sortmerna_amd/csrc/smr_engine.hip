@@ -115,6 +115,8 @@ int check_params(smr_ctx* c, const smr_params* p) {
   if (!p) { c->err = "null params"; return SMR_ERR_ARG; }
   if (p->index_num >= 64) { c->err = "index_num must be < 64"; return SMR_ERR_ARG; }
   if (p->num_seeds < 1 || p->gap_open < 0 || p->gap_ext < 0 || p->match <= 0 || p->mismatch > 0) { c->err = "bad scoring/seed options"; return SMR_ERR_ARG; }
+  // the reference's scoring matrix is int8_t (ssw_init, ssw.h:88); the SW kernel keeps a row's scores as 4 signed bytes
+  if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { c->err = "scores must fit int8 / gaps uint8 like the reference's"; return SMR_ERR_ARG; }
   // The reference's striped kernels never open a gap in one sequence directly after a gap in the other when the
   // second gap would cross a SIMD stripe (ssw.c:267,496).  Under 2*gap_open >= |mismatch| and 2*gap_ext >= |mismatch|
   // such paths are never optimal and the standard affine recurrence computed here is cell-for-cell identical.
