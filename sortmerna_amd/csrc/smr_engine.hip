@@ -57,7 +57,7 @@ struct smr_ctx {
   Batch* b = &bt[0];
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
-  uint32_t hcap = 16;
+  uint32_t hcap = 8;
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t chain_blocks = 0;
@@ -696,8 +696,8 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
     if (getenv("SMR_DEBUG_PHASES")) {
       unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
       for (int s2 = 0; s2 < C_NSHARD; s2++) for (int q = 0; q < 7; q++) ph[q] += t[C_SHARDS + 16 * s2 + 9 + q];
-      fprintf(stderr, "[smr] k_chain phase cycles (batch %d): other/claim %llu gather+prefix %llu walk1 %llu walk2+cands %llu pairs+sort %llu window/lis/book %llu sw %llu\n",
-              k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+      fprintf(stderr, "[smr] phase cycles (batch %d): %llu %llu %llu %llu %llu %llu %llu  (-DSMR_CHAIN_PHASES: claim, gather+prefix, walk1, walk2+cands, pairs+sort, "
+              "window/lis/book, sw; -DSMR_SEED_PHASES: setup, node walk, flatten, stage A, stage B, output, -)\n", k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
     }
     fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];

@@ -92,12 +92,12 @@ __device__ __forceinline__ uint32_t lev_next(unsigned long long row, uint32_t st
 //   PLAIN   1-error hit: appended unless the id is already present
 // ------------------------------------------------------------------------------------------------
 #define SEED_STK 10                                    // trie depth < partialwin - 1 <= 9
-#define SEED_OWN_CAP 4096u                             // entries of one round that get a direct entry -> bucket byte map
+#define SEED_OWN_CAP 2048u                             // entries of one round that get a direct entry -> bucket byte map
 #define SEED_MAXPW 10u
 #define SEED_K 4                                       // buckets a lane may collect per round
-#define SEED_GATHER 48u                                // ... or until it holds this many entries
+#define SEED_GATHER 32u                                // ... or until it holds this many entries
 // dynamic LDS words of k_seed_search: hit lists, node stacks (offsets + level state), row-index table, pref/pb/nat, FIFO, owner map
-#define SEED_LDS_WORDS(hcap) (64u * (hcap) + 2u * SEED_STK * 64u + (SEED_MAXPW + 1u) * 64u + 3u * 64u * SEED_K + 3u * 128u + SEED_OWN_CAP / 4u)
+#define SEED_LDS_WORDS(hcap) (64u * (hcap) + SEED_STK * 64u + (SEED_MAXPW + 1u) * 64u + 2u * 64u * SEED_K + 3u * 128u + SEED_OWN_CAP / 4u)
 #define SEED_ZERO_BIT 0x80000000u
 
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
@@ -250,12 +250,10 @@ struct SeedLane {           // per-lane search result
 // LDS of one search wave (32-bit words unless noted)
 struct SeedLds {
   uint32_t* hl;        // [hcap][64]   lane-local hit lists (ids), element k of lane l at k*64+l
-  uint32_t* stk;       // [SEED_STK][64] node offsets of the DFS stack
-  uint32_t* lvl;       // [SEED_STK][64] per level: pending-element mask (4 bits) | the 4 elements' states << 4
+  uint32_t* stk;       // [SEED_STK][64] DFS stack: node offset | pending-element mask << 22 | state the node was entered with << 26
   uint32_t* rt;        // [SEED_MAXPW+1][64] per depth: the 4 LEV row indices (5 bits each) of the lane's window
   uint32_t* pref;      // [64*SEED_K]  first flattened entry of bucket (lane*K+slot) in this round
   uint32_t* pb;        // [64*SEED_K]  bucket offset | depth << 22 | state << 26
-  uint32_t* nat;       // [64*SEED_K]  nodes visited when the bucket was reached << 8 | entries
   uint32_t* sq;        // [3][128]     survivor FIFO: id, remaining tail, (bucket | state<<8 | depth<<12 | q<<16)
   uint8_t* own;        // [SEED_OWN_CAP] flattened entry -> bucket (lane*K+slot)
 };
@@ -281,8 +279,17 @@ __device__ __forceinline__ uint32_t node_states(const uint4 nd, uint32_t rtw, ui
 // entries -- most of them --, the survivors are compacted through a FIFO in LDS and stage B finishes them 64 at a
 // time; (3) accepted entries go back to the owning lane in entry order.  Work counters follow the reference's
 // sequential scan: nothing after a 0-error match is counted.
+#ifdef SMR_SEED_PHASES                                    // per-phase cycle accounting (debug build, SMR_DEBUG_PHASES=1)
+#define SPH(i) { const unsigned long long tn_ = clock64(); sph[i] += tn_ - slast; slast = tn_; }
+#else
+#define SPH(i)
+#endif
 __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ trie, bool mine, uint32_t chars, uint32_t pw, bool full,
-                                                 const unsigned long long* s_row, const SeedLds L, uint32_t hcap, SeedLane& out) {
+                                                 const unsigned long long* s_row, const SeedLds L, uint32_t hcap, SeedLane& out
+#ifdef SMR_SEED_PHASES
+                                                 , unsigned long long* sph, unsigned long long& slast
+#endif
+                                                 ) {
   const int lane = lane_id();
   uint32_t nh = out.nh;
   bool zero = false, overflow = false;
@@ -300,13 +307,20 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
     sp = 0; L.stk[lane] = 0; cur = *reinterpret_cast<const uint4*>(trie); n_node = 1;
     st = node_states(cur, L.rt[lane], 0, s_row);
   }
+  SPH(0)
   for (;;) {
     // ---------- (1) node walk: collect this lane's next buckets ----------
     uint32_t nb = 0, my_total = 0;
+    uint32_t nent_pk = 0, nnode_pk = 0;                    // per collected bucket: entries / nodes visited so far in this round (8 bits each)
+    const uint32_t n_node0 = n_node;
     while (sp >= 0 && nb < SEED_K && my_total < SEED_GATHER) {
-      if ((st & 15u) == 0) {                               // node exhausted: back to the parent
+      if ((st & 15u) == 0) {                               // node exhausted: back to the parent (its element states are recomputed)
         sp--;
-        if (sp >= 0) { cur = *reinterpret_cast<const uint4*>(trie + L.stk[sp * 64 + lane]); st = L.lvl[sp * 64 + lane]; }
+        if (sp >= 0) {
+          const uint32_t sw = L.stk[sp * 64 + lane];
+          cur = *reinterpret_cast<const uint4*>(trie + (sw & ELEM_OFF_MASK));
+          st = (node_states(cur, L.rt[sp * 64 + lane], sw >> 26, s_row) & ~15u) | ((sw >> 22) & 15u);
+        }
         continue;
       }
       const uint32_t ne = (uint32_t)__ffs((int)(st & 15u)) - 1;
@@ -314,19 +328,20 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
       const uint32_t e = ne == 0 ? cur.x : (ne == 1 ? cur.y : (ne == 2 ? cur.z : cur.w));
       const uint32_t lev_t = (st >> (4 + 4 * ne)) & 15u;
       if ((e >> ELEM_FLAG_SHIFT) == 1) {                    // child node
-        L.lvl[sp * 64 + lane] = st;
+        L.stk[sp * 64 + lane] = (L.stk[sp * 64 + lane] & ~(15u << 22)) | ((st & 15u) << 22);
         sp++;
-        L.stk[sp * 64 + lane] = e & ELEM_OFF_MASK;
+        L.stk[sp * 64 + lane] = (e & ELEM_OFF_MASK) | (lev_t << 26);
         cur = *reinterpret_cast<const uint4*>(trie + (e & ELEM_OFF_MASK)); n_node++;
         st = node_states(cur, L.rt[sp * 64 + lane], lev_t, s_row);
         continue;
       }
       const uint32_t nent = (e >> ELEM_NENT_SHIFT) & 0xFFu;
       L.pb[lane * SEED_K + nb] = (e & ELEM_OFF_MASK) | ((uint32_t)sp << 22) | (lev_t << 26);
-      L.nat[lane * SEED_K + nb] = (n_node << 8) | nent;
       L.pref[lane * SEED_K + nb] = my_total;                 // lane-relative for now
+      nent_pk |= nent << (8 * nb); nnode_pk |= min(n_node - n_node0, 255u) << (8 * nb);
       my_total += nent; nb++;
     }
+    SPH(1)
     if (!__any(nb > 0)) break;
     // ---------- (2) flatten: lane-major prefix, entry -> bucket map ----------
     uint32_t incl = my_total;
@@ -337,31 +352,41 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
     const bool direct = T <= SEED_OWN_CAP;
     if (direct) {
       for (uint32_t k = 0; k < nb; k++) {
-        const uint32_t f = L.pref[lane * SEED_K + k], c = L.nat[lane * SEED_K + k] & 0xFFu;
+        const uint32_t f = L.pref[lane * SEED_K + k], c = (nent_pk >> (8 * k)) & 0xFFu;
         for (uint32_t q = 0; q < c; q++) L.own[f + q] = (uint8_t)(lane * SEED_K + k);
       }
     }
     __syncthreads();
+    SPH(2)
     bool zero_round = false;                               // a 0-error match was found in this round (owner lane)
     uint32_t qn = 0;                                       // survivors waiting in the FIFO (wave-uniform)
+    // stage A's inputs (owner map, bucket descriptor, the entry itself) are fetched one chunk ahead
+    uint32_t f_bk = 0, f_q = 0, f_pbv = 0, f_str = 0, f_id = 0;
+    auto fetch = [&](uint32_t base) {
+      const uint32_t e = base + lane;
+      const bool v = e < T;
+      uint32_t bk = 0;
+      if (v) {
+        if (direct) bk = L.own[e];
+        else for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t t = bk + step; if (t < 64 * SEED_K && L.pref[t] <= e) bk = t; }
+      }
+      f_bk = bk; f_q = e - L.pref[bk]; f_pbv = L.pb[bk];
+      // (shuffle outside the branch: a bpermute reads 0 from lanes that are masked off)
+      const uint32_t* otrie = reinterpret_cast<const uint32_t*>(__shfl((unsigned long long)trie, bk / SEED_K, 64));
+      f_str = 0; f_id = 0;
+      if (v) { const uint2 en = *reinterpret_cast<const uint2*>(otrie + (f_pbv & ELEM_OFF_MASK) + 2 * f_q); f_str = en.x; f_id = en.y; }
+    };
+    if (T > 0) fetch(0);
     for (uint32_t base = 0; base < T || qn > 0; base += 64) {
       // ----- stage A: up to 2 automaton steps at non-accepting depths for 64 fresh entries -----
       if (base < T) {
-        const uint32_t e = base + lane;
-        const bool v = e < T;
-        uint32_t bk = 0;
-        if (v) {
-          if (direct) bk = L.own[e];
-          else for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t t = bk + step; if (t < 64 * SEED_K && L.pref[t] <= e) bk = t; }
-        }
-        const uint32_t q = e - L.pref[bk];
-        const uint32_t pbv = L.pb[bk];
+        const bool v = base + lane < T;
+        const uint32_t bk = f_bk, q = f_q, pbv = f_pbv;
+        uint32_t str = f_str;
+        const uint32_t id = f_id;
+        if (base + 64 < T) fetch(base + 64);
         uint32_t db = ((pbv >> 22) & 15u) + 1, lv = pbv >> 26;
         const uint32_t olane = bk / SEED_K;
-        uint32_t str = 0, id = 0;
-        // (shuffle outside the branch: a bpermute reads 0 from lanes that are masked off)
-        const uint32_t* otrie = reinterpret_cast<const uint32_t*>(__shfl((unsigned long long)trie, olane, 64));
-        if (v) { const uint2 en = *reinterpret_cast<const uint2*>(otrie + (pbv & ELEM_OFF_MASK) + 2 * q); str = en.x; id = en.y; }
         bool alive = v;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
@@ -378,6 +403,7 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
         }
         qn += (uint32_t)__popcll(am);
         __syncthreads();
+        SPH(3)
       }
       // ----- stage B: finish 64 survivors (or the rest at the end of the round) -----
       if (qn >= 64 || (base + 64 >= T && qn > 0)) {
@@ -420,9 +446,9 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
               L.hl[lane] = idc; nh = 1; zero = true; zero_round = true;
               // the reference stops at the 0-error entry: count the buckets before it, this one up to the entry, no later node
               const uint32_t zs = bc % SEED_K;
-              for (uint32_t k = 0; k < zs; k++) n_entry += L.nat[lane * SEED_K + k] & 0xFFu;
+              for (uint32_t k = 0; k < zs; k++) n_entry += (nent_pk >> (8 * k)) & 0xFFu;
               n_entry += qc + 1;
-              n_node = L.nat[lane * SEED_K + zs] >> 8;
+              n_node = n_node0 + ((nnode_pk >> (8 * zs)) & 0xFFu);
             } else if (!present) {
               if (nh < hcap) { L.hl[nh * 64 + lane] = idc; nh++; } else overflow = true;
             }
@@ -432,6 +458,7 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
         if (mv) { L.sq[lane] = mv_id; L.sq[128 + lane] = mv_str; L.sq[256 + lane] = mv_meta; }
         qn -= cnt;
         __syncthreads();
+        SPH(4)
       }
     }
     if (!zero_round) n_entry += my_total;
@@ -450,12 +477,10 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   SeedLds L;
   L.hl = lds_dyn;
   L.stk = L.hl + 64 * hcap;
-  L.lvl = L.stk + SEED_STK * 64;
-  L.rt = L.lvl + SEED_STK * 64;
+  L.rt = L.stk + SEED_STK * 64;
   L.pref = L.rt + (SEED_MAXPW + 1) * 64;
   L.pb = L.pref + 64 * SEED_K;
-  L.nat = L.pb + 64 * SEED_K;
-  L.sq = L.nat + 64 * SEED_K;
+  L.sq = L.pb + 64 * SEED_K;
   L.own = reinterpret_cast<uint8_t*>(L.sq + 3 * 128);
   uint32_t* hl = L.hl;
   __shared__ unsigned long long s_row[LEV_ROWS];
@@ -485,7 +510,12 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     }
   }
   __syncthreads();
+#ifdef SMR_SEED_PHASES
+  unsigned long long sph[6] = {0, 0, 0, 0, 0, 0}, slast = clock64();
+  seed_search_wave(trie, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl, sph, slast);
+#else
   seed_search_wave(trie, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
+#endif
   // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
   const bool wr = mine && (DIR == 0 ? sl.nh > 0 : (sl.zero || sl.nh > n_prev));
   const uint32_t need = wr ? 2 + 2 * sl.nh : 0;
@@ -514,6 +544,10 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
     if (lane == 0 && x) ctr_add(ctr, C_NODE + c, x);
   }
+#ifdef SMR_SEED_PHASES
+  SPH(5)
+  if (lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], sph[q]);
+#endif
 }
 
 // per read: copy the hit segments of this pass's windows into ONE contiguous block (k_chain then reads a strand's
