@@ -132,6 +132,47 @@ def main():
         G[name] = run_case(name, [db], [reads], len(seqs), extra, tmp, with_reports=(name in ("syn_default", "syn_all")))
         G[name]["params"] = params
         print(name, "aligned", G[name]["log"].get("num_aligned"), "records", G[name]["n_records"], "parts", G[name]["index_parts"])
+    # ---- real data: a slice of the bundled silva-arc-16s-id95 DB (IUPAC letters, long headers) and set4 reads that hit it ----
+    real_db = os.path.join(HERE, "real_db.fasta")
+    src_db = os.path.join(paths.REF_DATA, "rRNA_databases", "silva-arc-16s-id95.fasta")
+    with open(src_db) as f, open(real_db, "w") as g:
+        nseq = 0
+        for line in f:
+            if line.startswith(">"):
+                nseq += 1
+                if nseq > 48:
+                    break
+            g.write(line)
+    from helpers import fastx
+    allr = fastx.read_fastx(os.path.join(paths.REF_DATA, "set4_mate_pairs_metatranscriptomics_1.fastq"))
+    tmp_reads = os.path.join(tmp, "set4_all.fasta")
+    with open(tmp_reads, "w") as f:
+        for i, (h, sq, _) in enumerate(allr):
+            f.write(">q%d\n%s\n" % (i, sq))
+    res = refrun.run_reference([real_db], [tmp_reads], os.path.join(tmp, "real_pick"), extra=["-v"], threads=1)
+    assert res.rc == 0, res.stdout[-1500:]
+    hit = [i for i in range(len(allr)) if res.kvdb.get(b"0_%d" % i)]
+    miss = [i for i in range(len(allr)) if not res.kvdb.get(b"0_%d" % i)]
+    pick = sorted(hit[:260] + miss[:90])
+    real_reads = os.path.join(HERE, "real_reads.fasta")
+    with open(real_reads, "w") as f:
+        for i in pick:
+            f.write(">%s\n%s\n" % (allr[i][0][1:].split()[0], allr[i][1]))
+    for name, extra, params in (("real_default", [], {}), ("real_all", ["-num_alignments", "0"], {"num_alignments": 0})):
+        G[name] = run_case(name, [real_db], [real_reads], len(pick), extra, tmp, with_reports=(name == "real_default"))
+        G[name]["params"] = params
+        print(name, "aligned", G[name]["log"].get("num_aligned"), "records", G[name]["n_records"])
+    # ---- two reference DBs in one run (index_num 0 and 1; per-read state carried across indexes) ----
+    both = os.path.join(tmp, "both_reads.fasta")
+    with open(both, "w") as f:
+        f.write(open(reads).read())
+        f.write(open(real_reads).read())
+    shutil.copyfile(both, os.path.join(HERE, "two_db_reads.fasta"))
+    n_both = len(seqs) + len(pick)
+    for name, extra, params in (("two_db_default", [], {}), ("two_db_all", ["-num_alignments", "0"], {"num_alignments": 0})):
+        G[name] = run_case(name, [db, real_db], [os.path.join(HERE, "two_db_reads.fasta")], n_both, extra, tmp, with_reports=False)
+        G[name]["params"] = params
+        print(name, "aligned", G[name]["log"].get("num_aligned"), "per db", G[name]["readstats"].get("reads_matched_per_db"))
     json.dump(G, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
     shutil.rmtree(tmp, ignore_errors=True)
     print("t0 blast:", G["t0"]["blast"])

@@ -30,10 +30,12 @@ def records(case):
 
 
 def inputs(case):
-    """-> (db fasta path, reads fasta path, [read sequences])"""
-    stem = case if case in ("t0", "t9") else "syn"
-    db = os.path.join(paths.GOLDEN, {"t0": "t0_ref.fasta", "t9": "t9_ref.fasta", "syn": "syn_db.fasta"}[stem])
-    rd = os.path.join(paths.GOLDEN, {"t0": "t0_read.fasta", "t9": "t9_reads.fasta", "syn": "syn_reads.fasta"}[stem])
+    """-> (db fasta path or list of paths, reads fasta path, [read sequences])"""
+    stem = case.split("_")[0] if case.startswith(("syn", "real")) else ("two" if case.startswith("two_db") else case)
+    dbs = {"t0": "t0_ref.fasta", "t9": "t9_ref.fasta", "syn": "syn_db.fasta", "real": "real_db.fasta", "two": ["syn_db.fasta", "real_db.fasta"]}[stem]
+    rd = os.path.join(paths.GOLDEN, {"t0": "t0_read.fasta", "t9": "t9_reads.fasta", "syn": "syn_reads.fasta", "real": "real_reads.fasta",
+                                     "two": "two_db_reads.fasta"}[stem])
+    db = [os.path.join(paths.GOLDEN, d) for d in dbs] if isinstance(dbs, list) else os.path.join(paths.GOLDEN, dbs)
     return db, rd, [r[1] for r in fastx.read_fastx(rd)]
 
 

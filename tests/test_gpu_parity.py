@@ -109,6 +109,41 @@ def test_longer_reads(engine, tmp_path):
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 50
 
 
+def test_long_noisy_reads(engine, tmp_path):
+    """PacBio-like reads (0.8-3 kb, ~10 % errors incl. indels): several SW strips, wide traceback bands, many seeds."""
+    import numpy as np
+    from sortmerna_amd import synth
+    from helpers import orc
+    w = Workload(str(tmp_path), db_nt=150_000, n_reads=20, seed=41, family_size=6)
+    codes, offs = synth.load_db_codes(w.db)
+    rng = np.random.Generator(np.random.PCG64(99))
+    seqs = []
+    for i in range(48):
+        sq = int(rng.integers(0, len(offs) - 1))
+        ln = int(min(offs[sq + 1] - offs[sq], rng.integers(800, 3000)))
+        st = int(offs[sq] + rng.integers(0, offs[sq + 1] - offs[sq] - ln + 1))
+        out = []
+        for c in codes[st:st + ln]:
+            u = rng.random()
+            if u < 0.03:
+                continue                                   # deletion
+            if u < 0.06:
+                out.append(int(rng.integers(0, 4)))        # insertion before the base
+            out.append(int((c + rng.integers(1, 4)) & 3) if u > 0.96 else int(c))
+        s = "".join("ACGT"[c] for c in out)
+        if i % 2:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        seqs.append(s)
+    seqs += ["".join("ACGT"[c] for c in rng.integers(0, 4, size=2000)) for _ in range(6)]     # background
+    w.seqs = seqs
+    w.reads = smr.Reads.from_seqs(seqs)
+    w.minimal_score = smr.minimal_score(0.618874, 0.343238, w.parts[0].info(), len(seqs), sum(map(len, seqs)))
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "long noisy reads")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 40
+
+
 def test_empty_batch(engine, wl):
     r = smr.Reads.from_seqs([])
     p = smr.default_params(minimal_score=wl.minimal_score)
