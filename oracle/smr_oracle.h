@@ -109,6 +109,9 @@ void orc_align_part(const orc_index*, const orc_refs*, const orc_params*,
 uint32_t orc_window_hits(const orc_index*, const uint8_t* iseq, uint32_t win_pos, uint32_t lnwin,
                          uint32_t minoccur, int is_full_search, uint32_t* ids, uint32_t cap, int* zero_err);
 
+/* the LEV(1) automaton over one complete (pattern, text) pair; see smr_oracle.c */
+uint32_t orc_lev_accepts(uint32_t pchars, uint32_t tchars, uint32_t partialwin);
+
 typedef struct {
   uint16_t score1; int32_t ref_begin1, ref_end1, read_begin1, read_end1;
   uint32_t cigar_len; uint32_t cigar[4096];

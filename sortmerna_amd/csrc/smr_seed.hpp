@@ -61,6 +61,26 @@ __device__ __forceinline__ uint32_t lev_row_index(const BitVec& bv, uint32_t dep
 }
 __device__ __forceinline__ uint32_t lev_next(unsigned long long row, uint32_t state) { return (uint32_t)(row >> (4 * state)) & 15u; }
 
+// The LEV(1) automaton over a COMPLETE candidate string in closed form (tests/test_lev_closed_form.py proves it equal to
+// the table automaton for every seed length): P = the window's pw automaton chars, T = the pw+1 chars of trie path +
+// bucket tail (2 bits per char, char i at bits 2i).  With a = common prefix length and s0/s1/s2 = trailing equal chars
+// of P vs T, P vs T>>1 char, P>>1 char vs T:  accepted  <=>  a+s2 >= pw-1 (at depth pw-2)  or  a+s0 >= pw-1 (depth pw-1)
+// or  a+s1 >= pw (depth pw);  0-error match (state 9 at depth pw-1)  <=>  a >= pw, and then it was accepted at pw-2.
+// returns bit 0 = accepted, bit 1 = 0-error match
+__device__ __forceinline__ uint32_t lev1_entry(uint32_t P, uint32_t T, uint32_t pw) {
+  const uint32_t m2 = (1u << (2 * pw)) - 1u, m2b = m2 >> 2, ev = 0x55555555u;
+  const uint32_t x0 = P ^ T, x1 = P ^ (T >> 2), x2 = (P >> 2) ^ T;
+  const uint32_t d0 = (x0 | (x0 >> 1)) & ev & m2;            // bit 2i set iff chars i differ
+  const uint32_t d1 = (x1 | (x1 >> 1)) & ev & m2;
+  const uint32_t d2 = (x2 | (x2 >> 1)) & ev & m2b;
+  const uint32_t a = (uint32_t)__builtin_ctz(d0 | (1u << (2 * pw))) >> 1;
+  const uint32_t s0 = min((uint32_t)__clz((int)(d0 << (32 - 2 * pw))) >> 1, pw);
+  const uint32_t s1 = min((uint32_t)__clz((int)(d1 << (32 - 2 * pw))) >> 1, pw);
+  const uint32_t s2 = min((uint32_t)__clz((int)(d2 << (34 - 2 * pw))) >> 1, pw - 1);
+  const bool acc = (a + s2 >= pw - 1) || (a + s0 >= pw - 1) || (a + s1 >= pw);
+  return (acc ? 1u : 0u) | (a >= pw ? 2u : 0u);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The seed stage of one (strand, pass): window scan + burst-trie descent, organised as a sort-merge join.
 //
@@ -97,7 +117,7 @@ __device__ __forceinline__ uint32_t lev_next(unsigned long long row, uint32_t st
 #define SEED_K 4                                       // buckets a lane may collect per round
 #define SEED_GATHER 32u                                // ... or until it holds this many entries
 // dynamic LDS words of k_seed_search: hit lists, node stacks (offsets + level state), row-index table, pref/pb/nat, FIFO, owner map
-#define SEED_LDS_WORDS(hcap) (64u * (hcap) + SEED_STK * 64u + (SEED_MAXPW + 1u) * 64u + 2u * 64u * SEED_K + 3u * 128u + SEED_OWN_CAP / 4u)
+#define SEED_LDS_WORDS(hcap) (64u * (hcap) + SEED_STK * 64u + (SEED_MAXPW + 1u) * 64u + 3u * 64u * SEED_K + 64u + SEED_OWN_CAP / 4u)
 #define SEED_ZERO_BIT 0x80000000u
 
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
@@ -254,7 +274,8 @@ struct SeedLds {
   uint32_t* rt;        // [SEED_MAXPW+1][64] per depth: the 4 LEV row indices (5 bits each) of the lane's window
   uint32_t* pref;      // [64*SEED_K]  first flattened entry of bucket (lane*K+slot) in this round
   uint32_t* pb;        // [64*SEED_K]  bucket offset | depth << 22 | state << 26
-  uint32_t* sq;        // [3][128]     survivor FIFO: id, remaining tail, (bucket | state<<8 | depth<<12 | q<<16)
+  uint32_t* pth;       // [64*SEED_K]  the bucket's trie path (depth+1 chars, 2 bits each)
+  uint32_t* pat;       // [64]         the lane's automaton chars (pattern P)
   uint8_t* own;        // [SEED_OWN_CAP] flattened entry -> bucket (lane*K+slot)
 };
 
@@ -297,6 +318,8 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
   int sp = -1;
   uint32_t st = 0;                                      // pending mask | states of the node on top of the stack
   uint4 cur = make_uint4(0, 0, 0, 0);                   // its 4 elements
+  uint32_t path = 0;                                    // chars of the DFS path, level l at bits 2l
+  L.pat[lane] = chars;
   if (mine) {
     const BitVec bv = make_bitvec(chars, pw);
     for (uint32_t d = 0; d <= pw; d++) {
@@ -329,6 +352,7 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
       const uint32_t lev_t = (st >> (4 + 4 * ne)) & 15u;
       if ((e >> ELEM_FLAG_SHIFT) == 1) {                    // child node
         L.stk[sp * 64 + lane] = (L.stk[sp * 64 + lane] & ~(15u << 22)) | ((st & 15u) << 22);
+        path = (path & ((1u << (2 * sp)) - 1u)) | (ne << (2 * sp));
         sp++;
         L.stk[sp * 64 + lane] = (e & ELEM_OFF_MASK) | (lev_t << 26);
         cur = *reinterpret_cast<const uint4*>(trie + (e & ELEM_OFF_MASK)); n_node++;
@@ -337,6 +361,7 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
       }
       const uint32_t nent = (e >> ELEM_NENT_SHIFT) & 0xFFu;
       L.pb[lane * SEED_K + nb] = (e & ELEM_OFF_MASK) | ((uint32_t)sp << 22) | (lev_t << 26);
+      L.pth[lane * SEED_K + nb] = (path & ((1u << (2 * sp)) - 1u)) | (ne << (2 * sp));
       L.pref[lane * SEED_K + nb] = my_total;                 // lane-relative for now
       nent_pk |= nent << (8 * nb); nnode_pk |= min(n_node - n_node0, 255u) << (8 * nb);
       my_total += nent; nb++;
@@ -359,8 +384,7 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
     __syncthreads();
     SPH(2)
     bool zero_round = false;                               // a 0-error match was found in this round (owner lane)
-    uint32_t qn = 0;                                       // survivors waiting in the FIFO (wave-uniform)
-    // stage A's inputs (owner map, bucket descriptor, the entry itself) are fetched one chunk ahead
+    // entry scan: one lane per entry; owner map, bucket descriptor and the entry itself are fetched one chunk ahead
     uint32_t f_bk = 0, f_q = 0, f_pbv = 0, f_str = 0, f_id = 0;
     auto fetch = [&](uint32_t base) {
       const uint32_t e = base + lane;
@@ -377,89 +401,36 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
       if (v) { const uint2 en = *reinterpret_cast<const uint2*>(otrie + (f_pbv & ELEM_OFF_MASK) + 2 * f_q); f_str = en.x; f_id = en.y; }
     };
     if (T > 0) fetch(0);
-    for (uint32_t base = 0; base < T || qn > 0; base += 64) {
-      // ----- stage A: up to 2 automaton steps at non-accepting depths for 64 fresh entries -----
-      if (base < T) {
-        const bool v = base + lane < T;
-        const uint32_t bk = f_bk, q = f_q, pbv = f_pbv;
-        uint32_t str = f_str;
-        const uint32_t id = f_id;
-        if (base + 64 < T) fetch(base + 64);
-        uint32_t db = ((pbv >> 22) & 15u) + 1, lv = pbv >> 26;
-        const uint32_t olane = bk / SEED_K;
-        bool alive = v;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          if (alive && db + 3 <= pw) {                       // db <= pw-3: no accept / 0-error decision at this depth
-            lv = lev_next(s_row[(L.rt[db * 64 + olane] >> (5 * (str & 3u))) & 31u], lv);
-            str >>= 2; db++;
-            if (lv == 14) alive = false;
+    for (uint32_t base = 0; base < T; base += 64) {
+      const bool v = base + lane < T;
+      const uint32_t bk = f_bk, q = f_q, pbv = f_pbv, str = f_str, id = f_id;
+      if (base + 64 < T) fetch(base + 64);
+      const uint32_t olane = bk / SEED_K;
+      const uint32_t nchar = ((pbv >> 22) & 15u) + 1;        // chars of the trie path in front of the tail
+      const uint32_t tstr = L.pth[bk] | (str << (2 * nchar));
+      const uint32_t r = v ? lev1_entry(L.pat[olane], tstr, pw) : 0u;
+      const uint32_t kind = ((r & 2u) && !full) ? CK_COND : CK_PLAIN;   // a 0-error match is accepted one step before state 9 shows
+      // hand the candidates back to their owners, in entry order
+      unsigned long long cm = __ballot((r & 1u) != 0);
+      while (cm) {
+        const int c = __ffsll((long long)cm) - 1; cm &= cm - 1;
+        const uint32_t o = __shfl(olane, c, 64), idc = __shfl(id, c, 64), kc = __shfl(kind, c, 64), qc = __shfl(q, c, 64), bc = __shfl(bk, c, 64);
+        if ((uint32_t)lane == o && !zero) {
+          bool present = false;
+          for (uint32_t f = 0; f < nh; f++) if (L.hl[f * 64 + lane] == idc) { present = true; break; }
+          if (kc == CK_UNCOND || (kc == CK_COND && !present)) {
+            L.hl[lane] = idc; nh = 1; zero = true; zero_round = true;
+            // the reference stops at the 0-error entry: count the buckets before it, this one up to the entry, no later node
+            const uint32_t zs = bc % SEED_K;
+            for (uint32_t k = 0; k < zs; k++) n_entry += (nent_pk >> (8 * k)) & 0xFFu;
+            n_entry += qc + 1;
+            n_node = n_node0 + ((nnode_pk >> (8 * zs)) & 0xFFu);
+          } else if (!present) {
+            if (nh < hcap) { L.hl[nh * 64 + lane] = idc; nh++; } else overflow = true;
           }
         }
-        const unsigned long long am = __ballot(alive);
-        if (alive) {
-          const uint32_t pos = qn + (uint32_t)__popcll(am & ((1ull << lane) - 1));
-          L.sq[pos] = id; L.sq[128 + pos] = str; L.sq[256 + pos] = bk | (lv << 8) | (db << 12) | (q << 16);
-        }
-        qn += (uint32_t)__popcll(am);
-        __syncthreads();
-        SPH(3)
       }
-      // ----- stage B: finish 64 survivors (or the rest at the end of the round) -----
-      if (qn >= 64 || (base + 64 >= T && qn > 0)) {
-        const uint32_t cnt = min(qn, 64u);
-        const bool v = (uint32_t)lane < cnt;
-        uint32_t id = 0, str = 0, meta = 0;
-        if (v) { id = L.sq[lane]; str = L.sq[128 + lane]; meta = L.sq[256 + lane]; }
-        uint32_t mv_id = 0, mv_str = 0, mv_meta = 0;
-        const bool mv = 64u + lane < qn;
-        if (mv) { mv_id = L.sq[64 + lane]; mv_str = L.sq[192 + lane]; mv_meta = L.sq[320 + lane]; }
-        const uint32_t bk = meta & 0xFFu, olane = bk / SEED_K, q = meta >> 16;
-        uint32_t lv = (meta >> 8) & 15u, db = (meta >> 12) & 15u;
-        bool alive = v, acc = false;
-        uint32_t kind = CK_PLAIN;
-        while (__any(alive)) {                              // traverse_bursttrie.cpp:200-287 for one entry
-          if (alive) {
-            if (db > pw) alive = false;
-            else {
-              lv = lev_next(s_row[(L.rt[db * 64 + olane] >> (5 * (str & 3u))) & 31u], lv);
-              str >>= 2;
-              if (lv == 14) alive = false;
-              else if (db + 2 >= pw) {
-                const bool z = (db + 1 == pw && lv == 9 && !full);
-                if (!acc) { if (lv >= 8) { acc = true; if (z) kind = CK_UNCOND; } }
-                else { if (z) kind = CK_COND; alive = false; }
-              }
-              db++;
-            }
-          }
-        }
-        // hand the candidates back to their owners, in entry order
-        unsigned long long cm = __ballot(acc);
-        while (cm) {
-          const int c = __ffsll((long long)cm) - 1; cm &= cm - 1;
-          const uint32_t o = __shfl(olane, c, 64), idc = __shfl(id, c, 64), kc = __shfl(kind, c, 64), qc = __shfl(q, c, 64), bc = __shfl(bk, c, 64);
-          if ((uint32_t)lane == o && !zero) {
-            bool present = false;
-            for (uint32_t f = 0; f < nh; f++) if (L.hl[f * 64 + lane] == idc) { present = true; break; }
-            if (kc == CK_UNCOND || (kc == CK_COND && !present)) {
-              L.hl[lane] = idc; nh = 1; zero = true; zero_round = true;
-              // the reference stops at the 0-error entry: count the buckets before it, this one up to the entry, no later node
-              const uint32_t zs = bc % SEED_K;
-              for (uint32_t k = 0; k < zs; k++) n_entry += (nent_pk >> (8 * k)) & 0xFFu;
-              n_entry += qc + 1;
-              n_node = n_node0 + ((nnode_pk >> (8 * zs)) & 0xFFu);
-            } else if (!present) {
-              if (nh < hcap) { L.hl[nh * 64 + lane] = idc; nh++; } else overflow = true;
-            }
-          }
-        }
-        __syncthreads();
-        if (mv) { L.sq[lane] = mv_id; L.sq[128 + lane] = mv_str; L.sq[256 + lane] = mv_meta; }
-        qn -= cnt;
-        __syncthreads();
-        SPH(4)
-      }
+      SPH(3)
     }
     if (!zero_round) n_entry += my_total;
     if (zero) sp = -1;                                   // 0-error match: the reference unwinds the recursion (:167,256-262)
@@ -480,8 +451,9 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   L.rt = L.stk + SEED_STK * 64;
   L.pref = L.rt + (SEED_MAXPW + 1) * 64;
   L.pb = L.pref + 64 * SEED_K;
-  L.sq = L.pb + 64 * SEED_K;
-  L.own = reinterpret_cast<uint8_t*>(L.sq + 3 * 128);
+  L.pth = L.pb + 64 * SEED_K;
+  L.pat = L.pth + 64 * SEED_K;
+  L.own = reinterpret_cast<uint8_t*>(L.pat + 64);
   uint32_t* hl = L.hl;
   __shared__ unsigned long long s_row[LEV_ROWS];
   const int lane = lane_id();

@@ -1,0 +1,81 @@
+"""CPU: the closed form k_seed_search uses for bucket entries == the reference's table-driven LEV(1) automaton.
+
+traverse_bursttrie.cpp:100-298 feeds the characteristic bit-vectors of the window's 9-mer P (partialwin chars) and the 10 chars
+T of (trie path + bucket tail) through the universal Levenshtein-1 tables (:68-98) and accepts an entry at the first depth
+>= partialwin-2 with state >= 8; state 9 at depth partialwin-1 is the 0-error match.  With a = longest common prefix of (P, T) and
+s0 / s1 / s2 = the number of trailing equal characters of P vs T, P vs T shifted left by one, P shifted left by one vs T:
+    accepted at depth pw-2  <=>  a + s2 >= pw-1        (edit distance(P, T[0..pw-1)) <= 1 : a deletion)
+    else at depth pw-1      <=>  a + s0 >= pw-1        (at most one substitution in the first pw chars)
+    else at depth pw        <=>  a + s1 >= pw          (one insertion)
+    0-error match           <=>  a >= pw               (and then the entry was already accepted at depth pw-2)
+The oracle's orc_lev_accepts() runs the tables; this test compares the closed form with it for every supported seed length on
+structured (0, 1, 2 edits) and random pairs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import orc
+
+
+def closed_form(P, T, pw):
+    """-> (accepted, first accepting depth, zero) with the bit tricks of smr_seed.hpp::lev1_entry, on Python ints"""
+    eq0 = [((P >> (2 * i)) & 3) == ((T >> (2 * i)) & 3) for i in range(pw)]
+    eq1 = [((P >> (2 * i)) & 3) == ((T >> (2 * (i + 1))) & 3) for i in range(pw)]
+    eq2 = [((P >> (2 * (i + 1))) & 3) == ((T >> (2 * i)) & 3) for i in range(pw - 1)]
+
+    def lead(v):
+        n = 0
+        while n < len(v) and v[n]:
+            n += 1
+        return n
+
+    a, s0, s1, s2 = lead(eq0), lead(eq0[::-1]), lead(eq1[::-1]), lead(eq2[::-1])
+    c8, c9, c10 = a + s2 >= pw - 1, a + s0 >= pw - 1, a + s1 >= pw
+    depth = pw - 2 if c8 else (pw - 1 if c9 else pw)
+    return (c8 or c9 or c10), depth, a >= pw
+
+
+@pytest.mark.parametrize("pw", [4, 5, 6, 7, 8, 9, 10])
+def test_closed_form_equals_table_automaton(pw):
+    L = orc.lib()
+    L.orc_lev_accepts.restype = C.c_uint32
+    L.orc_lev_accepts.argtypes = [C.c_uint32] * 3
+    rng = np.random.default_rng(100 + pw)
+    n_acc = 0
+
+    def check(P, T):
+        nonlocal n_acc
+        r = L.orc_lev_accepts(P, T, pw)
+        acc, depth, zero = closed_form(P, T, pw)
+        assert bool(r & 1) == acc, (pw, P, T, hex(r))
+        if acc:
+            n_acc += 1
+            assert (r >> 8) == depth, (pw, P, T, hex(r), depth)
+            assert bool(r & 2) == zero, (pw, P, T, hex(r))
+            if zero:
+                assert depth == pw - 2          # a 0-error match is always a COND candidate, never UNCOND
+
+    for _ in range(12000):
+        P = int(rng.integers(0, 4 ** pw))
+        pl = [(P >> (2 * i)) & 3 for i in range(pw)]
+        for kind in range(6):
+            t = pl[:]
+            if kind == 1:
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + int(rng.integers(1, 4))) & 3
+            elif kind == 2:
+                t.insert(int(rng.integers(0, pw + 1)), int(rng.integers(0, 4)))
+            elif kind == 3:
+                del t[int(rng.integers(0, pw))]
+            elif kind == 4:
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + 1) & 3
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + 2) & 3
+            elif kind == 5:
+                del t[int(rng.integers(0, pw))]
+                t.insert(int(rng.integers(0, pw)), int(rng.integers(0, 4)))
+            while len(t) < pw + 1:
+                t.append(int(rng.integers(0, 4)))
+            check(P, sum(c << (2 * i) for i, c in enumerate(t[:pw + 1])))
+    for _ in range(30000):
+        check(int(rng.integers(0, 4 ** pw)), int(rng.integers(0, 4 ** (pw + 1))))
+    assert n_acc > 20000
