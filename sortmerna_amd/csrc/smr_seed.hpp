@@ -273,8 +273,8 @@ struct SeedLds {
   uint32_t* stk;       // [SEED_STK][64] DFS stack: node offset | pending-element mask << 22 | state the node was entered with << 26
   uint32_t* rt;        // [SEED_MAXPW+1][64] per depth: the 4 LEV row indices (5 bits each) of the lane's window
   uint32_t* pref;      // [64*SEED_K]  first flattened entry of bucket (lane*K+slot) in this round
-  uint32_t* pb;        // [64*SEED_K]  bucket offset | depth << 22 | state << 26
-  uint32_t* pth;       // [64*SEED_K]  the bucket's trie path (depth+1 chars, 2 bits each)
+  uint32_t* pb;        // [64*SEED_K]  absolute arena offset of the bucket
+  uint32_t* pth;       // [64*SEED_K]  the bucket's trie path (2 bits per char) | number of path chars << 24
   uint32_t* pat;       // [64]         the lane's automaton chars (pattern P)
   uint8_t* own;        // [SEED_OWN_CAP] flattened entry -> bucket (lane*K+slot)
 };
@@ -305,7 +305,7 @@ __device__ __forceinline__ uint32_t node_states(const uint4 nd, uint32_t rtw, ui
 #else
 #define SPH(i)
 #endif
-__device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ trie, bool mine, uint32_t chars, uint32_t pw, bool full,
+__device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ arena, uint32_t root, bool mine, uint32_t chars, uint32_t pw, bool full,
                                                  const unsigned long long* s_row, const SeedLds L, uint32_t hcap, SeedLane& out
 #ifdef SMR_SEED_PHASES
                                                  , unsigned long long* sph, unsigned long long& slast
@@ -327,7 +327,7 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
       for (uint32_t nt = 0; nt < 4; nt++) w |= lev_row_index(bv, d, nt, pw) << (5 * nt);
       L.rt[d * 64 + lane] = w;
     }
-    sp = 0; L.stk[lane] = 0; cur = *reinterpret_cast<const uint4*>(trie); n_node = 1;
+    sp = 0; L.stk[lane] = 0; cur = *reinterpret_cast<const uint4*>(arena + root); n_node = 1;
     st = node_states(cur, L.rt[lane], 0, s_row);
   }
   SPH(0)
@@ -337,34 +337,43 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
     uint32_t nent_pk = 0, nnode_pk = 0;                    // per collected bucket: entries / nodes visited so far in this round (8 bits each)
     const uint32_t n_node0 = n_node;
     while (sp >= 0 && nb < SEED_K && my_total < SEED_GATHER) {
-      if ((st & 15u) == 0) {                               // node exhausted: back to the parent (its element states are recomputed)
+      // one DFS move per iteration; the expensive part -- fetch a node and compute its 4 element states -- is shared by
+      // "descend into a child" and "return to a parent that still has pending elements"
+      uint32_t ld_off = NONE, ld_piv = 0, ld_mask = 15u;
+      if ((st & 15u) == 0) {                               // node exhausted: back to the nearest ancestor with pending elements
         sp--;
         if (sp >= 0) {
           const uint32_t sw = L.stk[sp * 64 + lane];
-          cur = *reinterpret_cast<const uint4*>(trie + (sw & ELEM_OFF_MASK));
-          st = (node_states(cur, L.rt[sp * 64 + lane], sw >> 26, s_row) & ~15u) | ((sw >> 22) & 15u);
+          ld_mask = (sw >> 22) & 15u;
+          if (ld_mask != 0) { ld_off = sw & ELEM_OFF_MASK; ld_piv = sw >> 26; }
         }
-        continue;
+      } else {
+        const uint32_t ne = (uint32_t)__ffs((int)(st & 15u)) - 1;
+        st &= ~(1u << ne);
+        const uint32_t e = ne == 0 ? cur.x : (ne == 1 ? cur.y : (ne == 2 ? cur.z : cur.w));
+        const uint32_t lev_t = (st >> (4 + 4 * ne)) & 15u;
+        if ((e >> ELEM_FLAG_SHIFT) == 1) {                  // child node
+          L.stk[sp * 64 + lane] = (L.stk[sp * 64 + lane] & ~(15u << 22)) | ((st & 15u) << 22);
+          path = (path & ((1u << (2 * sp)) - 1u)) | (ne << (2 * sp));
+          sp++;
+          ld_off = e & ELEM_OFF_MASK; ld_piv = lev_t;
+          L.stk[sp * 64 + lane] = ld_off | (lev_t << 26);
+          n_node++;
+        } else {                                            // bucket
+          const uint32_t nent = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+          L.pb[lane * SEED_K + nb] = root + (e & ELEM_OFF_MASK);
+          L.pth[lane * SEED_K + nb] = (path & ((1u << (2 * sp)) - 1u)) | (ne << (2 * sp)) | ((uint32_t)(sp + 1) << 24);
+          L.pref[lane * SEED_K + nb] = my_total;             // lane-relative for now
+          nent_pk |= nent << (8 * nb); nnode_pk |= min(n_node - n_node0, 255u) << (8 * nb);
+          my_total += nent; nb++;
+        }
       }
-      const uint32_t ne = (uint32_t)__ffs((int)(st & 15u)) - 1;
-      st &= ~(1u << ne);
-      const uint32_t e = ne == 0 ? cur.x : (ne == 1 ? cur.y : (ne == 2 ? cur.z : cur.w));
-      const uint32_t lev_t = (st >> (4 + 4 * ne)) & 15u;
-      if ((e >> ELEM_FLAG_SHIFT) == 1) {                    // child node
-        L.stk[sp * 64 + lane] = (L.stk[sp * 64 + lane] & ~(15u << 22)) | ((st & 15u) << 22);
-        path = (path & ((1u << (2 * sp)) - 1u)) | (ne << (2 * sp));
-        sp++;
-        L.stk[sp * 64 + lane] = (e & ELEM_OFF_MASK) | (lev_t << 26);
-        cur = *reinterpret_cast<const uint4*>(trie + (e & ELEM_OFF_MASK)); n_node++;
-        st = node_states(cur, L.rt[sp * 64 + lane], lev_t, s_row);
-        continue;
+      if (ld_off != NONE) {
+        cur = *reinterpret_cast<const uint4*>(arena + root + ld_off);
+        st = (node_states(cur, L.rt[sp * 64 + lane], ld_piv, s_row) & (~15u | ld_mask));
+      } else if (sp >= 0 && (st & 15u) == 0 && ld_mask == 0) {
+        st = 0;                                             // exhausted ancestor: keep climbing
       }
-      const uint32_t nent = (e >> ELEM_NENT_SHIFT) & 0xFFu;
-      L.pb[lane * SEED_K + nb] = (e & ELEM_OFF_MASK) | ((uint32_t)sp << 22) | (lev_t << 26);
-      L.pth[lane * SEED_K + nb] = (path & ((1u << (2 * sp)) - 1u)) | (ne << (2 * sp));
-      L.pref[lane * SEED_K + nb] = my_total;                 // lane-relative for now
-      nent_pk |= nent << (8 * nb); nnode_pk |= min(n_node - n_node0, 255u) << (8 * nb);
-      my_total += nent; nb++;
     }
     SPH(1)
     if (!__any(nb > 0)) break;
@@ -394,11 +403,9 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
         if (direct) bk = L.own[e];
         else for (uint32_t step = 128; step > 0; step >>= 1) { const uint32_t t = bk + step; if (t < 64 * SEED_K && L.pref[t] <= e) bk = t; }
       }
-      f_bk = bk; f_q = e - L.pref[bk]; f_pbv = L.pb[bk];
-      // (shuffle outside the branch: a bpermute reads 0 from lanes that are masked off)
-      const uint32_t* otrie = reinterpret_cast<const uint32_t*>(__shfl((unsigned long long)trie, bk / SEED_K, 64));
+      f_bk = bk; f_q = e - L.pref[bk]; f_pbv = L.pth[bk];
       f_str = 0; f_id = 0;
-      if (v) { const uint2 en = *reinterpret_cast<const uint2*>(otrie + (f_pbv & ELEM_OFF_MASK) + 2 * f_q); f_str = en.x; f_id = en.y; }
+      if (v) { const uint2 en = *reinterpret_cast<const uint2*>(arena + L.pb[bk] + 2 * f_q); f_str = en.x; f_id = en.y; }
     };
     if (T > 0) fetch(0);
     for (uint32_t base = 0; base < T; base += 64) {
@@ -406,8 +413,8 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ tr
       const uint32_t bk = f_bk, q = f_q, pbv = f_pbv, str = f_str, id = f_id;
       if (base + 64 < T) fetch(base + 64);
       const uint32_t olane = bk / SEED_K;
-      const uint32_t nchar = ((pbv >> 22) & 15u) + 1;        // chars of the trie path in front of the tail
-      const uint32_t tstr = L.pth[bk] | (str << (2 * nchar));
+      const uint32_t nchar = pbv >> 24;                      // chars of the trie path in front of the tail
+      const uint32_t tstr = (pbv & 0xFFFFFFu) | (str << (2 * nchar));
       const uint32_t r = v ? lev1_entry(L.pat[olane], tstr, pw) : 0u;
       const uint32_t kind = ((r & 2u) && !full) ? CK_COND : CK_PLAIN;   // a 0-error match is accepted one step before state 9 shows
       // hand the candidates back to their owners, in entry order
@@ -461,14 +468,14 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   const uint32_t pos = blockIdx.x * 64u + lane;
   const bool mine = pos < n_tup;
   uint32_t r = 0, win_pos = 0, chars = 0;
-  const uint32_t* trie = ix.trie;
+  uint32_t root = 0;
   size_t slot = 0;
   SeedLane sl; sl.nh = 0; sl.zero = false; sl.overflow = false; sl.n_node = 0; sl.n_entry = 0;
   uint32_t n_prev = 0;
   if (mine) {
     const unsigned long long pl = sb.tup[pos];
     const Lookup lk = ix.lookup[sb.tkey[pos]];
-    trie = ix.trie + (DIR == 0 ? lk.rootF : lk.rootR);
+    root = DIR == 0 ? lk.rootF : lk.rootR;
     r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
     slot = (size_t)r * sb.maxwin + win_pos / P.skip[pass];
     if (DIR == 1) {                                      // the window's list so far = the forward search's hits
@@ -484,9 +491,9 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   __syncthreads();
 #ifdef SMR_SEED_PHASES
   unsigned long long sph[6] = {0, 0, 0, 0, 0, 0}, slast = clock64();
-  seed_search_wave(trie, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl, sph, slast);
+  seed_search_wave(ix.trie, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl, sph, slast);
 #else
-  seed_search_wave(trie, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
+  seed_search_wave(ix.trie, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
 #endif
   // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
   const bool wr = mine && (DIR == 0 ? sl.nh > 0 : (sl.zero || sl.nh > n_prev));
