@@ -144,6 +144,11 @@ int smr_index_unload(smr_ctx*, int slot);
  * state, its Readstats counter block and its CIGAR pool; the caller sums the counters of its batches. */
 int smr_batch_select(smr_ctx*, int batch);
 
+/* Seed-search kernel selection.  0 (default): the work-queue kernel k_seed_bfs.  1: the per-lane DFS kernel k_seed_search for
+ * every window; slower, but its work counters (smr_prof_get: n_node, n_entry) follow the reference's sequential scan exactly
+ * (nothing after a 0-error match is counted) -- used to obtain the algorithmic byte counts of a workload.  Results are identical. */
+int smr_set_seed_mode(smr_ctx*, int exact_counters);
+
 /* Copy a read batch to HBM (into the selected batch) and allocate its persistent per-read state (what the reference keeps in
  * the KVDB between index parts, read.cpp:429-539).  Resets all state and counters. */
 int smr_reads_upload(smr_ctx*, const smr_reads*, uint32_t max_alignments_per_read);

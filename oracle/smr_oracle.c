@@ -424,6 +424,24 @@ uint32_t orc_lev_accepts(uint32_t pchars, uint32_t tchars, uint32_t partialwin) 
   return res;
 }
 
+/* number of leading text chars the automaton survives (state != 14): 0 .. partialwin+1 */
+uint32_t orc_lev_alive_depth(uint32_t pchars, uint32_t tchars, uint32_t partialwin) {
+  uint8_t p[16], bv[64];
+  memset(bv, 0, sizeof bv);
+  for (uint32_t i = 0; i < partialwin; i++) p[i] = (uint8_t)((pchars >> (2 * i)) & 3);
+  init_win(p, 1, bv, (int)(4 * (partialwin - 3)));
+  const uint8_t* win_k1_ptr = bv;
+  const uint8_t* win_k1_full = bv + (partialwin - 3) * 4;
+  uint32_t lev_t = 0;
+  for (uint32_t depth_b = 0; depth_b <= partialwin; depth_b++) {
+    uint32_t nt = (tchars >> (2 * depth_b)) & 3;
+    if (depth_b < partialwin - 2) lev_t = LEV[0][win_k1_ptr[(depth_b << 2) + nt]][lev_t];
+    else lev_t = LEV[3 - partialwin + depth_b][win_k1_full[nt] & ((2u << (partialwin - depth_b)) - 1)][lev_t];
+    if (lev_t == 14) return depth_b;
+  }
+  return partialwin + 1;
+}
+
 /* hash of a partialwin-mer, MSB first: read.cpp:601-611 */
 static uint32_t hash_kmer(const uint8_t* s, uint32_t len) {
   uint32_t h = 0;

@@ -111,6 +111,7 @@ uint32_t orc_window_hits(const orc_index*, const uint8_t* iseq, uint32_t win_pos
 
 /* the LEV(1) automaton over one complete (pattern, text) pair; see smr_oracle.c */
 uint32_t orc_lev_accepts(uint32_t pchars, uint32_t tchars, uint32_t partialwin);
+uint32_t orc_lev_alive_depth(uint32_t pchars, uint32_t tchars, uint32_t partialwin);
 
 typedef struct {
   uint16_t score1; int32_t ref_begin1, ref_end1, read_begin1, read_end1;

@@ -38,7 +38,7 @@ EXPORTS = [
     "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_write_files", "smr_index_free",
     "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_free",
     "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
-    "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_reads_upload", "smr_state_reset", "smr_align_part",
+    "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_prof_reset", "smr_prof_get",
 ]
@@ -92,6 +92,8 @@ def load(rebuild_if_stale=True):
     L.smr_index_unload.argtypes = [vp, i32]
     L.smr_batch_select.restype = i32
     L.smr_batch_select.argtypes = [vp, i32]
+    L.smr_set_seed_mode.restype = i32
+    L.smr_set_seed_mode.argtypes = [vp, i32]
     L.smr_reads_upload.restype = i32
     L.smr_reads_upload.argtypes = [vp, vp, u32]
     L.smr_state_reset.restype = i32

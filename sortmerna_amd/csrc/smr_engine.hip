@@ -58,6 +58,7 @@ struct smr_ctx {
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 8;
+  int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_bfs (+ redo)
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t chain_blocks = 0;
@@ -73,6 +74,8 @@ struct smr_ctx {
   std::vector<EvPair> events;
   double seed_ms = 0, chain_ms = 0, trace_ms = 0; uint64_t seed_l = 0, chain_l = 0, trace_l = 0;
 };
+
+#define SEED_REDO_CAP 16384u
 
 namespace {
 
@@ -180,6 +183,7 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   int rc;
   if (c->sb_nk < nk) {
     if ((rc = dev_alloc(c, &c->sb.hist, nk))) return rc;
+    if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
     if ((rc = dev_alloc(c, &c->sb.bin_off, (size_t)nk + 1))) return rc;
     if (!c->sb.sn && (rc = dev_alloc(c, &c->sb.sn, SN_COUNT))) return rc;
     c->sb_nk = nk;
@@ -203,7 +207,8 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
   const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
   sb.cap_tuples = (uint32_t)slots;
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4;
+  sb.cap_redo = SEED_REDO_CAP;
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_bfs = (size_t)BFS_LDS_WORDS(c->hcap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gk = (uint32_t)((slots + 255) / 256), gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024);
   ev_begin(c, 0);
@@ -214,8 +219,21 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
     else hipLaunchKernelGGL(k_seed_keys<1>, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
     hipLaunchKernelGGL(k_seed_scan, dim3(1), dim3(1024), 0, c->stream, sb);
     hipLaunchKernelGGL(k_seed_scatter, dim3(gk), dim3(256), 0, c->stream, sb);
-    if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
-    else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+    const uint32_t* no_redo = nullptr;
+    if (c->seed_exact) {
+      if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
+      else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
+    } else {
+      // work-queue search; the (rare) waves whose LDS queues overflowed are searched again by the DFS kernel
+      const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
+      if (dir == 0) {
+        hipLaunchKernelGGL(k_seed_bfs<0>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
+      } else {
+        hipLaunchKernelGGL(k_seed_bfs<1>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
+      }
+    }
   }
   hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, pool_words, c->b->d_ctr);
   ev_end(c);
@@ -283,6 +301,7 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
     if (err && errcap) snprintf(err, errcap, "cannot initialise device %d", device);
     delete c; return SMR_ERR_DEVICE;
   }
+  if (const char* e = getenv("SMR_SEED_EXACT")) c->seed_exact = atoi(e) != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
@@ -304,7 +323,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_cigar);
   }
   dev_free(&c->sb.hist); dev_free(&c->sb.bin_off); dev_free(&c->sb.tmp);
-  dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
+  dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_dir); dev_free(&c->d_hbuf); dev_free(&c->d_cig);
   (void)hipStreamDestroy(c->stream);
@@ -355,6 +374,12 @@ extern "C" int smr_batch_select(smr_ctx* c, int batch) {
   }
   B.used = true;
   c->b = &B;
+  return SMR_OK;
+}
+
+extern "C" int smr_set_seed_mode(smr_ctx* c, int exact_counters) {
+  if (!c) return SMR_ERR_ARG;
+  c->seed_exact = exact_counters ? 1 : 0;
   return SMR_OK;
 }
 
@@ -419,7 +444,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     std::vector<unsigned long long> init = snap;
     init[C_NUM_SHORT] = 0;
     for (int k = C_ERR_HITCAP; k <= C_ERR_TRACE; k++) init[k] = 0;
-    init[C_ERR_SCAP] = 0;
+    init[C_ERR_SCAP] = 0; init[C_ERR_REDO] = 0;
     init[C_POOL_CURSOR] = 0; init[C_WORK_NEXT] = 0;
     for (int q = 0; q < C_NSHARD; q++) init[C_PCUR + q] = 0;
     HIPCHK(c, hipMemcpyAsync(c->b->d_ctr, init.data(), C_TOTAL * 8, hipMemcpyHostToDevice, c->stream));
@@ -445,6 +470,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       if (c->pairs_cap > (1u << 22)) { c->err = "per-read candidate scratch exceeds capacity"; return SMR_ERR_CAPACITY; }
       retry = true;
     }
+    if (h[C_ERR_REDO]) { c->seed_exact = 1; retry = true; }     // too many overflowing waves for the redo list: use the DFS kernel throughout
     if (h[C_ERR_SCAP]) {
       c->chain_scap *= 4; retry = true;
       if (c->chain_scap > 4096) { c->err = "more than 3072 references share seeds with one read (candidate set capacity)"; return SMR_ERR_CAPACITY; }

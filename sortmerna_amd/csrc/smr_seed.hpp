@@ -81,6 +81,19 @@ __device__ __forceinline__ uint32_t lev1_entry(uint32_t P, uint32_t T, uint32_t 
   return (acc ? 1u : 0u) | (a >= pw ? 2u : 0u);
 }
 
+// Is the automaton still alive after the first m chars of T (m = depth + 1 <= pw - 1 at trie nodes)?  Closed form, proven
+// equal to "state != 14" in tests/test_lev_closed_form.py: with a = common prefix of (P, T[0..m)), alive <=> a >= m, or the
+// rest matches after ONE edit at position a: T[i]==P[i] (substitution), T[i]==P[i-1] (extra char in T) for i in (a, m),
+// or T[i]==P[i+1] for i in [a, m) (char of P skipped).
+__device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
+  const uint32_t mm = (1u << (2 * m)) - 1u, ev = 0x55555555u;
+  const uint32_t x0 = P ^ T, x1 = (P << 2) ^ T, x2 = (P >> 2) ^ T;
+  const uint32_t d0 = (x0 | (x0 >> 1)) & ev & mm;
+  const uint32_t a2 = (uint32_t)__builtin_ctz(d0 | (1u << (2 * m)));        // 2 * common prefix length
+  const uint32_t d1 = (x1 | (x1 >> 1)) & ev & mm, d2 = (x2 | (x2 >> 1)) & ev & mm;
+  return d0 == 0 || (d0 >> (a2 + 2)) == 0 || (d1 >> (a2 + 2)) == 0 || (d2 >> a2) == 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The seed stage of one (strand, pass): window scan + burst-trie descent, organised as a sort-merge join.
 //
@@ -121,7 +134,7 @@ __device__ __forceinline__ uint32_t lev1_entry(uint32_t P, uint32_t T, uint32_t 
 #define SEED_ZERO_BIT 0x80000000u
 
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
-enum { SN_TUPLES = 0, SN_COUNT = 4 };                  // device counters of the seed stage (u32)
+enum { SN_TUPLES = 0, SN_REDO = 1, SN_COUNT = 4 };                  // device counters of the seed stage (u32)
 
 struct SeedTmp { uint32_t key, rank; unsigned long long payload; };   // payload: read | win_pos << 24 | chars << 40
 
@@ -133,7 +146,8 @@ struct SeedBufs {
   uint32_t* tkey;            // keys in key order
   uint32_t* wseg;            // [n * maxwin] pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
   uint32_t* sn;              // SN_* counters
-  uint32_t nk, maxwin, cap_tuples;
+  uint32_t* redo;            // waves of k_seed_bfs to be searched again by k_seed_search
+  uint32_t nk, maxwin, cap_tuples, cap_redo;
 };
 
 // nbits <= 40 bits starting at bit `bit0` of a little-endian word stream (reads up to 2 words past the first)
@@ -448,9 +462,15 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ ar
 
 template <int DIR>
 __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
-                                                    uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
+                                                    uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr,
+                                                    const uint32_t* __restrict__ redo) {
   const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples);
-  if (blockIdx.x * 64u >= n_tup) return;
+  uint32_t wave = blockIdx.x;
+  if (redo) {                                            // only the waves listed by k_seed_bfs (its LDS queues overflowed)
+    if (blockIdx.x >= min(sb.sn[SN_REDO], sb.cap_redo)) return;
+    wave = redo[blockIdx.x];
+  }
+  if (wave * 64u >= n_tup) return;
   extern __shared__ __align__(16) uint32_t lds_dyn[];
   SeedLds L;
   L.hl = lds_dyn;
@@ -465,7 +485,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   __shared__ unsigned long long s_row[LEV_ROWS];
   const int lane = lane_id();
   build_lev_rows(s_row);
-  const uint32_t pos = blockIdx.x * 64u + lane;
+  const uint32_t pos = wave * 64u + lane;
   const bool mine = pos < n_tup;
   uint32_t r = 0, win_pos = 0, chars = 0;
   uint32_t root = 0;

@@ -163,6 +163,10 @@ class Engine:
         self.n_reads = self._batch_n.get(batch, 0)
         self._cur = batch
 
+    def set_seed_mode(self, exact_counters):
+        """0: work-queue seed search (default); 1: per-lane DFS kernel with reference-exact work counters (same results)"""
+        self._chk(self.L.smr_set_seed_mode(self.h, int(bool(exact_counters))), "smr_set_seed_mode")
+
     def upload_reads(self, reads, max_alignments_per_read=1):
         self._chk(self.L.smr_reads_upload(self.h, reads.h, max_alignments_per_read), "smr_reads_upload")
         self.n_reads = reads.count

@@ -11,9 +11,10 @@ from helpers.cases import CASES, gpu_run
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine():
+@pytest.fixture(scope="module", params=[0, 1], ids=["bfs", "dfs"])
+def engine(request):
     e = smr.Engine(0)      # raises without a GPU / without the HIP library: no CPU fallback
+    e.set_seed_mode(request.param)
     yield e
     e.close()
 

@@ -12,9 +12,11 @@ from helpers.workload import Workload, iseq_for_strand
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine():
+@pytest.fixture(scope="module", params=[0, 1], ids=["bfs", "dfs"])
+def engine(request):
+    """every test runs with both seed-search kernels: the work-queue kernel (default) and the per-lane DFS kernel"""
     e = smr.Engine(0)      # raises without a GPU / without the HIP library: no CPU fallback
+    e.set_seed_mode(request.param)
     yield e
     e.close()
 

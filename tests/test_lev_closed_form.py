@@ -36,6 +36,57 @@ def closed_form(P, T, pw):
     return (c8 or c9 or c10), depth, a >= pw
 
 
+def alive_closed_form(P, T, m, pw):
+    """smr_seed.hpp::lev1_alive on Python ints: is the automaton alive after the first m chars of T?"""
+    p = [(P >> (2 * i)) & 3 for i in range(pw)]
+    t = [(T >> (2 * i)) & 3 for i in range(pw + 1)]
+
+    def pe(i):
+        return p[i] if 0 <= i < pw else -1
+
+    a = 0
+    while a < m and a < pw and p[a] == t[a]:
+        a += 1
+    if a >= m:
+        return True
+    return (all(pe(i) == t[i] for i in range(a + 1, m)) or all(pe(i - 1) == t[i] for i in range(a + 1, m))
+            or all(pe(i + 1) == t[i] for i in range(a, m)))
+
+
+@pytest.mark.parametrize("pw", [4, 5, 6, 7, 8, 9, 10])
+def test_prefix_viability_equals_table_automaton(pw):
+    """trie nodes: `state != 14` after the first m chars  <=>  lev1_alive(P, T, m), for every prefix length"""
+    L = orc.lib()
+    L.orc_lev_alive_depth.restype = C.c_uint32
+    L.orc_lev_alive_depth.argtypes = [C.c_uint32] * 3
+    rng = np.random.default_rng(200 + pw)
+    for _ in range(6000):
+        P = int(rng.integers(0, 4 ** pw))
+        pl = [(P >> (2 * i)) & 3 for i in range(pw)]
+        for kind in range(7):
+            t = pl[:]
+            if kind == 1:
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + int(rng.integers(1, 4))) & 3
+            elif kind == 2:
+                t.insert(int(rng.integers(0, pw + 1)), int(rng.integers(0, 4)))
+            elif kind == 3:
+                del t[int(rng.integers(0, pw))]
+            elif kind == 4:
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + 1) & 3
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + 2) & 3
+            elif kind == 5:
+                del t[int(rng.integers(0, pw))]
+                t.insert(int(rng.integers(0, pw)), int(rng.integers(0, 4)))
+            elif kind == 6:
+                t = [int(x) for x in rng.integers(0, 4, size=pw + 1)]
+            while len(t) < pw + 1:
+                t.append(int(rng.integers(0, 4)))
+            T = sum(c << (2 * i) for i, c in enumerate(t[:pw + 1]))
+            ad = L.orc_lev_alive_depth(P, T, pw)
+            for m in range(1, pw + 2):
+                assert (ad >= m) == alive_closed_form(P, T, m, pw), (pw, P, T, m, ad)
+
+
 @pytest.mark.parametrize("pw", [4, 5, 6, 7, 8, 9, 10])
 def test_closed_form_equals_table_automaton(pw):
     L = orc.lib()
