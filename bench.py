@@ -16,8 +16,9 @@ collectives are the two tiny all-reduces the reference's semantics need: global 
 minimal_score, refstats.cpp:247-265) and the Readstats counters after (RCCL).
 
 The JSON line also carries
-  roofline      seed-scan kernel (k_seed): algorithmic bytes (SURVEY.md 8d formula, from exact device work counters)
-                / HIP-event time of its launches, against the 8 TB/s HBM3E peak
+  roofline      seed stage (k_seed_keys/scan/scatter/bfs/finish = "k_seed"): algorithmic bytes (SURVEY.md 8d formula, from exact
+                device work counters of an untimed counting pass over the same batches) / HIP-event time of its launches in the
+                timed steps, against the 8 TB/s HBM3E peak
   kernels       HIP-event time and launch count of each kernel family in the timed region
   cpu_baseline  the UNMODIFIED reference (oracle/_ref/sortmerna_ref) timed on this host's cores on a bounded sample of
                 the same reads with the same index files (rank 0, N=1 only)
@@ -44,6 +45,11 @@ HBM_PEAK_GBS = 8000.0
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def eng_counters_aligned(eng, b):
+    eng.select_batch(b)
+    return int(eng.counters(1)["num_aligned"])
 
 
 def make_batch(synth, codes, offs, n, read_len, seed):
@@ -212,6 +218,16 @@ def main():
 
     for b in range(args.warmup):
         step(b)
+    # Algorithmic bytes of the timed batches: a workload property, counted by the per-lane DFS seed kernel whose work counters
+    # follow the reference's sequential scan exactly (untimed; the timed steps use the work-queue kernel, same results).
+    eng.prof_reset()
+    eng.set_seed_mode(1)
+    for b in range(args.warmup, nb):
+        step(b)
+    eng.set_seed_mode(0)
+    pe = eng.prof()
+    exact = [pe.n_windows, pe.n_lookup, pe.n_node, pe.n_entry, pe.n_hit, pe.n_read_bytes]
+    exact_aligned = sum(eng_counters_aligned(eng, b) for b in range(args.warmup, nb))
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -229,9 +245,9 @@ def main():
         ctr += np.array([c["num_aligned"], c["num_short"], c["reads_matched_per_db"][0]], dtype=np.int64)
     ctr_t = shard.reduce_counters(ctr.tolist(), device="cuda")
     pr = eng.prof()
-    prof = torch.tensor([pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.seed_launches, pr.chain_launches, pr.trace_launches,
-                         pr.n_windows, pr.n_lookup, pr.n_node, pr.n_entry, pr.n_hit, pr.n_read_bytes, pr.n_sw_fwd, pr.n_sw_rev,
-                         pr.n_sw_cells], dtype=torch.float64, device="cuda")
+    assert int(ctr[0]) == exact_aligned, "the two seed kernels disagree on num_aligned: %d vs %d" % (int(ctr[0]), exact_aligned)
+    prof = torch.tensor([pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.seed_launches, pr.chain_launches, pr.trace_launches] +
+                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(prof)
     prof = [float(x) for x in prof.cpu()]
@@ -243,6 +259,14 @@ def main():
         b_seed = n_read_bytes + 12 * n_lookup + 16 * n_node + 8 * n_entry + 8 * n_hit
         # per-rank kernel time: ranks run concurrently, the sums above are over ranks
         ach = (b_seed / args.gpus) / (seed_ms / args.gpus * 1e-3) / 1e9 if seed_ms > 0 else 0.0
+        traffic = None                                      # PMC HBM bytes per seed-stage launch, measured with rocprofv3 in separate counter passes
+        try:
+            tj = json.load(open(os.path.join(HERE, "profiles", "hbm_traffic.json")))
+            w = tj["workload"]
+            if (w["batch_reads"], w["read_len"], w["db_nt"]) == (args.batch_reads, args.read_len, args.db_nt):
+                traffic = tj["seed_stage_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "value": reads_timed / dt, "unit": "reads/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -253,8 +277,10 @@ def main():
                        "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
                        "cigar": not args.no_cigar},
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
+            "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,
+                              "entries": n_entry / reads_timed, "hits": n_hit / reads_timed},
             "roofline": {"kernel": "k_seed", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": b_seed / max(seed_l, 1), "avg_launch_ms": seed_ms / max(seed_l, 1),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": b_seed / max(seed_l, 1), "avg_launch_ms": seed_ms / max(seed_l, 1),
                          "bytes_per_read": b_seed / reads_timed},
             "kernels": {"k_seed": {"ms": seed_ms / args.gpus, "launches": seed_l / args.gpus},
                         "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
