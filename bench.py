@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--batch-reads", type=int, default=2_000_000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--db-nt", type=int, default=140_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
@@ -263,8 +263,8 @@ def main():
         try:
             tj = json.load(open(os.path.join(HERE, "profiles", "hbm_traffic.json")))
             w = tj["workload"]
-            if (w["batch_reads"], w["read_len"], w["db_nt"]) == (args.batch_reads, args.read_len, args.db_nt):
-                traffic = tj["seed_stage_bytes_per_launch"]
+            if (w["read_len"], w["db_nt"]) == (args.read_len, args.db_nt):    # measured per 1 M-read launch; per-read traffic scales with the batch
+                traffic = tj["seed_stage_bytes_per_launch"] * args.batch_reads / w["batch_reads"]
         except Exception:
             pass
         out = {
