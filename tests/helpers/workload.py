@@ -17,7 +17,8 @@ GUMBEL_UNIFORM = (0.618874, 0.343238)
 
 class Workload:
     def __init__(self, tmpdir, db_nt=300_000, n_reads=4000, read_len=150, frac_db=0.4, seed=5, max_mb=3072.0,
-                 n_rate=0.002, family_size=40):
+                 n_rate=0.002, family_size=40, lnwin=18):
+        self.lnwin = lnwin
         self.dir = tmpdir
         self.db = os.path.join(tmpdir, "db_%d_%d.fasta" % (db_nt, seed))
         synth.make_db(self.db, db_nt, seed=seed, family_size=family_size)
@@ -27,12 +28,12 @@ class Workload:
         self.seqs = [bytes(x).decode() for x in self.letters]
         rng = np.random.Generator(np.random.PCG64(seed + 2))
         for i in range(0, n_reads, 17):
-            self.seqs[i] = self.seqs[i][: int(rng.integers(18, read_len))]
+            self.seqs[i] = self.seqs[i][: int(rng.integers(lnwin, read_len))]
         if n_reads > 10:
             self.seqs[3] = self.seqs[3][:12]
             self.seqs[7] = ""
-            self.seqs[9] = self.seqs[9][:18]
-        self.parts = smr.Index.build(self.db, 18, max_mb, 10000, 0)
+            self.seqs[9] = self.seqs[9][:lnwin]
+        self.parts = smr.Index.build(self.db, lnwin, max_mb, 10000, 0)
         self.prefix = os.path.join(tmpdir, "idx_%d_%d" % (db_nt, seed))
         smr.Index.write_files(self.parts, self.db, self.prefix)
         self.stats = orc.load_stats(self.prefix)
@@ -43,6 +44,9 @@ class Workload:
     def oracle_records(self, **kw):
         """Run the CPU oracle over all parts; returns (records, counters)."""
         p = orc.default_params(minimal_score=self.minimal_score, **kw)
+        if "skiplengths" not in kw:
+            p.lnwin = self.lnwin
+            p.skiplengths[0], p.skiplengths[1], p.skiplengths[2] = self.lnwin, self.lnwin // 2, 3      # refstats.cpp:159-166
         run = orc.Run(self.seqs)
         for part in range(self.stats.nparts):
             p.part = part

@@ -111,6 +111,24 @@ def test_longer_reads(engine, tmp_path):
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 50
 
 
+@pytest.mark.parametrize("lnwin", [12, 14, 16])
+def test_other_seed_lengths(engine, tmp_path, lnwin):
+    """-L 12/14/16: other window lengths (partialwin 6/7/8), their trie depth limits and automaton tail tables"""
+    w = Workload(str(tmp_path), db_nt=120_000, n_reads=1200, seed=50 + lnwin, frac_db=0.5, lnwin=lnwin)
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "L=%d" % lnwin)
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 100
+
+
+def test_non_default_strides(engine, wl):
+    """-passes 18,6,2 (the reference's own parser of that option is broken, options.cpp:704-732, so this is oracle-only)"""
+    recs_o, ctr_o = wl.oracle_records(skiplengths=[18, 6, 2])
+    recs_g, ctr_g = wl.gpu_records(engine, skiplengths=[18, 6, 2])
+    _compare(recs_g, recs_o, "passes 18,6,2")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"]
+
+
 def test_long_noisy_reads(engine, tmp_path):
     """PacBio-like reads (0.8-3 kb, ~10 % errors incl. indels): several SW strips, wide traceback bands, many seeds."""
     import numpy as np
