@@ -57,7 +57,7 @@ struct smr_ctx {
   Batch* b = &bt[0];
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
-  uint32_t hcap = 8;
+  uint32_t hcap = 4;                      // lane-local hit list capacity; doubles (and the part is redone) on overflow
   int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_bfs (+ redo)
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;

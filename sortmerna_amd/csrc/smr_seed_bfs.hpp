@@ -23,10 +23,18 @@ namespace smr {
 // algorithmic-byte counts come from k_seed_search (smr_set_seed_mode).  A wave whose queues overflow hands its 64
 // tuples to k_seed_search through the redo list.
 // ------------------------------------------------------------------------------------------------
-#define BFS_NS_CAP 512u         // node items
+// The LDS queues are small on purpose: occupancy is worth more than the (rare) redo of an overflowing wave
+// (12 KB/wave -> 13 waves/CU: 20.7 ms per stage; 8 KB -> 18+ waves/CU: 16.8 ms).
+#ifndef BFS_NS_CAP
+#define BFS_NS_CAP 256u         // node items
+#endif
 #define BFS_BQ_CAP 128u         // bucket items
-#define BFS_CAND_CAP 128u       // candidates
-#define BFS_OWN_CAP 2048u       // entries of one bucket batch with a direct entry -> bucket byte map
+#ifndef BFS_CAND_CAP
+#define BFS_CAND_CAP 64u        // candidates
+#endif
+#ifndef BFS_OWN_CAP
+#define BFS_OWN_CAP 1024u       // entries of one bucket batch with a direct entry -> bucket byte map
+#endif
 // dynamic LDS words: pat, root, hit lists, node LIFO (2 words), bucket queue (3 words), pref, candidates (3 words), owner map
 #define BFS_LDS_WORDS(hcap) (64u + 64u + 64u * (hcap) + 2u * BFS_NS_CAP + 3u * BFS_BQ_CAP + 64u + 3u * BFS_CAND_CAP + BFS_OWN_CAP / 4u)
 
