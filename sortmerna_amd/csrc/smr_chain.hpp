@@ -163,9 +163,9 @@ struct ChainScratch {
   uint32_t keys_cap, pairs_cap, hits_cap;
 };
 
-#define CH_KEYS_LDS 256
+#define CH_KEYS_LDS 128
 #define CH_PAIRS_LDS 256
-#define CH_HITS_LDS 256
+#define CH_HITS_LDS 128
 
 // find_lis (alignment.cpp:58-98) over a[0..n): keys = ref_pos<<32 | read_pos ; compares read_pos (.second).
 // executed redundantly by every lane (uniform control flow); b,p hold indices.
@@ -195,7 +195,7 @@ __device__ uint32_t find_lis_dev(const unsigned long long* a, uint32_t n, uint32
 // open-addressing set S.  Most background reads leave S empty and are done.  Walk 2 counts exactly, for the
 // references in S only, and records their (pos, win) tuples; candidates are the members of S with count >= num_seeds,
 // and each candidate's (ref_pos, read_pos) pairs are a filter over the tuples instead of per-hit binary searches.
-__global__ void __launch_bounds__(64, 3) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
+__global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
                                               RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,

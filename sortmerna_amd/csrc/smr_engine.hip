@@ -137,7 +137,7 @@ DIndex dindex(const DevIndex& d) {
 DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off = c->b->d_rec_off; r.len = c->b->d_len; r.n = c->b->n; r.max_len = c->b->max_len; return r; }
 
 int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
-  if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * (getenv("SMR_CHAIN_WPC") ? atoi(getenv("SMR_CHAIN_WPC")) : 12);
+  if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * (getenv("SMR_CHAIN_WPC") ? atoi(getenv("SMR_CHAIN_WPC")) : 15);
   (void)di;
   uint32_t need_keys = std::max(c->chain_scap, 1024u);
   if (c->keys_cap < need_keys) { int rc = dev_alloc(c, &c->d_keys, (size_t)c->chain_blocks * need_keys); if (rc) return rc; c->keys_cap = need_keys; }
