@@ -137,15 +137,27 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU fallback of the product path)")
+    # test knobs (single-GPU dry run of the multi-rank path): SMR_BENCH_BACKEND=gloo puts the tiny collectives on the CPU,
+    # SMR_BENCH_DEVICE=k maps every rank to GPU k
+    backend = os.environ.get("SMR_BENCH_BACKEND", "nccl")
+    if "SMR_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["SMR_BENCH_DEVICE"])
+    cdev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local])
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # ---------------- workload: DB + index (rank 0 builds, the others load its files) ----------------
@@ -207,7 +219,7 @@ def main():
     log("%d batches of %d reads resident (%.1fs)" % (nb, args.batch_reads, time.time() - t0))
 
     # C1: global read totals -> the same minimal_score on every rank (refstats.cpp:247-265)
-    g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, args.read_len, args.read_len, device="cuda")
+    g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, args.read_len, args.read_len, device=cdev)
     ms = smr.minimal_score(GUMBEL[0], GUMBEL[1], info, g_reads, g_len)
     params = smr.default_params(minimal_score=ms)
 
@@ -235,7 +247,7 @@ def main():
         step(b)
     barrier()
     dt = time.perf_counter() - t0
-    dt = shard.time_max(dt, device="cuda")
+    dt = shard.time_max(dt, device=cdev)
 
     # C2: Readstats counters of the timed batches, summed over ranks (RCCL)
     ctr = np.zeros(3, dtype=np.int64)
@@ -243,11 +255,11 @@ def main():
         eng.select_batch(b)
         c = eng.counters(1)
         ctr += np.array([c["num_aligned"], c["num_short"], c["reads_matched_per_db"][0]], dtype=np.int64)
-    ctr_t = shard.reduce_counters(ctr.tolist(), device="cuda")
+    ctr_t = shard.reduce_counters(ctr.tolist(), device=cdev)
     pr = eng.prof()
     assert int(ctr[0]) == exact_aligned, "the two seed kernels disagree on num_aligned: %d vs %d" % (int(ctr[0]), exact_aligned)
     prof = torch.tensor([pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.seed_launches, pr.chain_launches, pr.trace_launches] +
-                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells], dtype=torch.float64, device="cuda")
+                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(prof)
     prof = [float(x) for x in prof.cpu()]
@@ -296,7 +308,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
     eng.close()
 
