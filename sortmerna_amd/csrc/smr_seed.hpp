@@ -109,27 +109,29 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 //   k_seed_keys<DIR>    window -> (key, rank in bin, payload)            [9-mer hash, lookup probe, Read::flip34 view]
 //   k_seed_scan         exclusive scan of the bin counts
 //   k_seed_scatter      tuples to bin order
-//   k_seed_search<DIR>  the searches (below)
+//   k_seed_bfs<DIR>     the searches, work-queue formulation (smr_seed_bfs.hpp) -- the default
+//   k_seed_search<DIR>  the searches, per-lane DFS formulation (below): overflow redo + exact work counters
 //   k_seed_finish       per read: gather the windows' hits into one block, hit_seeds / hit_total (paralleltraversal.cpp:242-249)
 //
 // k_seed_search, one wave per 64 tuples: lane = one window's search.  A lane walks its mini-trie exactly in the
 // reference's DFS order (A<C<G<T, traverse_bursttrie.cpp:117), but the walk is cut into ROUNDS: in a round every lane
 // advances over trie NODES only and collects its next few buckets; then the whole wave scans the entries of all
-// collected buckets together, one lane per ENTRY, so the dominant work -- the LEV(1) automaton over bucket entries --
-// runs with full lanes.  Accepted entries ("candidates", rare) are handed back to the owning lane in entry order,
-// which applies the reference's sequential rules to its lane-local hit list in LDS:
+// collected buckets together, one lane per ENTRY (lev1_entry: the automaton over a complete candidate string in closed
+// form), so the dominant work runs with full lanes.  Accepted entries ("candidates", rare) are handed back to the owning
+// lane in entry order, which applies the reference's sequential rules to its lane-local hit list in LDS:
 //   entry accepted at t_a = first step with depth_b >= pw-2 and state >= 8   (traverse_bursttrie.cpp:229-235)
-//   UNCOND  state 9 at depth_b == pw-1 in the accepting step itself  -> 0-error hit: list = {id}, search over (:256-262)
-//   COND    accepted at pw-2 and state 9 one step later: the reference reaches that step only if the id was NOT
-//           already in the list when it was accepted (otherwise the duplicate check `break`s first, :265-277)
+//   COND    0-error entry (state 9 at depth_b == pw-1): it is accepted one step earlier, at pw-2, and the reference reaches
+//           the 0-error step only if the id was NOT already in the list then (otherwise the duplicate check `break`s
+//           first, :265-277); when it fires: list = {id}, search over (:256-262)
 //   PLAIN   1-error hit: appended unless the id is already present
+//   (UNCOND, state 9 in the accepting step itself, cannot occur: tests/test_lev_closed_form.py)
 // ------------------------------------------------------------------------------------------------
 #define SEED_STK 10                                    // trie depth < partialwin - 1 <= 9
 #define SEED_OWN_CAP 2048u                             // entries of one round that get a direct entry -> bucket byte map
 #define SEED_MAXPW 10u
 #define SEED_K 4                                       // buckets a lane may collect per round
 #define SEED_GATHER 32u                                // ... or until it holds this many entries
-// dynamic LDS words of k_seed_search: hit lists, node stacks (offsets + level state), row-index table, pref/pb/nat, FIFO, owner map
+// dynamic LDS words of k_seed_search: hit lists, node stack, row-index table, pref/pb/pth, patterns, owner map
 #define SEED_LDS_WORDS(hcap) (64u * (hcap) + SEED_STK * 64u + (SEED_MAXPW + 1u) * 64u + 3u * 64u * SEED_K + 64u + SEED_OWN_CAP / 4u)
 #define SEED_ZERO_BIT 0x80000000u
 
@@ -308,12 +310,11 @@ __device__ __forceinline__ uint32_t node_states(const uint4 nd, uint32_t rtw, ui
 // All searches of one wave; lane-varying mini-trie root `trie` (offsets inside are relative to it).  hl holds the
 // lane-local hit lists (nh entries already present for DIR 1: the forward search's hits).
 //
-// Round = (1) every lane walks trie nodes in DFS order and collects its next <= SEED_K buckets; (2) the entries of all
-// collected buckets are flattened lane-major (so one window's entries stay in DFS order) and scanned one lane per
-// entry in two stages: stage A runs the first <= 2 automaton steps (never an accepting depth) and drops the dead
-// entries -- most of them --, the survivors are compacted through a FIFO in LDS and stage B finishes them 64 at a
-// time; (3) accepted entries go back to the owning lane in entry order.  Work counters follow the reference's
-// sequential scan: nothing after a 0-error match is counted.
+// Round = (1) every lane walks trie nodes in DFS order (pruned by the table automaton: all four element states of a
+// node from a per-window table of LEV row indices) and collects its next <= SEED_K buckets; (2) the entries of all
+// collected buckets are flattened lane-major (so one window's entries stay in DFS order) and evaluated one lane per
+// entry, inputs fetched one chunk ahead; (3) accepted entries go back to the owning lane in entry order.  Work
+// counters follow the reference's sequential scan: nothing after a 0-error match is counted.
 #ifdef SMR_SEED_PHASES                                    // per-phase cycle accounting (debug build, SMR_DEBUG_PHASES=1)
 #define SPH(i) { const unsigned long long tn_ = clock64(); sph[i] += tn_ - slast; slast = tn_; }
 #else
