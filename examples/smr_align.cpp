@@ -1,0 +1,137 @@
+// smr_align.cpp -- a C++17 host driver over the C ABI of libsmr_hip (include/smr_hip.h): the shape of the reference's
+// align() (/root/reference/src/sortmerna/processor.cpp:173-285) with the N x align2() thread loop of every (index, part)
+// replaced by one batched GPU call, for one or more --ref databases.  It writes what the reference keeps in its KVDB:
+//   <out>/records.bin   u64 n, then n x (u64 klen, key "0_<i>", u64 vlen, Read::toBinString bytes)   (reads with a record only)
+//   <out>/summary.txt   total reads, reads passing the E-value threshold, per-DB counts, too-short reads
+// Build:  g++ -std=c++17 -O2 examples/smr_align.cpp -Iinclude -Lsortmerna_amd/lib -lsmr_hip -Wl,-rpath,$PWD/sortmerna_amd/lib -o smr_align
+// There is no CPU fallback: without a HIP device smr_create fails and the program exits like the reference does (ERR + exit 1).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smr_hip.h"
+
+namespace {
+[[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR: %s\n", m.c_str()); exit(EXIT_FAILURE); }
+struct Db { std::string fasta, idx_prefix; double lambda = 0.618874, K = 0.343238; std::vector<smr_index*> parts; };
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::vector<Db> dbs;
+  std::string reads_path, out_dir = ".";
+  smr_params base; smr_params_default(&base);
+  double evalue = 1.0;
+  int device = 0;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value after " + a); return argv[++i]; };
+    if (a == "-ref" || a == "--ref") { Db d; d.fasta = val(); dbs.push_back(d); }
+    else if (a == "-idx" || a == "--idx") { if (dbs.empty()) die("--idx before --ref"); dbs.back().idx_prefix = val(); }   // reference-format index files
+    else if (a == "-gumbel" || a == "--gumbel") { if (dbs.empty()) die("--gumbel before --ref"); dbs.back().lambda = atof(val().c_str()); dbs.back().K = atof(val().c_str()); }
+    else if (a == "-reads" || a == "--reads") reads_path = val();
+    else if (a == "-out" || a == "--out") out_dir = val();
+    else if (a == "-e") evalue = atof(val().c_str());
+    else if (a == "-num_alignments" || a == "--num_alignments") base.num_alignments = (uint32_t)atoi(val().c_str());
+    else if (a == "-no-best" || a == "--no-best") base.is_best = 0;
+    else if (a == "-min_lis" || a == "--min_lis") base.min_lis = atoi(val().c_str());
+    else if (a == "-num_seeds" || a == "--num_seeds") base.num_seeds = atoi(val().c_str());
+    else if (a == "-edges" || a == "--edges") base.edges = atoi(val().c_str());
+    else if (a == "-full_search" || a == "--full_search") base.is_full_search = 1;
+    else if (a == "-F") base.is_reverse = 0;
+    else if (a == "-R") base.is_forward = 0;
+    else if (a == "-match") base.match = atoi(val().c_str());
+    else if (a == "-mismatch") { base.mismatch = atoi(val().c_str()); base.score_N = base.mismatch; }
+    else if (a == "-gap_open") base.gap_open = atoi(val().c_str());
+    else if (a == "-gap_ext") base.gap_ext = atoi(val().c_str());
+    else if (a == "-device") device = atoi(val().c_str());
+    else if (a == "-h" || a == "--help") {
+      printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq [--out DIR]\n"
+             "       [-e EVALUE] [-num_alignments N] [-no-best] [-min_lis N] [-num_seeds N] [-edges N] [-full_search] [-F|-R]\n"
+             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K]\n");
+      return 0;
+    } else die("unknown option " + a);
+  }
+  if (dbs.empty() || reads_path.empty()) die("--ref and --reads are required (see --help)");
+  char err[512] = "";
+
+  // reads (Readfeed::next -> Read::init, readfeed.hpp:124 / read.cpp:264-347)
+  smr_reads* reads = nullptr;
+  if (smr_reads_load_fastx(reads_path.c_str(), 0, 0, &reads, err, sizeof err) != SMR_OK) die(err);
+  const uint32_t n = smr_reads_count(reads);
+
+  // indexes: reference-built files when a prefix is given, else our own builder (Index ctor / build_index, index.cpp:61-107)
+  for (auto& d : dbs) {
+    if (!d.idx_prefix.empty()) {
+      smr_index* p0 = nullptr;
+      if (smr_index_load_files(d.idx_prefix.c_str(), 0, d.fasta.c_str(), &p0, err, sizeof err) != SMR_OK) die(err);
+      smr_index_info info; smr_index_get_info(p0, &info);
+      d.parts.push_back(p0);
+      for (uint32_t k = 1; k < info.n_parts; k++) {
+        smr_index* pk = nullptr;
+        if (smr_index_load_files(d.idx_prefix.c_str(), k, d.fasta.c_str(), &pk, err, sizeof err) != SMR_OK) die(err);
+        d.parts.push_back(pk);
+      }
+    } else {
+      smr_index* arr[256]; uint32_t np = 0;
+      if (smr_index_build(d.fasta.c_str(), 18, 3072.0, 10000, 0, arr, 256, &np, err, sizeof err) != SMR_OK) die(err);
+      d.parts.assign(arr, arr + np);
+    }
+  }
+
+  smr_ctx* gpu = nullptr;
+  if (smr_create(device, &gpu, err, sizeof err) != SMR_OK) die(err);
+  const uint32_t slots = base.num_alignments > 0 ? base.num_alignments : 256;
+  if (smr_reads_upload(gpu, reads, slots) != SMR_OK) die(smr_last_error(gpu));
+
+  // the (index, part) loop of processor.cpp:219-277
+  for (size_t k = 0; k < dbs.size(); k++) {
+    smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
+    smr_params p = base;
+    p.minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, n, smr_reads_total_len(reads), evalue);
+    p.index_num = (uint32_t)k;
+    for (size_t part = 0; part < dbs[k].parts.size(); part++) {
+      p.part = (uint32_t)part;
+      p.is_last_index_part = (k + 1 == dbs.size() && part + 1 == dbs[k].parts.size());
+      if (smr_index_upload(gpu, dbs[k].parts[part], 0) != SMR_OK) die(smr_last_error(gpu));
+      if (smr_align_part(gpu, 0, &p) != SMR_OK) die(smr_last_error(gpu));
+      if (smr_traceback(gpu, 0, &p) != SMR_OK) die(smr_last_error(gpu));
+      smr_index_unload(gpu, 0);
+    }
+  }
+  if (smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
+
+  // kvdb.put(read.id, read.toBinString()) (processor.cpp:150-155) -> records.bin ; Readstats -> summary.txt
+  const std::string rp = out_dir + "/records.bin", sp = out_dir + "/summary.txt";
+  FILE* f = fopen(rp.c_str(), "wb");
+  if (!f) die("cannot write " + rp);
+  uint64_t nrec = 0;
+  fwrite(&nrec, 8, 1, f);
+  std::vector<uint8_t> buf;
+  for (uint32_t i = 0; i < n; i++) {
+    const size_t len = smr_result_record(gpu, i, nullptr, 0);
+    if (!len) continue;
+    buf.resize(len);
+    smr_result_record(gpu, i, buf.data(), len);
+    const std::string key = "0_" + std::to_string(i);
+    const uint64_t kl = key.size(), vl = len;
+    fwrite(&kl, 8, 1, f); fwrite(key.data(), 1, kl, f); fwrite(&vl, 8, 1, f); fwrite(buf.data(), 1, vl, f);
+    nrec++;
+  }
+  fseek(f, 0, SEEK_SET); fwrite(&nrec, 8, 1, f); fclose(f);
+  std::vector<uint64_t> ctr(2 + dbs.size());
+  smr_counters(gpu, ctr.data(), (uint32_t)dbs.size());
+  f = fopen(sp.c_str(), "w");
+  if (!f) die("cannot write " + sp);
+  fprintf(f, "Total reads = %u\nTotal reads passing E-value threshold = %llu\nToo short reads (last part) = %llu\n", n,
+          (unsigned long long)ctr[0], (unsigned long long)ctr[1]);
+  for (size_t k = 0; k < dbs.size(); k++) fprintf(f, "%s\t%llu\n", dbs[k].fasta.c_str(), (unsigned long long)ctr[2 + k]);
+  fclose(f);
+  printf("%u reads, %llu aligned, %llu records -> %s\n", n, (unsigned long long)ctr[0], (unsigned long long)nrec, rp.c_str());
+  for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
+  smr_reads_free(reads);
+  smr_destroy(gpu);
+  return 0;
+}

@@ -1,0 +1,55 @@
+"""The C++17 host driver over the C ABI (examples/smr_align.cpp): builds with plain g++ against include/smr_hip.h, fails loudly without a
+GPU, and on the GPU box reproduces the reference's per-read records for a one-DB and a two-DB golden case."""
+import os
+import struct
+import subprocess
+
+import pytest
+
+from helpers import golden, paths, refrun
+
+EXE = os.path.join(paths.REPO, "examples", "build", "smr_align")
+
+
+def build_driver():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    lib = os.path.join(paths.REPO, "sortmerna_amd", "lib")
+    import sortmerna_amd.capi as capi
+    capi.load()                                   # makes sure libsmr_hip.so is built
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(paths.REPO, "examples", "smr_align.cpp"),
+                           "-I", os.path.join(paths.REPO, "include"), "-L", lib, "-lsmr_hip", "-Wl,-rpath," + lib, "-o", EXE])
+    return EXE
+
+
+def test_driver_builds_and_fails_loudly_without_gpu(tmp_path):
+    exe = build_driver()
+    assert "usage: smr_align" in subprocess.check_output([exe, "--help"]).decode()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    db, rd, _ = golden.inputs("syn_default")
+    p = subprocess.run([exe, "--ref", db, "--reads", rd, "--out", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"no CPU fallback" in p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["syn_default", "syn_all", "two_db_default"])
+def test_driver_reproduces_reference_records(case, tmp_path):
+    exe = build_driver()
+    g = golden.load()[case]
+    dbs, rd, seqs = golden.inputs(case)
+    if not isinstance(dbs, list):
+        dbs = [dbs]
+    cmd = [exe, "--reads", rd, "--out", str(tmp_path)]
+    for k, db in enumerate(dbs):
+        cmd += ["--ref", db, "--gumbel", repr(g["log"]["lambda"][k]), repr(g["log"]["K"][k])]
+    if "num_alignments" in g["params"]:
+        cmd += ["-num_alignments", str(g["params"]["num_alignments"])]
+    subprocess.check_call(cmd)
+    kv = refrun.parse_kvdb_dump(str(tmp_path / "records.bin"))
+    got = [kv.get(b"0_%d" % i, b"") for i in range(len(seqs))]
+    exp = golden.records(case)
+    bad = [i for i in range(len(seqs)) if got[i] != exp[i]]
+    assert not bad, "%d records differ, first %d" % (len(bad), bad[0])
+    summary = open(tmp_path / "summary.txt").read()
+    assert "Total reads passing E-value threshold = %d" % g["readstats"]["num_aligned"] in summary
