@@ -519,8 +519,11 @@ extern "C" int smr_traceback(smr_ctx* c, int slot, const smr_params* p) {
   }
   std::vector<unsigned long long> h;
   const uint32_t maxL = c->b->max_len + 2 * (uint32_t)std::max(P.edges, 0) + 16;
-  // level 0: band <= 32 ; level 1: worst case (band < 2*maxL)
-  for (int level = 0; level < 2; level++) {
+  // scratch is sized for a maximum band that grows level by level (32, 256, 2048, worst case 2*maxL): alignments whose
+  // band doubling (ssw.c:669-671) exceeds the level's band fail there and are picked up by the next level
+  const uint32_t level_band[4] = {32u, 256u, 2048u, 2 * maxL};
+  for (int level = 0; level < 4; level++) {
+    if (level > 0 && level_band[level - 1] >= 2 * maxL) break;
     for (int grow = 0; grow < 6; grow++) {
       HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_TRACE_NEXT], 0, 8, c->stream));
       HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_CIGAR], 0, 16, c->stream));     // C_ERR_CIGAR, C_ERR_TRACE
@@ -528,12 +531,12 @@ extern "C" int smr_traceback(smr_ctx* c, int slot, const smr_params* p) {
       if ((rc = read_ctr(c, h))) return rc;
       uint32_t n_tasks = (uint32_t)h[C_TRACE_NEXT];
       if (n_tasks == 0) return SMR_OK;
-      uint32_t band = level == 0 ? 32u : 2 * maxL;
+      uint32_t band = std::min(level_band[level], 2 * maxL);
       uint32_t wcap = 2 * band + 8;
       uint64_t dir_cap = (uint64_t)(2 * band + 1) * maxL * 3 + 16;
       uint32_t cig_cap = 2 * maxL + 16;
       uint64_t per_block = dir_cap * 64 + (uint64_t)3 * wcap * 64 * 4 + (uint64_t)cig_cap * 64 * 4;
-      uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((4ull << 30) / per_block, 1), (uint64_t)c->n_cu * 8);
+      uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((32ull << 30) / per_block, 1), (uint64_t)c->n_cu * 8);
       blocks = std::min<uint32_t>(blocks, (n_tasks + 63) / 64);
       if (c->tr_dir_cap != dir_cap || c->tr_wcap != wcap || c->tr_blocks < blocks || c->tr_cig_cap != cig_cap) {
         if ((rc = dev_alloc(c, &c->d_dir, (size_t)blocks * dir_cap * 64))) return rc;

@@ -164,6 +164,47 @@ def test_long_noisy_reads(engine, tmp_path):
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 40
 
 
+@pytest.mark.parametrize("scoring", [{}, {"match": 5, "mismatch": -4, "score_N": -4}], ids=["2_-3", "5_-4"])
+def test_long_reads_with_large_gaps(engine, tmp_path, scoring):
+    """3-5 kb reads with one 120-400 nt deletion or insertion: 16-bit SW range, >= 12 SW strips, traceback bands of
+    hundreds of columns (the second/third scratch level of smr_traceback); with match 5 the scores exceed 16383, which takes
+    the SW kernel's unpacked running-maximum path"""
+    import numpy as np
+    from sortmerna_amd import synth
+    w = Workload(str(tmp_path), db_nt=200_000, n_reads=20, seed=61, family_size=3, mean_len=6000)
+    codes, offs = synth.load_db_codes(w.db)
+    rng = np.random.Generator(np.random.PCG64(7))
+    seqs = []
+    for i in range(10):
+        sq = int(rng.integers(0, len(offs) - 1))
+        ln = int(min(offs[sq + 1] - offs[sq], rng.integers(3000, 5000)))
+        st = int(offs[sq] + rng.integers(0, offs[sq + 1] - offs[sq] - ln + 1))
+        s = codes[st:st + ln].copy()
+        m = rng.random(len(s)) < 0.02
+        s[m] = (s[m] + rng.integers(1, 4, size=int(m.sum()), dtype=np.uint8)) & 3
+        cut = int(rng.integers(1000, ln - 1000))
+        gap = int(rng.integers(120, 400))
+        if i % 2:
+            s = np.concatenate([s[:cut], s[cut + gap:]])                                   # deletion in the read
+        else:
+            s = np.concatenate([s[:cut], rng.integers(0, 4, size=gap, dtype=np.uint8), s[cut:]])   # insertion
+        t = "".join("ACGT"[c] for c in s)
+        if i % 3 == 0:
+            t = t[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        seqs.append(t)
+    w.seqs = seqs
+    w.reads = smr.Reads.from_seqs(seqs)
+    w.minimal_score = smr.minimal_score(0.618874, 0.343238, w.parts[0].info(), len(seqs), sum(map(len, seqs)))
+    recs_o, ctr_o = w.oracle_records(**scoring)
+    recs_g, ctr_g = w.gpu_records(engine, **scoring)
+    _compare(recs_g, recs_o, "long reads with large gaps")
+    if scoring:
+        assert max(refrun.parse_record(r)["alignv"][0]["score1"] for r in recs_o if r) > 16383
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 8
+    spans = [refrun.parse_record(r)["alignv"][0] for r in recs_o if r]
+    assert max(a["read_end1"] - a["read_begin1"] for a in spans) > 2500          # alignments really span the gap
+
+
 def test_empty_batch(engine, wl):
     r = smr.Reads.from_seqs([])
     p = smr.default_params(minimal_score=wl.minimal_score)
