@@ -75,7 +75,7 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
         t0 = time.time()
         smr.Index.write_files(parts, db, os.path.join(idx, h))
         log("index files for the reference written in %.1fs" % (time.time() - t0))
-        threads = min(cores, 64)
+        threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 64)
         cmd = [ref_bin, "-ref", db, "-reads", reads, "-workdir", os.path.join(wd, "run"), "-idx-dir", idx, "-threads", str(threads), "-fastx", "-v"]
         t0 = time.time()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--db-nt", type=int, default=140_000_000)
     ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the reference CPU baseline (0 = min(host cores, 64))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cigar", action="store_true", help="skip the banded traceback (not the reference's behaviour)")
     args = ap.parse_args()
