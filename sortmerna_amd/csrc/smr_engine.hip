@@ -178,8 +178,8 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   uint32_t mw = 1;
   for (int p = 0; p < 3; p++) mw = std::max(mw, num_windows(c->b->max_len, P.lnwin, P.skip[p]));
   const uint64_t slots = (uint64_t)std::max(c->b->n, 1u) * mw;
-  const uint32_t nk = 1u << P.lnwin;                      // 4^(L/2)
-  if (slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^32): use smaller batches"; return SMR_ERR_CAPACITY; }
+  const uint32_t nk = 2u << P.lnwin;                      // 2 x 4^(L/2) bins: forward and reverse keys
+  if (2 * slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^32): use smaller batches"; return SMR_ERR_CAPACITY; }
   int rc;
   if (c->sb_nk < nk) {
     if ((rc = dev_alloc(c, &c->sb.hist, nk))) return rc;
@@ -189,13 +189,13 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
     c->sb_nk = nk;
   }
   if (c->sb_slots < slots) {
-    if ((rc = dev_alloc(c, &c->sb.tmp, slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.tup, slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.tkey, slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.tmp, 2 * slots))) return rc;       // a forward and a reverse tuple per window
+    if ((rc = dev_alloc(c, &c->sb.tup, 2 * slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.tkey, 2 * slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.wseg, slots))) return rc;
     c->sb_slots = slots;
   }
-  c->sb.nk = nk;
+  c->sb.nk = nk; c->sb.nkh = nk / 2;
   return SMR_OK;
 }
 
@@ -206,19 +206,19 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   SeedBufs sb = c->sb;
   sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
   const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
-  sb.cap_tuples = (uint32_t)slots;
+  sb.cap_tuples = (uint32_t)(2 * slots);
   sb.cap_redo = SEED_REDO_CAP;
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_bfs = (size_t)BFS_LDS_WORDS(c->hcap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gk = (uint32_t)((slots + 255) / 256), gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024);
+  const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024), gs = (uint32_t)((2 * slots + 255) / 256);
   ev_begin(c, 0);
+  // one counting sort for the forward and the reverse tuples of the stage
+  HIPCHK(c, hipMemsetAsync(sb.hist, 0, (size_t)sb.nk * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
+  hipLaunchKernelGGL(k_seed_keys, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
+  hipLaunchKernelGGL(k_seed_scan, dim3(1), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_scatter, dim3(gs), dim3(256), 0, c->stream, sb);
   for (int dir = 0; dir < 2; dir++) {
-    HIPCHK(c, hipMemsetAsync(sb.hist, 0, (size_t)sb.nk * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
-    if (dir == 0) hipLaunchKernelGGL(k_seed_keys<0>, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
-    else hipLaunchKernelGGL(k_seed_keys<1>, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
-    hipLaunchKernelGGL(k_seed_scan, dim3(1), dim3(1024), 0, c->stream, sb);
-    hipLaunchKernelGGL(k_seed_scatter, dim3(gk), dim3(256), 0, c->stream, sb);
     const uint32_t* no_redo = nullptr;
     if (c->seed_exact) {
       if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
@@ -226,6 +226,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
     } else {
       // work-queue search; the (rare) waves whose LDS queues overflowed are searched again by the DFS kernel
       const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
+      HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       if (dir == 0) {
         hipLaunchKernelGGL(k_seed_bfs<0>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);

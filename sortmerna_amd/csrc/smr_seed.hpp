@@ -106,7 +106,7 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 // paralleltraversal.cpp:188), seeded with the forward hit list so that the reference's in-order de-duplication rules
 // are applied exactly.
 //
-//   k_seed_keys<DIR>    window -> (key, rank in bin, payload)            [9-mer hash, lookup probe, Read::flip34 view]
+//   k_seed_keys         window -> forward and reverse (key, rank in bin, payload)  [9-mer hash, lookup probes, flip34 view]
 //   k_seed_scan         exclusive scan of the bin counts
 //   k_seed_scatter      tuples to bin order
 //   k_seed_bfs<DIR>     the searches, work-queue formulation (smr_seed_bfs.hpp) -- the default
@@ -149,7 +149,7 @@ struct SeedBufs {
   uint32_t* wseg;            // [n * maxwin] pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
   uint32_t* sn;              // SN_* counters
   uint32_t* redo;            // waves of k_seed_bfs to be searched again by k_seed_search
-  uint32_t nk, maxwin, cap_tuples, cap_redo;
+  uint32_t nk, nkh, maxwin, cap_tuples, cap_redo;     // nk = 2 * nkh bins: forward keys [0, nkh), reverse keys [nkh, 2 nkh)
 };
 
 // nbits <= 40 bits starting at bit `bit0` of a little-endian word stream (reads up to 2 words past the first)
@@ -181,18 +181,20 @@ __device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, 
   return wchars;
 }
 
-// DIR 0: forward half-seed (key = first 9-mer, automaton fed by chars [pw, 2pw): init_win_f bitvector.cpp:57-91)
-// DIR 1: reverse half-seed (key = second 9-mer, automaton fed by chars pw-1 .. 0: init_win_r :99-132)
-template <int DIR>
+// Both half-seed searches of a window become tuples in ONE pass (so the counting sort runs once per stage):
+//   forward: key = first 9-mer, automaton fed by chars [pw, 2pw)          (init_win_f bitvector.cpp:57-91)  -> bins [0, nkh)
+//   reverse: key = second 9-mer, automaton fed by chars pw-1 .. 0         (init_win_r :99-132)              -> bins [nkh, 2 nkh)
+// The reverse tuple is speculative: the reverse search kernel drops it when the forward search ended with a 0-error match
+// (accept_zero_kmer, paralleltraversal.cpp:188).
 __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
                                                    const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, L = P.lnwin;
-  bool emit = false;
-  uint32_t key = 0, is_win = 0, is_lookup = 0;
-  unsigned long long payload = 0;
+  bool emit[2] = {false, false};
+  uint32_t key[2] = {0, 0}, is_win = 0;
+  unsigned long long payload[2] = {0, 0};
   if (r < rd.n) {
     const RWork w = rw[r];
     const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
@@ -202,9 +204,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     bool mine = k < numwin;
     const uint32_t win_pos = k * stride;
     if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
-    const size_t slot = (size_t)r * sb.maxwin + k;
-    if (DIR == 0) { if (active) sb.wseg[slot] = NONE; }
-    else if (mine) { const uint32_t s = sb.wseg[slot]; if (s != NONE && (s & SEED_ZERO_BIT)) mine = false; }   // accept_zero_kmer (:188)
+    if (active) sb.wseg[(size_t)r * sb.maxwin + k] = NONE;
     if (mine) {
       // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
       const uint32_t aval = w.is04 ? 0 : w.aval;
@@ -212,41 +212,42 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
       const unsigned long long half = (1ull << (2 * pw)) - 1ull;
       // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
       const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
-      const uint32_t sel = DIR == 0 ? a : b;
-      uint32_t rv = __brev(sel) >> (32 - 2 * pw);
-      rv = ((rv & 0x55555555u) << 1) | ((rv >> 1) & 0x55555555u);
-      key = rv;
-      // DIR 0: automaton chars = second half in order; DIR 1: first half walked backwards (chars pw-1 .. 0)
-      uint32_t chars;
-      if (DIR == 0) chars = b;
-      else { uint32_t ra = __brev(a) >> (32 - 2 * pw); chars = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u); }
-      is_win = DIR == 0 ? 1 : 0; is_lookup = 1;
-      const Lookup lk = ix.lookup[key];
-      emit = lk.count > P.minoccur && (DIR == 0 ? lk.rootF : lk.rootR) != NONE;
-      payload = (unsigned long long)r | ((unsigned long long)win_pos << 24) | ((unsigned long long)chars << 40);
+      uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
+      ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
+      rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
+      is_win = 1;
+      const Lookup lf = ix.lookup[ra], lr = ix.lookup[rb];
+      emit[0] = lf.count > P.minoccur && lf.rootF != NONE;
+      emit[1] = lr.count > P.minoccur && lr.rootR != NONE;
+      key[0] = ra; key[1] = sb.nkh + rb;
+      const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
+      payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
+      payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
     }
   }
   // block-aggregated slot allocation in the unsorted tuple array (one atomic per 1024 slots)
-  __shared__ uint32_t s_cnt[16], s_win[16], s_lk[16], s_base;
+  __shared__ uint32_t s_cnt[2][16], s_win[16], s_base;
   const uint32_t wv = threadIdx.x >> 6;
-  const unsigned long long em = __ballot(emit), wm = __ballot(is_win), lm = __ballot(is_lookup);
-  if (lane == 0) { s_cnt[wv] = (uint32_t)__popcll(em); s_win[wv] = (uint32_t)__popcll(wm); s_lk[wv] = (uint32_t)__popcll(lm); }
+  const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]), wm = __ballot(is_win);
+  if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t tc = 0, tw = 0, tl = 0;
-    for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { tc += s_cnt[q]; tw += s_win[q]; tl += s_lk[q]; }
+    uint32_t tc = 0, tw = 0;
+    for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { tc += s_cnt[0][q] + s_cnt[1][q]; tw += s_win[q]; }
     s_base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
-    if (tw) ctr_add(ctr, C_WINDOWS, tw);
-    if (tl) ctr_add(ctr, C_LOOKUP, tl);
+    if (tw) { ctr_add(ctr, C_WINDOWS, tw); ctr_add(ctr, C_LOOKUP, tw); }     // the forward lookups; the reverse ones are counted by k_seed_finish
   }
   __syncthreads();
-  if (emit) {
-    uint32_t base = s_base;
-    for (uint32_t q = 0; q < wv; q++) base += s_cnt[q];
-    const uint32_t idx = base + (uint32_t)__popcll(em & ((1ull << lane) - 1));
-    if (idx < sb.cap_tuples) {
-      SeedTmp t; t.key = key; t.rank = atomicAdd(&sb.hist[key], 1u); t.payload = payload;
-      sb.tmp[idx] = t;
+#pragma unroll
+  for (int d = 0; d < 2; d++) {
+    if (emit[d]) {
+      uint32_t base = s_base;
+      for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { if (d == 1) base += s_cnt[0][q]; if (q < wv) base += s_cnt[d][q]; }
+      const uint32_t idx = base + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
+      if (idx < sb.cap_tuples) {
+        SeedTmp t; t.key = key[d]; t.rank = atomicAdd(&sb.hist[key[d]], 1u); t.payload = payload[d];
+        sb.tmp[idx] = t;
+      }
     }
   }
 }
@@ -465,7 +466,9 @@ template <int DIR>
 __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
                                                     uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr,
                                                     const uint32_t* __restrict__ redo) {
-  const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples);
+  // this phase's tuples: forward bins first, reverse bins after them
+  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
+  const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
   uint32_t wave = blockIdx.x;
   if (redo) {                                            // only the waves listed by k_seed_bfs (its LDS queues overflowed)
     if (blockIdx.x >= min(sb.sn[SN_REDO], sb.cap_redo)) return;
@@ -486,8 +489,8 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   __shared__ unsigned long long s_row[LEV_ROWS];
   const int lane = lane_id();
   build_lev_rows(s_row);
-  const uint32_t pos = wave * 64u + lane;
-  const bool mine = pos < n_tup;
+  const uint32_t pos = first + wave * 64u + lane;
+  bool mine = wave * 64u + lane < n_tup;
   uint32_t r = 0, win_pos = 0, chars = 0;
   uint32_t root = 0;
   size_t slot = 0;
@@ -495,13 +498,14 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   uint32_t n_prev = 0;
   if (mine) {
     const unsigned long long pl = sb.tup[pos];
-    const Lookup lk = ix.lookup[sb.tkey[pos]];
+    const Lookup lk = ix.lookup[sb.tkey[pos] - (DIR ? sb.nkh : 0u)];
     root = DIR == 0 ? lk.rootF : lk.rootR;
     r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
     slot = (size_t)r * sb.maxwin + win_pos / P.skip[pass];
     if (DIR == 1) {                                      // the window's list so far = the forward search's hits
       const uint32_t seg = sb.wseg[slot];
-      if (seg != NONE) {
+      if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+      else if (seg != NONE) {
         n_prev = pool[seg + 1];
         for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
         if (n_prev > hcap) { sl.overflow = true; n_prev = hcap; }
@@ -557,18 +561,22 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long hits = 0, bytes = 0;
+  unsigned long long hits = 0, bytes = 0, looks = 0;
   if (r < rd.n) {
     RWork w = rw[r];
     if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
       const uint32_t len = rd.len[r], stride = P.skip[pass];
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
-      uint32_t seeds = 0, total = 0;
+      uint32_t seeds = 0, total = 0, rlook = 0;
       for (uint32_t k = 0; k < numwin; k++) {
         const uint32_t s = sb.wseg[(size_t)r * sb.maxwin + k];
+        bool searched = true;                                // windows of this pass: not searched by an earlier pass (:128-131)
+        for (int q = 0; q < pass; q++) if ((k * stride) % P.skip[q] == 0) searched = false;
+        if (searched && !(s != NONE && (s & SEED_ZERO_BIT))) rlook++;     // the reverse lookup happens unless the forward search hit exactly (:188-198)
         if (s == NONE) continue;
         seeds++; total += pool[(s & ~SEED_ZERO_BIT) + 1];
       }
+      looks = rlook;
       uint32_t base = 0;
       if (total) {
         const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
@@ -591,8 +599,8 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       hits = total; bytes = (len + 3) / 4;
     }
   }
-  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); }
-  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); }
+  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); }
+  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); if (looks) ctr_add(ctr, C_LOOKUP, looks); }
 }
 
 }  // namespace smr

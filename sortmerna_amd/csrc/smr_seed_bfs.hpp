@@ -47,7 +47,9 @@ __device__ __forceinline__ uint32_t path_order_key(uint32_t path) {
 template <int DIR>
 __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
                                                  uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
-  const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples);
+  // this phase's tuples: forward bins first, reverse bins after them
+  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
+  const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
   if (blockIdx.x * 64u >= n_tup) return;
   extern __shared__ __align__(16) uint32_t lds_dyn[];
   uint32_t* pat = lds_dyn;
@@ -70,14 +72,14 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
   const unsigned long long lt = (1ull << lane) - 1ull;
 
   // ---- the wave's 64 searches ----
-  const uint32_t pos = blockIdx.x * 64u + lane;
-  const bool mine = pos < n_tup;
+  const uint32_t pos = first + blockIdx.x * 64u + lane;
+  bool mine = blockIdx.x * 64u + lane < n_tup;
   uint32_t win_pos = 0, nh = 0, n_prev = 0, root = 0;
   size_t slot = 0;
   bool hl_over = false;
   if (mine) {
     const unsigned long long pl = sb.tup[pos];
-    const Lookup lk = ix.lookup[sb.tkey[pos]];
+    const Lookup lk = ix.lookup[sb.tkey[pos] - (DIR ? sb.nkh : 0u)];
     root = DIR == 0 ? lk.rootF : lk.rootR;
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
@@ -85,7 +87,8 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
     slot = (size_t)r * sb.maxwin + win_pos / P.skip[pass];
     if (DIR == 1) {                                      // the window's list so far = the forward search's hits
       const uint32_t seg = sb.wseg[slot];
-      if (seg != NONE) {
+      if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+      else if (seg != NONE) {
         n_prev = pool[seg + 1];
         for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
         if (n_prev > hcap) { hl_over = true; n_prev = hcap; }
