@@ -215,7 +215,10 @@ def main():
         eng.upload_reads(r, 1)
         tot_reads += r.count
         tot_len += r.total_len
-        r.free()
+        if b == nb - 1:
+            last_packed = r                                  # kept on the host for the PCIe-inclusive measurement below
+        else:
+            r.free()
     del codes, offs
     log("%d batches of %d reads resident (%.1fs)" % (nb, args.batch_reads, time.time() - t0))
 
@@ -265,6 +268,17 @@ def main():
         dist.all_reduce(prof)
     prof = [float(x) for x in prof.cpu()]
 
+    # informational: the same step when the boundary hands over a HOST buffer (packed batch -> smr_reads_upload: allocations + H2D over
+    # PCIe + state reset), serial, no overlap with the previous batch.  Never `value`.
+    t0 = time.perf_counter()
+    for _ in range(2):
+        eng.select_batch(nb - 1)
+        eng.upload_reads(last_packed, 1)
+        smr.align_resident(eng, idx_slots, [params], with_cigar=not args.no_cigar)
+    torch.cuda.synchronize()
+    pcie_rate = 2 * args.batch_reads / (time.perf_counter() - t0)
+    last_packed.free()
+
     if rank == 0:
         reads_timed = args.gpus * args.steps * args.batch_reads
         seed_ms, chain_ms, trace_ms, seed_l, chain_l, trace_l = prof[0:6]
@@ -289,6 +303,7 @@ def main():
                        "batch_reads": args.batch_reads, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
                        "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
                        "cigar": not args.no_cigar},
+            "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,
                               "entries": n_entry / reads_timed, "hits": n_hit / reads_timed},
