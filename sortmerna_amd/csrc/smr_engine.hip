@@ -19,6 +19,7 @@ namespace {
 struct DevIndex {
   bool used = false;
   Lookup* lookup = nullptr; uint32_t* trie = nullptr; uint32_t* pos_off = nullptr; uint2* pos_arr = nullptr;
+  uint32_t* trie2 = nullptr; uint32_t* root2 = nullptr;
   uint8_t* ref_seq = nullptr; uint64_t* ref_off = nullptr;
   uint32_t n_refs = 0, n_ids = 0, lnwin = 0;
   uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0;
@@ -130,7 +131,7 @@ int check_params(smr_ctx* c, const smr_params* p) {
 }
 
 DIndex dindex(const DevIndex& d) {
-  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
+  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.trie2 = d.trie2; x.root2 = d.root2; x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
   x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2;
   return x;
 }
@@ -340,6 +341,15 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   DevIndex& d = c->idx[slot];
   d.lnwin = ix->lnwin; d.n_refs = ix->n_refs(); d.n_ids = ix->n_ids(); d.trie_words = ix->trie.size(); d.n_pos = ix->pos_arr.size() / 2; d.ref_bytes = ix->ref_seq.size();
   int rc;
+  {
+    // the bit-sliced second layout of the tries (host transform, cached in the smr_index)
+    std::string why;
+    if (!smr_build_bitsliced(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
+  }
+  if ((rc = dev_alloc(c, &d.trie2, ix->trie2.size()))) return rc;
+  if ((rc = dev_alloc(c, &d.root2, ix->root2.size()))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d.trie2, ix->trie2.data(), ix->trie2.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d.root2, ix->root2.data(), ix->root2.size() * 4, hipMemcpyHostToDevice, c->stream));
   if ((rc = dev_alloc(c, &d.lookup, ix->lookup.size()))) return rc;
   if ((rc = dev_alloc(c, &d.trie, ix->trie.size()))) return rc;
   if ((rc = dev_alloc(c, &d.pos_off, ix->pos_off.size()))) return rc;
@@ -360,7 +370,7 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
 extern "C" int smr_index_unload(smr_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
   DevIndex& d = c->idx[slot];
-  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
+  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.trie2); dev_free(&d.root2); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
   d = DevIndex();
   return SMR_OK;
 }

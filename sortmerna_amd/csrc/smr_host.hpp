@@ -31,6 +31,16 @@ static constexpr uint32_t ELEM_NENT_SHIFT = 22;
 static constexpr uint32_t ELEM_OFF_MASK = (1u << 22) - 1;
 static constexpr uint32_t ELEM_NENT_MAX = 255;
 
+// Second device layout of the mini-tries, used by the work-queue seed search (k_seed_bfs): subtrees with at most
+// BS_UNIT entries are collapsed into ONE bucket (entries in DFS order, tails extended by the collapsed path), and a
+// bucket is stored BIT-SLICED in units of 32 entries: for every position j = 0..pw of the complete candidate string (trie
+// path + tail; the path positions hold the same char for all entries) a pair of words {lo_j, hi_j} whose bit e is the low /
+// high bit of character j of entry e, padded to a multiple of 4 words, then the 32 ids.  All units have the same size, and
+// one lane evaluates the LEV(1) closed form for 32 entries at once with plain bitwise logic.  Nodes keep the 4-word format.
+static constexpr uint32_t BS_UNIT = 32;
+__host__ __device__ inline uint32_t bs_plane_words(uint32_t pw) { return (2 * (pw + 1) + 3) & ~3u; }
+__host__ __device__ inline uint32_t bs_unit_words(uint32_t pw) { return bs_plane_words(pw) + BS_UNIT; }
+
 struct PartStats {
   uint64_t start_part = 0, seq_part_size = 0;
   uint32_t numseq_part = 0;
@@ -48,6 +58,8 @@ struct smr_index {
   std::vector<uint8_t> ref_seq;         // 0..4 per nt (References::convert_fix, references.cpp:162-169)
   std::vector<uint64_t> ref_off;        // n_refs + 1
   uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
+  std::vector<uint32_t> trie2;          // bit-sliced arena (built on demand by smr_build_bitsliced)
+  std::vector<uint32_t> root2;          // 2 * 4^(L/2): root word offset in trie2 of the forward / reverse mini-trie of key k at [2k], [2k+1]
   // whole-DB statistics (.stats)
   double bg[4] = {0.25, 0.25, 0.25, 0.25};
   uint64_t full_len = 0, numseq = 0, filesize = 0;
@@ -56,6 +68,9 @@ struct smr_index {
   uint32_t n_ids() const { return pos_off.empty() ? 0 : (uint32_t)pos_off.size() - 1; }
   uint32_t n_refs() const { return ref_off.empty() ? 0 : (uint32_t)ref_off.size() - 1; }
 };
+
+// builds trie2/root2 from trie/lookup (idempotent); false + message when a mini-trie does not fit the element encoding
+bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why);
 
 // Packed read batch.  Record i = ceil(len/16) words of 2-bit codes (nt k in bits 2*(k%16) of word k/16)
 // followed by ceil(len/32) words of ambiguity mask (bit k%32 of word k/32 set when the input letter

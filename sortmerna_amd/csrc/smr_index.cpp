@@ -415,6 +415,129 @@ struct TrieBuilder {
 
 }  // namespace
 
+// ---- bit-sliced arena (smr_host.hpp) -----------------------------------------------------------
+namespace {
+struct BsEnt { uint32_t tail, id; };
+
+uint32_t bs_count(const uint32_t* t, uint32_t node) {
+  uint32_t n = 0;
+  for (int ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    if (fl == 2) n += (e >> ELEM_NENT_SHIFT) & 0xFFu;
+    else if (fl == 1) n += bs_count(t, e & ELEM_OFF_MASK);
+  }
+  return n;
+}
+// entries below `node` (whose elements sit at level `lvl`) in DFS order; `pre` = chars of the levels between the
+// collapse root and `node`, `plen` their number
+void bs_collect(const uint32_t* t, uint32_t node, uint32_t pre, uint32_t plen, std::vector<BsEnt>& out) {
+  for (uint32_t ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    const uint32_t p2 = pre | (ne << (2 * plen));
+    if (fl == 2) {
+      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+      const uint32_t* b = t + (e & ELEM_OFF_MASK);
+      for (uint32_t q = 0; q < n; q++) out.push_back({p2 | (b[2 * q] << (2 * (plen + 1))), b[2 * q + 1]});
+    } else if (fl == 1) bs_collect(t, e & ELEM_OFF_MASK, p2, plen + 1, out);
+  }
+}
+// path = the nc chars of the trie path of the bucket's element (levels 0..nc-1), v[].tail = the remaining pw+1-nc chars
+uint32_t bs_emit_bucket(const BsEnt* v, uint32_t n, uint32_t path, uint32_t nc, uint32_t pw, std::vector<uint32_t>& out) {
+  const uint32_t off = (uint32_t)out.size();
+  for (uint32_t u = 0; u < n; u += BS_UNIT) {
+    const uint32_t c = std::min(BS_UNIT, n - u);
+    const size_t base = out.size();
+    out.resize(base + bs_unit_words(pw), 0);
+    for (uint32_t j = 0; j <= pw; j++) {
+      uint32_t lo = 0, hi = 0;
+      if (j < nc) { const uint32_t ch = (path >> (2 * j)) & 3u; lo = 0u - (ch & 1u); hi = 0u - (ch >> 1); }
+      else for (uint32_t e = 0; e < c; e++) { const uint32_t ch = (v[u + e].tail >> (2 * (j - nc))) & 3u; lo |= (ch & 1u) << e; hi |= (ch >> 1) << e; }
+      out[base + 2 * j] = lo; out[base + 2 * j + 1] = hi;
+    }
+    for (uint32_t e = 0; e < c; e++) out[base + bs_plane_words(pw) + e] = v[u + e].id;
+  }
+  return off;
+}
+bool bs_emit_node(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t path, uint32_t pw, uint32_t out_off, std::vector<uint32_t>& out,
+                  std::vector<BsEnt>& tmp) {
+  for (uint32_t ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    const uint32_t epath = path | (ne << (2 * depth));        // chars of levels 0..depth
+    uint32_t w = 0;
+    if (fl == 2) {
+      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+      tmp.clear();
+      const uint32_t* b = t + (e & ELEM_OFF_MASK);
+      for (uint32_t q = 0; q < n; q++) tmp.push_back({b[2 * q], b[2 * q + 1]});
+      const uint32_t off = bs_emit_bucket(tmp.data(), n, epath, depth + 1, pw, out);
+      w = (2u << ELEM_FLAG_SHIFT) | (n << ELEM_NENT_SHIFT) | off;
+      if (off > ELEM_OFF_MASK) return false;
+    } else if (fl == 1) {
+      const uint32_t child = e & ELEM_OFF_MASK;
+      const uint32_t cnt = bs_count(t, child);
+      if (cnt <= BS_UNIT) {                                  // collapse the subtree into one bucket of this element
+        tmp.clear();
+        bs_collect(t, child, 0, 0, tmp);
+        const uint32_t off = bs_emit_bucket(tmp.data(), cnt, epath, depth + 1, pw, out);
+        w = (2u << ELEM_FLAG_SHIFT) | (cnt << ELEM_NENT_SHIFT) | off;
+        if (off > ELEM_OFF_MASK) return false;
+      } else {
+        const uint32_t off = (uint32_t)out.size();
+        if (off > ELEM_OFF_MASK) return false;
+        out.resize(out.size() + 4, 0);
+        w = (1u << ELEM_FLAG_SHIFT) | off;
+        if (!bs_emit_node(t, child, depth + 1, epath, pw, off, out, tmp)) return false;
+      }
+    }
+    out[out_off + ne] = w;
+  }
+  return true;
+}
+}  // namespace
+
+bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why) {
+  if (!ix.root2.empty()) return true;
+  const size_t nk = ix.lookup.size();
+  const uint32_t pw = ix.lnwin / 2;
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min<uint32_t>(threads, 64);
+  std::vector<std::vector<uint32_t>> local(threads);
+  std::vector<uint32_t> root2(2 * nk, NONE);
+  std::vector<size_t> t_lo(threads, 0), t_hi(threads, 0);
+  bool ok = true;
+  parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
+    t_lo[tid] = lo; t_hi[tid] = hi;
+    std::vector<uint32_t>& out = local[tid];
+    std::vector<BsEnt> tmp;
+    for (size_t k = lo; k < hi; k++) {
+      for (int d = 0; d < 2; d++) {
+        const uint32_t root = d == 0 ? ix.lookup[k].rootF : ix.lookup[k].rootR;
+        if (root == NONE) continue;
+        const size_t base = out.size();
+        std::vector<uint32_t> one(4, 0);
+        if (!bs_emit_node(ix.trie.data() + root, 0, 0, 0, pw, 0, one, tmp)) { ok = false; return; }
+        out.insert(out.end(), one.begin(), one.end());
+        root2[2 * k + d] = (uint32_t)base;                   // thread-local for now
+      }
+    }
+  });
+  if (!ok) { why = "a bit-sliced mini-trie exceeds 2^22 words"; return false; }
+  size_t total = 0;
+  std::vector<size_t> tbase(threads, 0);
+  for (uint32_t t = 0; t < threads; t++) { tbase[t] = total; total += local[t].size(); }
+  if (total > 0xFFFFFFF0ull) { why = "bit-sliced trie arena exceeds 2^32 words"; return false; }
+  ix.trie2.resize(total);
+  parallel_for(threads, threads, [&](size_t lo, size_t hi, uint32_t) {
+    for (size_t t = lo; t < hi; t++) {
+      if (!local[t].empty()) memcpy(ix.trie2.data() + tbase[t], local[t].data(), local[t].size() * 4);
+      for (size_t k = t_lo[t]; k < t_hi[t]; k++)
+        for (int d = 0; d < 2; d++) if (root2[2 * k + d] != NONE) root2[2 * k + d] += (uint32_t)tbase[t];
+    }
+  });
+  ix.root2.swap(root2);
+  return true;
+}
+
 extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads,
                                smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
   if (!ref_fasta || !parts_out || !n_parts_out) return SMR_ERR_ARG;

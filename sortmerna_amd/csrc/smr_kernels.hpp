@@ -32,6 +32,8 @@ namespace smr {
 struct DIndex {
   const Lookup* lookup;
   const uint32_t* trie;
+  const uint32_t* trie2;       // bit-sliced arena (smr_host.hpp) and its roots: forward / reverse mini-trie of key k at [2k], [2k+1]
+  const uint32_t* root2;
   const uint32_t* pos_off;
   const uint2* pos_arr;        // {pos, seq}
   const uint8_t* ref_seq;

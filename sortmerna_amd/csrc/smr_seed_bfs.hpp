@@ -12,8 +12,10 @@ namespace smr {
 //   node items   (search, node, path)   popped 16 at a time from a LIFO in LDS; lane = (item, element A/C/G/T): one 16-byte
 //                                       node is read by 4 adjacent lanes; alive child nodes are pushed back, alive buckets
 //                                       go to the bucket queue
-//   bucket items (search, bucket, path) taken 64 at a time; their entries are flattened (prefix sum + owner byte map) and
-//                                       evaluated one lane per entry
+//   bucket items (search, bucket, path) taken 64 at a time, ONE LANE PER BUCKET: the index is stored a second time with small
+//                                       subtrees collapsed into buckets of <= 32 entries kept BIT-SLICED (smr_host.hpp), and
+//                                       lev1_unit evaluates the closed form for all 32 entries of a unit at once with bitwise
+//                                       logic (tests/test_lev_closed_form.py::test_bitsliced_unit_equals_closed_form)
 //   candidates   (search, order key, id, kind)  accepted entries (rare), collected in a small pool
 // The reference's sequential semantics (traverse_bursttrie.cpp:100-298: DFS order A<C<G<T, 0-error match clears the list
 // and ends the search, duplicate `break`) are restored at the end: each search applies ITS candidates in DFS order, the
@@ -32,11 +34,9 @@ namespace smr {
 #ifndef BFS_CAND_CAP
 #define BFS_CAND_CAP 64u        // candidates
 #endif
-#ifndef BFS_OWN_CAP
-#define BFS_OWN_CAP 1024u       // entries of one bucket batch with a direct entry -> bucket byte map
-#endif
-// dynamic LDS words: pat, root, hit lists, node LIFO (2 words), bucket queue (3 words), pref, candidates (3 words), owner map
-#define BFS_LDS_WORDS(hcap) (64u + 64u + 64u * (hcap) + 2u * BFS_NS_CAP + 3u * BFS_BQ_CAP + 64u + 3u * BFS_CAND_CAP + BFS_OWN_CAP / 4u)
+
+// dynamic LDS words: pat, root, hit lists, node LIFO (2 words), bucket queue (3 words), candidates (3 words)
+#define BFS_LDS_WORDS(hcap) (64u + 64u + 64u * (hcap) + 2u * BFS_NS_CAP + 3u * BFS_BQ_CAP + 3u * BFS_CAND_CAP)
 
 // most-significant-char-first version of a 2-bit packed path (char l at bits 2l) in the top 20 bits of a word
 __device__ __forceinline__ uint32_t path_order_key(uint32_t path) {
@@ -44,8 +44,52 @@ __device__ __forceinline__ uint32_t path_order_key(uint32_t path) {
   return (((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1)) >> 12;
 }
 
+// The closed form of lev1_entry for the <= 32 candidate strings of one bit-sliced unit at once: bit e of every mask = entry e.
+// The unit holds a {lo_j, hi_j} plane pair for every string position j = 0..pw (smr_host.hpp).  With E0/E1/E2_j = entries whose
+// char j equals P[j] / P[j-1] / P[j+1], Pr = running AND of E0 from the front, S0/S1/S2 = running ANDs from the back:
+//   accepted = OR_k Pr_{k-1} & (S1_{k+1} | S0_{k+1} | S2_k),   0-error = Pr_{pw-1}.
+__device__ __forceinline__ void lev1_unit(const uint32_t* __restrict__ unit, uint32_t P, uint32_t pw, uint32_t& acc_out, uint32_t& zero_out) {
+  constexpr int NP = SEED_MAXPW + 1;                       // string positions 0..SEED_MAXPW
+  uint32_t pl[2 * NP + 2];                                 // the planes: pl[2j] = lo_j, pl[2j+1] = hi_j
+  const uint32_t nq = (2 * (pw + 1) + 3) >> 2;             // 16-byte chunks of the plane block
+#pragma unroll
+  for (int q = 0; q < (2 * NP + 2) / 4; q++) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((uint32_t)q < nq) v = *reinterpret_cast<const uint4*>(unit + 4 * q);
+    pl[4 * q] = v.x; pl[4 * q + 1] = v.y; pl[4 * q + 2] = v.z; pl[4 * q + 3] = v.w;
+  }
+  // entries whose char at string position j equals pattern char pj: (lo ^ mlo) & (hi ^ mhi), mlo = P's low bit ? 0 : ~0
+  auto eq = [&](int j, int pj) -> uint32_t {
+    const uint32_t mlo = ((P >> (2 * pj)) & 1u) - 1u, mhi = ((P >> (2 * pj + 1)) & 1u) - 1u;
+    return (pl[2 * j] ^ mlo) & (pl[2 * j + 1] ^ mhi);
+  };
+  // front to back: Pr[k] = Pr_{k-1}
+  uint32_t Pr[NP + 1];
+  uint32_t pr = ~0u;
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    Pr[k] = pr;
+    if ((uint32_t)k < pw) pr &= eq(k, k);
+  }
+  zero_out = pr;                                           // all pw chars equal
+  // back to front: s0 = S0_{j+1}, s1 = S1_{j+1}, s2 = S2_{j+1} when position j is entered
+  uint32_t acc = 0, s0 = ~0u, s1 = ~0u, s2 = ~0u;
+#pragma unroll
+  for (int j = NP - 1; j >= 0; j--) {
+    if ((uint32_t)j <= pw) {
+      if ((uint32_t)j + 2 <= pw) s2 &= eq(j, j + 1);        // S2_j
+      uint32_t t = s1;
+      if ((uint32_t)j < pw) t |= s0 | s2;
+      acc |= Pr[j] & t;                                     // the term k = j
+      if ((uint32_t)j < pw) s0 &= eq(j, j);
+      if (j >= 1) s1 &= eq(j, j - 1);
+    }
+  }
+  acc_out = acc;
+}
+
 template <int DIR>
-__global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
+__global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
                                                  uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
   // this phase's tuples: forward bins first, reverse bins after them
   const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
@@ -60,15 +104,14 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
   uint32_t* bq0 = ns1 + BFS_NS_CAP;
   uint32_t* bq1 = bq0 + BFS_BQ_CAP;
   uint32_t* bq2 = bq1 + BFS_BQ_CAP;
-  uint32_t* pref = bq2 + BFS_BQ_CAP;
-  uint32_t* cd0 = pref + 64;
+  uint32_t* cd0 = bq2 + BFS_BQ_CAP;
   uint32_t* cd1 = cd0 + BFS_CAND_CAP;
   uint32_t* cd2 = cd1 + BFS_CAND_CAP;
-  uint8_t* own = reinterpret_cast<uint8_t*>(cd2 + BFS_CAND_CAP);
+  __shared__ uint32_t s_ncand;
   const int lane = lane_id();
   const uint32_t pw = P.partialwin;
   const bool full = P.is_full_search != 0;
-  const uint32_t* __restrict__ arena = ix.trie;
+  const uint32_t* __restrict__ arena = ix.trie2;           // the bit-sliced arena
   const unsigned long long lt = (1ull << lane) - 1ull;
 
   // ---- the wave's 64 searches ----
@@ -79,8 +122,7 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
   bool hl_over = false;
   if (mine) {
     const unsigned long long pl = sb.tup[pos];
-    const Lookup lk = ix.lookup[sb.tkey[pos] - (DIR ? sb.nkh : 0u)];
-    root = DIR == 0 ? lk.rootF : lk.rootR;
+    root = ix.root2[2 * (sb.tkey[pos] - (DIR ? sb.nkh : 0u)) + DIR];
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
     pat[lane] = (uint32_t)(pl >> 40);
@@ -98,7 +140,8 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
   }
   rootw[lane] = root;
   // root node items
-  uint32_t top = 0, bqn = 0, ncand = 0;
+  uint32_t top = 0, bqn = 0;
+  if (lane == 0) s_ncand = 0;
   unsigned long long w_node = 0, w_entry = 0;            // wave totals (uniform)
   bool overflow = false;                                 // a queue overflowed: the wave is redone by k_seed_search
   {
@@ -134,47 +177,38 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
       }
       __syncthreads();
     } else {
-      // ---------- bucket batch: up to 64 buckets, one lane per entry ----------
+      // ---------- bucket batch: up to 64 buckets, one lane per bucket (its <= 32-entry units bit-sliced) ----------
       const uint32_t nb = min(64u, bqn);
-      const uint32_t my_n = (uint32_t)lane < nb ? bq2[lane] : 0u;
-      uint32_t incl = my_n;
-      for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-      const uint32_t Tn = __shfl(incl, 63, 64);
-      const uint32_t my_first = incl - my_n;
-      pref[lane] = my_first;
-      const bool direct = Tn <= BFS_OWN_CAP;
-      if (direct) for (uint32_t q = 0; q < my_n; q++) own[my_first + q] = (uint8_t)lane;
-      w_entry += Tn;
-      __syncthreads();
-      for (uint32_t eb = 0; eb < Tn; eb += 64) {
-        const uint32_t e = eb + lane;
-        const bool v = e < Tn;
-        uint32_t bk = 0;
-        if (v) {
-          if (direct) bk = own[e];
-          else for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = bk + step; if (t < 64 && pref[t] <= e) bk = t; }
-        }
-        const uint32_t q = e - pref[bk];
-        const uint32_t meta = bq1[bk];
-        uint32_t str = 0, id = 0;
-        if (v) { const uint2 en = *reinterpret_cast<const uint2*>(arena + bq0[bk] + 2 * q); str = en.x; id = en.y; }
-        const uint32_t nchar = (meta >> 20) & 15u, slane = meta >> 24;
-        const uint32_t tstr = (meta & 0xFFFFFu) | (str << (2 * nchar));
-        const uint32_t r = v ? lev1_entry(pat[slane], tstr, pw) : 0u;
-        const bool acc = (r & 1u) != 0;
-        const unsigned long long am = __ballot(acc);
-        if (am) {
-          const uint32_t p = ncand + (uint32_t)__popcll(am & lt);
-          if (acc && p < BFS_CAND_CAP) {
-            cd0[p] = slane | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 8);
-            cd1[p] = (path_order_key(meta & 0xFFFFFu) << 8) | q;
-            cd2[p] = id;
+      uint32_t my_n = 0, boff = 0, meta = 0;
+      if ((uint32_t)lane < nb) { my_n = bq2[lane]; boff = bq0[lane]; meta = bq1[lane]; }
+      const uint32_t slane = meta >> 24, bpath = meta & 0xFFFFFu;
+      const uint32_t P9 = pat[slane];
+      const uint32_t uw = bs_unit_words(pw), pwords = bs_plane_words(pw);
+      {
+        uint32_t wsum = my_n;
+        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+        w_entry += wsum;
+      }
+      for (uint32_t u0 = 0; __any(u0 < my_n); u0 += 32) {       // a bucket has more than one unit only at the deepest level
+        uint32_t acc = 0, zr = 0;
+        if (u0 < my_n) {
+          const uint32_t* unit = arena + boff + (u0 >> 5) * uw;
+          lev1_unit(unit, P9, pw, acc, zr);
+          const uint32_t c = my_n - u0;
+          acc &= c >= 32 ? ~0u : ((1u << c) - 1u);
+          while (acc) {
+            const uint32_t b = (uint32_t)__builtin_ctz(acc); acc &= acc - 1;
+            const uint32_t p = atomicAdd(&s_ncand, 1u);
+            if (p < BFS_CAND_CAP) {
+              cd0[p] = slane | (((((zr >> b) & 1u) && !full) ? CK_COND : CK_PLAIN) << 8);
+              cd1[p] = (path_order_key(bpath) << 8) | (u0 + b);
+              cd2[p] = unit[pwords + b];
+            }
           }
-          ncand += (uint32_t)__popcll(am);
-          if (ncand > BFS_CAND_CAP) overflow = true;
         }
       }
       __syncthreads();
+      if (s_ncand > BFS_CAND_CAP) overflow = true;
       // drop the processed buckets: move the rest (< 64) to the front
       const uint32_t rest = bqn - nb;
       uint32_t m0 = 0, m1 = 0, m2 = 0;
@@ -195,6 +229,7 @@ __global__ void __launch_bounds__(64) k_seed_bfs(DIndex ix, DParams P, int pass,
   // ---------- every search applies its candidates in DFS order (selection by increasing key) ----------
   bool zero = false;
   {
+    const uint32_t ncand = min(s_ncand, BFS_CAND_CAP);
     uint32_t last = 0;                                     // keys already applied are < last
     bool more = mine;
     while (__any(more)) {

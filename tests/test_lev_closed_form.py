@@ -130,3 +130,74 @@ def test_closed_form_equals_table_automaton(pw):
     for _ in range(30000):
         check(int(rng.integers(0, 4 ** pw)), int(rng.integers(0, 4 ** (pw + 1))))
     assert n_acc > 20000
+
+
+def bitsliced_accept(P, Ts, pw):
+    """smr_seed_bfs.hpp::lev1_unit on Python ints: the closed form for up to 32 candidate strings at once, one bit per string.
+    Position j of string e is given by bit e of tlo[j] / thi[j].  -> (accept mask, 0-error mask)"""
+    n = len(Ts)
+    full = (1 << n) - 1
+    tlo = [sum((((T >> (2 * j)) & 1) << e) for e, T in enumerate(Ts)) for j in range(pw + 1)]
+    thi = [sum((((T >> (2 * j + 1)) & 1) << e) for e, T in enumerate(Ts)) for j in range(pw + 1)]
+
+    def eq(j, pj):                                   # strings whose char j equals char pj of P
+        c = (P >> (2 * pj)) & 3
+        lo = tlo[j] if c & 1 else ~tlo[j]
+        hi = thi[j] if c & 2 else ~thi[j]
+        return lo & hi & full
+
+    E0 = [eq(j, j) for j in range(pw)]
+    E1 = [None] + [eq(j, j - 1) for j in range(1, pw + 1)]
+    E2 = [eq(j, j + 1) for j in range(pw - 1)]
+    S0 = [full] * (pw + 2)
+    for j in range(pw - 1, -1, -1):
+        S0[j] = S0[j + 1] & E0[j]
+    S1 = [full] * (pw + 3)
+    for j in range(pw, 0, -1):
+        S1[j] = S1[j + 1] & E1[j]
+    S2 = [full] * (pw + 1)
+    for j in range(pw - 2, -1, -1):
+        S2[j] = S2[j + 1] & E2[j]
+    acc, pr = 0, full                                # pr = Pr_{k-1}
+    for k in range(pw + 1):
+        if k <= pw - 1:
+            acc |= pr & S0[k + 1]
+            acc |= pr & S2[k]
+        acc |= pr & S1[k + 1]
+        if k < pw:
+            pr &= E0[k]
+    return acc, pr                                   # pr is now Pr_{pw-1}: all pw chars equal
+
+
+@pytest.mark.parametrize("pw", [4, 6, 7, 8, 9, 10])
+def test_bitsliced_unit_equals_closed_form(pw):
+    rng = np.random.default_rng(300 + pw)
+    n_acc = 0
+    for _ in range(1500):
+        P = int(rng.integers(0, 4 ** pw))
+        pl = [(P >> (2 * i)) & 3 for i in range(pw)]
+        Ts = []
+        for e in range(int(rng.integers(1, 33))):
+            t = pl[:]
+            kind = int(rng.integers(0, 7))
+            if kind == 1:
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + int(rng.integers(1, 4))) & 3
+            elif kind == 2:
+                t.insert(int(rng.integers(0, pw + 1)), int(rng.integers(0, 4)))
+            elif kind == 3:
+                del t[int(rng.integers(0, pw))]
+            elif kind == 4:
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + 1) & 3
+                j = int(rng.integers(0, pw)); t[j] = (t[j] + 2) & 3
+            elif kind >= 5:
+                t = [int(x) for x in rng.integers(0, 4, size=pw + 1)]
+            while len(t) < pw + 1:
+                t.append(int(rng.integers(0, 4)))
+            Ts.append(sum(c << (2 * i) for i, c in enumerate(t[:pw + 1])))
+        acc, zero = bitsliced_accept(P, Ts, pw)
+        for e, T in enumerate(Ts):
+            a, _, z = closed_form(P, T, pw)
+            assert bool((acc >> e) & 1) == a, (pw, P, T)
+            assert bool((zero >> e) & 1) == z, (pw, P, T)
+            n_acc += a
+    assert n_acc > 5000
