@@ -88,6 +88,9 @@ int smr_index_build(const char* ref_fasta, uint32_t seed_win_len, double max_fil
 /* Write one part in the REFERENCE's on-disk format (so the reference binary can consume our index). */
 int smr_index_write_files(const smr_index* const* parts, uint32_t n_parts, const char* ref_fasta, const char* prefix,
                           char* err, size_t errcap);
+/* Consistency check of the two device layouts of the mini-tries (reference-shaped arena for k_seed_search, bit-sliced arena for
+ * k_seed_bfs): both must list the same (candidate string, id) entries in the same DFS order.  0 = ok. */
+int smr_index_selfcheck(smr_index*, char* err, size_t errcap);
 void smr_index_free(smr_index*);
 
 typedef struct {

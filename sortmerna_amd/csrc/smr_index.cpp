@@ -284,6 +284,61 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   return SMR_OK;
 }
 
+// ---- self check of the bit-sliced layout ---------------------------------------------------------
+namespace {
+struct FullEnt { uint32_t str, id; };                       // the complete pw+1-char candidate string, 2 bits per char
+void sc_walk_ref(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t path, std::vector<FullEnt>& out) {
+  for (uint32_t ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    const uint32_t p2 = path | (ne << (2 * depth));
+    if (fl == 2) {
+      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+      const uint32_t* b = t + (e & ELEM_OFF_MASK);
+      for (uint32_t q = 0; q < n; q++) out.push_back({p2 | (b[2 * q] << (2 * (depth + 1))), b[2 * q + 1]});
+    } else if (fl == 1) sc_walk_ref(t, e & ELEM_OFF_MASK, depth + 1, p2, out);
+  }
+}
+bool sc_walk_bs(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t path, uint32_t pw, std::vector<FullEnt>& out) {
+  for (uint32_t ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    const uint32_t p2 = path | (ne << (2 * depth));
+    if (fl == 2) {
+      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+      for (uint32_t q = 0; q < n; q++) {
+        const uint32_t* unit = t + (e & ELEM_OFF_MASK) + (q / BS_UNIT) * bs_unit_words(pw);
+        uint32_t str = 0;
+        for (uint32_t j = 0; j <= pw; j++) str |= ((((unit[2 * j] >> (q % BS_UNIT)) & 1u)) | (((unit[2 * j + 1] >> (q % BS_UNIT)) & 1u) << 1)) << (2 * j);
+        if ((str & ((1u << (2 * (depth + 1))) - 1u)) != p2) return false;       // the path positions must hold the path's chars
+        out.push_back({str, unit[bs_plane_words(pw) + q % BS_UNIT]});
+      }
+    } else if (fl == 1) { if (!sc_walk_bs(t, e & ELEM_OFF_MASK, depth + 1, p2, pw, out)) return false; }
+  }
+  return true;
+}
+}  // namespace
+
+// The two device layouts of the mini-tries must list the same (candidate string, id) entries in the same DFS order.
+extern "C" int smr_index_selfcheck(smr_index* ix, char* err, size_t errcap) {
+  if (!ix) return SMR_ERR_ARG;
+  std::string why;
+  if (!smr_build_bitsliced(*ix, 0, why)) { set_err(err, errcap, why); return SMR_ERR_CAPACITY; }
+  const uint32_t pw = ix->lnwin / 2;
+  std::vector<FullEnt> a, b;
+  for (size_t k = 0; k < ix->lookup.size(); k++)
+    for (int d = 0; d < 2; d++) {
+      const uint32_t r1 = d == 0 ? ix->lookup[k].rootF : ix->lookup[k].rootR, r2 = ix->root2[2 * k + d];
+      if ((r1 == NONE) != (r2 == NONE)) { set_err(err, errcap, "bit-sliced layout: root presence differs at key " + std::to_string(k)); return SMR_ERR_STATE; }
+      if (r1 == NONE) continue;
+      a.clear(); b.clear();
+      sc_walk_ref(ix->trie.data() + r1, 0, 0, 0, a);
+      if (!sc_walk_bs(ix->trie2.data() + r2, 0, 0, 0, pw, b)) { set_err(err, errcap, "bit-sliced layout: path planes wrong at key " + std::to_string(k)); return SMR_ERR_STATE; }
+      bool same = a.size() == b.size();
+      for (size_t i = 0; same && i < a.size(); i++) same = a[i].str == b[i].str && a[i].id == b[i].id;
+      if (!same) { set_err(err, errcap, "bit-sliced layout: entries differ at key " + std::to_string(k)); return SMR_ERR_STATE; }
+    }
+  return SMR_OK;
+}
+
 extern "C" void smr_index_free(smr_index* ix) { delete ix; }
 
 extern "C" int smr_index_get_info(const smr_index* ix, smr_index_info* o) {

@@ -68,6 +68,13 @@ class Index:
         if rc != 0:
             raise SmrError("smr_index_write_files: %s (rc=%d)" % (err.value.decode(), rc))
 
+    def selfcheck(self):
+        """the bit-sliced device layout lists the same entries in the same DFS order as the reference-shaped one"""
+        err = C.create_string_buffer(512)
+        rc = capi.load().smr_index_selfcheck(self.h, err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_selfcheck: %s (rc=%d)" % (err.value.decode(), rc))
+
     def info(self):
         i = capi.IndexInfo()
         capi.load().smr_index_get_info(self.h, C.byref(i))
