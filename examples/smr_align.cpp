@@ -3,6 +3,8 @@
 // replaced by one batched GPU call, for one or more --ref databases.  It writes what the reference keeps in its KVDB:
 //   <out>/records.bin   u64 n, then n x (u64 klen, key "0_<i>", u64 vlen, Read::toBinString bytes)   (reads with a record only)
 //   <out>/summary.txt   total reads, reads passing the E-value threshold, per-DB counts, too-short reads
+// and, on request, the reference's reports through smr_report_* (aligned/other FASTX, BLAST tabular, SAM):
+//   --fastx --other --blast "1 cigar qcov qstrand" --sam
 // Build:  g++ -std=c++17 -O2 examples/smr_align.cpp -Iinclude -Lsortmerna_amd/lib -lsmr_hip -Wl,-rpath,$PWD/sortmerna_amd/lib -o smr_align
 // There is no CPU fallback: without a HIP device smr_create fails and the program exits like the reference does (ERR + exit 1).
 #include <cstdint>
@@ -16,6 +18,33 @@
 
 namespace {
 [[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR: %s\n", m.c_str()); exit(EXIT_FAILURE); }
+struct Rec { std::string header, seq, qual; };
+// FASTA (multi-line sequences joined) / FASTQ (4-line records); the header line is kept as in the file
+std::vector<Rec> read_fastx(const std::string& path, bool& is_fastq) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) die("cannot open " + path);
+  std::vector<Rec> out;
+  std::vector<std::string> lines;
+  std::string cur; int c;
+  while ((c = fgetc(f)) != EOF) { if (c == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); } else cur.push_back((char)c); }
+  if (!cur.empty()) lines.push_back(cur);
+  fclose(f);
+  is_fastq = false;
+  for (size_t i = 0; i < lines.size();) {
+    if (lines[i].empty()) { i++; continue; }
+    if (lines[i][0] == '>') {
+      Rec r; r.header = lines[i++];
+      while (i < lines.size() && (lines[i].empty() || lines[i][0] != '>')) r.seq += lines[i++];
+      out.push_back(r);
+    } else if (lines[i][0] == '@') {
+      is_fastq = true;
+      if (i + 3 >= lines.size()) die("truncated FASTQ record in " + path);
+      Rec r; r.header = lines[i]; r.seq = lines[i + 1]; r.qual = lines[i + 3];
+      out.push_back(r); i += 4;
+    } else die("unexpected line in " + path + ": " + lines[i].substr(0, 40));
+  }
+  return out;
+}
 struct Db { std::string fasta, idx_prefix; double lambda = 0.618874, K = 0.343238; std::vector<smr_index*> parts; };
 }  // namespace
 
@@ -25,6 +54,7 @@ int main(int argc, char** argv) {
   smr_params base; smr_params_default(&base);
   double evalue = 1.0;
   int device = 0;
+  smr_report_opts ro; memset(&ro, 0, sizeof ro);
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value after " + a); return argv[++i]; };
@@ -47,10 +77,21 @@ int main(int argc, char** argv) {
     else if (a == "-gap_open") base.gap_open = atoi(val().c_str());
     else if (a == "-gap_ext") base.gap_ext = atoi(val().c_str());
     else if (a == "-device") device = atoi(val().c_str());
+    else if (a == "-fastx" || a == "--fastx") ro.fastx = 1;
+    else if (a == "-other" || a == "--other") ro.other = 1;
+    else if (a == "-sam" || a == "--sam") ro.sam = 1;
+    else if (a == "-blast" || a == "--blast") {            // "1" = tabular, optionally followed by cigar / qcov / qstrand (options.cpp opt_blast)
+      const std::string v = val();
+      if (v.empty() || v[0] != '1') die("only the tabular BLAST format (-blast '1 ...') is supported");
+      ro.blast_tabular = 1;
+      const std::string cols = v.size() > 2 ? v.substr(2) : "";
+      if (cols.size() >= sizeof ro.blast_cols) die("-blast: too many columns");
+      strcpy(ro.blast_cols, cols.c_str());
+    }
     else if (a == "-h" || a == "--help") {
       printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq [--out DIR]\n"
              "       [-e EVALUE] [-num_alignments N] [-no-best] [-min_lis N] [-num_seeds N] [-edges N] [-full_search] [-F|-R]\n"
-             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K]\n");
+             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '1 cigar qcov qstrand'] [--sam]\n");
       return 0;
     } else die("unknown option " + a);
   }
@@ -58,8 +99,14 @@ int main(int argc, char** argv) {
   char err[512] = "";
 
   // reads (Readfeed::next -> Read::init, readfeed.hpp:124 / read.cpp:264-347)
+  bool is_fastq = false;
+  const std::vector<Rec> recs = read_fastx(reads_path, is_fastq);
   smr_reads* reads = nullptr;
-  if (smr_reads_load_fastx(reads_path.c_str(), 0, 0, &reads, err, sizeof err) != SMR_OK) die(err);
+  {
+    std::string blob; std::vector<uint64_t> offs{0};
+    for (auto& r : recs) { blob += r.seq; offs.push_back(blob.size()); }
+    if (smr_reads_pack(blob.data(), offs.data(), (uint32_t)recs.size(), &reads) != SMR_OK) die("smr_reads_pack failed");
+  }
   const uint32_t n = smr_reads_count(reads);
 
   // indexes: reference-built files when a prefix is given, else our own builder (Index ctor / build_index, index.cpp:61-107)
@@ -103,6 +150,18 @@ int main(int argc, char** argv) {
   }
   if (smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
 
+  // reports (writeReports, output.cpp:169-272)
+  smr_report* rep = nullptr;
+  if (ro.fastx || ro.other || ro.blast_tabular || ro.sam) {
+    if (smr_report_open(out_dir.c_str(), &ro, is_fastq, &rep, err, sizeof err) != SMR_OK) die(err);
+    for (size_t k = 0; k < dbs.size(); k++) {
+      smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
+      uint64_t fr = 0, fq = 0;
+      smr_refstats_corrected(dbs[k].K, info.bg, info.full_len, info.numseq, n, smr_reads_total_len(reads), &fr, &fq);
+      smr_report_set_db(rep, (uint32_t)k, dbs[k].lambda, dbs[k].K, fr, fq);
+      for (size_t part = 0; part < dbs[k].parts.size(); part++) smr_report_set_part(rep, (uint32_t)k, (uint32_t)part, dbs[k].parts[part]);
+    }
+  }
   // kvdb.put(read.id, read.toBinString()) (processor.cpp:150-155) -> records.bin ; Readstats -> summary.txt
   const std::string rp = out_dir + "/records.bin", sp = out_dir + "/summary.txt";
   FILE* f = fopen(rp.c_str(), "wb");
@@ -112,15 +171,18 @@ int main(int argc, char** argv) {
   std::vector<uint8_t> buf;
   for (uint32_t i = 0; i < n; i++) {
     const size_t len = smr_result_record(gpu, i, nullptr, 0);
-    if (!len) continue;
     buf.resize(len);
-    smr_result_record(gpu, i, buf.data(), len);
+    if (len) smr_result_record(gpu, i, buf.data(), len);
+    if (rep && smr_report_add(rep, recs[i].header.c_str(), recs[i].seq.c_str(), is_fastq ? recs[i].qual.c_str() : nullptr, buf.data(), len) != SMR_OK)
+      die(smr_report_last_error(rep));
+    if (!len) continue;
     const std::string key = "0_" + std::to_string(i);
     const uint64_t kl = key.size(), vl = len;
     fwrite(&kl, 8, 1, f); fwrite(key.data(), 1, kl, f); fwrite(&vl, 8, 1, f); fwrite(buf.data(), 1, vl, f);
     nrec++;
   }
   fseek(f, 0, SEEK_SET); fwrite(&nrec, 8, 1, f); fclose(f);
+  if (rep && smr_report_close(rep) != SMR_OK) die("cannot write the report files");
   std::vector<uint64_t> ctr(2 + dbs.size());
   smr_counters(gpu, ctr.data(), (uint32_t)dbs.size());
   f = fopen(sp.c_str(), "w");

@@ -115,6 +115,10 @@ int smr_index_get_info(const smr_index*, smr_index_info* out);
 uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq,
                            uint64_t all_reads_count, uint64_t all_reads_len, double evalue);
 
+/* The length-corrected database / read sizes of Refstats (refstats.cpp:238-257) that the e-value of the BLAST report uses. */
+void smr_refstats_corrected(double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
+                            uint64_t* full_ref_corr, uint64_t* full_read_corr);
+
 /* ------------------------------------------------------------------------------------------------
  * Reads (host side): 2-bit packed + ambiguity mask (Read::seqToIntStr: ACGT(U) -> 0..3, other -> 0
  * and the position is remembered, read.cpp:334-347).
@@ -195,6 +199,29 @@ typedef struct {
 } smr_prof;
 int smr_prof_reset(smr_ctx*);
 int smr_prof_get(smr_ctx*, smr_prof* out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reports (host side): the reference's second pass over reads + KVDB (writeReports, output.cpp:169-272), fed by
+ * smr_result_record.  Files in out_dir: aligned.fa|fq, other.fa|fq (report_fx_base.cpp:176-205), aligned.blast = BLAST tabular m8
+ * with the optional columns of `-blast '1 cigar qcov qstrand'` (report_blast.cpp:253-354), aligned.sam (report_sam.cpp:64-152).
+ * Rows are written per (index, part) in --ref order, within a part in the order the reads were added, like the reference's loop.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct smr_report smr_report;
+typedef struct {
+  int fastx;             /* -fastx   aligned.fa|fq */
+  int other;             /* -other   other.fa|fq   */
+  int blast_tabular;     /* -blast 1 ...           */
+  char blast_cols[64];   /* optional BLAST columns, space separated, in output order: "cigar", "qcov", "qstrand" */
+  int sam;               /* -sam                   */
+} smr_report_opts;
+int smr_report_open(const char* out_dir, const smr_report_opts*, int is_fastq, smr_report** out, char* err, size_t errcap);
+/* per --ref: Gumbel parameters and the corrected sizes (smr_refstats_corrected); per (index, part): where its reference ids/sequences are */
+int smr_report_set_db(smr_report*, uint32_t index_num, double lambda, double K, uint64_t full_ref_corr, uint64_t full_read_corr);
+int smr_report_set_part(smr_report*, uint32_t index_num, uint32_t part, const smr_index*);
+/* one read: its header line as in the file (with '>' / '@'), letters, quality (NULL for FASTA), and its record (NULL, 0: none) */
+int smr_report_add(smr_report*, const char* header, const char* seq, const char* qual, const uint8_t* record, size_t record_len);
+int smr_report_close(smr_report*);      /* writes aligned.blast / aligned.sam, closes the files, frees the object */
+const char* smr_report_last_error(const smr_report*);
 
 #ifdef __cplusplus
 }

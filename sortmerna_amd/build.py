@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsmr_hip.so")
-SOURCES = ["smr_engine.hip", "smr_index.cpp", "smr_reads.cpp"]
+SOURCES = ["smr_engine.hip", "smr_index.cpp", "smr_reads.cpp", "smr_report.cpp"]
 HEADERS = ["smr_kernels.hpp", "smr_seed.hpp", "smr_seed_bfs.hpp", "smr_chain.hpp", "smr_trace.hpp", "smr_host.hpp", os.path.join("..", "..", "include", "smr_hip.h")]
 
 

@@ -25,6 +25,10 @@ class IndexInfo(C.Structure):
     ]
 
 
+class ReportOpts(C.Structure):
+    _fields_ = [("fastx", C.c_int), ("other", C.c_int), ("blast_tabular", C.c_int), ("blast_cols", C.c_char * 64), ("sam", C.c_int)]
+
+
 class Prof(C.Structure):
     _fields_ = [
         ("seed_ms", C.c_double), ("seed_launches", C.c_uint64), ("chain_ms", C.c_double), ("chain_launches", C.c_uint64),
@@ -40,7 +44,8 @@ EXPORTS = [
     "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
-    "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_prof_reset", "smr_prof_get",
+    "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_prof_reset", "smr_prof_get", "smr_refstats_corrected", "smr_report_open",
+    "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_close", "smr_report_last_error",
 ]
 
 _lib = None
@@ -122,5 +127,18 @@ def load(rebuild_if_stale=True):
     L.smr_prof_reset.argtypes = [vp]
     L.smr_prof_get.restype = i32
     L.smr_prof_get.argtypes = [vp, C.POINTER(Prof)]
+    L.smr_refstats_corrected.argtypes = [C.c_double, C.POINTER(C.c_double), u64, u64, u64, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.smr_report_open.restype = i32
+    L.smr_report_open.argtypes = [cp, C.POINTER(ReportOpts), i32, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_report_set_db.restype = i32
+    L.smr_report_set_db.argtypes = [vp, u32, C.c_double, C.c_double, u64, u64]
+    L.smr_report_set_part.restype = i32
+    L.smr_report_set_part.argtypes = [vp, u32, u32, vp]
+    L.smr_report_add.restype = i32
+    L.smr_report_add.argtypes = [vp, cp, cp, cp, cp, C.c_size_t]
+    L.smr_report_close.restype = i32
+    L.smr_report_close.argtypes = [vp]
+    L.smr_report_last_error.restype = cp
+    L.smr_report_last_error.argtypes = [vp]
     _lib = L
     return L

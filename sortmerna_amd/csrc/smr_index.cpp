@@ -350,6 +350,18 @@ extern "C" int smr_index_get_info(const smr_index* ix, smr_index_info* o) {
   return SMR_OK;
 }
 
+// refstats.cpp:238-257: expected HSP length, length-corrected sizes
+extern "C" void smr_refstats_corrected(double K, const double bg[4], uint64_t full_ref, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
+                                       uint64_t* full_ref_corr, uint64_t* full_read_corr) {
+  double H = -(bg[0] * std::log2(bg[0]) + bg[1] * std::log2(bg[1]) + bg[2] * std::log2(bg[2]) + bg[3] * std::log2(bg[3]));
+  uint64_t full_read = all_reads_len;
+  uint64_t expect_L = static_cast<uint64_t>(std::log(K * full_ref * full_read / 1) / H);
+  if (full_ref > expect_L * numseq) full_ref -= expect_L * numseq;
+  full_read -= expect_L * all_reads_count / 1;
+  if (full_ref_corr) *full_ref_corr = full_ref;
+  if (full_read_corr) *full_read_corr = full_read;
+}
+
 // refstats.cpp:238-265
 extern "C" uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref, uint64_t numseq,
                                       uint64_t all_reads_count, uint64_t all_reads_len, double evalue) {

@@ -1,0 +1,211 @@
+// smr_report.cpp -- host side, SURVEY.md 8(f) N1: the report writers, fed by the per-read records of libsmr_hip.
+//
+// Replaces, row for row, the reference's second pass over reads + KVDB (writeReports, /root/reference/src/sortmerna/output.cpp:169-272):
+//   aligned / other FASTX      ReportFxBase::write_a_read         report_fx_base.cpp:176-205, report_fastx.cpp:134-146, report_fx_other.cpp
+//   BLAST tabular (+ cigar / qcov / qstrand)   ReportBlast::append   report_blast.cpp:253-354 (e-value / bit score :118-125)
+//   SAM                        ReportSam::append                  report_sam.cpp:64-152
+//   %id / mismatches / gaps    Read::calc_miss_gap_match          read.cpp:547-589
+// Input per read: the original header line, letters, quality and the Read::toBinString record (read.cpp:429-462) that
+// smr_result_record returns.  Rows are buffered per (index, part) and written in that order, like the reference's loop.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "smr_host.hpp"
+
+namespace {
+struct Aln {
+  std::vector<uint32_t> cigar;
+  uint32_t ref_num = 0; int32_t ref_begin1 = 0, ref_end1 = 0, read_begin1 = 0, read_end1 = 0; uint32_t readlen = 0;
+  uint16_t score1 = 0, part = 0, index_num = 0; uint8_t strand = 0;
+};
+struct Db { double lambda = 0, K = 0; uint64_t full_ref = 0, full_read = 0; };
+
+// Read::toBinString layout (read.cpp:429-462, ssw.hpp:106-140)
+bool parse_record(const uint8_t* b, size_t n, bool& is_hit, std::vector<Aln>& out) {
+  out.clear(); is_hit = false;
+  if (n == 0) return true;
+  size_t o = 0;
+  auto rd = [&](void* dst, size_t k) { if (o + k > n) return false; memcpy(dst, b + o, k); o += k; return true; };
+  uint32_t u32[6]; uint8_t fl[3]; uint16_t sw; int32_t na; uint32_t hs; uint64_t asz; uint32_t mn, mx; uint64_t cnt;
+  if (!rd(u32, 24) || !rd(fl, 3) || !rd(&sw, 2) || !rd(&na, 4) || !rd(&hs, 4) || !rd(&asz, 8) || !rd(&mn, 4) || !rd(&mx, 4) || !rd(&cnt, 8)) return false;
+  is_hit = fl[1] != 0;
+  for (uint64_t k = 0; k < cnt; k++) {
+    uint64_t rl, cl;
+    if (!rd(&rl, 8) || !rd(&cl, 8)) return false;
+    Aln a; a.cigar.resize(cl);
+    if (cl && !rd(a.cigar.data(), cl * 4)) return false;
+    if (!rd(&a.ref_num, 4) || !rd(&a.ref_begin1, 4) || !rd(&a.ref_end1, 4) || !rd(&a.read_begin1, 4) || !rd(&a.read_end1, 4) || !rd(&a.readlen, 4) ||
+        !rd(&a.score1, 2) || !rd(&a.part, 2) || !rd(&a.index_num, 2) || !rd(&a.strand, 1)) return false;
+    out.push_back(std::move(a));
+  }
+  return o == n;
+}
+
+inline int nt_code(unsigned char c) {
+  switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': case 'U': case 'u': return 3; default: return 4; }
+}
+std::string cigar_text(const Aln& a, size_t readlen) {        // soft clips as report_blast.cpp:293-311 / report_sam.cpp:96-113
+  std::ostringstream ss;
+  if (a.read_begin1 != 0) ss << a.read_begin1 << "S";
+  for (uint32_t c : a.cigar) ss << (c >> 4) << ((c & 0xF) == 0 ? "M" : ((c & 0xF) == 1 ? "I" : "D"));
+  const long end_mask = (long)readlen - a.read_end1 - 1;
+  if (end_mask > 0) ss << end_mask << "S";
+  return ss.str();
+}
+}  // namespace
+
+struct smr_report {
+  std::string dir; smr_report_opts o; bool fastq = false;
+  FILE* f_aligned = nullptr; FILE* f_other = nullptr;
+  std::map<uint32_t, Db> dbs;
+  std::map<std::pair<uint32_t, uint32_t>, const smr_index*> parts;
+  std::map<std::pair<uint32_t, uint32_t>, std::string> blast, sam;     // rows per (index, part)
+  std::string err;
+};
+
+extern "C" int smr_report_open(const char* out_dir, const smr_report_opts* opts, int is_fastq, smr_report** out, char* err, size_t errcap) {
+  if (!out_dir || !opts || !out) return SMR_ERR_ARG;
+  auto r = new smr_report();
+  r->dir = out_dir; r->o = *opts; r->fastq = is_fastq != 0;
+  const std::string ext = is_fastq ? ".fq" : ".fa";
+  if (opts->fastx) r->f_aligned = fopen((r->dir + "/aligned" + ext).c_str(), "wb");
+  if (opts->other) r->f_other = fopen((r->dir + "/other" + ext).c_str(), "wb");
+  if ((opts->fastx && !r->f_aligned) || (opts->other && !r->f_other)) {
+    if (err && errcap) snprintf(err, errcap, "cannot create report files in %s", out_dir);
+    if (r->f_aligned) fclose(r->f_aligned);
+    if (r->f_other) fclose(r->f_other);
+    delete r; return SMR_ERR_IO;
+  }
+  *out = r;
+  return SMR_OK;
+}
+
+extern "C" int smr_report_set_db(smr_report* r, uint32_t index_num, double lambda, double K, uint64_t full_ref_corr, uint64_t full_read_corr) {
+  if (!r) return SMR_ERR_ARG;
+  Db d; d.lambda = lambda; d.K = K; d.full_ref = full_ref_corr; d.full_read = full_read_corr;
+  r->dbs[index_num] = d;
+  return SMR_OK;
+}
+
+extern "C" int smr_report_set_part(smr_report* r, uint32_t index_num, uint32_t part, const smr_index* ix) {
+  if (!r || !ix) return SMR_ERR_ARG;
+  r->parts[{index_num, part}] = ix;
+  return SMR_OK;
+}
+
+extern "C" int smr_report_add(smr_report* r, const char* header, const char* seq, const char* qual, const uint8_t* record, size_t record_len) {
+  if (!r || !header || !seq) return SMR_ERR_ARG;
+  bool is_hit = false;
+  std::vector<Aln> alns;
+  if (!parse_record(record, record_len, is_hit, alns)) { r->err = "malformed record"; return SMR_ERR_ARG; }
+  // aligned / other FASTX: the record as read (report_fx_base.cpp:176-181)
+  FILE* f = is_hit ? r->f_aligned : r->f_other;
+  if (f) {
+    fprintf(f, "%s\n%s\n", header, seq);
+    if (r->fastq) fprintf(f, "+\n%s\n", qual ? qual : "");
+  }
+  if (alns.empty() || (!r->o.blast_tabular && !r->o.sam)) return SMR_OK;
+  // Read::getSeqId (read.cpp:371-377)
+  std::string id(header);
+  id = id.substr(0, id.find(' '));
+  size_t k0 = 0; while (k0 < id.size() && (id[k0] == '>' || id[k0] == '@')) k0++;
+  id = id.substr(k0);
+  const size_t len = strlen(seq);
+  // the read in the 0..4 alphabet (flip34 to 04: ambiguous letters are 4), forward and reverse-complement
+  std::string fwd(len, 0), rev(len, 0);
+  for (size_t i = 0; i < len; i++) fwd[i] = (char)nt_code((unsigned char)seq[i]);
+  for (size_t i = 0; i < len; i++) { const int c = fwd[len - 1 - i]; rev[i] = (char)(c == 4 ? 4 : 3 - c); }
+  static const char nt_map[5] = {'A', 'C', 'G', 'T', 'N'};
+  std::map<std::pair<uint32_t, uint32_t>, std::string> quals;     // ReportSam reverses read.quality IN PLACE per reverse alignment (report_sam.cpp:123-127)
+  for (const Aln& a : alns) {
+    const std::pair<uint32_t, uint32_t> key{a.index_num, a.part};
+    auto pit = r->parts.find(key);
+    auto dit = r->dbs.find(a.index_num);
+    if (pit == r->parts.end() || dit == r->dbs.end()) { r->err = "alignment refers to an (index, part) that was not registered"; return SMR_ERR_STATE; }
+    const smr_index* ix = pit->second;
+    if (a.ref_num >= ix->n_refs()) { r->err = "ref_num out of range"; return SMR_ERR_ARG; }
+    size_t first_seq = 0;
+    for (uint32_t q = 0; q < a.part && q < ix->parts.size(); q++) first_seq += ix->parts[q].numseq_part;
+    const std::string ref_id = first_seq + a.ref_num < ix->sq_header.size() ? ix->sq_header[first_seq + a.ref_num].first : std::string("*");
+    const uint8_t* refseq = ix->ref_seq.data() + ix->ref_off[a.ref_num];
+    const std::string& iseq = a.strand ? fwd : rev;           // `if (align.strand == read.reversed) read.revIntStr()`
+    // Read::calc_miss_gap_match (read.cpp:547-589)
+    uint32_t n_miss = 0, n_gap = 0, n_match = 0;
+    {
+      int64_t qb = a.ref_begin1, pb = a.read_begin1;
+      for (uint32_t c : a.cigar) {
+        const uint32_t letter = c & 0xF, length = c >> 4;
+        if (letter == 0) { for (uint32_t u = 0; u < length; u++) { if ((char)refseq[qb] != iseq[pb]) ++n_miss; else ++n_match; ++qb; ++pb; } }
+        else if (letter == 1) { pb += length; n_gap += length; }
+        else { qb += length; n_gap += length; }
+      }
+    }
+    const double idf = (double)n_match / (double)(n_miss + n_gap + n_match);
+    const double cov = (double)std::abs(a.read_end1 - a.read_begin1 + 1) / (double)a.readlen;
+    if (r->o.blast_tabular) {
+      const Db& d = dit->second;
+      const uint32_t bitscore = (uint32_t)((float)(d.lambda * a.score1 - std::log(d.K)) / (float)std::log(2));
+      const double evalue = (double)d.K * d.full_ref * d.full_read * std::exp(-d.lambda * a.score1);
+      std::ostringstream ss;
+      ss << id << "\t" << ref_id << "\t";
+      ss.precision(3);
+      ss << idf * 100 << "\t" << (a.read_end1 - a.read_begin1 + 1) << "\t" << n_miss << "\t" << n_gap << "\t" << a.read_begin1 + 1 << "\t" << a.read_end1 + 1
+         << "\t" << a.ref_begin1 + 1 << "\t" << a.ref_end1 + 1 << "\t" << evalue << "\t" << bitscore;
+      // optional columns in the order they were requested ("cigar", "qcov", "qstrand")
+      for (const char* p = r->o.blast_cols; *p;) {
+        const char* e = strchr(p, ' '); const std::string col = e ? std::string(p, e) : std::string(p);
+        if (col == "cigar") ss << "\t" << cigar_text(a, len);
+        else if (col == "qcov") { ss.precision(3); ss << "\t" << cov * 100; }
+        else if (col == "qstrand") ss << "\t" << (a.strand ? '+' : '-');
+        p = e ? e + 1 : p + col.size();
+      }
+      ss << "\n";
+      r->blast[key] += ss.str();
+    }
+    if (r->o.sam) {
+      std::ostringstream ss;
+      ss << id << (a.strand ? "\t0\t" : "\t16\t") << ref_id << "\t" << a.ref_begin1 + 1 << "\t255\t" << cigar_text(a, len) << "\t*\t0\t0\t";
+      for (size_t i = 0; i < len; i++) ss << nt_map[(int)iseq[i]];
+      ss << "\t";
+      if (qual && *qual) {
+        auto qit = quals.find(key);
+        if (qit == quals.end()) qit = quals.emplace(key, std::string(qual)).first;
+        if (!a.strand) std::reverse(qit->second.begin(), qit->second.end());
+        ss << qit->second;
+      } else ss << "*";
+      ss << "\tAS:i:" << a.score1 << "\tNM:i:" << n_miss + n_gap << "\n";
+      r->sam[key] += ss.str();
+    }
+  }
+  return SMR_OK;
+}
+
+extern "C" int smr_report_close(smr_report* r) {
+  if (!r) return SMR_ERR_ARG;
+  int rc = SMR_OK;
+  if (r->f_aligned) fclose(r->f_aligned);
+  if (r->f_other) fclose(r->f_other);
+  if (r->o.blast_tabular) {
+    FILE* f = fopen((r->dir + "/aligned.blast").c_str(), "wb");
+    if (!f) rc = SMR_ERR_IO; else { for (auto& kv : r->blast) fwrite(kv.second.data(), 1, kv.second.size(), f); fclose(f); }
+  }
+  if (r->o.sam) {
+    FILE* f = fopen((r->dir + "/aligned.sam").c_str(), "wb");
+    if (!f) rc = SMR_ERR_IO;
+    else {
+      fprintf(f, "@HD\tVN:1.0\tSO:unsorted\n@PG\tID:sortmerna\tVN:1.0\tCL:libsmr_hip\n");     // report_sam.cpp:157-175 (CL = the caller's command line)
+      for (auto& kv : r->sam) fwrite(kv.second.data(), 1, kv.second.size(), f);
+      fclose(f);
+    }
+  }
+  delete r;
+  return rc;
+}
+
+extern "C" const char* smr_report_last_error(const smr_report* r) { return r ? r->err.c_str() : "null report"; }

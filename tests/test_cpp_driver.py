@@ -45,7 +45,17 @@ def test_driver_reproduces_reference_records(case, tmp_path):
         cmd += ["--ref", db, "--gumbel", repr(g["log"]["lambda"][k]), repr(g["log"]["K"][k])]
     if "num_alignments" in g["params"]:
         cmd += ["-num_alignments", str(g["params"]["num_alignments"])]
+    if case == "syn_default":
+        cmd += ["--fastx", "--other", "--sam", "--blast", "1 qstrand cigar"]
     subprocess.check_call(cmd)
+    if case == "syn_default":            # the reference's own report files for the same options (row-exact except the e-value's last digit)
+        sam = [l.rstrip("\n") for l in open(tmp_path / "aligned.sam") if not l.startswith("@")]
+        assert sam == [l for l in g["sam"] if not l.startswith("@")]
+        blast = [l.rstrip("\n").split("\t") for l in open(tmp_path / "aligned.blast")]
+        exp_b = [l.split("\t") for l in g["blast"]]
+        assert [a[:10] + a[11:] for a in blast] == [b[:10] + b[11:] for b in exp_b]
+        assert [l.split()[0][1:] for l in open(tmp_path / "aligned.fa") if l.startswith(">")] == g["aligned_ids"]
+        assert [l.split()[0][1:] for l in open(tmp_path / "other.fa") if l.startswith(">")] == g["other_ids"]
     kv = refrun.parse_kvdb_dump(str(tmp_path / "records.bin"))
     got = [kv.get(b"0_%d" % i, b"") for i in range(len(seqs))]
     exp = golden.records(case)
