@@ -40,8 +40,8 @@ class Prof(C.Structure):
 
 EXPORTS = [
     "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_write_files", "smr_index_selfcheck", "smr_index_free",
-    "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_free",
-    "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
+    "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_free",
+    "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_prof_reset", "smr_prof_get", "smr_refstats_corrected", "smr_report_open",
@@ -82,10 +82,14 @@ def load(rebuild_if_stale=True):
     L.smr_reads_pack.argtypes = [cp, vp, u32, C.POINTER(vp)]
     L.smr_reads_load_fastx.restype = i32
     L.smr_reads_load_fastx.argtypes = [cp, u64, u64, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_reads_load_fastx_mt.restype = i32
+    L.smr_reads_load_fastx_mt.argtypes = [cp, u32, C.POINTER(vp), cp, C.c_size_t]
     L.smr_reads_free.argtypes = [vp]
     for f in ("smr_reads_count", "smr_reads_min_len", "smr_reads_max_len"):
         getattr(L, f).restype = u32
         getattr(L, f).argtypes = [vp]
+    L.smr_reads_digest.restype = u64
+    L.smr_reads_digest.argtypes = [vp]
     L.smr_reads_total_len.restype = u64
     L.smr_reads_total_len.argtypes = [vp]
     L.smr_create.restype = i32

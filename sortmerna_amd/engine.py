@@ -113,6 +113,21 @@ class Reads:
             raise SmrError("smr_reads_load_fastx: %s (rc=%d)" % (err.value.decode(), rc))
         return Reads(h)
 
+    @staticmethod
+    def from_fastx_mt(path, threads=0):
+        """whole file, parsed and packed by `threads` threads (0 = all cores)"""
+        L = capi.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.smr_reads_load_fastx_mt(path.encode(), threads, C.byref(h), err, 512)
+        if rc != 0:
+            raise SmrError("smr_reads_load_fastx_mt: %s (rc=%d)" % (err.value.decode(), rc))
+        return Reads(h)
+
+    @property
+    def digest(self):
+        return capi.load().smr_reads_digest(self.h)
+
     @property
     def count(self):
         return capi.load().smr_reads_count(self.h)

@@ -68,6 +68,52 @@ def test_reads_load_fastx_multiline_and_range(tmp_path):
     assert smr.Reads.from_fastx(str(e)).count == 0
 
 
+def test_multithreaded_reader_equals_the_serial_one(tmp_path):
+    """smr_reads_load_fastx_mt (byte ranges cut at record boundaries, one thread each) == smr_reads_load_fastx on FASTQ with '@' / '+'
+    at the start of quality lines, multi-line FASTA, CRLF, a missing final newline, N letters, ragged lengths; any thread count"""
+    rng = np.random.default_rng(5)
+    L = np.frombuffer(b"ACGTN", dtype=np.uint8)
+    fq = tmp_path / "r.fastq"
+    with open(fq, "wb") as f:
+        for i in range(30000):
+            n = int(rng.integers(30, 200))
+            seq = L[rng.choice(5, size=n, p=[.245, .245, .245, .245, .02])].tobytes()
+            q = bytes(rng.integers(33, 74, size=n, dtype=np.uint8))
+            if i % 7 == 0:
+                q = b"@" + q[1:]                  # quality lines may start with '@' ...
+            if i % 11 == 0:
+                q = b"+" + q[1:]                  # ... or '+'
+            f.write(b"@r%d some text\n" % i + seq + (b"\r\n" if i % 5 == 0 else b"\n") + b"+\n" + q + (b"" if i == 29999 else b"\n"))
+    fa = tmp_path / "r.fasta"
+    with open(fa, "wb") as f:
+        for i in range(20000):
+            n = int(rng.integers(1, 400))
+            seq = L[rng.choice(5, size=n, p=[.245, .245, .245, .245, .02])].tobytes()
+            f.write(b">s%d\n" % i)
+            for k in range(0, n, 60):
+                f.write(seq[k:k + 60] + b"\n")
+    import gzip
+    gz = tmp_path / "r.fastq.gz"                     # two gzip members back to back = the same text
+    raw = fq.read_bytes()
+    cutb = raw.index(b"\n@r15000 ") + 1
+    gz.write_bytes(gzip.compress(raw[:cutb]) + gzip.compress(raw[cutb:]))
+    for p in (fq, fa, gz):
+        serial = smr.Reads.from_fastx(str(fq if p is gz else p))
+        for t in (1, 2, 3, 8, 31):
+            mt = smr.Reads.from_fastx_mt(str(p), t)
+            assert (mt.count, mt.total_len, mt.min_len, mt.max_len) == (serial.count, serial.total_len, serial.min_len, serial.max_len), (p, t)
+            assert mt.digest == serial.digest, (p, t)
+            mt.free()
+        serial.free()
+    e = tmp_path / "empty.fa"
+    e.write_text("")
+    assert smr.Reads.from_fastx_mt(str(e), 4).count == 0
+    bad = tmp_path / "bad.gz"
+    bad.write_bytes(gz.read_bytes()[:5000])
+    with pytest.raises(RuntimeError, match="gzip"):
+        smr.Reads.from_fastx_mt(str(bad), 2)
+
+
 def test_minimal_score_equals_reference_log():
     g = golden.load()["syn_default"]
     db, _, seqs = golden.inputs("syn_default")
