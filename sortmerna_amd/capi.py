@@ -62,7 +62,12 @@ def load(rebuild_if_stale=True):
         path = _build.build_library()
     if not os.path.isfile(path):
         raise RuntimeError("libsmr_hip.so is missing; run sortmerna_amd/build.py (needs hipcc)")
-    L = C.CDLL(path)
+    _lib = bind(C.CDLL(path))
+    return _lib
+
+
+def bind(L):
+    """Attach the argument/result types of include/smr_hip.h to a loaded library."""
     vp, cp, u32, u64, i32 = C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_int
     L.smr_params_default.argtypes = [C.POINTER(Params)]
     L.smr_index_load_files.restype = i32
@@ -144,5 +149,4 @@ def load(rebuild_if_stale=True):
     L.smr_report_close.argtypes = [vp]
     L.smr_report_last_error.restype = cp
     L.smr_report_last_error.argtypes = [vp]
-    _lib = L
     return L

@@ -139,7 +139,7 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
   return rr;
 }
 
-__device__ __noinline__ SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+__device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                          int* bound, int match, int mismatch, int scoreN, int go, int ge) {
   const bool small = (long long)m * match < 16384 && n < 65535 && match < 128 && mismatch > -128 && scoreN > -128 && scoreN < 128;
 #define SW_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
                                               uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap) {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
+  SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
   const int lane = lane_id();

@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     wave = redo[blockIdx.x];
   }
   if (wave * 64u >= n_tup) return;
-  extern __shared__ __align__(16) uint32_t lds_dyn[];
+  SMR_DYN_LDS(uint32_t, lds_dyn);
   SeedLds L;
   L.hl = lds_dyn;
   L.stk = L.hl + 64 * hcap;

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
   const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
   const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
   if (blockIdx.x * 64u >= n_tup) return;
-  extern __shared__ __align__(16) uint32_t lds_dyn[];
+  SMR_DYN_LDS(uint32_t, lds_dyn);
   uint32_t* pat = lds_dyn;
   uint32_t* rootw = pat + 64;
   uint32_t* hl = rootw + 64;
