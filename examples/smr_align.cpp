@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -80,9 +81,11 @@ int main(int argc, char** argv) {
     else if (a == "-fastx" || a == "--fastx") ro.fastx = 1;
     else if (a == "-other" || a == "--other") ro.other = 1;
     else if (a == "-sam" || a == "--sam") ro.sam = 1;
+    else if (a == "-SQ" || a == "--SQ") ro.sam_sq = 1;
     else if (a == "-blast" || a == "--blast") {            // "1" = tabular, optionally followed by cigar / qcov / qstrand (options.cpp opt_blast)
       const std::string v = val();
-      if (v.empty() || v[0] != '1') die("only the tabular BLAST format (-blast '1 ...') is supported");
+      if (v == "0") { ro.blast_pairwise = 1; continue; }   // BLAST-like pairwise text
+      if (v.empty() || v[0] != '1') die("-blast: '0' (pairwise) or '1 [cigar] [qcov] [qstrand]' (tabular)");
       ro.blast_tabular = 1;
       const std::string cols = v.size() > 2 ? v.substr(2) : "";
       if (cols.size() >= sizeof ro.blast_cols) die("-blast: too many columns");
@@ -91,7 +94,7 @@ int main(int argc, char** argv) {
     else if (a == "-h" || a == "--help") {
       printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq [--out DIR]\n"
              "       [-e EVALUE] [-num_alignments N] [-no-best] [-min_lis N] [-num_seeds N] [-edges N] [-full_search] [-F|-R]\n"
-             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '1 cigar qcov qstrand'] [--sam]\n");
+             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '0' | '1 cigar qcov qstrand'] [--sam [-SQ]]\n");
       return 0;
     } else die("unknown option " + a);
   }
@@ -152,8 +155,11 @@ int main(int argc, char** argv) {
 
   // reports (writeReports, output.cpp:169-272)
   smr_report* rep = nullptr;
-  if (ro.fastx || ro.other || ro.blast_tabular || ro.sam) {
+  std::string cmdline;
+  for (int i = 0; i < argc; i++) { cmdline += argv[i]; cmdline += ' '; }       // the reference's opts.cmdline keeps the trailing blank
+  if (ro.fastx || ro.other || ro.blast_tabular || ro.blast_pairwise || ro.sam) {
     if (smr_report_open(out_dir.c_str(), &ro, is_fastq, &rep, err, sizeof err) != SMR_OK) die(err);
+    smr_report_set_cmdline(rep, cmdline.c_str());
     for (size_t k = 0; k < dbs.size(); k++) {
       smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
       uint64_t fr = 0, fq = 0;
@@ -191,6 +197,29 @@ int main(int argc, char** argv) {
           (unsigned long long)ctr[0], (unsigned long long)ctr[1]);
   for (size_t k = 0; k < dbs.size(); k++) fprintf(f, "%s\t%llu\n", dbs[k].fasta.c_str(), (unsigned long long)ctr[2 + k]);
   fclose(f);
+  {  // aligned.log (Summary::write, summary.cpp:57-100)
+    std::vector<smr_summary_db> sdb(dbs.size());
+    for (size_t k = 0; k < dbs.size(); k++) {
+      smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
+      sdb[k].ref_file = dbs[k].fasta.c_str();
+      sdb[k].skiplengths[0] = info.lnwin; sdb[k].skiplengths[1] = info.lnwin / 2; sdb[k].skiplengths[2] = 3;
+      sdb[k].lambda = dbs[k].lambda; sdb[k].K = dbs[k].K;
+      sdb[k].minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, n, smr_reads_total_len(reads), evalue);
+      sdb[k].reads_matched = ctr[2 + k];
+    }
+    const time_t now = time(nullptr);
+    const std::string stamp = ctime(&now);
+    const char* rf[1] = {reads_path.c_str()};
+    smr_summary sm; memset(&sm, 0, sizeof sm);
+    sm.cmdline = cmdline.c_str(); sm.pid = ""; sm.timestamp = stamp.c_str();
+    sm.seed_len = 18; sm.num_seeds = base.num_seeds; sm.edges = base.edges; sm.match = base.match; sm.mismatch = base.mismatch;
+    sm.gap_open = base.gap_open; sm.gap_ext = base.gap_ext; sm.score_N = base.score_N; sm.sam_sq = ro.sam_sq; sm.threads = 1;
+    sm.reads_files = rf; sm.n_reads_files = 1;
+    sm.total_reads = n; sm.num_aligned = ctr[0]; sm.all_reads_len = smr_reads_total_len(reads);
+    sm.min_read_len = smr_reads_min_len(reads); sm.max_read_len = smr_reads_max_len(reads);
+    sm.dbs = sdb.data(); sm.n_dbs = (uint32_t)sdb.size();
+    if (smr_summary_write((out_dir + "/aligned.log").c_str(), &sm) != SMR_OK) die("cannot write aligned.log");
+  }
   printf("%u reads, %llu aligned, %llu records -> %s\n", n, (unsigned long long)ctr[0], (unsigned long long)nrec, rp.c_str());
   for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
   smr_reads_free(reads);

@@ -218,6 +218,8 @@ typedef struct {
   int blast_tabular;     /* -blast 1 ...           */
   char blast_cols[64];   /* optional BLAST columns, space separated, in output order: "cigar", "qcov", "qstrand" */
   int sam;               /* -sam                   */
+  int blast_pairwise;    /* -blast 0: the BLAST-like pairwise text (report_blast.cpp:130-252) instead of tabular rows */
+  int sam_sq;            /* -SQ: @SQ lines of every reference sequence in the SAM header (report_sam.cpp:155-211) */
 } smr_report_opts;
 int smr_report_open(const char* out_dir, const smr_report_opts*, int is_fastq, smr_report** out, char* err, size_t errcap);
 /* per --ref: Gumbel parameters and the corrected sizes (smr_refstats_corrected); per (index, part): where its reference ids/sequences are */
@@ -225,8 +227,27 @@ int smr_report_set_db(smr_report*, uint32_t index_num, double lambda, double K, 
 int smr_report_set_part(smr_report*, uint32_t index_num, uint32_t part, const smr_index*);
 /* one read: its header line as in the file (with '>' / '@'), letters, quality (NULL for FASTA), and its record (NULL, 0: none) */
 int smr_report_add(smr_report*, const char* header, const char* seq, const char* qual, const uint8_t* record, size_t record_len);
+int smr_report_set_cmdline(smr_report*, const char* cmdline);   /* text after "CL:" in the SAM @PG line (default "libsmr_hip") */
 int smr_report_close(smr_report*);      /* writes aligned.blast / aligned.sam, closes the files, frees the object */
 const char* smr_report_last_error(const smr_report*);
+
+/* aligned.log: the run summary of Summary::to_string (summary.cpp:102-175), same text for the same numbers.
+ * cmdline / pid / timestamp are printed as given (the reference prints its own command line, pid string and ctime()). */
+typedef struct {
+  const char* ref_file;      /* as given to --ref */
+  uint32_t skiplengths[3];
+  double lambda, K;          /* Gumbel parameters */
+  uint32_t minimal_score;
+  uint64_t reads_matched;    /* Readstats::reads_matched_per_db[i] */
+} smr_summary_db;
+typedef struct {
+  const char* cmdline; const char* pid; const char* timestamp;
+  uint32_t seed_len; int32_t num_seeds, edges, match, mismatch, gap_open, gap_ext, score_N; int32_t sam_sq; int32_t threads;
+  const char* const* reads_files; uint32_t n_reads_files;
+  uint64_t total_reads, num_aligned, all_reads_len; uint32_t min_read_len, max_read_len;
+  const smr_summary_db* dbs; uint32_t n_dbs;
+} smr_summary;
+int smr_summary_write(const char* path, const smr_summary*);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,22 @@ class IndexInfo(C.Structure):
 
 
 class ReportOpts(C.Structure):
-    _fields_ = [("fastx", C.c_int), ("other", C.c_int), ("blast_tabular", C.c_int), ("blast_cols", C.c_char * 64), ("sam", C.c_int)]
+    _fields_ = [("fastx", C.c_int), ("other", C.c_int), ("blast_tabular", C.c_int), ("blast_cols", C.c_char * 64), ("sam", C.c_int),
+                ("blast_pairwise", C.c_int), ("sam_sq", C.c_int)]
+
+
+class SummaryDb(C.Structure):
+    _fields_ = [("ref_file", C.c_char_p), ("skiplengths", C.c_uint32 * 3), ("lam", C.c_double), ("K", C.c_double),
+                ("minimal_score", C.c_uint32), ("reads_matched", C.c_uint64)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("cmdline", C.c_char_p), ("pid", C.c_char_p), ("timestamp", C.c_char_p), ("seed_len", C.c_uint32),
+                ("num_seeds", C.c_int32), ("edges", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32),
+                ("gap_ext", C.c_int32), ("score_N", C.c_int32), ("sam_sq", C.c_int32), ("threads", C.c_int32),
+                ("reads_files", C.POINTER(C.c_char_p)), ("n_reads_files", C.c_uint32),
+                ("total_reads", C.c_uint64), ("num_aligned", C.c_uint64), ("all_reads_len", C.c_uint64),
+                ("min_read_len", C.c_uint32), ("max_read_len", C.c_uint32), ("dbs", C.POINTER(SummaryDb)), ("n_dbs", C.c_uint32)]
 
 
 class Prof(C.Structure):
@@ -45,7 +60,8 @@ EXPORTS = [
     "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_prof_reset", "smr_prof_get", "smr_refstats_corrected", "smr_report_open",
-    "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_close", "smr_report_last_error",
+    "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
+    "smr_summary_write",
 ]
 
 _lib = None
@@ -145,6 +161,10 @@ def bind(L):
     L.smr_report_set_part.argtypes = [vp, u32, u32, vp]
     L.smr_report_add.restype = i32
     L.smr_report_add.argtypes = [vp, cp, cp, cp, cp, C.c_size_t]
+    L.smr_report_set_cmdline.restype = i32
+    L.smr_report_set_cmdline.argtypes = [vp, cp]
+    L.smr_summary_write.restype = i32
+    L.smr_summary_write.argtypes = [cp, C.POINTER(Summary)]
     L.smr_report_close.restype = i32
     L.smr_report_close.argtypes = [vp]
     L.smr_report_last_error.restype = cp

@@ -3,7 +3,9 @@
 // Replaces, row for row, the reference's second pass over reads + KVDB (writeReports, /root/reference/src/sortmerna/output.cpp:169-272):
 //   aligned / other FASTX      ReportFxBase::write_a_read         report_fx_base.cpp:176-205, report_fastx.cpp:134-146, report_fx_other.cpp
 //   BLAST tabular (+ cigar / qcov / qstrand)   ReportBlast::append   report_blast.cpp:253-354 (e-value / bit score :118-125)
-//   SAM                        ReportSam::append                  report_sam.cpp:64-152
+//   BLAST pairwise (-blast 0)  ReportBlast::append                report_blast.cpp:130-252
+//   SAM (+ @SQ header lines)   ReportSam::append / write_header   report_sam.cpp:64-152, 155-211
+//   aligned.log                Summary::to_string                 summary.cpp:102-175
 //   %id / mismatches / gaps    Read::calc_miss_gap_match          read.cpp:547-589
 // Input per read: the original header line, letters, quality and the Read::toBinString record (read.cpp:429-462) that
 // smr_result_record returns.  Rows are buffered per (index, part) and written in that order, like the reference's loop.
@@ -11,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <iomanip>
 #include <map>
 #include <sstream>
 #include <string>
@@ -66,7 +69,7 @@ struct smr_report {
   std::map<uint32_t, Db> dbs;
   std::map<std::pair<uint32_t, uint32_t>, const smr_index*> parts;
   std::map<std::pair<uint32_t, uint32_t>, std::string> blast, sam;     // rows per (index, part)
-  std::string err;
+  std::string err, cmdline = "libsmr_hip";
 };
 
 extern "C" int smr_report_open(const char* out_dir, const smr_report_opts* opts, int is_fastq, smr_report** out, char* err, size_t errcap) {
@@ -110,7 +113,7 @@ extern "C" int smr_report_add(smr_report* r, const char* header, const char* seq
     fprintf(f, "%s\n%s\n", header, seq);
     if (r->fastq) fprintf(f, "+\n%s\n", qual ? qual : "");
   }
-  if (alns.empty() || (!r->o.blast_tabular && !r->o.sam)) return SMR_OK;
+  if (alns.empty() || (!r->o.blast_tabular && !r->o.blast_pairwise && !r->o.sam)) return SMR_OK;
   // Read::getSeqId (read.cpp:371-377)
   std::string id(header);
   id = id.substr(0, id.find(' '));
@@ -148,6 +151,39 @@ extern "C" int smr_report_add(smr_report* r, const char* header, const char* seq
     }
     const double idf = (double)n_match / (double)(n_miss + n_gap + n_match);
     const double cov = (double)std::abs(a.read_end1 - a.read_begin1 + 1) / (double)a.readlen;
+    if (r->o.blast_pairwise && !r->o.blast_tabular) {
+      // The alignment as rows of at most 60 columns: reference letters ('-' where the read has an insertion), match marks,
+      // read letters ('-' where the read has a deletion); the numbers are the 1-based first / last position of the row.
+      const Db& d = dit->second;
+      const uint32_t bitscore = (uint32_t)((float)(d.lambda * a.score1 - std::log(d.K)) / (float)std::log(2));
+      const double evalue = (double)d.K * d.full_ref * d.full_read * std::exp(-d.lambda * a.score1);
+      std::ostringstream ss;
+      ss << "Sequence ID: " << ref_id << "\n" << "Query ID: " << id << "\n";
+      ss << "Score: " << a.score1 << " bits (" << bitscore << ")\t";
+      ss.precision(3);
+      ss << "Expect: " << evalue << "\t" << "strand: " << (a.strand ? '+' : '-') << "\n\n";
+      std::string ops;                                     // one char per alignment column: 0 = M, 1 = I, 2 = D
+      for (uint32_t c : a.cigar) ops.append(c >> 4, (char)(c & 0xF));
+      int64_t q = a.ref_begin1, p = a.read_begin1;
+      for (size_t c0 = 0; c0 < ops.size(); c0 += 60) {
+        const size_t c1 = std::min(ops.size(), c0 + 60);
+        std::string tl, ml, ql;
+        const int64_t q0 = q, p0 = p;
+        for (size_t c = c0; c < c1; c++) {
+          const char op = ops[c];
+          if (op == 0) {
+            const char rc = nt_map[refseq[q]], qc = nt_map[(int)iseq[p]];
+            tl += rc; ql += qc; ml += rc == qc ? '|' : '*';
+            ++q; ++p;
+          } else if (op == 1) { tl += '-'; ml += ' '; ql += nt_map[(int)iseq[p]]; ++p; }
+          else { tl += nt_map[refseq[q]]; ml += ' '; ql += '-'; ++q; }
+        }
+        ss << "Target: " << std::setw(8) << q0 + 1 << "    " << tl << "    " << q << "\n";
+        ss << std::setw(20) << " " << ml;
+        ss << "\nQuery: " << std::setw(9) << p0 + 1 << "    " << ql << "    " << p << "\n\n";
+      }
+      r->blast[key] += ss.str();
+    }
     if (r->o.blast_tabular) {
       const Db& d = dit->second;
       const uint32_t bitscore = (uint32_t)((float)(d.lambda * a.score1 - std::log(d.K)) / (float)std::log(2));
@@ -191,7 +227,7 @@ extern "C" int smr_report_close(smr_report* r) {
   int rc = SMR_OK;
   if (r->f_aligned) fclose(r->f_aligned);
   if (r->f_other) fclose(r->f_other);
-  if (r->o.blast_tabular) {
+  if (r->o.blast_tabular || r->o.blast_pairwise) {
     FILE* f = fopen((r->dir + "/aligned.blast").c_str(), "wb");
     if (!f) rc = SMR_ERR_IO; else { for (auto& kv : r->blast) fwrite(kv.second.data(), 1, kv.second.size(), f); fclose(f); }
   }
@@ -199,13 +235,67 @@ extern "C" int smr_report_close(smr_report* r) {
     FILE* f = fopen((r->dir + "/aligned.sam").c_str(), "wb");
     if (!f) rc = SMR_ERR_IO;
     else {
-      fprintf(f, "@HD\tVN:1.0\tSO:unsorted\n@PG\tID:sortmerna\tVN:1.0\tCL:libsmr_hip\n");     // report_sam.cpp:157-175 (CL = the caller's command line)
+      fprintf(f, "@HD\tVN:1.0\tSO:unsorted\n");
+      if (r->o.sam_sq) {                                  // every sequence of every --ref, in --ref order (from <index>.stats)
+        uint32_t last = 0xFFFFFFFFu;
+        for (auto& kv : r->parts) {
+          if (kv.first.first == last) continue;
+          last = kv.first.first;
+          for (auto& sq : kv.second->sq_header) fprintf(f, "@SQ\tSN:%s\tLN:%u\n", sq.first.c_str(), sq.second);
+        }
+      }
+      fprintf(f, "@PG\tID:sortmerna\tVN:1.0\tCL:%s\n", r->cmdline.c_str());
       for (auto& kv : r->sam) fwrite(kv.second.data(), 1, kv.second.size(), f);
       fclose(f);
     }
   }
   delete r;
   return rc;
+}
+
+extern "C" int smr_report_set_cmdline(smr_report* r, const char* cmdline) {
+  if (!r || !cmdline) return SMR_ERR_ARG;
+  r->cmdline = cmdline;
+  return SMR_OK;
+}
+
+extern "C" int smr_summary_write(const char* path, const smr_summary* s) {
+  if (!path || !s || (s->n_dbs && !s->dbs) || (s->n_reads_files && !s->reads_files)) return SMR_ERR_ARG;
+  std::ostringstream ss;
+  ss << " Command:\n    " << (s->cmdline ? s->cmdline : "") << "\n\n" << " Process pid = " << (s->pid ? s->pid : "") << "\n\n" << " Parameters summary: \n";
+  for (uint32_t i = 0; i < s->n_dbs; i++) {
+    const smr_summary_db& d = s->dbs[i];
+    ss << "    Reference file: " << (d.ref_file ? d.ref_file : "") << "\n"
+       << "        Seed length = " << s->seed_len << "\n"
+       << "        Pass 1 = " << d.skiplengths[0] << ", Pass 2 = " << d.skiplengths[1] << ", Pass 3 = " << d.skiplengths[2] << "\n"
+       << "        Gumbel lambda = " << d.lambda << "\n"
+       << "        Gumbel K = " << d.K << "\n"
+       << "        Minimal SW score based on E-value = " << d.minimal_score << "\n";
+  }
+  ss << "    Number of seeds = " << s->num_seeds << "\n" << "    Edges = " << s->edges << "\n" << "    SW match = " << s->match << "\n"
+     << "    SW mismatch = " << s->mismatch << "\n" << "    SW gap open penalty = " << s->gap_open << "\n"
+     << "    SW gap extend penalty = " << s->gap_ext << "\n" << "    SW ambiguous nucleotide = " << s->score_N << "\n"
+     << "    SQ tags are " << (s->sam_sq ? "" : "not ") << "output\n"
+     << "    Number of alignment processing threads = " << s->threads << "\n";
+  for (uint32_t i = 0; i < s->n_reads_files; i++) ss << "    Reads file: " << s->reads_files[i] << "\n";
+  ss << "    Total reads = " << s->total_reads << "\n\n" << " Results:\n";
+  const float ratio = (float)s->num_aligned / s->total_reads;
+  ss << std::setprecision(2) << std::fixed
+     << "    Total reads passing E-value threshold = " << s->num_aligned << " (" << (ratio * 100) << ")\n"
+     << "    Total reads failing E-value threshold = " << s->total_reads - s->num_aligned << " (" << (1 - ratio) * 100 << ")\n"
+     << "    Minimum read length = " << s->min_read_len << "\n" << "    Maximum read length = " << s->max_read_len << "\n"
+     << "    Mean read length    = " << (s->total_reads ? s->all_reads_len / s->total_reads : 0) << "\n\n" << " Coverage by database:\n";
+  for (uint32_t i = 0; i < s->n_dbs; i++) {
+    const float pcn = (float)((float)s->dbs[i].reads_matched / s->total_reads) * 100;
+    ss << "    " << (s->dbs[i].ref_file ? s->dbs[i].ref_file : "") << "\t\t" << pcn << "\n";
+  }
+  ss << "\n " << (s->timestamp ? s->timestamp : "") << "\n";
+  FILE* f = fopen(path, "wb");
+  if (!f) return SMR_ERR_IO;
+  const std::string t = ss.str();
+  fwrite(t.data(), 1, t.size(), f);
+  fclose(f);
+  return SMR_OK;
 }
 
 extern "C" const char* smr_report_last_error(const smr_report* r) { return r ? r->err.c_str() : "null report"; }

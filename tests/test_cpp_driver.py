@@ -32,10 +32,7 @@ def test_driver_builds_and_fails_loudly_without_gpu(tmp_path):
     assert p.returncode != 0 and b"no CPU fallback" in p.stderr
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", ["syn_default", "syn_all", "two_db_default"])
-def test_driver_reproduces_reference_records(case, tmp_path):
-    exe = build_driver()
+def _check_case(exe, case, tmp_path):
     g = golden.load()[case]
     dbs, rd, seqs = golden.inputs(case)
     if not isinstance(dbs, list):
@@ -63,3 +60,32 @@ def test_driver_reproduces_reference_records(case, tmp_path):
     assert not bad, "%d records differ, first %d" % (len(bad), bad[0])
     summary = open(tmp_path / "summary.txt").read()
     assert "Total reads passing E-value threshold = %d" % g["readstats"]["num_aligned"] in summary
+    if case == "syn_default":            # second run: `-blast 0 -sam -SQ` and aligned.log against tests/golden/reports2 (written by the reference)
+        r2 = os.path.join(paths.REPO, "tests", "golden", "reports2")
+        out2 = tmp_path / "pw"
+        os.makedirs(out2)
+        subprocess.check_call([exe, "--reads", rd, "--out", str(out2), "--ref", dbs[0], "--gumbel", repr(g["log"]["lambda"][0]), repr(g["log"]["K"][0]),
+                               "--blast", "0", "--sam", "-SQ"])
+        strip_e = lambda t: [l.split("\tExpect:")[0] + "\t" + l.split("\t")[-1] if l.startswith("Score: ") else l for l in t.split("\n")]
+        assert strip_e(open(out2 / "aligned.blast").read()) == strip_e(open(os.path.join(r2, case + ".pairwise.txt")).read())
+        sq = lambda p: [l for l in open(p).read().splitlines() if l.startswith("@SQ") or l.startswith("@HD")]
+        assert sq(out2 / "aligned.sam") == sq(os.path.join(r2, case + ".sam_header.txt"))
+        body = lambda t: [l.replace(os.path.dirname(dbs[0]) + "/", "") for l in t.split("\n")[3:-3]]     # without the command line and the time stamp
+        assert body(open(out2 / "aligned.log").read()) == body(open(os.path.join(r2, case + ".log.txt")).read())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["syn_default", "syn_all", "two_db_default"])
+def test_driver_reproduces_reference_records(case, tmp_path):
+    _check_case(build_driver(), case, tmp_path)
+
+
+@pytest.mark.parametrize("case", ["syn_default", "two_db_default"])
+def test_driver_on_the_kernel_emulator(case, tmp_path):
+    """the same driver source linked with tests/emu's host build of the kernels (development aid, see tests/test_emu_kernels.py)"""
+    from helpers import emu
+    lib = emu.build()
+    exe = os.path.join(os.path.dirname(lib), "smr_align_emu")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(paths.REPO, "examples", "smr_align.cpp"),
+                           "-I", os.path.join(paths.REPO, "include"), lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    _check_case(exe, case, tmp_path)
