@@ -202,6 +202,11 @@ typedef struct {
   uint64_t n_windows, n_lookup, n_node, n_entry, n_hit, n_read_bytes;
   uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;
 } smr_prof;
+/* Device self-check: n_cases seeded random (read, reference window) pairs, 1..max_len nt, for two scoring schemes: the packed 16-bit
+ * Smith-Waterman kernel against the 32-bit kernel (score, end cell; forward and reverse pass), both on the GPU.  smr_create runs it
+ * (SMR_SW_SELFCHECK=<cases>, 0 = skip) and falls back to the 32-bit kernel if any case differs; SMR_SW_PACKED=0 disables the packed kernel. */
+int smr_sw_selfcheck(smr_ctx*, uint32_t n_cases, uint32_t seed, uint32_t max_len, uint64_t* n_bad);
+int smr_sw_mode(smr_ctx*, int set_to);   /* set_to 0 / 1: use the 32-bit / the packed kernel; other values: query; returns the mode in use */
 int smr_prof_reset(smr_ctx*);
 int smr_prof_get(smr_ctx*, smr_prof* out);
 

@@ -139,10 +139,27 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
   return rr;
 }
 
+}  // namespace smr
+#include "smr_sw_pk.hpp"
+namespace smr {
+
+// mode 1: the packed 16-bit kernel (smr_sw_pk.hpp) where its preconditions hold; mode 0: always the 32-bit kernel
 __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
-                                         int* bound, int match, int mismatch, int scoreN, int go, int ge) {
-  const bool small = (long long)m * match < 16384 && n < 65535 && match < 128 && mismatch > -128 && scoreN > -128 && scoreN < 128;
+                                         int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
 #define SW_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge
+  if (mode == 1 && (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255) {
+    bool hasn = false;
+    for (int q = lane_id(); q < n; q += 64) hasn |= rfq[rf0 + rfstep * q] == 4;
+    if (__any(hasn)) {
+      if (m <= 128) return sw_wave_pk_r<1, true>(SW_ARGS);
+      if (m <= 256) return sw_wave_pk_r<2, true>(SW_ARGS);
+      return sw_wave_pk_r<4, true>(SW_ARGS);
+    }
+    if (m <= 128) return sw_wave_pk_r<1, false>(SW_ARGS);
+    if (m <= 256) return sw_wave_pk_r<2, false>(SW_ARGS);
+    return sw_wave_pk_r<4, false>(SW_ARGS);
+  }
+  const bool small = (long long)m * match < 16384 && n < 65535 && match < 128 && mismatch > -128 && scoreN > -128 && scoreN < 128;
   if (small) {
     if (m <= 64) return sw_wave_r<1, true>(SW_ARGS);
     if (m <= 128) return sw_wave_r<2, true>(SW_ARGS);
@@ -455,7 +472,7 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
                   for (int q = lane; q < nref; q += 64) rfq[q] = ix.ref_seq[rf_start + q];
                   __syncthreads();
                   TPH(5)
-                  fw = sw_wave(rdq, m, 0, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
+                  fw = sw_wave(rdq, m, 0, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
                   TPH(6)
                   n_fwd++; n_cells += (unsigned long long)m * nref;
                 }
@@ -466,7 +483,7 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
                   // reverse pass (ssw.c:900-918) on the prefixes ending at (read_end1, ref_end1)
                   TPH(5)
                   SwRes bw = sw_wave(rdq, read_end1 + 1, read_end1, -1, rfq, ref_end1 + 1, ref_end1, -1, bound,
-                                     P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
+                                     P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
                   ref_begin1 = ref_end1 - bw.end_ref;
                   read_begin1 = read_end1 - bw.end_read;
                   TPH(6)

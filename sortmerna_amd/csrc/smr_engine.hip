@@ -64,6 +64,8 @@ struct smr_ctx {
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t chain_blocks = 0;
   unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
+  size_t chain_lds_attr = 0;
+  int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 1;   // 1: packed 16-bit Smith-Waterman kernel (smr_sw_pk.hpp) where it applies
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
@@ -112,6 +114,7 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
   P.is_best = p->is_best; P.is_full_search = p->is_full_search; P.is_forward = p->is_forward; P.is_reverse = p->is_reverse;
   P.minoccur = p->minoccur; P.index_num = p->index_num; P.part = p->part; P.is_last_index_part = p->is_last_index_part;
   P.slots = c->b->slots;
+  P.sw_mode = c->sw_mode;
   return P;
 }
 
@@ -255,6 +258,10 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   uint32_t ml, rf; size_t lds;
   chain_lds(c, P, ml, rf, lds);
   HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
+  if (lds > 64 * 1024 && lds > c->chain_lds_attr) {     // reads beyond ~5.6 kb: more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->chain_lds_attr = lds;
+  }
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
   ev_begin(c, 1);
   hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
@@ -288,6 +295,91 @@ int read_ctr(smr_ctx* c, std::vector<unsigned long long>& h) {
 }  // namespace
 
 // =================================================================================================
+// Device self-check of the packed Smith-Waterman kernel against the 32-bit one (both on the GPU): one wave per case, seeded
+// pseudo-random read (1..max_m nt, ~1.5 % N) against either a mutated copy of it with substitutions and indels or a random
+// sequence; forward pass and the reverse-direction pass on the prefixes ending in the forward end cell, like k_chain's two calls.
+__device__ __forceinline__ uint32_t sc_hash(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (c + 0x165667B1u) * 0xC2B2AE35u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+__global__ void __launch_bounds__(64) k_sw_selfcheck(uint32_t n_cases, uint32_t seed, uint32_t max_m, uint32_t lds_m, uint32_t lds_n,
+                                                     int match, int mismatch, int scoreN, int go, int ge, unsigned long long* out) {
+  SMR_DYN_LDS(unsigned char, lds_raw);
+  uint8_t* rdq = lds_raw;
+  uint8_t* rfq = rdq + lds_m;
+  int* bound = (int*)(rfq + lds_n);
+  __shared__ int s_n;
+  const int lane = smr::lane_id();
+  for (uint32_t cs = blockIdx.x; cs < n_cases; cs += gridDim.x) {
+    const uint32_t hm = sc_hash(seed, cs, 1);
+    const int m = 1 + (int)(hm % max_m);
+    for (int q = lane; q < m; q += 64) { const uint32_t h = sc_hash(seed, cs, 100u + (uint32_t)q); rdq[q] = (h & 63u) == 0 ? 4 : (uint8_t)((h >> 8) & 3u); }
+    __syncthreads();
+    if (lane == 0) {
+      int n = 0;
+      const bool homolog = (hm >> 20) & 3u;                       // 3 of 4 cases: a mutated copy (with a random flank), else unrelated
+      const int flank = (int)((hm >> 24) & 15u);
+      for (int q = 0; q < flank; q++) rfq[n++] = (uint8_t)(sc_hash(seed, cs, 5000u + (uint32_t)q) & 3u);
+      for (int q = 0; q < m && n + 2 < (int)lds_n; q++) {
+        const uint32_t h = sc_hash(seed, cs, 9000u + (uint32_t)q);
+        if (!homolog) { rfq[n++] = (uint8_t)(h & 3u); continue; }
+        const uint32_t ev = (h >> 4) & 63u;
+        if (ev == 0) continue;                                      // deletion in the reference
+        if (ev == 1) rfq[n++] = (uint8_t)((h >> 12) & 3u);          // insertion
+        if (ev == 2) { rfq[n++] = 4; continue; }                    // N in the reference
+        rfq[n++] = ev < 6 ? (uint8_t)((h >> 16) & 3u) : (rdq[q] == 4 ? (uint8_t)0 : rdq[q]);
+      }
+      for (int q = 0; q < flank && n + 1 < (int)lds_n; q++) rfq[n++] = (uint8_t)(sc_hash(seed, cs, 7000u + (uint32_t)q) & 3u);
+      s_n = n;
+    }
+    __syncthreads();
+    const int n = s_n;
+    const smr::SwRes a0 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, 0);
+    __syncthreads();
+    const smr::SwRes a1 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, 1);
+    __syncthreads();
+    bool bad = a0.score != a1.score || a0.end_ref != a1.end_ref || a0.end_read != a1.end_read;
+    if (a0.score > 0 && a0.end_ref >= 0) {
+      const smr::SwRes b0 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, 0);
+      __syncthreads();
+      const smr::SwRes b1 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, 1);
+      __syncthreads();
+      bad = bad || b0.score != b1.score || b0.end_ref != b1.end_ref || b0.end_read != b1.end_read;
+    }
+    if (lane == 0) { atomicAdd(&out[0], 1ull); if (bad) atomicAdd(&out[1], 1ull); atomicAdd(&out[2], (unsigned long long)a0.score); }
+    __syncthreads();
+  }
+}
+
+extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uint32_t max_len, uint64_t* n_bad) {
+  if (!c || !n_bad || max_len == 0 || max_len > 4000) return SMR_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  unsigned long long* d = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d, 3 * 8));
+  HIPCHK(c, hipMemsetAsync(d, 0, 3 * 8, c->stream));
+  const uint32_t lm = (max_len + 15) & ~15u, ln = (max_len + max_len / 16 + 64 + 15) & ~15u;
+  const size_t lds = (size_t)lm + ln + (size_t)2 * ln * 4;
+  const int sc[2][3] = {{2, -3, -3}, {5, -4, -4}};
+  for (int k = 0; k < 2 && n_cases; k++)
+    hipLaunchKernelGGL(k_sw_selfcheck, dim3(std::min<uint32_t>(n_cases, (uint32_t)c->n_cu * 8u)), dim3(64), lds, c->stream, n_cases, seed + 7919u * (uint32_t)k, max_len, lm, ln,
+                       sc[k][0], sc[k][1], sc[k][2], 5, 2, d);
+  unsigned long long h[3] = {0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, d, 3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  if (h[0] != 2ull * n_cases) { c->err = "SW self-check did not run all cases"; return SMR_ERR_DEVICE; }
+  *n_bad = h[1];
+  return SMR_OK;
+}
+
+extern "C" int smr_sw_mode(smr_ctx* c, int set_to) {      // set_to: 0 / 1 = select, anything else = query only; returns the mode in use
+  if (!c) return SMR_ERR_ARG;
+  if (set_to == 0 || set_to == 1) c->sw_mode = set_to;
+  return c->sw_mode;
+}
+
+// =================================================================================================
 extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   if (!out) return SMR_ERR_ARG;
   int ndev = 0;
@@ -309,6 +401,20 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
   (void)hipMemset(c->b->d_ctr, 0, C_TOTAL * 8);
   c->b->used = true;
+  if (c->sw_mode == 1) {
+    // the packed Smith-Waterman kernel must agree with the 32-bit kernel on this device, or it is not used
+#ifdef SMR_EMU
+    uint32_t cases = 8;
+#else
+    uint32_t cases = 512;
+#endif
+    if (const char* e2 = getenv("SMR_SW_SELFCHECK")) cases = (uint32_t)atoi(e2);
+    uint64_t bad = 0;
+    if (cases > 0 && (smr_sw_selfcheck(c, cases, 20260926u, 700, &bad) != SMR_OK || bad != 0)) {
+      fprintf(stderr, "libsmr_hip: packed Smith-Waterman kernel disagrees with the 32-bit kernel on %llu self-check cases; using the 32-bit kernel\n", (unsigned long long)bad);
+      c->sw_mode = 0;
+    }
+  }
   *out = c;
   return SMR_OK;
 }

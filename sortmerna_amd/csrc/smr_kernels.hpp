@@ -98,6 +98,7 @@ struct DParams {
   uint32_t minoccur, index_num, part;
   int32_t is_last_index_part;
   uint32_t slots;               // alignment slots per read
+  int32_t sw_mode;              // 1: packed 16-bit Smith-Waterman kernel where it applies (smr_sw_pk.hpp), 0: 32-bit kernel only
 };
 
 // global counters (u64 each)

@@ -1,0 +1,171 @@
+// smr_sw_pk.hpp -- Smith-Waterman score + end cell on packed 16-bit lanes (v_pk_*_i16): the anti-diagonal systolic
+// array of smr_chain.hpp with 128 VIRTUAL lanes per wave.  The low half of every 32-bit register belongs to virtual
+// lane l, the high half to virtual lane l + 64; virtual lane v owns R consecutive read rows and works on reference
+// column t - v at step t, so the high half of lane 0 continues where the low half of lane 63 stopped (one readlane
+// per stream and step), and one v_pk op advances two DP cells.  Same recurrence and the same end-cell rule as
+// sw_wave_r (ssw.c:150-373, 305-336); results are bit-identical (tests: the packed and the scalar kernel are compared
+// with the oracle and with each other, and smr_create checks one against the other on the device).
+//
+// Representation (all signed 16 bit):  Y = H - gap_open (so e = max(E - ge, Y), f = max(F_up - ge, Y_up)), score table
+// T = score + gap_open >= 0 selected per step by ONE v_perm_b32 for both halves (byte 0..3 of the low row's table,
+// 4..7 of the high row's; selector 0x0C = constant 0 = "score -gap_open", used for the columns before 0 and after n-1
+// and for the rows >= m, which therefore never reach the maximum: every value there is strictly smaller than a valid
+// cell's, or 0).  h = max(Y_diag + T, e, f, 0).  Per cell pair: perm, add, 2 x (sub, max), 3 x max, sub = 10 VALU ops
+// + 3 for the running maximum key (h << 16 | first column | half), instead of ~20 per single cell.  The inputs of virtual
+// lane 0 (reference letters; the boundary row of the previous strip) are loaded 64 columns at a time, one per lane, and
+// read back with v_readlane, so the step loop has no memory access.
+// Preconditions (checked by the caller): m * match + 255 < 32768, n + 128 <= 8191, gap_open + min(score) >= 0,
+// match + gap_open <= 255.
+#pragma once
+
+namespace smr {
+
+#ifdef SMR_EMU
+struct pk16 { int16_t lo, hi; };
+__device__ inline pk16 pk_from(uint32_t v) { pk16 r; r.lo = (int16_t)(v & 0xFFFF); r.hi = (int16_t)(v >> 16); return r; }
+__device__ inline uint32_t pk_bits(pk16 v) { return (uint32_t)(uint16_t)v.lo | ((uint32_t)(uint16_t)v.hi << 16); }
+__device__ inline pk16 pk_add(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo + b.lo); r.hi = (int16_t)(a.hi + b.hi); return r; }
+__device__ inline pk16 pk_sub(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo - b.lo); r.hi = (int16_t)(a.hi - b.hi); return r; }
+__device__ inline pk16 pk_max(pk16 a, pk16 b) { pk16 r; r.lo = a.lo > b.lo ? a.lo : b.lo; r.hi = a.hi > b.hi ? a.hi : b.hi; return r; }
+__device__ inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {          // v_perm_b32: bytes 0-3 = s1, 4-7 = s0, 12 = 0x00, >= 13 = 0xFF
+  const unsigned long long src = ((unsigned long long)s0 << 32) | s1;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t s = (sel >> (8 * i)) & 0xFF;
+    uint32_t b;
+    if (s < 8) b = (uint32_t)(src >> (8 * s)) & 0xFF;
+    else if (s < 12) b = ((src >> (8 * (2 * (s - 8) + 1) + 7)) & 1) ? 0xFF : 0x00;
+    else if (s == 12) b = 0x00;
+    else b = 0xFF;
+    r |= b << (8 * i);
+  }
+  return r;
+}
+#else
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_add(pk16 a, pk16 b) { return a + b; }
+__device__ __forceinline__ pk16 pk_sub(pk16 a, pk16 b) { return a - b; }
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+#endif
+__device__ __forceinline__ pk16 pk_splat(int v) { return pk_from(((uint32_t)v & 0xFFFFu) * 0x00010001u); }
+
+#define PK_SEL_NONE 0x0C0Cu          // half selector: both bytes constant 0
+#define PK_SEL_N 0x0D0Cu             // reference letter N: marker in the high byte (the result is replaced by T_N)
+
+// selector half of reference letter c for the low half; +4 moves it to the high half's table
+__device__ __forceinline__ uint32_t pk_sel_of(int c) { return c < 4 ? (0x0C00u | (uint32_t)c) : PK_SEL_N; }
+__device__ __forceinline__ uint32_t pk_sel_to_hi(uint32_t s) { return (s & 0xFFu) < 4u ? s + 4u : s; }
+
+template <int R, bool HASN>
+__device__ __forceinline__ SwRes sw_wave_pk_r(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                              int* bound, int match, int mismatch, int scoreN, int go, int ge) {
+  const int lane = lane_id();
+  int bestH = 0, bestcol = 0x1FFFFF, bestrow = 0x1FFFFF;
+  const int rps = 128 * R;
+  const int nstrips = (m + rps - 1) / rps;
+  const pk16 GE = pk_splat(ge), GO = pk_splat(go), ZERO = pk_splat(0);
+  const uint32_t TN = (((uint32_t)(scoreN + go)) & 0xFFFFu) * 0x00010001u;
+  for (int s = 0; s < nstrips; s++) {
+    const int row0 = s * rps;
+    // score tables: byte b of tlo[j] / thi[j] = score(read letter of the row, reference letter b) + gap_open; rows >= m: 0
+    uint32_t tlo[R], thi[R];
+    pk16 Y[R], E[R];
+    uint32_t key[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      uint32_t t2[2];
+      for (int hf = 0; hf < 2; hf++) {
+        const int row = row0 + (lane + 64 * hf) * R + j;
+        uint32_t t = 0;
+        if (row < m) {
+          const int c = rdq[rd0 + rdstep * row];
+          for (int b = 0; b < 4; b++) t |= (uint32_t)((c == 4 ? scoreN : (c == b ? match : mismatch)) + go) << (8 * b);
+        }
+        t2[hf] = t;
+      }
+      tlo[j] = t2[0]; thi[j] = t2[1];
+      Y[j] = pk_splat(-go); E[j] = ZERO; key[j] = 0;
+    }
+    const bool has_prev = s > 0, has_next = s + 1 < nstrips;
+    const int vused = has_next ? 128 : (m - row0 + R - 1) / R;       // virtual lanes that own a valid row
+    const int steps = n + vused - 1;
+    // streams entering a virtual lane from the one above it: Y and F of its last row, and the selector (= reference letter)
+    uint32_t lastY = pk_bits(pk_splat(-go)), lastF = 0, selcur = PK_SEL_NONE * 0x00010001u;
+    pk16 diag0 = pk_splat(-go);
+    // running-maximum key: h << 16 | (0x3FFF - column) << 1 | (1 for the low half): larger = higher score, then earlier column, then
+    // the low half (smaller row); 15 bits hold the column term for every column -127 .. 8191, so nothing spills into h
+    uint32_t xlo = ((uint32_t)(0x3FFF + lane) << 1) | 1u;
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+      // the inputs of virtual lane 0 for the next 64 steps (columns t0 .. t0+63), one per lane; read back with v_readlane
+      const int cq = t0 + lane;
+      uint32_t chS = PK_SEL_NONE;
+      int chY = -go, chF = 0;
+      if (cq < n) {
+        chS = pk_sel_of(rfq[rf0 + rfstep * cq]);
+        if (has_prev) { chY = bound[2 * cq] - go; chF = bound[2 * cq + 1]; }
+      }
+      const int tend = min(64, steps - t0);
+      for (int tt = 0; tt < tend; tt++) {
+        const uint32_t inS = (uint32_t)__builtin_amdgcn_readlane((int)chS, tt);
+        const uint32_t inY = (uint32_t)__builtin_amdgcn_readlane(chY, tt), inF = (uint32_t)__builtin_amdgcn_readlane(chF, tt);
+        // virtual lane 64 (high half of lane 0) continues what lane 63's low half produced in the previous step
+        const uint32_t y63 = (uint32_t)__builtin_amdgcn_readlane((int)lastY, 63), f63 = (uint32_t)__builtin_amdgcn_readlane((int)lastF, 63),
+                       s63 = (uint32_t)__builtin_amdgcn_readlane((int)selcur, 63);
+        const uint32_t injY = (y63 << 16) | (inY & 0xFFFFu), injF = (f63 << 16) | (inF & 0xFFFFu),
+                       injS = (pk_sel_to_hi(s63 & 0xFFFFu) << 16) | inS;
+        const pk16 upY = pk_from((uint32_t)dpp_shr1((int)injY, (int)lastY));
+        const pk16 upF = pk_from((uint32_t)dpp_shr1((int)injF, (int)lastF));
+        selcur = (uint32_t)dpp_shr1((int)injS, (int)selcur);
+        uint32_t nmask = 0;
+        if (HASN) nmask = ((selcur >> 8) & 0x00010001u) * 0xFFFFu;               // 0xFFFF in the halves whose letter is N
+        const uint32_t xhi = xlo + 127u;                                           // the high half is 64 columns behind, flag 0
+        pk16 diag = diag0, uy = upY, uf = upF;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+          uint32_t T = perm_b32(thi[j], tlo[j], selcur);
+          if (HASN) T = (T & ~nmask) | (TN & nmask);
+          const pk16 a = pk_add(diag, pk_from(T));
+          const pk16 e = pk_max(pk_sub(E[j], GE), Y[j]);
+          const pk16 f = pk_max(pk_sub(uf, GE), uy);
+          const pk16 h = pk_max(pk_max(a, e), pk_max(f, ZERO));
+          diag = Y[j];                                      // Y(row, col-1): the diagonal of the next row
+          const pk16 y = pk_sub(h, GO);
+          Y[j] = y; E[j] = e;
+          const uint32_t hu = pk_bits(h);
+          key[j] = max(key[j], max((hu << 16) | xlo, (hu & 0xFFFF0000u) | xhi));
+          uy = y; uf = f;
+        }
+        diag0 = upY;                                         // Y(row0 - 1, col): diagonal of the first row at the next column
+        lastY = pk_bits(uy); lastF = pk_bits(uf);
+        xlo -= 2u;
+        if (has_next && lane == 63) {                        // virtual lane 127 hands its last row to the next strip
+          const int c127 = t0 + tt - 127;
+          if (c127 >= 0 && c127 < n) { bound[2 * c127] = (int)(int16_t)(lastY >> 16) + go; bound[2 * c127 + 1] = (int)(int16_t)(lastF >> 16); }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      const int h = (int)(key[j] >> 16);
+      const int hf = (key[j] & 1u) ? 0 : 1;
+      const int col = 0x3FFF - (int)((key[j] >> 1) & 0x7FFFu);      // the winning half's own column (xlo / xhi above)
+      const int row = row0 + (lane + 64 * hf) * R + j;
+      if (h > bestH || (h == bestH && h > 0 && (col < bestcol || (col == bestcol && row < bestrow)))) { bestH = h; bestcol = col; bestrow = row; }
+    }
+    __syncthreads();
+  }
+  unsigned long long k64 = bestH > 0 ? (((unsigned long long)bestH << 42) | ((unsigned long long)(0x1FFFFF - bestcol) << 21) |
+                                        (unsigned long long)(0x1FFFFF - bestrow)) : 0ull;
+  k64 = wave_max_u64(k64);
+  SwRes rr;
+  if (k64 == 0) { rr.score = 0; rr.end_ref = -1; rr.end_read = m - 1; return rr; }
+  rr.score = (int)(k64 >> 42);
+  rr.end_ref = 0x1FFFFF - (int)((k64 >> 21) & 0x1FFFFF);
+  rr.end_read = 0x1FFFFF - (int)(k64 & 0x1FFFFF);
+  return rr;
+}
+
+}  // namespace smr

@@ -189,6 +189,16 @@ class Engine:
         """0: work-queue seed search (default); 1: per-lane DFS kernel with reference-exact work counters (same results)"""
         self._chk(self.L.smr_set_seed_mode(self.h, int(bool(exact_counters))), "smr_set_seed_mode")
 
+    def sw_mode(self, set_to=-1):
+        """Smith-Waterman kernel in use: 1 = packed 16-bit (default when the device self-check passes), 0 = 32-bit; set_to 0/1 selects"""
+        return self.L.smr_sw_mode(self.h, set_to)
+
+    def sw_selfcheck(self, n_cases=256, seed=1, max_len=700):
+        """packed vs 32-bit Smith-Waterman kernel on n_cases random pairs x 2 scoring schemes, on the device; returns the number of differing cases"""
+        bad = C.c_uint64()
+        self._chk(self.L.smr_sw_selfcheck(self.h, n_cases, seed, max_len, C.byref(bad)), "smr_sw_selfcheck")
+        return bad.value
+
     def upload_reads(self, reads, max_alignments_per_read=1):
         self._chk(self.L.smr_reads_upload(self.h, reads.h, max_alignments_per_read), "smr_reads_upload")
         self.n_reads = reads.count

@@ -105,6 +105,11 @@ __attribute__((noinline)) inline int update_dpp(int site, int old, int src, int 
   if (l == 0 || !((m >> (l - 1)) & 1)) return old;
   return (int)(uint32_t)res[l - 1];
 }
+__attribute__((noinline)) inline int readlane(int site, int v, int l) {          // v_readlane_b32: every lane gets lane l's value
+  const uint64_t* res; const uint64_t m = wave_exchange((uint32_t)v, &res, site, EMU_RA);
+  if (!((m >> (l & 63)) & 1)) { fprintf(stderr, "emu: readlane of a lane that is not active\n"); abort(); }
+  return (int)(uint32_t)res[l & 63];
+}
 __attribute__((noinline)) inline void wave_sync() { const uint64_t* res; wave_exchange(0, &res, 0, EMU_RA); }   // lockstep point (site 0 = not compared)
 }  // namespace emu
 #define __shfl(...) emu::shfl(__COUNTER__ + 1, __VA_ARGS__)
@@ -114,6 +119,7 @@ __attribute__((noinline)) inline void wave_sync() { const uint64_t* res; wave_ex
 #define __ballot(p) emu::ballot(__COUNTER__ + 1, (p))
 #define __any(p) (emu::ballot(__COUNTER__ + 1, (p)) != 0)
 #define __all(p) emu::all(__COUNTER__ + 1, (p))
+#define __builtin_amdgcn_readlane(v, l) emu::readlane(__COUNTER__ + 1, (v), (l))
 #define __builtin_amdgcn_update_dpp(...) emu::update_dpp(__COUNTER__ + 1, __VA_ARGS__)
 static inline int emu_sbfe(int v, unsigned off, unsigned width) {          // v_bfe_i32
   off &= 31; width &= 31; if (width == 0) return 0;
@@ -175,6 +181,8 @@ hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipGetLastError();
 hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);
 const char* hipGetErrorString(hipError_t e);

@@ -30,8 +30,9 @@ def build(force=False):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(EMU, "shim"), "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            os.path.join(EMU, "emu_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "smr_engine.hip"), "-x", "none", "-D__host__=", "-D__device__=",
            os.path.join(CSRC, "smr_index.cpp"), os.path.join(CSRC, "smr_reads.cpp"), os.path.join(CSRC, "smr_report.cpp"),
-           "-o", LIB, "-lpthread", "-lz", "-ldl"] + os.environ.get("SMR_EMU_EXTRA_FLAGS", "").split()
+           "-o", LIB + ".tmp", "-lpthread", "-lz", "-ldl"] + os.environ.get("SMR_EMU_EXTRA_FLAGS", "").split()
     subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)            # new inode: a process that has the old library mapped keeps running
     return LIB
 
 

@@ -56,3 +56,24 @@ def test_emulated_kernels_equal_reference_records(engine_both, case, tmp_path):
 @pytest.fixture(scope="module")
 def wl(tmp_path_factory, emulator):
     return Workload(str(tmp_path_factory.mktemp("wl")))
+
+
+def test_packed_smith_waterman_equals_the_32bit_kernel(emulator):
+    """smr_sw_selfcheck: the packed 16-bit SW kernel (smr_sw_pk.hpp: 128 virtual lanes, v_perm score lookup) against the 32-bit
+    systolic kernel on seeded random pairs -- single strip (<= 128 / 256 rows), several strips, N in read and reference,
+    two scoring schemes, forward and reverse pass."""
+    e = smr.Engine(0)
+    assert e.sw_mode() == 1                         # smr_create's own check passed
+    for max_len, cases in ((100, 24), (250, 24), (700, 16), (1500, 8)):
+        assert e.sw_selfcheck(cases, 11 + max_len, max_len) == 0
+    e.close()
+
+
+def test_both_smith_waterman_kernels_give_the_same_records(emulator, wl):
+    e = smr.Engine(0)
+    recs = {}
+    for mode in (0, 1):
+        assert e.sw_mode(mode) == mode
+        recs[mode], _ = wl.gpu_records(e)
+    assert recs[0] == recs[1]
+    e.close()

@@ -211,3 +211,22 @@ def test_empty_batch(engine, wl):
     smr.align(engine, r, [wl.parts], [p])
     assert engine.records() == []
     assert engine.counters(1)["num_aligned"] == 0
+
+
+def test_packed_smith_waterman_selfcheck_on_the_device(engine):
+    """the packed 16-bit SW kernel against the 32-bit kernel, both on the GPU (smr_sw_selfcheck), and smr_create's own check passed"""
+    assert engine.sw_selfcheck(2000, 3, 300) == 0
+    assert engine.sw_selfcheck(1000, 4, 1200) == 0
+    assert engine.sw_selfcheck(200, 5, 3500) == 0
+    assert engine.sw_mode() == 1
+
+
+def test_both_smith_waterman_kernels_give_the_same_records(engine, wl):
+    recs = {}
+    try:
+        for mode in (0, 1):
+            assert engine.sw_mode(mode) == mode
+            recs[mode], _ = wl.gpu_records(engine)
+    finally:
+        engine.sw_mode(1)
+    assert recs[0] == recs[1]
