@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "smr_host.hpp"
+#include "smr_trie_layout.hpp"
 
 using namespace smr;
 
@@ -437,50 +438,6 @@ void bucket_sort_u64(std::vector<uint64_t>& a, int keybits, uint32_t threads) {
   for (auto& x : th) x.join();
 }
 
-// build one mini-trie from entries sorted by tail (tails given MSB-first in `tailbits` = 2*T bits).
-// ent[i] = (tail << 32) | id ; T = L/2 + 1 characters.
-struct TrieBuilder {
-  int T;                 // tail length in nt
-  int burst_depth;       // elements with (0-based node depth + 1) < burst_depth may burst   (indexdb.cpp:225)
-  std::vector<TmpNode> nodes;
-  std::vector<uint32_t> ents;
-  const uint64_t* e = nullptr;
-  static inline uint32_t nt_at(uint64_t tail, int T, int k) { return (uint32_t)(tail >> (2 * (T - 1 - k))) & 3u; }
-  void build_node(uint32_t node, size_t lo, size_t hi, int depth) {
-    size_t p = lo;
-    for (uint32_t c = 0; c < 4; c++) {
-      size_t q = p;
-      while (q < hi && nt_at(e[q] >> 32, T, depth) == c) q++;
-      TmpElem el;
-      if (q > p) {
-        size_t cnt = q - p;
-        if (cnt > 16 && depth + 1 < burst_depth) {
-          el.flag = 1; el.child = (uint32_t)nodes.size();
-          nodes.emplace_back();
-          nodes[node].e[c] = el;
-          build_node(el.child, p, q, depth + 1);
-          p = q;
-          continue;
-        }
-        el.flag = 2; el.ent_begin = (uint32_t)(ents.size() / 2); el.ent_count = (uint32_t)cnt;
-        int s = T - 1 - depth;                       // remaining characters per entry
-        for (size_t i = p; i < q; i++) {
-          uint64_t tail = e[i] >> 32; uint32_t enc = 0;
-          for (int k = 0; k < s; k++) enc |= nt_at(tail, T, depth + 1 + k) << (2 * k);   // first nt in the low bits
-          ents.push_back(enc); ents.push_back((uint32_t)e[i]);
-        }
-      }
-      nodes[node].e[c] = el;
-      p = q;
-    }
-  }
-  void build(const uint64_t* ent, size_t n) {
-    nodes.clear(); ents.clear(); e = ent;
-    nodes.emplace_back();
-    build_node(0, 0, n, 0);
-  }
-};
-
 }  // namespace
 
 // ---- bit-sliced arena (smr_host.hpp) -----------------------------------------------------------
@@ -742,21 +699,42 @@ extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb,
     std::vector<size_t> fstart((size_t)NK + 1, 0);
     for (size_t i = 0; i < M; i++) fstart[f_key[i] + 1]++;
     for (uint32_t k = 0; k < NK; k++) fstart[k + 1] += fstart[k];
-    // emit tries
-    TrieBuilder tb; tb.T = (int)T; tb.burst_depth = (int)(W - P - 3);
-    for (uint32_t k = 0; k < NK; k++) {
-      size_t nf = fstart[k + 1] - fstart[k], nr = rstart[k + 1] - rstart[k];
-      ix->lookup[k].count = (uint32_t)(nf + nr);             // only tested as `count > minoccur`
-      for (int j = 0; j < 2; j++) {
-        size_t cnt = j == 0 ? nf : nr;
+    // emit tries: size of every mini-trie (parallel) -> offsets -> layout (parallel); one function shared with the device builder
+    const int burst_depth = (int)(W - P - 3);
+    std::vector<uint64_t> toff((size_t)2 * NK + 1, 0);
+    std::vector<uint32_t> tnodes((size_t)2 * NK, 0), tbuckets((size_t)2 * NK, 0);
+    std::atomic<int> bad{TRIE_OK};
+    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t k = lo; k < hi; k++) for (int j = 0; j < 2; j++) {
+        const size_t cnt = j == 0 ? fstart[k + 1] - fstart[k] : rstart[k + 1] - rstart[k];
         if (!cnt) continue;
-        tb.build(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], cnt);
-        uint32_t root = NONE;
-        if (!emit_minitrie(tb.nodes, tb.ents, ix->trie, root, *ix, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_IO; }
-        if (j == 0) { ix->lookup[k].rootF = root; ix->lookup[k].wordsF = (uint32_t)(ix->trie.size() - root); }
-        else { ix->lookup[k].rootR = root; ix->lookup[k].wordsR = (uint32_t)(ix->trie.size() - root); }
+        int st = TRIE_OK;
+        toff[2 * k + j + 1] = minitrie_layout<false>(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], (uint32_t)cnt, (int)T, burst_depth,
+                                                     nullptr, &tnodes[2 * k + j], &tbuckets[2 * k + j], &st);
+        if (st != TRIE_OK) bad = st;
       }
-    }
+    });
+    if (bad != TRIE_OK) { delete ix; set_err(err, errcap, bad == TRIE_ERR_BUCKET ? "bucket with more than 255 entries" : "mini-trie larger than 2^22 words"); return SMR_ERR_IO; }
+    for (size_t i = 0; i < (size_t)2 * NK; i++) { toff[i + 1] += toff[i]; ix->n_nodes += tnodes[i]; ix->n_buckets += tbuckets[i]; }
+    if (toff.back() > 0xFFFFFFF0ull) { delete ix; set_err(err, errcap, "trie arena exceeds 2^32 words"); return SMR_ERR_IO; }
+    ix->n_entries += 2 * M;
+    ix->trie.resize(toff.back());
+    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t k = lo; k < hi; k++) {
+        const size_t nf = fstart[k + 1] - fstart[k], nr = rstart[k + 1] - rstart[k];
+        ix->lookup[k].count = (uint32_t)(nf + nr);             // only tested as `count > minoccur`
+        for (int j = 0; j < 2; j++) {
+          const size_t cnt = j == 0 ? nf : nr;
+          if (!cnt) continue;
+          int st = TRIE_OK;
+          const uint32_t root = (uint32_t)toff[2 * k + j];
+          const uint32_t words = minitrie_layout<true>(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], (uint32_t)cnt, (int)T, burst_depth,
+                                                       ix->trie.data() + root, nullptr, nullptr, &st);
+          if (j == 0) { ix->lookup[k].rootF = root; ix->lookup[k].wordsF = words; }
+          else { ix->lookup[k].rootR = root; ix->lookup[k].wordsR = words; }
+        }
+      }
+    });
     parts_out[pi] = ix;
   }
   *n_parts_out = (uint32_t)pr.size();

@@ -27,15 +27,22 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="first N reads only (0 = all 100 000)")
     ap.add_argument("--all", action="store_true", help="-num_alignments 0")
     ap.add_argument("--oracle", action="store_true")
-    ap.add_argument("--db", default=os.path.join(paths.REF_DATA, "rRNA_databases", "silva-arc-16s-id95.fasta"))
+    ap.add_argument("--db", action="append", help="reference FASTA (repeatable: several --ref in one run); default silva-arc-16s-id95")
+    ap.add_argument("--reads-file", default=None, help="FASTA/FASTQ instead of the bundled set2 (.gz accepted)")
     a = ap.parse_args()
+    if not a.db:
+        a.db = [os.path.join(paths.REF_DATA, "rRNA_databases", "silva-arc-16s-id95.fasta")]
     tmp = tempfile.mkdtemp(prefix="smr_full_")
-    gz = os.path.join(paths.REF_DATA, "set2_environmental_study_550_amplicon.fasta.gz")
-    flat = os.path.join(tmp, "set2.fasta")
-    with gzip.open(gz, "rb") as f, open(flat, "wb") as g:
+    gz = a.reads_file or os.path.join(paths.REF_DATA, "set2_environmental_study_550_amplicon.fasta.gz")
+    is_fq = ".fastq" in gz or ".fq" in gz
+    flat = os.path.join(tmp, "reads.fastq" if is_fq else "reads.fasta")
+    with (gzip.open(gz, "rb") if gz.endswith(".gz") else open(gz, "rb")) as f, open(flat, "wb") as g:
         data = f.read()
         if a.reads:
-            data = b">".join(data.split(b">")[: a.reads + 1])
+            if is_fq:
+                data = b"\n".join(data.split(b"\n")[: 4 * a.reads]) + b"\n"
+            else:
+                data = b">".join(data.split(b">")[: a.reads + 1])
         g.write(data)
     recs_in = fastx.read_fastx(flat)
     seqs = [r[1] for r in recs_in]
@@ -44,24 +51,24 @@ def main():
     params = {"num_alignments": 0} if a.all else {}
     t = time.time()
     cache = os.path.join(paths.ORACLE_DIR, "_ref", "idx_cache")
-    res = refrun.run_reference([a.db], [flat], os.path.join(tmp, "wd"), extra=extra + ["-v"], threads=1, idx_dir=cache, timeout=7200)
+    res = refrun.run_reference(a.db, [flat], os.path.join(tmp, "wd"), extra=extra + ["-v"], threads=1, idx_dir=cache, timeout=7200)
     assert res.rc == 0, res.stdout[-2000:]
     exp = [res.kvdb.get(b"0_%d" % i, b"") for i in range(len(seqs))]
-    print("reference: %.0f s, aligned %d, minimal_score %d" % (time.time() - t, res.log["num_aligned"], res.log["minimal_score"][0]))
+    print("reference: %.0f s, aligned %d, minimal_score %s" % (time.time() - t, res.log["num_aligned"], res.log["minimal_score"]))
     ms = res.log["minimal_score"][0]
     with emu.active():
         t = time.time()
-        parts = smr.Index.build(a.db, 18, 3072.0, 10000, 0)
-        print("index build: %.0f s, %d part(s)" % (time.time() - t, len(parts)))
+        parts = [smr.Index.build(db, 18, 3072.0, 10000, 0) for db in a.db]
+        print("index build: %.0f s, parts %s" % (time.time() - t, [len(x) for x in parts]))
         reads = smr.Reads.from_fastx_mt(gz if not a.reads else flat, 0)
         assert reads.count == len(seqs)
         eng = smr.Engine(0)
-        p = smr.default_params(minimal_score=ms, **params)
+        plist = [smr.default_params(minimal_score=res.log["minimal_score"][k], **params) for k in range(len(a.db))]
         t = time.time()
-        smr.align(eng, reads, [parts], [p], with_cigar=True, max_alignments_per_read=256 if a.all else None)
+        smr.align(eng, reads, parts, plist, with_cigar=True, max_alignments_per_read=256 if a.all else None)
         got = eng.records()
-        ctr = eng.counters(1)
-        print("emulated kernels: %.0f s, aligned %d" % (time.time() - t, ctr["num_aligned"]))
+        ctr = eng.counters(len(a.db))
+        print("emulated kernels (SW kernel mode %d): %.0f s, aligned %d, per db %s" % (eng.sw_mode(), time.time() - t, ctr["num_aligned"], ctr["reads_matched_per_db"]))
         eng.close()
     bad = [i for i in range(len(seqs)) if got[i] != exp[i]]
     print("kernels vs reference: %d of %d records differ%s" % (len(bad), len(seqs), (" first " + str(bad[:5])) if bad else ""))
@@ -71,6 +78,8 @@ def main():
         print(" exp", refrun.parse_record(exp[i]))
     assert ctr["num_aligned"] == res.log["num_aligned"]
     if a.oracle:
+        assert len(a.db) == 1, "--oracle: one --db"
+        a.db = a.db[0]
         prefix = refrun.index_prefix_for(cache, a.db)
         st = orc.load_stats(prefix)
         run = orc.Run(seqs)
