@@ -202,6 +202,12 @@ typedef struct {
   uint64_t n_windows, n_lookup, n_node, n_entry, n_hit, n_read_bytes;
   uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;
 } smr_prof;
+/* smr_index_build with the per-occurrence work (sorting all (L+1)-mers, ids, position lists, mini-trie layout) done
+ * on the device: same arguments (threads does not apply), same smr_index objects, byte-identical index files
+ * (replaces build_index, indexdb.cpp:1119-2095). */
+int smr_index_build_gpu(smr_ctx*, const char* ref_fasta, uint32_t lnwin, double max_mb, uint32_t max_pos,
+                        smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap);
+
 /* Device self-check: n_cases seeded random (read, reference window) pairs, 1..max_len nt, for two scoring schemes: the packed 16-bit
  * Smith-Waterman kernel against the 32-bit kernel (score, end cell; forward and reverse pass), both on the GPU.  smr_create runs it
  * (SMR_SW_SELFCHECK=<cases>, 0 = skip) and falls back to the 32-bit kernel if any case differs; SMR_SW_PACKED=0 disables the packed kernel. */

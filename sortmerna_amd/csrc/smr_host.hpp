@@ -69,6 +69,15 @@ struct smr_index {
   uint32_t n_refs() const { return ref_off.empty() ? 0 : (uint32_t)ref_off.size() - 1; }
 };
 
+// One index part as the builders see it: the member sequences in the index alphabet (indexdb.cpp map_nt), concatenated.
+namespace smr {
+struct IBuildInput { const uint8_t* codes; const uint64_t* seq_off; uint32_t n_seqs, L, max_pos, threads; };
+}
+// fills lookup / trie / pos_off / pos_arr / n_nodes / n_buckets / n_entries of ix
+typedef int (*smr_ibuild_part_fn)(void* user, const smr::IBuildInput& in, smr_index& ix, std::string& why);
+int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads, smr_ibuild_part_fn fn, void* user,
+                         smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap);
+
 // builds trie2/root2 from trie/lookup (idempotent); false + message when a mini-trie does not fit the element encoding
 bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why);
 

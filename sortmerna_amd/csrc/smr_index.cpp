@@ -567,9 +567,133 @@ bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why) {
   return true;
 }
 
-extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads,
-                               smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
-  if (!ref_fasta || !parts_out || !n_parts_out) return SMR_ERR_ARG;
+// occurrences of one part -> lookup table, mini-tries, positions (host version)
+int ib_part_host(void*, const smr::IBuildInput& in, smr_index& ix, std::string& why) {
+  const uint32_t L = in.L, max_pos = in.max_pos, threads = in.threads;
+  const uint32_t P = L / 2, W = L + 1, T = P + 1;
+    // occurrences: key = (18-mer prefix, 2L bits) << occbits | occurrence number (scan order)
+    std::vector<uint64_t> occ_start((size_t)in.n_seqs + 1, 0);
+    for (size_t m = 0; m < in.n_seqs; m++) occ_start[m + 1] = occ_start[m] + (in.seq_off[m + 1] - in.seq_off[m] - W + 1);
+    uint64_t N = occ_start.back();
+    int occbits = 1; while ((1ull << occbits) < N) occbits++;
+    if ((int)(2 * L) + occbits > 64) { why = "part too large for the builder (reduce -m)"; return SMR_ERR_ARG; }
+    std::vector<uint64_t> keys(N);
+    std::vector<uint8_t> last_nt(N);     // nt at position p+L of occurrence (the 19th)
+    parallel_for(threads, in.n_seqs, [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t m = lo; m < hi; m++) {
+        const uint8_t* s = in.codes + in.seq_off[m];
+        const uint32_t len = (uint32_t)(in.seq_off[m + 1] - in.seq_off[m]);
+        uint64_t code = 0, mask = (L == 32) ? ~0ull : ((1ull << (2 * L)) - 1);
+        for (uint32_t k = 0; k < L; k++) code = (code << 2) | s[k];
+        uint64_t o = occ_start[m];
+        for (uint32_t p = 0; p + W <= len; p++) {
+          keys[o + p] = (code << occbits) | (o + p);
+          last_nt[o + p] = s[p + L];
+          if (p + W < len) code = ((code << 2) | s[p + L]) & mask;
+        }
+      }
+    });
+    bucket_sort_u64(keys, 2 * (int)L + occbits, threads);
+    // ids, positions CSR, unique 19-mers
+    const uint64_t occmask = (1ull << occbits) - 1;
+    auto occ_to_seqpos = [&](uint64_t occ, uint32_t& seq, uint32_t& pos) {
+      size_t m = std::upper_bound(occ_start.begin(), occ_start.end(), occ) - occ_start.begin() - 1;
+      seq = (uint32_t)m; pos = (uint32_t)(occ - occ_start[m]);
+    };
+    // F entries (keyF, tail, id) come out already sorted; R entries need regrouping by keyR
+    std::vector<uint64_t> fent;                       // (prefix19 code) kept implicit: we store key|tail|id in parallel arrays
+    std::vector<uint32_t> f_key; std::vector<uint64_t> f_tail_id;
+    std::vector<uint32_t> r_key; std::vector<uint64_t> r_tail_id;
+    ix.pos_off.assign(1, 0);
+    uint32_t id = 0;
+    for (uint64_t i = 0; i < N;) {
+      uint64_t pre = keys[i] >> occbits;
+      uint64_t j = i; uint32_t present = 0;
+      uint32_t stored = 0;
+      while (j < N && (keys[j] >> occbits) == pre) {
+        uint64_t occ = keys[j] & occmask;
+        present |= 1u << last_nt[occ];
+        if (max_pos == 0 || stored == 0 || stored < max_pos) {      // indexdb.cpp:318-349
+          uint32_t sq_, ps_; occ_to_seqpos(occ, sq_, ps_);
+          ix.pos_arr.push_back(ps_); ix.pos_arr.push_back(sq_); stored++;
+        }
+        j++;
+      }
+      ix.pos_off.push_back((uint32_t)(ix.pos_arr.size() / 2));
+      for (uint32_t c = 0; c < 4; c++) if (present & (1u << c)) {
+        uint64_t code19 = (pre << 2) | c;                         // 2W bits
+        uint32_t keyF = (uint32_t)(code19 >> (2 * T));            // first P nt
+        uint64_t tailF = code19 & ((1ull << (2 * T)) - 1);        // last T nt, MSB-first
+        f_key.push_back(keyF); f_tail_id.push_back((tailF << 32) | id);
+        uint32_t keyR = (uint32_t)(code19 & ((1ull << (2 * P)) - 1));   // last P nt
+        uint64_t head = code19 >> (2 * P);                        // first T nt, MSB-first
+        uint64_t tailR = 0;                                        // reversed head (indexdb.cpp:1441-1444)
+        for (uint32_t k = 0; k < T; k++) tailR = (tailR << 2) | ((head >> (2 * k)) & 3);
+        r_key.push_back(keyR); r_tail_id.push_back((tailR << 32) | id);
+      }
+      id++;
+      i = j;
+    }
+    keys.clear(); keys.shrink_to_fit(); last_nt.clear(); last_nt.shrink_to_fit();
+    const uint32_t NK = 1u << L;
+    ix.lookup.assign(NK, Lookup{0, NONE, NONE, 0, 0});
+    // group R by key (counting sort), sort each group by tail
+    size_t M = f_key.size();
+    std::vector<size_t> rstart((size_t)NK + 1, 0);
+    for (size_t i = 0; i < M; i++) rstart[r_key[i] + 1]++;
+    for (uint32_t k = 0; k < NK; k++) rstart[k + 1] += rstart[k];
+    std::vector<uint64_t> rsorted(M);
+    { std::vector<size_t> cur(rstart.begin(), rstart.end() - 1); for (size_t i = 0; i < M; i++) rsorted[cur[r_key[i]]++] = r_tail_id[i]; }
+    r_tail_id.clear(); r_tail_id.shrink_to_fit(); r_key.clear(); r_key.shrink_to_fit();
+    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) { for (size_t k = lo; k < hi; k++) std::sort(rsorted.begin() + rstart[k], rsorted.begin() + rstart[k + 1]); });
+    std::vector<size_t> fstart((size_t)NK + 1, 0);
+    for (size_t i = 0; i < M; i++) fstart[f_key[i] + 1]++;
+    for (uint32_t k = 0; k < NK; k++) fstart[k + 1] += fstart[k];
+    // emit tries: size of every mini-trie (parallel) -> offsets -> layout (parallel); one function shared with the device builder
+    const int burst_depth = (int)(W - P - 3);
+    std::vector<uint64_t> toff((size_t)2 * NK + 1, 0);
+    std::vector<uint32_t> tnodes((size_t)2 * NK, 0), tbuckets((size_t)2 * NK, 0);
+    std::atomic<int> bad{TRIE_OK};
+    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t k = lo; k < hi; k++) for (int j = 0; j < 2; j++) {
+        const size_t cnt = j == 0 ? fstart[k + 1] - fstart[k] : rstart[k + 1] - rstart[k];
+        if (!cnt) continue;
+        int st = TRIE_OK;
+        toff[2 * k + j + 1] = minitrie_layout<false>(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], (uint32_t)cnt, (int)T, burst_depth,
+                                                     nullptr, &tnodes[2 * k + j], &tbuckets[2 * k + j], &st);
+        if (st != TRIE_OK) bad = st;
+      }
+    });
+    if (bad != TRIE_OK) { why = bad == TRIE_ERR_BUCKET ? "bucket with more than 255 entries" : "mini-trie larger than 2^22 words"; return SMR_ERR_IO; }
+    for (size_t i = 0; i < (size_t)2 * NK; i++) { toff[i + 1] += toff[i]; ix.n_nodes += tnodes[i]; ix.n_buckets += tbuckets[i]; }
+    if (toff.back() > 0xFFFFFFF0ull) { why = "trie arena exceeds 2^32 words"; return SMR_ERR_IO; }
+    ix.n_entries += 2 * M;
+    ix.trie.resize(toff.back());
+    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t k = lo; k < hi; k++) {
+        const size_t nf = fstart[k + 1] - fstart[k], nr = rstart[k + 1] - rstart[k];
+        ix.lookup[k].count = (uint32_t)(nf + nr);             // only tested as `count > minoccur`
+        for (int j = 0; j < 2; j++) {
+          const size_t cnt = j == 0 ? nf : nr;
+          if (!cnt) continue;
+          int st = TRIE_OK;
+          const uint32_t root = (uint32_t)toff[2 * k + j];
+          const uint32_t words = minitrie_layout<true>(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], (uint32_t)cnt, (int)T, burst_depth,
+                                                       ix.trie.data() + root, nullptr, nullptr, &st);
+          if (j == 0) { ix.lookup[k].rootF = root; ix.lookup[k].wordsF = words; }
+          else { ix.lookup[k].rootR = root; ix.lookup[k].wordsR = words; }
+        }
+      }
+    });
+  return SMR_OK;
+}
+
+// Everything of the build that is not per-occurrence work: FASTA parsing, statistics, the split into parts, the reference
+// sequences for SW; the occurrences -> (lookup, tries, positions) step of every part is done by `fn` (host: ib_part_host below;
+// device: smr_index_build_gpu in smr_engine.hip).
+int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads, smr_ibuild_part_fn fn, void* user,
+                         smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
+  if (!ref_fasta || !parts_out || !n_parts_out || !fn) return SMR_ERR_ARG;
   if (L < 8 || L > 18 || (L & 1)) { set_err(err, errcap, "builder supports even seed lengths 8..18"); return SMR_ERR_ARG; }
   if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
   std::vector<uint8_t> file;
@@ -621,124 +745,26 @@ extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb,
       for (uint32_t k = 0; k < recs[s].len; k++) ix->ref_seq.push_back(nt_sw(raw[recs[s].seq_begin + k]));
       ix->ref_off.push_back(ix->ref_seq.size());
     }
-    // occurrences: key = (18-mer prefix, 2L bits) << occbits | occurrence number (scan order)
-    std::vector<uint64_t> occ_start(members.size() + 1, 0);
-    for (size_t m = 0; m < members.size(); m++) occ_start[m + 1] = occ_start[m] + (recs[members[m]].len - W + 1);
-    uint64_t N = occ_start.back();
-    int occbits = 1; while ((1ull << occbits) < N) occbits++;
-    if ((int)(2 * L) + occbits > 64) { delete ix; set_err(err, errcap, "part too large for the builder (reduce -m)"); return SMR_ERR_ARG; }
-    std::vector<uint64_t> keys(N);
-    std::vector<uint8_t> last_nt(N);     // nt at position p+L of occurrence (the 19th)
-    parallel_for(threads, members.size(), [&](size_t lo, size_t hi, uint32_t) {
-      for (size_t m = lo; m < hi; m++) {
-        const SeqRec& r = recs[members[m]];
-        const uint8_t* s = raw.data() + r.seq_begin;
-        uint64_t code = 0, mask = (L == 32) ? ~0ull : ((1ull << (2 * L)) - 1);
-        for (uint32_t k = 0; k < L; k++) code = (code << 2) | nt_index(s[k]);
-        uint64_t o = occ_start[m];
-        for (uint32_t p = 0; p + W <= r.len; p++) {
-          keys[o + p] = (code << occbits) | (o + p);
-          last_nt[o + p] = nt_index(s[p + L]);
-          if (p + W < r.len) code = ((code << 2) | nt_index(s[p + L])) & mask;
-        }
-      }
-    });
-    bucket_sort_u64(keys, 2 * (int)L + occbits, threads);
-    // ids, positions CSR, unique 19-mers
-    const uint64_t occmask = (1ull << occbits) - 1;
-    auto occ_to_seqpos = [&](uint64_t occ, uint32_t& seq, uint32_t& pos) {
-      size_t m = std::upper_bound(occ_start.begin(), occ_start.end(), occ) - occ_start.begin() - 1;
-      seq = (uint32_t)m; pos = (uint32_t)(occ - occ_start[m]);
-    };
-    // F entries (keyF, tail, id) come out already sorted; R entries need regrouping by keyR
-    std::vector<uint64_t> fent;                       // (prefix19 code) kept implicit: we store key|tail|id in parallel arrays
-    std::vector<uint32_t> f_key; std::vector<uint64_t> f_tail_id;
-    std::vector<uint32_t> r_key; std::vector<uint64_t> r_tail_id;
-    ix->pos_off.assign(1, 0);
-    uint32_t id = 0;
-    for (uint64_t i = 0; i < N;) {
-      uint64_t pre = keys[i] >> occbits;
-      uint64_t j = i; uint32_t present = 0;
-      uint32_t stored = 0;
-      while (j < N && (keys[j] >> occbits) == pre) {
-        uint64_t occ = keys[j] & occmask;
-        present |= 1u << last_nt[occ];
-        if (max_pos == 0 || stored == 0 || stored < max_pos) {      // indexdb.cpp:318-349
-          uint32_t sq_, ps_; occ_to_seqpos(occ, sq_, ps_);
-          ix->pos_arr.push_back(ps_); ix->pos_arr.push_back(sq_); stored++;
-        }
-        j++;
-      }
-      ix->pos_off.push_back((uint32_t)(ix->pos_arr.size() / 2));
-      for (uint32_t c = 0; c < 4; c++) if (present & (1u << c)) {
-        uint64_t code19 = (pre << 2) | c;                         // 2W bits
-        uint32_t keyF = (uint32_t)(code19 >> (2 * T));            // first P nt
-        uint64_t tailF = code19 & ((1ull << (2 * T)) - 1);        // last T nt, MSB-first
-        f_key.push_back(keyF); f_tail_id.push_back((tailF << 32) | id);
-        uint32_t keyR = (uint32_t)(code19 & ((1ull << (2 * P)) - 1));   // last P nt
-        uint64_t head = code19 >> (2 * P);                        // first T nt, MSB-first
-        uint64_t tailR = 0;                                        // reversed head (indexdb.cpp:1441-1444)
-        for (uint32_t k = 0; k < T; k++) tailR = (tailR << 2) | ((head >> (2 * k)) & 3);
-        r_key.push_back(keyR); r_tail_id.push_back((tailR << 32) | id);
-      }
-      id++;
-      i = j;
+    // nt codes of the index alphabet (map_nt) of the members, concatenated
+    std::vector<uint8_t> codes; std::vector<uint64_t> seq_off(1, 0);
+    for (size_t s : members) {
+      const size_t o = codes.size();
+      codes.resize(o + recs[s].len);
+      for (uint32_t k = 0; k < recs[s].len; k++) codes[o + k] = nt_index(raw[recs[s].seq_begin + k]);
+      seq_off.push_back(codes.size());
     }
-    keys.clear(); keys.shrink_to_fit(); last_nt.clear(); last_nt.shrink_to_fit();
-    const uint32_t NK = 1u << L;
-    ix->lookup.assign(NK, Lookup{0, NONE, NONE, 0, 0});
-    // group R by key (counting sort), sort each group by tail
-    size_t M = f_key.size();
-    std::vector<size_t> rstart((size_t)NK + 1, 0);
-    for (size_t i = 0; i < M; i++) rstart[r_key[i] + 1]++;
-    for (uint32_t k = 0; k < NK; k++) rstart[k + 1] += rstart[k];
-    std::vector<uint64_t> rsorted(M);
-    { std::vector<size_t> cur(rstart.begin(), rstart.end() - 1); for (size_t i = 0; i < M; i++) rsorted[cur[r_key[i]]++] = r_tail_id[i]; }
-    r_tail_id.clear(); r_tail_id.shrink_to_fit(); r_key.clear(); r_key.shrink_to_fit();
-    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) { for (size_t k = lo; k < hi; k++) std::sort(rsorted.begin() + rstart[k], rsorted.begin() + rstart[k + 1]); });
-    std::vector<size_t> fstart((size_t)NK + 1, 0);
-    for (size_t i = 0; i < M; i++) fstart[f_key[i] + 1]++;
-    for (uint32_t k = 0; k < NK; k++) fstart[k + 1] += fstart[k];
-    // emit tries: size of every mini-trie (parallel) -> offsets -> layout (parallel); one function shared with the device builder
-    const int burst_depth = (int)(W - P - 3);
-    std::vector<uint64_t> toff((size_t)2 * NK + 1, 0);
-    std::vector<uint32_t> tnodes((size_t)2 * NK, 0), tbuckets((size_t)2 * NK, 0);
-    std::atomic<int> bad{TRIE_OK};
-    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) {
-      for (size_t k = lo; k < hi; k++) for (int j = 0; j < 2; j++) {
-        const size_t cnt = j == 0 ? fstart[k + 1] - fstart[k] : rstart[k + 1] - rstart[k];
-        if (!cnt) continue;
-        int st = TRIE_OK;
-        toff[2 * k + j + 1] = minitrie_layout<false>(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], (uint32_t)cnt, (int)T, burst_depth,
-                                                     nullptr, &tnodes[2 * k + j], &tbuckets[2 * k + j], &st);
-        if (st != TRIE_OK) bad = st;
-      }
-    });
-    if (bad != TRIE_OK) { delete ix; set_err(err, errcap, bad == TRIE_ERR_BUCKET ? "bucket with more than 255 entries" : "mini-trie larger than 2^22 words"); return SMR_ERR_IO; }
-    for (size_t i = 0; i < (size_t)2 * NK; i++) { toff[i + 1] += toff[i]; ix->n_nodes += tnodes[i]; ix->n_buckets += tbuckets[i]; }
-    if (toff.back() > 0xFFFFFFF0ull) { delete ix; set_err(err, errcap, "trie arena exceeds 2^32 words"); return SMR_ERR_IO; }
-    ix->n_entries += 2 * M;
-    ix->trie.resize(toff.back());
-    parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) {
-      for (size_t k = lo; k < hi; k++) {
-        const size_t nf = fstart[k + 1] - fstart[k], nr = rstart[k + 1] - rstart[k];
-        ix->lookup[k].count = (uint32_t)(nf + nr);             // only tested as `count > minoccur`
-        for (int j = 0; j < 2; j++) {
-          const size_t cnt = j == 0 ? nf : nr;
-          if (!cnt) continue;
-          int st = TRIE_OK;
-          const uint32_t root = (uint32_t)toff[2 * k + j];
-          const uint32_t words = minitrie_layout<true>(j == 0 ? f_tail_id.data() + fstart[k] : rsorted.data() + rstart[k], (uint32_t)cnt, (int)T, burst_depth,
-                                                       ix->trie.data() + root, nullptr, nullptr, &st);
-          if (j == 0) { ix->lookup[k].rootF = root; ix->lookup[k].wordsF = words; }
-          else { ix->lookup[k].rootR = root; ix->lookup[k].wordsR = words; }
-        }
-      }
-    });
+    smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
+    const int rc = fn(user, in, *ix, why);
+    if (rc != SMR_OK) { delete ix; set_err(err, errcap, why); return rc; }
     parts_out[pi] = ix;
   }
   *n_parts_out = (uint32_t)pr.size();
   return SMR_OK;
+}
+
+extern "C" int smr_index_build(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads,
+                               smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
+  return smr_index_build_with(ref_fasta, L, max_mb, max_pos, threads, ib_part_host, nullptr, parts_out, cap_parts, n_parts_out, err, errcap);
 }
 
 // =================================================================================================

@@ -60,6 +60,20 @@ class Index:
         return [Index(C.c_void_p(arr[i])) for i in range(n.value)]
 
     @staticmethod
+    def build_gpu(engine, ref_fasta, seed_win_len=18, max_file_size_mb=3072.0, max_pos=10000):
+        """like build(), with the sorting / id / position / mini-trie work on the device (smr_index_build_gpu)"""
+        L = capi.load()
+        cap = 256
+        arr = (C.c_void_p * cap)()
+        n = C.c_uint32()
+        err = C.create_string_buffer(512)
+        rc = L.smr_index_build_gpu(engine.h, ref_fasta.encode(), seed_win_len, max_file_size_mb, max_pos,
+                                   C.cast(arr, C.POINTER(C.c_void_p)), cap, C.byref(n), err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_build_gpu: %s (rc=%d)" % (err.value.decode(), rc))
+        return [Index(C.c_void_p(arr[i])) for i in range(n.value)]
+
+    @staticmethod
     def write_files(parts, ref_fasta, prefix):
         L = capi.load()
         arr = (C.c_void_p * len(parts))(*[p.h for p in parts])

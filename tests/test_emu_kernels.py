@@ -16,6 +16,7 @@ from helpers.workload import Workload
 
 from test_gpu_parity import (test_seed_scan_matches_oracle, test_align_records_match_oracle, test_multi_part_index,  # noqa: F401
                              test_longer_reads, test_other_seed_lengths, test_non_default_strides, test_empty_batch)
+from test_gpu_parity import test_device_index_build_equals_the_host_build as test_device_index_build_gpu_test_body  # noqa: F401
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 
 FULL = os.environ.get("SMR_EMU_FULL", "0") == "1"
@@ -76,4 +77,32 @@ def test_both_smith_waterman_kernels_give_the_same_records(emulator, wl):
         assert e.sw_mode(mode) == mode
         recs[mode], _ = wl.gpu_records(e)
     assert recs[0] == recs[1]
+    e.close()
+
+
+def _index_files_digest(parts, db, tmp):
+    import hashlib
+    os.makedirs(tmp, exist_ok=True)
+    smr.Index.write_files(parts, db, os.path.join(tmp, "i"))
+    h = hashlib.md5()
+    for f in sorted(os.listdir(tmp)):
+        h.update(f.encode())
+        h.update(open(os.path.join(tmp, f), "rb").read())
+    i = parts[0].info()
+    return h.hexdigest(), len(parts), i.n_nodes, i.n_buckets, i.n_entries, i.n_ids, i.n_pos
+
+
+@pytest.mark.parametrize("db,max_mb,lnwin,max_pos", [("t9_ref.fasta", 3072.0, 18, 10000), ("syn_db.fasta", 3072.0, 18, 10000),
+                                                     ("syn_db.fasta", 0.15, 18, 3), ("real_db.fasta", 3072.0, 14, 10000)])
+def test_device_index_build_equals_the_host_build(emulator, tmp_path, db, max_mb, lnwin, max_pos):
+    """smr_index_build_gpu (sorting, ids, positions with max_pos truncation, mini-trie layout on the device; smr_ibuild.hpp) writes
+    the same index files, byte for byte, as the host builder: one part / several parts, L = 18 / 14, IUPAC letters in the DB"""
+    from helpers import paths
+    path = os.path.join(paths.REPO, "tests", "golden", db)
+    e = smr.Engine(0)
+    host = smr.Index.build(path, lnwin, max_mb, max_pos, 0)
+    dev = smr.Index.build_gpu(e, path, lnwin, max_mb, max_pos)
+    assert _index_files_digest(dev, path, str(tmp_path / "d")) == _index_files_digest(host, path, str(tmp_path / "h"))
+    for ix in dev:
+        ix.selfcheck()
     e.close()
