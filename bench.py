@@ -302,7 +302,8 @@ def main():
                                    "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); default options (--fastx, best 1)" % args.db_nt,
                        "batch_reads": args.batch_reads, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
                        "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
-                       "cigar": not args.no_cigar},
+                       "cigar": not args.no_cigar,
+                       "sw_kernel": "packed 16-bit (v_pk, 128 virtual lanes)" if eng.sw_mode() == 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,

@@ -1,0 +1,54 @@
+"""bench.py's whole control flow (workload generation, resident batches, counting pass, timed steps, JSON line, CPU-baseline leg)
+executed without a GPU: torch.cuda's three calls are stubbed and the binding is routed to the kernel emulator (tests/emu), on a tiny
+workload.  Checks the contract of the JSON line, not any number in it."""
+import io
+import json
+import os
+import sys
+from contextlib import redirect_stdout
+
+import pytest
+
+from helpers import emu, paths
+
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"]
+
+
+@pytest.mark.parametrize("baseline", [False, True], ids=["no_cpu_baseline", "cpu_baseline"])
+def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, baseline):
+    if baseline and not paths.have_ref_bin():
+        pytest.skip("needs oracle/_ref/sortmerna_ref")
+    import torch
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setenv("SMR_BENCH_BACKEND", "gloo")          # the (world-size-1) reductions on CPU tensors
+    import tempfile
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    argv = ["bench.py", "--steps", "2", "--warmup", "1", "--batch-reads", "1500", "--db-nt", "150000", "--cpu-sample-reads", "1500", "--cpu-threads", "2"]
+    if not baseline:
+        argv.append("--no-cpu-baseline")
+    monkeypatch.setattr(sys, "argv", argv)
+    sys.path.insert(0, paths.REPO)
+    import importlib
+    bench = importlib.import_module("bench")
+    buf = io.StringIO()
+    with emu.active(), redirect_stdout(buf):
+        bench.main()
+    line = [l for l in buf.getvalue().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    for k in KEYS:
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "reads/s" and out["value"] > 0
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert "workload" in out["config"] and "sw_kernel" in out["config"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert out["counters"]["reads"] == 2 * 1500
+    if baseline:
+        cb = out["cpu_baseline"]
+        assert cb["kind"] == "reference" and cb["unit"] == "reads/s" and cb["cores"] == 2 and cb["value"] and cb["value"] > 0, cb
+    else:
+        assert out["cpu_baseline"] is None

@@ -106,3 +106,9 @@ def test_device_index_build_equals_the_host_build(emulator, tmp_path, db, max_mb
     for ix in dev:
         ix.selfcheck()
     e.close()
+
+
+def test_smoke_entry_point_on_the_emulator(emulator):
+    """__graft_entry__.smoke() end to end (it is written for cuda:0; here the binding is routed to the emulator build)"""
+    import __graft_entry__ as entry
+    entry.smoke()
