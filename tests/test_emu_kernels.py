@@ -16,7 +16,7 @@ from helpers.workload import Workload
 
 from test_gpu_parity import (test_seed_scan_matches_oracle, test_align_records_match_oracle, test_multi_part_index,  # noqa: F401
                              test_longer_reads, test_other_seed_lengths, test_non_default_strides, test_empty_batch)
-from test_gpu_parity import test_device_index_build_equals_the_host_build as test_device_index_build_gpu_test_body  # noqa: F401
+from test_gpu_sw_and_index_build import test_device_index_build_equals_the_host_build as test_device_index_build_gpu_test_body  # noqa: F401
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 
 FULL = os.environ.get("SMR_EMU_FULL", "0") == "1"

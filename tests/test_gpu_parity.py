@@ -212,51 +212,3 @@ def test_empty_batch(engine, wl):
     assert engine.records() == []
     assert engine.counters(1)["num_aligned"] == 0
 
-
-def test_packed_smith_waterman_selfcheck_on_the_device(engine):
-    """the packed 16-bit SW kernel against the 32-bit kernel, both on the GPU (smr_sw_selfcheck), and smr_create's own check passed"""
-    assert engine.sw_selfcheck(2000, 3, 300) == 0
-    assert engine.sw_selfcheck(1000, 4, 1200) == 0
-    assert engine.sw_selfcheck(200, 5, 3500) == 0
-    assert engine.sw_mode() == 1
-
-
-def test_both_smith_waterman_kernels_give_the_same_records(engine, wl):
-    recs = {}
-    try:
-        for mode in (0, 1):
-            assert engine.sw_mode(mode) == mode
-            recs[mode], _ = wl.gpu_records(engine)
-    finally:
-        engine.sw_mode(1)
-    assert recs[0] == recs[1]
-
-
-def test_device_index_build_equals_the_host_build(engine, wl, tmp_path):
-    """smr_index_build_gpu writes the same index files, byte for byte, as the host builder (one part, four parts
-    with max_pos truncation, seed length 14), and the aligner gives the same records with it"""
-    import hashlib
-    import os
-    from helpers import paths
-
-    def digest(parts, db, tmp):
-        os.makedirs(tmp, exist_ok=True)
-        smr.Index.write_files(parts, db, os.path.join(tmp, "i"))
-        h = hashlib.md5()
-        for f in sorted(os.listdir(tmp)):
-            h.update(f.encode())
-            h.update(open(os.path.join(tmp, f), "rb").read())
-        return h.hexdigest()
-
-    cases = [(wl.db, 3072.0, 18, 10000), (wl.db, 1.0, 18, 5), (os.path.join(paths.REPO, "tests", "golden", "real_db.fasta"), 3072.0, 14, 10000)]
-    for k, (db, mb, L, mp) in enumerate(cases):
-        host = smr.Index.build(db, L, mb, mp, 0)
-        dev = smr.Index.build_gpu(engine, db, L, mb, mp)
-        assert len(host) == len(dev)
-        assert digest(dev, db, str(tmp_path / ("d%d" % k))) == digest(host, db, str(tmp_path / ("h%d" % k)))
-    dev = smr.Index.build_gpu(engine, wl.db, 18, 3072.0, 10000)
-    p = smr.default_params(minimal_score=wl.minimal_score)
-    smr.align(engine, wl.reads, [dev], [p], with_cigar=True)
-    recs_dev = engine.records()
-    recs_host, _ = wl.gpu_records(engine)
-    assert recs_dev == recs_host
