@@ -19,33 +19,6 @@
 
 namespace {
 [[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR: %s\n", m.c_str()); exit(EXIT_FAILURE); }
-struct Rec { std::string header, seq, qual; };
-// FASTA (multi-line sequences joined) / FASTQ (4-line records); the header line is kept as in the file
-std::vector<Rec> read_fastx(const std::string& path, bool& is_fastq) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) die("cannot open " + path);
-  std::vector<Rec> out;
-  std::vector<std::string> lines;
-  std::string cur; int c;
-  while ((c = fgetc(f)) != EOF) { if (c == '\n') { if (!cur.empty() && cur.back() == '\r') cur.pop_back(); lines.push_back(cur); cur.clear(); } else cur.push_back((char)c); }
-  if (!cur.empty()) lines.push_back(cur);
-  fclose(f);
-  is_fastq = false;
-  for (size_t i = 0; i < lines.size();) {
-    if (lines[i].empty()) { i++; continue; }
-    if (lines[i][0] == '>') {
-      Rec r; r.header = lines[i++];
-      while (i < lines.size() && (lines[i].empty() || lines[i][0] != '>')) r.seq += lines[i++];
-      out.push_back(r);
-    } else if (lines[i][0] == '@') {
-      is_fastq = true;
-      if (i + 3 >= lines.size()) die("truncated FASTQ record in " + path);
-      Rec r; r.header = lines[i]; r.seq = lines[i + 1]; r.qual = lines[i + 3];
-      out.push_back(r); i += 4;
-    } else die("unexpected line in " + path + ": " + lines[i].substr(0, 40));
-  }
-  return out;
-}
 struct Db { std::string fasta, idx_prefix; double lambda = 0.618874, K = 0.343238; std::vector<smr_index*> parts; };
 }  // namespace
 
@@ -100,16 +73,11 @@ int main(int argc, char** argv) {
   }
   if (dbs.empty() || reads_path.empty()) die("--ref and --reads are required (see --help)");
   char err[512] = "";
-
   // reads (Readfeed::next -> Read::init, readfeed.hpp:124 / read.cpp:264-347)
-  bool is_fastq = false;
-  const std::vector<Rec> recs = read_fastx(reads_path, is_fastq);
+  // (all cores parse and 2-bit pack the FASTA / FASTQ / .gz file; the text stays mapped for the report writers)
   smr_reads* reads = nullptr;
-  {
-    std::string blob; std::vector<uint64_t> offs{0};
-    for (auto& r : recs) { blob += r.seq; offs.push_back(blob.size()); }
-    if (smr_reads_pack(blob.data(), offs.data(), (uint32_t)recs.size(), &reads) != SMR_OK) die("smr_reads_pack failed");
-  }
+  if (smr_reads_load_fastx_text(reads_path.c_str(), 0, &reads, err, sizeof err) != SMR_OK) die(err);
+  const bool is_fastq = smr_reads_is_fastq(reads) != 0;
   const uint32_t n = smr_reads_count(reads);
 
   // indexes: reference-built files when a prefix is given, else our own builder (Index ctor / build_index, index.cpp:61-107)
@@ -175,12 +143,18 @@ int main(int argc, char** argv) {
   uint64_t nrec = 0;
   fwrite(&nrec, 8, 1, f);
   std::vector<uint8_t> buf;
+  std::vector<char> th, ts, tq;
   for (uint32_t i = 0; i < n; i++) {
     const size_t len = smr_result_record(gpu, i, nullptr, 0);
     buf.resize(len);
     if (len) smr_result_record(gpu, i, buf.data(), len);
-    if (rep && smr_report_add(rep, recs[i].header.c_str(), recs[i].seq.c_str(), is_fastq ? recs[i].qual.c_str() : nullptr, buf.data(), len) != SMR_OK)
-      die(smr_report_last_error(rep));
+    if (rep) {
+      size_t tl[3];
+      smr_reads_record_text(reads, i, nullptr, 0, nullptr, 0, nullptr, 0, tl);
+      th.resize(tl[0] + 1); ts.resize(tl[1] + 1); tq.resize(tl[2] + 1);
+      smr_reads_record_text(reads, i, th.data(), th.size(), ts.data(), ts.size(), tq.data(), tq.size(), tl);
+      if (smr_report_add(rep, th.data(), ts.data(), is_fastq ? tq.data() : nullptr, buf.data(), len) != SMR_OK) die(smr_report_last_error(rep));
+    }
     if (!len) continue;
     const std::string key = "0_" + std::to_string(i);
     const uint64_t kl = key.size(), vl = len;

@@ -133,6 +133,12 @@ int smr_reads_load_fastx(const char* path, uint64_t first, uint64_t count, smr_r
  * smr_reads_load_fastx(path, 0, 0, ...). */
 int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap);
 void smr_reads_free(smr_reads*);
+/* like smr_reads_load_fastx_mt, and keeps the file text so that smr_reads_record_text can hand out every record's header line (as in the
+ * file, with '>' / '@'), letters (line breaks removed) and quality line for the report writers; lens = {header, letters, quality} lengths;
+ * a NULL / too small buffer is skipped / filled as far as it goes (always NUL-terminated) */
+int smr_reads_load_fastx_text(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap);
+int smr_reads_is_fastq(const smr_reads*);
+int smr_reads_record_text(const smr_reads*, uint32_t i, char* hdr, size_t hdr_cap, char* seq, size_t seq_cap, char* qual, size_t qual_cap, size_t lens[3]);
 uint64_t smr_reads_digest(const smr_reads*);   /* hash of the packed batch (lengths, offsets, words): equal digests = same reads, same order */
 uint32_t smr_reads_count(const smr_reads*);
 uint64_t smr_reads_total_len(const smr_reads*);

@@ -55,7 +55,7 @@ class Prof(C.Structure):
 
 EXPORTS = [
     "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_selfcheck", "smr_index_free",
-    "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_free",
+    "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free",
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
@@ -107,6 +107,12 @@ def bind(L):
     L.smr_reads_load_fastx.argtypes = [cp, u64, u64, C.POINTER(vp), cp, C.c_size_t]
     L.smr_reads_load_fastx_mt.restype = i32
     L.smr_reads_load_fastx_mt.argtypes = [cp, u32, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_reads_load_fastx_text.restype = i32
+    L.smr_reads_load_fastx_text.argtypes = [cp, u32, C.POINTER(vp), cp, C.c_size_t]
+    L.smr_reads_is_fastq.restype = i32
+    L.smr_reads_is_fastq.argtypes = [vp]
+    L.smr_reads_record_text.restype = i32
+    L.smr_reads_record_text.argtypes = [vp, u32, cp, C.c_size_t, cp, C.c_size_t, cp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.smr_reads_free.argtypes = [vp]
     for f in ("smr_reads_count", "smr_reads_min_len", "smr_reads_max_len"):
         getattr(L, f).restype = u32

@@ -1,6 +1,7 @@
 // smr_host.hpp -- host-side data model of libsmr_hip (index part, read batch).  Internal header.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -91,4 +92,8 @@ struct smr_reads {
   std::vector<uint32_t> len;       // n
   uint64_t total_len = 0;
   uint32_t min_len = 0, max_len = 0;
+  // smr_reads_load_fastx_text only: the file text (mapping or inflated copy) and where every record starts in it
+  std::shared_ptr<void> text_owner;
+  const char* text = nullptr; size_t text_n = 0; bool fastq = false;
+  std::vector<uint64_t> hdr_off, seq_off;      // offset of the header line / of the first sequence line
 };

@@ -171,20 +171,22 @@ bool is_record_start(const char* p, size_t o, size_t n, bool fastq) {
   const size_t l2 = next_line(p, next_line(p, o, n), n);
   return l2 < n && p[l2] == '+';
 }
-struct Rec { size_t off; uint32_t len; };          // sequence text starts at off (FASTA: first sequence line), len letters
+struct Rec { size_t off; uint32_t len; size_t hdr; };          // sequence text starts at off (FASTA: first sequence line), len letters; header line at hdr
 // sweep 1: records of [o, end)
 void list_range(const char* p, size_t n, size_t o, size_t end, std::vector<Rec>& recs, std::string& why) {
   while (o < end) {
     if (p[o] == '\n' || p[o] == '\r') { o++; continue; }
     if (p[o] == '>') {
+      const size_t h0 = o;
       o = next_line(p, o, n);
       const size_t s0 = o; size_t len = 0;
       while (o < n && p[o] != '>') { const size_t e = eol(p, o, n); len += rtrim(p, o, e) - o; o = e < n ? e + 1 : n; }
-      recs.push_back({s0, (uint32_t)len});
+      recs.push_back({s0, (uint32_t)len, h0});
     } else if (p[o] == '@') {
+      const size_t h0 = o;
       o = next_line(p, o, n);
       const size_t e = eol(p, o, n);
-      recs.push_back({std::min(o, n), (uint32_t)(rtrim(p, o, e) - o)});
+      recs.push_back({std::min(o, n), (uint32_t)(rtrim(p, o, e) - o), h0});
       o = e < n ? e + 1 : n;
       o = next_line(p, o, n);   // '+'
       o = next_line(p, o, n);   // quality
@@ -207,10 +209,12 @@ inline void pack_piece(uint32_t* cp, uint32_t* mp, size_t k0, const char* s, siz
 }
 }  // namespace
 
-extern "C" int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap) {
+namespace {
+int load_fastx_impl(const char* path, uint32_t threads, bool keep_text, smr_reads** out, char* err, size_t errcap) {
   if (!path || !out) return SMR_ERR_ARG;
   auto fail = [&](const std::string& w) { if (err && errcap) snprintf(err, errcap, "%s", w.c_str()); return SMR_ERR_IO; };
-  Bytes b; std::string w0;
+  auto bp = std::make_shared<Bytes>();
+  Bytes& b = *bp; std::string w0;
   if (!slurp(path, b, w0)) return fail(w0);
   const char* p = b.p; const size_t n = b.n;
   if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
@@ -246,6 +250,8 @@ extern "C" int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_r
   if (nrec[threads] > 0xfffffff0ull) return fail(std::string(path) + ": more than 2^32 records in one batch");
   auto r = new smr_reads();
   r->n = (uint32_t)nrec[threads];
+  r->fastq = fastq;
+  if (keep_text) { r->text_owner = bp; r->text = p; r->text_n = n; r->hdr_off.resize(r->n); r->seq_off.resize(r->n); }
   r->len.resize(r->n); r->rec_off.resize((size_t)r->n + 1); r->words.resize(nword[threads]);   // value-initialised (zero); first touched below, in parallel
   r->rec_off[0] = 0;
   uint32_t lo = 0xffffffffu, hi = 0;
@@ -258,10 +264,54 @@ extern "C" int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_r
       if (fastq) pack_piece(cp, mp, 0, p + rc.off, rc.len);
       else { size_t o = rc.off, done = 0; while (done < rc.len) { const size_t e = eol(p, o, n), le = rtrim(p, o, e); pack_piece(cp, mp, done, p + o, le - o); done += le - o; o = e + 1; } }
       wo += (rc.len + 15) / 16 + (rc.len + 31) / 32;
+      if (keep_text) { r->hdr_off[k] = rc.hdr; r->seq_off[k] = rc.off; }
       r->len[k] = rc.len; r->rec_off[++k] = wo;
     }
   });
   *out = r;
+  return SMR_OK;
+}
+}  // namespace
+
+extern "C" int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap) {
+  return load_fastx_impl(path, threads, false, out, err, errcap);
+}
+extern "C" int smr_reads_load_fastx_text(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap) {
+  return load_fastx_impl(path, threads, true, out, err, errcap);
+}
+extern "C" int smr_reads_is_fastq(const smr_reads* r) { return r && r->fastq ? 1 : 0; }
+
+// header line, letters (line breaks removed) and quality line of record i of a batch loaded by smr_reads_load_fastx_text
+extern "C" int smr_reads_record_text(const smr_reads* r, uint32_t i, char* hdr, size_t hdr_cap, char* seq, size_t seq_cap, char* qual, size_t qual_cap, size_t lens[3]) {
+  if (!r || !r->text || i >= r->n) return SMR_ERR_ARG;
+  const char* p = r->text; const size_t n = r->text_n;
+  auto put = [](char* dst, size_t cap, const char* src, size_t len, size_t at) {      // copies src[0..len) to dst[at..), keeps room for the NUL
+    if (!dst || cap == 0 || at + 1 >= cap) return;
+    const size_t k = std::min(len, cap - 1 - at);
+    memcpy(dst + at, src, k); dst[at + k] = 0;
+  };
+  if (hdr && hdr_cap) hdr[0] = 0;
+  if (seq && seq_cap) seq[0] = 0;
+  if (qual && qual_cap) qual[0] = 0;
+  size_t o = r->hdr_off[i];
+  size_t e = eol(p, o, n), le = rtrim(p, o, e);
+  put(hdr, hdr_cap, p + o, le - o, 0);
+  size_t l0 = le - o, l1 = 0, l2 = 0;
+  o = r->seq_off[i];
+  while (l1 < r->len[i]) {
+    e = eol(p, o, n); le = rtrim(p, o, e);
+    put(seq, seq_cap, p + o, le - o, l1);
+    l1 += le - o; o = e < n ? e + 1 : n;
+    if (o >= n) break;
+  }
+  if (r->fastq) {
+    if (r->len[i] == 0) o = next_line(p, r->seq_off[i], n);      // empty sequence line
+    o = next_line(p, o, n);                                      // the '+' line
+    e = eol(p, o, n); le = rtrim(p, o, e);
+    put(qual, qual_cap, p + o, le > o ? le - o : 0, 0);
+    l2 = le > o ? le - o : 0;
+  }
+  if (lens) { lens[0] = l0; lens[1] = l1; lens[2] = l2; }
   return SMR_OK;
 }
 

@@ -138,6 +138,31 @@ class Reads:
             raise SmrError("smr_reads_load_fastx_mt: %s (rc=%d)" % (err.value.decode(), rc))
         return Reads(h)
 
+    @staticmethod
+    def from_fastx_text(path, threads=0):
+        """from_fastx_mt + the file text kept, so that record_text(i) returns (header line, letters, quality) for the report writers"""
+        L = capi.load()
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = L.smr_reads_load_fastx_text(path.encode(), threads, C.byref(h), err, 512)
+        if rc != 0:
+            raise SmrError("smr_reads_load_fastx_text: %s (rc=%d)" % (err.value.decode(), rc))
+        return Reads(h)
+
+    @property
+    def is_fastq(self):
+        return bool(capi.load().smr_reads_is_fastq(self.h))
+
+    def record_text(self, i):
+        L = capi.load()
+        lens = (C.c_size_t * 3)()
+        rc = L.smr_reads_record_text(self.h, i, None, 0, None, 0, None, 0, lens)
+        if rc != 0:
+            raise SmrError("smr_reads_record_text rc=%d (batch not loaded with from_fastx_text?)" % rc)
+        bufs = [C.create_string_buffer(lens[k] + 1) for k in range(3)]
+        L.smr_reads_record_text(self.h, i, bufs[0], lens[0] + 1, bufs[1], lens[1] + 1, bufs[2], lens[2] + 1, lens)
+        return tuple(b.value.decode() for b in bufs)
+
     @property
     def digest(self):
         return capi.load().smr_reads_digest(self.h)
