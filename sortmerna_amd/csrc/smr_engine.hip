@@ -100,7 +100,6 @@ template <class T> int dev_alloc(smr_ctx* c, T** p, size_t count) {
 }
 template <class T> void dev_free(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
-uint32_t pow2ceil(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) {
   DParams P;

@@ -700,7 +700,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
   if (!slurp(ref_fasta, file)) { set_err(err, errcap, std::string("cannot read ") + ref_fasta); return SMR_ERR_IO; }
   std::vector<SeqRec> recs; std::vector<uint8_t> raw; std::string why;
   if (!parse_fasta(file, recs, raw, why)) { set_err(err, errcap, why); return SMR_ERR_IO; }
-  const uint32_t P = L / 2, W = L + 1, T = P + 1;
+  const uint32_t W = L + 1;
   // STEP 1 statistics (indexdb.cpp:1198-1268)
   double bgc[4] = {0, 0, 0, 0}; uint64_t full_len = 0;
   for (auto& r : recs) {

@@ -5,7 +5,7 @@ it catches logic errors and wave-divergent shuffles before GPU time is spent -- 
 timing, occupancy, LDS limits and memory-ordering effects of the real machine are not modelled.
 
 By default a subset runs (work-queue seed kernel everywhere, the DFS kernel on the golden cases; ~2 min);
-SMR_EMU_FULL=1 runs every GPU test body with both seed kernels (~10 min on 8 cores)."""
+SMR_EMU_FULL=1 runs every GPU test body with both seed kernels (~13 min on 8 cores)."""
 import os
 
 import pytest
@@ -14,14 +14,19 @@ import sortmerna_amd as smr
 from helpers import emu
 from helpers.workload import Workload
 
-from test_gpu_parity import (test_seed_scan_matches_oracle, test_align_records_match_oracle, test_multi_part_index,  # noqa: F401
-                             test_longer_reads, test_other_seed_lengths, test_non_default_strides, test_empty_batch)
-from test_gpu_sw_and_index_build import test_device_index_build_equals_the_host_build as test_device_index_build_gpu_test_body  # noqa: F401
+from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_index, test_longer_reads, test_empty_batch)  # noqa: F401
+from test_gpu_parity import test_align_records_match_oracle as _align_body
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 
 FULL = os.environ.get("SMR_EMU_FULL", "0") == "1"
 if FULL:
-    from test_gpu_parity import test_long_noisy_reads, test_long_reads_with_large_gaps  # noqa: F401
+    from test_gpu_parity import (test_align_records_match_oracle, test_other_seed_lengths, test_non_default_strides,  # noqa: F401
+                                 test_long_noisy_reads, test_long_reads_with_large_gaps)
+    from test_gpu_sw_and_index_build import test_device_index_build_equals_the_host_build as test_device_index_build_gpu_test_body  # noqa: F401
+else:
+    @pytest.mark.parametrize("opts", [{}, {"num_alignments": 0}, {"is_reverse": 0}], ids=["default", "all", "F"])
+    def test_align_records_match_oracle_subset(engine, wl, opts):
+        _align_body(engine, wl, opts)
 
 
 @pytest.fixture(scope="module", autouse=True)

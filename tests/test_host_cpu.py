@@ -63,18 +63,6 @@ def test_reads_load_fastx_multiline_and_range(tmp_path):
     assert (r3.count, r3.total_len) == (2, 7)
     with pytest.raises(smr.SmrError):
         smr.Reads.from_fastx(str(tmp_path / "missing.fa"))
-    # the text-keeping variant: same batch, and every record's header / letters / quality as the (python) reference reader sees them
-    from helpers import fastx
-    for p in (fq, fa, gz):
-        rt = smr.Reads.from_fastx_text(str(p), 5)
-        ser = smr.Reads.from_fastx(str(fq if p is gz else p))
-        assert rt.digest == ser.digest and rt.is_fastq == (p is not fa)
-        exp = fastx.read_fastx(str(fq if p is gz else p))
-        assert rt.count == len(exp)
-        for i in list(range(0, rt.count, 997)) + [rt.count - 1]:
-            h, sq, q = rt.record_text(i)
-            assert (h, sq, q) == (exp[i][0], exp[i][1].rstrip("\r"), exp[i][2] or ""), (p, i)
-        rt.free(); ser.free()
     e = tmp_path / "empty.fa"
     e.write_text("")
     assert smr.Reads.from_fastx(str(e)).count == 0
