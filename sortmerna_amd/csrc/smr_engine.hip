@@ -533,6 +533,66 @@ extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uin
   return SMR_OK;
 }
 
+
+// =================================================================================================
+// Batched Smith-Waterman at the ssw.h seam (SURVEY.md 8b "existing C ABI"): what k_chain does per candidate -- ssw_align(prof, ref,
+// refLen, gapO, gapE, flag = 2, filters, 0, 0) (ssw.c:834-941) without the CIGAR -- for n independent (read, reference window) pairs,
+// one wave per pair.  A unit-test surface for the SW kernels against the reference's own ssw.c (tests/golden/ssw_pairs.json).
+// =================================================================================================
+__global__ void __launch_bounds__(64) k_ssw_batch(uint32_t n_pairs, const uint8_t* __restrict__ reads, const unsigned long long* __restrict__ read_off,
+                                                  const uint8_t* __restrict__ refs, const unsigned long long* __restrict__ ref_off, uint32_t lds_m, uint32_t lds_n,
+                                                  int match, int mismatch, int scoreN, int go, int ge, uint32_t filters, int mode, int* __restrict__ out) {
+  SMR_DYN_LDS(unsigned char, lds_raw);
+  uint8_t* rdq = lds_raw;
+  uint8_t* rfq = rdq + lds_m;
+  int* bound = (int*)(rfq + lds_n);
+  const int lane = smr::lane_id();
+  for (uint32_t pi = blockIdx.x; pi < n_pairs; pi += gridDim.x) {
+    const int m = (int)(read_off[pi + 1] - read_off[pi]), n = (int)(ref_off[pi + 1] - ref_off[pi]);
+    for (int q = lane; q < m; q += 64) rdq[q] = reads[read_off[pi] + q];
+    for (int q = lane; q < n; q += 64) rfq[q] = refs[ref_off[pi] + q];
+    __syncthreads();
+    int res[5] = {0, -1, -1, -1, m - 1};          // score1, ref_begin1, ref_end1, read_begin1, read_end1
+    if (m > 0 && n > 0) {
+      const smr::SwRes fw = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, mode);
+      __syncthreads();
+      res[0] = fw.score > 65535 ? 65535 : fw.score; res[2] = fw.end_ref; res[4] = fw.end_read;
+      if ((uint32_t)res[0] >= filters && fw.score > 0) {
+        const smr::SwRes bw = smr::sw_wave(rdq, fw.end_read + 1, fw.end_read, -1, rfq, fw.end_ref + 1, fw.end_ref, -1, bound, match, mismatch, scoreN, go, ge, mode);
+        __syncthreads();
+        res[1] = fw.end_ref - bw.end_ref; res[3] = fw.end_read - bw.end_read;
+      }
+    }
+    if (lane < 5) out[(size_t)pi * 5 + lane] = res[lane];
+    __syncthreads();
+  }
+}
+
+extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
+                             int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out) {
+  if (!c || !read_off || !ref_off || !out || (mode != 0 && mode != 1)) return SMR_ERR_ARG;
+  if (n_pairs == 0) return SMR_OK;
+  (void)hipSetDevice(c->device);
+  uint64_t mx_m = 1, mx_n = 1;
+  for (uint32_t i = 0; i < n_pairs; i++) { mx_m = std::max(mx_m, read_off[i + 1] - read_off[i]); mx_n = std::max(mx_n, ref_off[i + 1] - ref_off[i]); }
+  const uint32_t lm = (uint32_t)((mx_m + 15) & ~15ull), ln = (uint32_t)((mx_n + 15) & ~15ull);
+  const size_t lds = (size_t)lm + ln + (size_t)2 * ln * 4;
+  if (lds > 60 * 1024) { c->err = "smr_ssw_batch: sequences too long for one LDS tile (read + 9 x reference window <= 60 KB)"; return SMR_ERR_CAPACITY; }
+  DevPool pool;
+  IB_GET(d_reads, uint8_t, read_off[n_pairs] + 1); IB_GET(d_refs, uint8_t, ref_off[n_pairs] + 1);
+  IB_GET(d_ro, unsigned long long, (size_t)n_pairs + 1); IB_GET(d_fo, unsigned long long, (size_t)n_pairs + 1);
+  IB_GET(d_out, int, (size_t)n_pairs * 5);
+  if (read_off[n_pairs]) HIPCHK(c, hipMemcpyAsync(d_reads, reads, read_off[n_pairs], hipMemcpyHostToDevice, c->stream));
+  if (ref_off[n_pairs]) HIPCHK(c, hipMemcpyAsync(d_refs, refs, ref_off[n_pairs], hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_ro, read_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_fo, ref_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_ssw_batch, dim3(std::min<uint32_t>(n_pairs, (uint32_t)c->n_cu * 8u)), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
+                     (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, mode, d_out);
+  HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n_pairs * 5 * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SMR_OK;
+}
+
 extern "C" int smr_sw_mode(smr_ctx* c, int set_to) {      // set_to: 0 / 1 = select, anything else = query only; returns the mode in use
   if (!c) return SMR_ERR_ARG;
   if (set_to == 0 || set_to == 1) c->sw_mode = set_to;

@@ -238,6 +238,19 @@ class Engine:
         self._chk(self.L.smr_sw_selfcheck(self.h, n_cases, seed, max_len, C.byref(bad)), "smr_sw_selfcheck")
         return bad.value
 
+    def ssw_batch(self, reads, refs, match=2, mismatch=-3, score_N=-3, gap_open=5, gap_ext=2, filters=0, mode=1):
+        """reads / refs: lists of byte strings in the 0..4 alphabet; -> int32 array (n, 5): score1, ref_begin1, ref_end1, read_begin1, read_end1
+        (ssw_align with flag 2, without the CIGAR), computed by the 32-bit (mode 0) or the packed (mode 1) SW kernel"""
+        import numpy as np
+        n = len(reads)
+        ro = np.zeros(n + 1, dtype=np.uint64); fo = np.zeros(n + 1, dtype=np.uint64)
+        ro[1:] = np.cumsum([len(x) for x in reads]); fo[1:] = np.cumsum([len(x) for x in refs])
+        rb = np.frombuffer(b"".join(reads) + b"\0", dtype=np.uint8).copy(); fb = np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8).copy()
+        out = np.zeros((n, 5), dtype=np.int32)
+        self._chk(self.L.smr_ssw_batch(self.h, n, rb.ctypes.data, ro.ctypes.data, fb.ctypes.data, fo.ctypes.data, match, mismatch, score_N,
+                                       gap_open, gap_ext, filters, mode, out.ctypes.data), "smr_ssw_batch")
+        return out
+
     def upload_reads(self, reads, max_alignments_per_read=1):
         self._chk(self.L.smr_reads_upload(self.h, reads.h, max_alignments_per_read), "smr_reads_upload")
         self.n_reads = reads.count

@@ -1,0 +1,36 @@
+"""tests/golden/ssw_pairs.json: (read, reference window) pairs and what the reference's own ssw_align returned for them
+(written by tests/golden/make_golden_ssw.py).  TEST INFRASTRUCTURE."""
+import json
+import os
+
+import numpy as np
+
+from . import paths
+
+_TR = bytes.maketrans(b"ACGTN", bytes(range(5)))
+
+
+def load():
+    g = json.load(open(os.path.join(paths.REPO, "tests", "golden", "ssw_pairs.json")))
+    for c in g["cases"]:
+        c["reads_b"] = [s.encode().translate(_TR) for s in c["reads"]]
+        c["refs_b"] = [s.encode().translate(_TR) for s in c["refs"]]
+        c["expected_a"] = np.array(c["expected"], dtype=np.int32)
+    return g["cases"]
+
+
+def check(engine, modes=(0, 1), max_pairs=None):
+    """both SW kernels through smr_ssw_batch against the reference's answers; returns the number of pairs checked"""
+    n = 0
+    for c in load():
+        sc = c["scoring"]
+        k = len(c["reads_b"]) if max_pairs is None else min(max_pairs, len(c["reads_b"]))
+        for mode in modes:
+            got = engine.ssw_batch(c["reads_b"][:k], c["refs_b"][:k], match=sc["match"], mismatch=sc["mismatch"], score_N=sc["score_N"],
+                                   gap_open=sc["gap_open"], gap_ext=sc["gap_ext"], filters=sc["filters"], mode=mode)
+            exp = c["expected_a"][:k]
+            bad = np.nonzero((got != exp).any(axis=1))[0]
+            assert bad.size == 0, "mode %d scoring %s: %d of %d pairs differ from ssw.c; first pair %d (m=%d, n=%d): got %s, ssw.c %s" % (
+                mode, sc, bad.size, k, bad[0], len(c["reads_b"][bad[0]]), len(c["refs_b"][bad[0]]), got[bad[0]].tolist(), exp[bad[0]].tolist())
+        n += k
+    return n

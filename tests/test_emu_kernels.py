@@ -117,3 +117,12 @@ def test_smoke_entry_point_on_the_emulator(emulator):
     """__graft_entry__.smoke() end to end (it is written for cuda:0; here the binding is routed to the emulator build)"""
     import __graft_entry__ as entry
     entry.smoke()
+
+
+def test_sw_kernels_equal_the_reference_ssw_c(emulator):
+    """smr_ssw_batch (32-bit and packed kernel) against tests/golden/ssw_pairs.json = answers of the reference's own ssw.c (ssw_align, flag 2)
+    for 320 seeded pairs: score1, ref_begin1/end1, read_begin1/end1"""
+    from helpers import sswgold
+    e = smr.Engine(0)
+    assert sswgold.check(e) == 320
+    e.close()

@@ -21,6 +21,12 @@ def wl(tmp_path_factory):
     return Workload(str(tmp_path_factory.mktemp("wl")))
 
 
+def test_sw_kernels_equal_the_reference_ssw_c(engine):
+    """smr_ssw_batch (32-bit and packed kernel) against the answers of the reference's own ssw.c (tests/golden/ssw_pairs.json)"""
+    from helpers import sswgold
+    assert sswgold.check(engine) == 320
+
+
 def test_packed_smith_waterman_selfcheck_on_the_device(engine):
     """the packed 16-bit SW kernel against the 32-bit kernel, both on the GPU (smr_sw_selfcheck), and smr_create's own check passed"""
     assert engine.sw_selfcheck(2000, 3, 300) == 0
