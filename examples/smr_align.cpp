@@ -24,7 +24,7 @@ struct Db { std::string fasta, idx_prefix; double lambda = 0.618874, K = 0.34323
 
 int main(int argc, char** argv) {
   std::vector<Db> dbs;
-  std::string reads_path, out_dir = ".";
+  std::vector<std::string> reads_paths; std::string out_dir = ".";
   smr_params base; smr_params_default(&base);
   double evalue = 1.0;
   int device = 0;
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     if (a == "-ref" || a == "--ref") { Db d; d.fasta = val(); dbs.push_back(d); }
     else if (a == "-idx" || a == "--idx") { if (dbs.empty()) die("--idx before --ref"); dbs.back().idx_prefix = val(); }   // reference-format index files
     else if (a == "-gumbel" || a == "--gumbel") { if (dbs.empty()) die("--gumbel before --ref"); dbs.back().lambda = atof(val().c_str()); dbs.back().K = atof(val().c_str()); }
-    else if (a == "-reads" || a == "--reads") reads_path = val();
+    else if (a == "-reads" || a == "--reads") { if (reads_paths.size() == 2) die("at most two --reads files (mates)"); reads_paths.push_back(val()); }
     else if (a == "-out" || a == "--out") out_dir = val();
     else if (a == "-e") evalue = atof(val().c_str());
     else if (a == "-num_alignments" || a == "--num_alignments") base.num_alignments = (uint32_t)atoi(val().c_str());
@@ -55,6 +55,10 @@ int main(int argc, char** argv) {
     else if (a == "-other" || a == "--other") ro.other = 1;
     else if (a == "-sam" || a == "--sam") ro.sam = 1;
     else if (a == "-SQ" || a == "--SQ") ro.sam_sq = 1;
+    else if (a == "-paired_in" || a == "--paired_in") ro.paired_in = 1;
+    else if (a == "-paired_out" || a == "--paired_out") ro.paired_out = 1;
+    else if (a == "-out2" || a == "--out2") ro.out2 = 1;
+    else if (a == "-sout" || a == "--sout") ro.sout = 1;
     else if (a == "-blast" || a == "--blast") {            // "1" = tabular, optionally followed by cigar / qcov / qstrand (options.cpp opt_blast)
       const std::string v = val();
       if (v == "0") { ro.blast_pairwise = 1; continue; }   // BLAST-like pairwise text
@@ -65,20 +69,30 @@ int main(int argc, char** argv) {
       strcpy(ro.blast_cols, cols.c_str());
     }
     else if (a == "-h" || a == "--help") {
-      printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq [--out DIR]\n"
+      printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq[.gz] [--reads MATES] [--out DIR]\n"
              "       [-e EVALUE] [-num_alignments N] [-no-best] [-min_lis N] [-num_seeds N] [-edges N] [-full_search] [-F|-R]\n"
-             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '0' | '1 cigar qcov qstrand'] [--sam [-SQ]]\n");
+             "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '0' | '1 cigar qcov qstrand'] [--sam [-SQ]]\n"
+             "       [-paired_in | -paired_out] [-out2] [-sout]     (two --reads files, or one interleaved file with -paired_in / -paired_out)\n");
       return 0;
     } else die("unknown option " + a);
   }
-  if (dbs.empty() || reads_path.empty()) die("--ref and --reads are required (see --help)");
+  if (dbs.empty() || reads_paths.empty()) die("--ref and --reads are required (see --help)");
   char err[512] = "";
   // reads (Readfeed::next -> Read::init, readfeed.hpp:124 / read.cpp:264-347)
   // (all cores parse and 2-bit pack the FASTA / FASTQ / .gz file; the text stays mapped for the report writers)
-  smr_reads* reads = nullptr;
-  if (smr_reads_load_fastx_text(reads_path.c_str(), 0, &reads, err, sizeof err) != SMR_OK) die(err);
-  const bool is_fastq = smr_reads_is_fastq(reads) != 0;
-  const uint32_t n = smr_reads_count(reads);
+  // one batch per reads file (the second file holds the mates of the first: options.cpp:1591 is_paired)
+  std::vector<smr_reads*> rf(reads_paths.size(), nullptr);
+  uint64_t n = 0, total_len = 0; uint32_t min_len = 0xFFFFFFFFu, max_len = 0;
+  for (size_t b = 0; b < rf.size(); b++) {
+    if (smr_reads_load_fastx_text(reads_paths[b].c_str(), 0, &rf[b], err, sizeof err) != SMR_OK) die(err);
+    n += smr_reads_count(rf[b]); total_len += smr_reads_total_len(rf[b]);
+    if (smr_reads_count(rf[b])) { min_len = std::min(min_len, smr_reads_min_len(rf[b])); max_len = std::max(max_len, smr_reads_max_len(rf[b])); }
+  }
+  if (n == 0) min_len = 0;
+  const bool is_fastq = smr_reads_is_fastq(rf[0]) != 0;
+  const bool paired = rf.size() == 2 || ro.paired_in || ro.paired_out;
+  if (rf.size() == 2 && smr_reads_count(rf[0]) != smr_reads_count(rf[1])) die("the two --reads files hold different numbers of reads");
+  if (rf.size() == 1 && paired && (smr_reads_count(rf[0]) & 1)) die("-paired_in / -paired_out with one file: odd number of reads");
 
   // indexes: reference-built files when a prefix is given, else our own builder (Index ctor / build_index, index.cpp:61-107)
   for (auto& d : dbs) {
@@ -102,24 +116,26 @@ int main(int argc, char** argv) {
   smr_ctx* gpu = nullptr;
   if (smr_create(device, &gpu, err, sizeof err) != SMR_OK) die(err);
   const uint32_t slots = base.num_alignments > 0 ? base.num_alignments : 256;
-  if (smr_reads_upload(gpu, reads, slots) != SMR_OK) die(smr_last_error(gpu));
+  for (size_t b = 0; b < rf.size(); b++)
+    if (smr_batch_select(gpu, (int)b) != SMR_OK || smr_reads_upload(gpu, rf[b], slots) != SMR_OK) die(smr_last_error(gpu));
 
   // the (index, part) loop of processor.cpp:219-277
   for (size_t k = 0; k < dbs.size(); k++) {
     smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
     smr_params p = base;
-    p.minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, n, smr_reads_total_len(reads), evalue);
+    p.minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, n, total_len, evalue);
     p.index_num = (uint32_t)k;
     for (size_t part = 0; part < dbs[k].parts.size(); part++) {
       p.part = (uint32_t)part;
       p.is_last_index_part = (k + 1 == dbs.size() && part + 1 == dbs[k].parts.size());
       if (smr_index_upload(gpu, dbs[k].parts[part], 0) != SMR_OK) die(smr_last_error(gpu));
-      if (smr_align_part(gpu, 0, &p) != SMR_OK) die(smr_last_error(gpu));
-      if (smr_traceback(gpu, 0, &p) != SMR_OK) die(smr_last_error(gpu));
+      for (size_t b = 0; b < rf.size(); b++) {
+        if (smr_batch_select(gpu, (int)b) != SMR_OK || smr_align_part(gpu, 0, &p) != SMR_OK || smr_traceback(gpu, 0, &p) != SMR_OK) die(smr_last_error(gpu));
+      }
       smr_index_unload(gpu, 0);
     }
   }
-  if (smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
+  for (size_t b = 0; b < rf.size(); b++) if (smr_batch_select(gpu, (int)b) != SMR_OK || smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
 
   // reports (writeReports, output.cpp:169-272)
   smr_report* rep = nullptr;
@@ -131,7 +147,7 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < dbs.size(); k++) {
       smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
       uint64_t fr = 0, fq = 0;
-      smr_refstats_corrected(dbs[k].K, info.bg, info.full_len, info.numseq, n, smr_reads_total_len(reads), &fr, &fq);
+      smr_refstats_corrected(dbs[k].K, info.bg, info.full_len, info.numseq, n, total_len, &fr, &fq);
       smr_report_set_db(rep, (uint32_t)k, dbs[k].lambda, dbs[k].K, fr, fq);
       for (size_t part = 0; part < dbs[k].parts.size(); part++) smr_report_set_part(rep, (uint32_t)k, (uint32_t)part, dbs[k].parts[part]);
     }
@@ -142,32 +158,50 @@ int main(int argc, char** argv) {
   if (!f) die("cannot write " + rp);
   uint64_t nrec = 0;
   fwrite(&nrec, 8, 1, f);
-  std::vector<uint8_t> buf;
-  std::vector<char> th, ts, tq;
-  for (uint32_t i = 0; i < n; i++) {
+  struct Mate { std::vector<uint8_t> rec; std::vector<char> h, s, q; };
+  auto load = [&](size_t b, uint32_t i, Mate& m) {                  // record + text of read i of batch b
+    smr_batch_select(gpu, (int)b);
     const size_t len = smr_result_record(gpu, i, nullptr, 0);
-    buf.resize(len);
-    if (len) smr_result_record(gpu, i, buf.data(), len);
+    m.rec.resize(len);
+    if (len) smr_result_record(gpu, i, m.rec.data(), len);
     if (rep) {
       size_t tl[3];
-      smr_reads_record_text(reads, i, nullptr, 0, nullptr, 0, nullptr, 0, tl);
-      th.resize(tl[0] + 1); ts.resize(tl[1] + 1); tq.resize(tl[2] + 1);
-      smr_reads_record_text(reads, i, th.data(), th.size(), ts.data(), ts.size(), tq.data(), tq.size(), tl);
-      if (smr_report_add(rep, th.data(), ts.data(), is_fastq ? tq.data() : nullptr, buf.data(), len) != SMR_OK) die(smr_report_last_error(rep));
+      smr_reads_record_text(rf[b], i, nullptr, 0, nullptr, 0, nullptr, 0, tl);
+      m.h.resize(tl[0] + 1); m.s.resize(tl[1] + 1); m.q.resize(tl[2] + 1);
+      smr_reads_record_text(rf[b], i, m.h.data(), m.h.size(), m.s.data(), m.s.size(), m.q.data(), m.q.size(), tl);
     }
-    if (!len) continue;
-    const std::string key = "0_" + std::to_string(i);
-    const uint64_t kl = key.size(), vl = len;
-    fwrite(&kl, 8, 1, f); fwrite(key.data(), 1, kl, f); fwrite(&vl, 8, 1, f); fwrite(buf.data(), 1, vl, f);
-    nrec++;
+    if (len) {
+      const std::string key = std::to_string(b) + "_" + std::to_string(i);      // KVDB key: <reads file>_<read number>
+      const uint64_t kl = key.size(), vl = len;
+      fwrite(&kl, 8, 1, f); fwrite(key.data(), 1, kl, f); fwrite(&vl, 8, 1, f); fwrite(m.rec.data(), 1, vl, f);
+      nrec++;
+    }
+  };
+  Mate m1, m2;
+  if (paired) {
+    const uint32_t np = rf.size() == 2 ? smr_reads_count(rf[0]) : smr_reads_count(rf[0]) / 2;
+    for (uint32_t i = 0; i < np; i++) {
+      if (rf.size() == 2) { load(0, i, m1); load(1, i, m2); } else { load(0, 2 * i, m1); load(0, 2 * i + 1, m2); }
+      if (rep && smr_report_add_pair(rep, m1.h.data(), m1.s.data(), is_fastq ? m1.q.data() : nullptr, m1.rec.data(), m1.rec.size(),
+                                     m2.h.data(), m2.s.data(), is_fastq ? m2.q.data() : nullptr, m2.rec.data(), m2.rec.size()) != SMR_OK) die(smr_report_last_error(rep));
+    }
+  } else {
+    for (uint32_t i = 0; i < smr_reads_count(rf[0]); i++) {
+      load(0, i, m1);
+      if (rep && smr_report_add(rep, m1.h.data(), m1.s.data(), is_fastq ? m1.q.data() : nullptr, m1.rec.data(), m1.rec.size()) != SMR_OK) die(smr_report_last_error(rep));
+    }
   }
   fseek(f, 0, SEEK_SET); fwrite(&nrec, 8, 1, f); fclose(f);
   if (rep && smr_report_close(rep) != SMR_OK) die("cannot write the report files");
-  std::vector<uint64_t> ctr(2 + dbs.size());
-  smr_counters(gpu, ctr.data(), (uint32_t)dbs.size());
+  std::vector<uint64_t> ctr(2 + dbs.size(), 0), cb(2 + dbs.size());
+  for (size_t b = 0; b < rf.size(); b++) {
+    smr_batch_select(gpu, (int)b);
+    smr_counters(gpu, cb.data(), (uint32_t)dbs.size());
+    for (size_t k = 0; k < ctr.size(); k++) ctr[k] += cb[k];
+  }
   f = fopen(sp.c_str(), "w");
   if (!f) die("cannot write " + sp);
-  fprintf(f, "Total reads = %u\nTotal reads passing E-value threshold = %llu\nToo short reads (last part) = %llu\n", n,
+  fprintf(f, "Total reads = %llu\nTotal reads passing E-value threshold = %llu\nToo short reads (last part) = %llu\n", (unsigned long long)n,
           (unsigned long long)ctr[0], (unsigned long long)ctr[1]);
   for (size_t k = 0; k < dbs.size(); k++) fprintf(f, "%s\t%llu\n", dbs[k].fasta.c_str(), (unsigned long long)ctr[2 + k]);
   fclose(f);
@@ -178,25 +212,25 @@ int main(int argc, char** argv) {
       sdb[k].ref_file = dbs[k].fasta.c_str();
       sdb[k].skiplengths[0] = info.lnwin; sdb[k].skiplengths[1] = info.lnwin / 2; sdb[k].skiplengths[2] = 3;
       sdb[k].lambda = dbs[k].lambda; sdb[k].K = dbs[k].K;
-      sdb[k].minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, n, smr_reads_total_len(reads), evalue);
+      sdb[k].minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, n, total_len, evalue);
       sdb[k].reads_matched = ctr[2 + k];
     }
     const time_t now = time(nullptr);
     const std::string stamp = ctime(&now);
-    const char* rf[1] = {reads_path.c_str()};
+    const char* rfn[2] = {reads_paths[0].c_str(), reads_paths.size() > 1 ? reads_paths[1].c_str() : nullptr};
     smr_summary sm; memset(&sm, 0, sizeof sm);
     sm.cmdline = cmdline.c_str(); sm.pid = ""; sm.timestamp = stamp.c_str();
     sm.seed_len = 18; sm.num_seeds = base.num_seeds; sm.edges = base.edges; sm.match = base.match; sm.mismatch = base.mismatch;
     sm.gap_open = base.gap_open; sm.gap_ext = base.gap_ext; sm.score_N = base.score_N; sm.sam_sq = ro.sam_sq; sm.threads = 1;
-    sm.reads_files = rf; sm.n_reads_files = 1;
-    sm.total_reads = n; sm.num_aligned = ctr[0]; sm.all_reads_len = smr_reads_total_len(reads);
-    sm.min_read_len = smr_reads_min_len(reads); sm.max_read_len = smr_reads_max_len(reads);
+    sm.reads_files = rfn; sm.n_reads_files = (uint32_t)reads_paths.size();
+    sm.total_reads = n; sm.num_aligned = ctr[0]; sm.all_reads_len = total_len;
+    sm.min_read_len = min_len; sm.max_read_len = max_len;
     sm.dbs = sdb.data(); sm.n_dbs = (uint32_t)sdb.size();
     if (smr_summary_write((out_dir + "/aligned.log").c_str(), &sm) != SMR_OK) die("cannot write aligned.log");
   }
-  printf("%u reads, %llu aligned, %llu records -> %s\n", n, (unsigned long long)ctr[0], (unsigned long long)nrec, rp.c_str());
+  printf("%llu reads, %llu aligned, %llu records -> %s\n", (unsigned long long)n, (unsigned long long)ctr[0], (unsigned long long)nrec, rp.c_str());
   for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
-  smr_reads_free(reads);
+  for (auto* r : rf) smr_reads_free(r);
   smr_destroy(gpu);
   return 0;
 }

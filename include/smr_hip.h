@@ -242,6 +242,12 @@ typedef struct {
   int sam;               /* -sam                   */
   int blast_pairwise;    /* -blast 0: the BLAST-like pairwise text (report_blast.cpp:130-252) instead of tabular rows */
   int sam_sq;            /* -SQ: @SQ lines of every reference sequence in the SAM header (report_sam.cpp:155-211) */
+  /* paired reads (two read files, or -paired_in / -paired_out): smr_report_add_pair routes the two mates like ReportFastx::append /
+   * ReportFxOther::append (report_fastx.cpp:57-133, report_fx_other.cpp:49-113) */
+  int paired_in;         /* -paired_in: a pair with one aligned mate goes to aligned.* entirely  */
+  int paired_out;        /* -paired_out: ... goes to other.* entirely                              */
+  int out2;              /* -out2: separate files for the mates: *_fwd / *_rev                     */
+  int sout;              /* -sout: separate files for pairs and singletons: *_paired / *_singleton */
 } smr_report_opts;
 int smr_report_open(const char* out_dir, const smr_report_opts*, int is_fastq, smr_report** out, char* err, size_t errcap);
 /* per --ref: Gumbel parameters and the corrected sizes (smr_refstats_corrected); per (index, part): where its reference ids/sequences are */
@@ -249,6 +255,9 @@ int smr_report_set_db(smr_report*, uint32_t index_num, double lambda, double K, 
 int smr_report_set_part(smr_report*, uint32_t index_num, uint32_t part, const smr_index*);
 /* one read: its header line as in the file (with '>' / '@'), letters, quality (NULL for FASTA), and its record (NULL, 0: none) */
 int smr_report_add(smr_report*, const char* header, const char* seq, const char* qual, const uint8_t* record, size_t record_len);
+/* a pair of mates (read i of the first and of the second file / two consecutive records of an interleaved file) */
+int smr_report_add_pair(smr_report*, const char* header1, const char* seq1, const char* qual1, const uint8_t* record1, size_t record1_len,
+                        const char* header2, const char* seq2, const char* qual2, const uint8_t* record2, size_t record2_len);
 int smr_report_set_cmdline(smr_report*, const char* cmdline);   /* text after "CL:" in the SAM @PG line (default "libsmr_hip") */
 int smr_report_close(smr_report*);      /* writes aligned.blast / aligned.sam, closes the files, frees the object */
 const char* smr_report_last_error(const smr_report*);

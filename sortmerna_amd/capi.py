@@ -27,7 +27,7 @@ class IndexInfo(C.Structure):
 
 class ReportOpts(C.Structure):
     _fields_ = [("fastx", C.c_int), ("other", C.c_int), ("blast_tabular", C.c_int), ("blast_cols", C.c_char * 64), ("sam", C.c_int),
-                ("blast_pairwise", C.c_int), ("sam_sq", C.c_int)]
+                ("blast_pairwise", C.c_int), ("sam_sq", C.c_int), ("paired_in", C.c_int), ("paired_out", C.c_int), ("out2", C.c_int), ("sout", C.c_int)]
 
 
 class SummaryDb(C.Structure):
@@ -60,7 +60,7 @@ EXPORTS = [
     "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_sw_selfcheck", "smr_sw_mode", "smr_ssw_batch", "smr_prof_reset", "smr_prof_get", "smr_refstats_corrected", "smr_report_open",
-    "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
+    "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_add_pair", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
     "smr_summary_write",
 ]
 
@@ -175,6 +175,8 @@ def bind(L):
     L.smr_report_set_part.argtypes = [vp, u32, u32, vp]
     L.smr_report_add.restype = i32
     L.smr_report_add.argtypes = [vp, cp, cp, cp, cp, C.c_size_t]
+    L.smr_report_add_pair.restype = i32
+    L.smr_report_add_pair.argtypes = [vp, cp, cp, cp, cp, C.c_size_t, cp, cp, cp, cp, C.c_size_t]
     L.smr_report_set_cmdline.restype = i32
     L.smr_report_set_cmdline.argtypes = [vp, cp]
     L.smr_summary_write.restype = i32

@@ -65,7 +65,8 @@ std::string cigar_text(const Aln& a, size_t readlen) {        // soft clips as r
 
 struct smr_report {
   std::string dir; smr_report_opts o; bool fastq = false;
-  FILE* f_aligned = nullptr; FILE* f_other = nullptr;
+  FILE* f_aligned[4] = {nullptr, nullptr, nullptr, nullptr}; FILE* f_other[4] = {nullptr, nullptr, nullptr, nullptr};
+  int num_out = 1;                                                     // ReportFxBase::set_num_out (report_fx_base.cpp:163-169)
   std::map<uint32_t, Db> dbs;
   std::map<std::pair<uint32_t, uint32_t>, const smr_index*> parts;
   std::map<std::pair<uint32_t, uint32_t>, std::string> blast, sam;     // rows per (index, part)
@@ -77,12 +78,25 @@ extern "C" int smr_report_open(const char* out_dir, const smr_report_opts* opts,
   auto r = new smr_report();
   r->dir = out_dir; r->o = *opts; r->fastq = is_fastq != 0;
   const std::string ext = is_fastq ? ".fq" : ".fa";
-  if (opts->fastx) r->f_aligned = fopen((r->dir + "/aligned" + ext).c_str(), "wb");
-  if (opts->other) r->f_other = fopen((r->dir + "/other" + ext).c_str(), "wb");
-  if ((opts->fastx && !r->f_aligned) || (opts->other && !r->f_other)) {
+  if ((opts->paired_in && opts->paired_out) || (opts->sout && (opts->paired_in || opts->paired_out))) {      // report_fx_base.cpp:131-136
+    if (err && errcap) snprintf(err, errcap, "invalid combination of paired_in / paired_out / sout");
+    delete r; return SMR_ERR_ARG;
+  }
+  r->num_out = (opts->out2 && opts->sout) ? 4 : (opts->out2 || opts->sout) ? 2 : 1;
+  // file name suffixes (report_fx_base.cpp:71-91; the per-split files are merged into these names, report.cpp:56-97)
+  auto sfx = [&](int j) -> std::string {
+    if (r->num_out == 4) return j == 0 ? "_paired_fwd" : j == 1 ? "_paired_rev" : j == 2 ? "_singleton_fwd" : "_singleton_rev";
+    if (r->num_out == 2) return opts->out2 ? (j == 0 ? "_fwd" : "_rev") : (j == 0 ? "_paired" : "_singleton");
+    return "";
+  };
+  bool ok = true;
+  for (int j = 0; j < r->num_out; j++) {
+    if (opts->fastx) { r->f_aligned[j] = fopen((r->dir + "/aligned" + sfx(j) + ext).c_str(), "wb"); ok = ok && r->f_aligned[j]; }
+    if (opts->other) { r->f_other[j] = fopen((r->dir + "/other" + sfx(j) + ext).c_str(), "wb"); ok = ok && r->f_other[j]; }
+  }
+  if (!ok) {
     if (err && errcap) snprintf(err, errcap, "cannot create report files in %s", out_dir);
-    if (r->f_aligned) fclose(r->f_aligned);
-    if (r->f_other) fclose(r->f_other);
+    for (int j = 0; j < 4; j++) { if (r->f_aligned[j]) fclose(r->f_aligned[j]); if (r->f_other[j]) fclose(r->f_other[j]); }
     delete r; return SMR_ERR_IO;
   }
   *out = r;
@@ -102,17 +116,61 @@ extern "C" int smr_report_set_part(smr_report* r, uint32_t index_num, uint32_t p
   return SMR_OK;
 }
 
+namespace {
+void write_fx(const smr_report* r, FILE* f, const char* header, const char* seq, const char* qual) {      // the record as read (report_fx_base.cpp:176-181)
+  if (!f) return;
+  fprintf(f, "%s\n%s\n", header, seq);
+  if (r->fastq) fprintf(f, "+\n%s\n", qual ? qual : "");
+}
+int add_rows(smr_report* r, const char* header, const char* seq, const char* qual, const std::vector<Aln>& alns);
+}  // namespace
+
 extern "C" int smr_report_add(smr_report* r, const char* header, const char* seq, const char* qual, const uint8_t* record, size_t record_len) {
   if (!r || !header || !seq) return SMR_ERR_ARG;
   bool is_hit = false;
   std::vector<Aln> alns;
   if (!parse_record(record, record_len, is_hit, alns)) { r->err = "malformed record"; return SMR_ERR_ARG; }
-  // aligned / other FASTX: the record as read (report_fx_base.cpp:176-181)
-  FILE* f = is_hit ? r->f_aligned : r->f_other;
-  if (f) {
-    fprintf(f, "%s\n%s\n", header, seq);
-    if (r->fastq) fprintf(f, "+\n%s\n", qual ? qual : "");
+  write_fx(r, is_hit ? r->f_aligned[0] : r->f_other[0], header, seq, qual);
+  return add_rows(r, header, seq, qual, alns);
+}
+
+extern "C" int smr_report_add_pair(smr_report* r, const char* header1, const char* seq1, const char* qual1, const uint8_t* record1, size_t record1_len,
+                                   const char* header2, const char* seq2, const char* qual2, const uint8_t* record2, size_t record2_len) {
+  if (!r || !header1 || !seq1 || !header2 || !seq2) return SMR_ERR_ARG;
+  bool hit[2] = {false, false};
+  std::vector<Aln> alns[2];
+  if (!parse_record(record1, record1_len, hit[0], alns[0]) || !parse_record(record2, record2_len, hit[1], alns[1])) { r->err = "malformed record"; return SMR_ERR_ARG; }
+  const char* hd[2] = {header1, header2}; const char* sq[2] = {seq1, seq2}; const char* ql[2] = {qual1, qual2};
+  const bool both = hit[0] && hit[1], any = hit[0] || hit[1];
+  const smr_report_opts& o = r->o;
+  // aligned.* (ReportFastx::append): nothing when neither mate aligned
+  if (any) {
+    for (int i = 0; i < 2; i++) {
+      int idx = -1;
+      if (r->num_out == 1) { if (o.paired_out ? both : (o.paired_in || hit[i])) idx = 0; }
+      else if (r->num_out == 2 && o.out2) { if (o.paired_out) { if (!both) break; idx = i; } else if (o.paired_in || hit[i]) idx = i; }
+      else if (r->num_out == 2) { if (both) idx = 0; else if (hit[i]) idx = 1; }                    // sout: pairs | singletons
+      else { if (both) idx = i; else if (hit[i]) idx = i + 2; }
+      if (idx >= 0) write_fx(r, r->f_aligned[idx], hd[i], sq[i], ql[i]);
+    }
   }
+  // other.* (ReportFxOther::append): nothing when both mates aligned
+  if (!both) {
+    for (int i = 0; i < 2; i++) {
+      int idx = -1;
+      if (r->num_out == 1) { if (o.paired_in ? !any : (o.paired_out || !hit[i])) idx = 0; }
+      else if (r->num_out == 2 && o.out2) { if (o.paired_in) { if (any) break; idx = i; } else if (o.paired_out || !hit[i]) idx = i; }
+      else if (r->num_out == 2) { if (!any) idx = 0; else if (!hit[i]) idx = 1; }
+      else { if (!any) idx = i; else if (!hit[i]) idx = i + 2; }
+      if (idx >= 0) write_fx(r, r->f_other[idx], hd[i], sq[i], ql[i]);
+    }
+  }
+  for (int i = 0; i < 2; i++) { const int rc = add_rows(r, hd[i], sq[i], ql[i], alns[i]); if (rc != SMR_OK) return rc; }
+  return SMR_OK;
+}
+
+namespace {
+int add_rows(smr_report* r, const char* header, const char* seq, const char* qual, const std::vector<Aln>& alns) {
   if (alns.empty() || (!r->o.blast_tabular && !r->o.blast_pairwise && !r->o.sam)) return SMR_OK;
   // Read::getSeqId (read.cpp:371-377)
   std::string id(header);
@@ -221,12 +279,12 @@ extern "C" int smr_report_add(smr_report* r, const char* header, const char* seq
   }
   return SMR_OK;
 }
+}  // namespace
 
 extern "C" int smr_report_close(smr_report* r) {
   if (!r) return SMR_ERR_ARG;
   int rc = SMR_OK;
-  if (r->f_aligned) fclose(r->f_aligned);
-  if (r->f_other) fclose(r->f_other);
+  for (int j = 0; j < 4; j++) { if (r->f_aligned[j]) fclose(r->f_aligned[j]); if (r->f_other[j]) fclose(r->f_other[j]); }
   if (r->o.blast_tabular || r->o.blast_pairwise) {
     FILE* f = fopen((r->dir + "/aligned.blast").c_str(), "wb");
     if (!f) rc = SMR_ERR_IO; else { for (auto& kv : r->blast) fwrite(kv.second.data(), 1, kv.second.size(), f); fclose(f); }

@@ -14,7 +14,8 @@ def corrected_sizes(K, info, all_reads_count, all_reads_len):
 
 
 class Report:
-    def __init__(self, out_dir, is_fastq, fastx=True, other=True, blast_cols=None, sam=False, blast_pairwise=False, sam_sq=False, cmdline=None):
+    def __init__(self, out_dir, is_fastq, fastx=True, other=True, blast_cols=None, sam=False, blast_pairwise=False, sam_sq=False, cmdline=None,
+                 paired_in=False, paired_out=False, out2=False, sout=False):
         """blast_cols: None = no tabular BLAST report, else a list out of "cigar", "qcov", "qstrand" (output order);
         blast_pairwise: the `-blast 0` text instead; sam_sq: @SQ header lines (-SQ); cmdline: text of the SAM @PG CL: field"""
         self.L = capi.load()
@@ -23,6 +24,7 @@ class Report:
         o.blast_tabular = int(blast_cols is not None)
         o.blast_cols = " ".join(blast_cols or []).encode()
         o.blast_pairwise, o.sam_sq = int(blast_pairwise), int(sam_sq)
+        o.paired_in, o.paired_out, o.out2, o.sout = int(paired_in), int(paired_out), int(out2), int(sout)
         h = C.c_void_p()
         err = C.create_string_buffer(512)
         rc = self.L.smr_report_open(out_dir.encode(), C.byref(o), int(is_fastq), C.byref(h), err, 512)
@@ -45,6 +47,12 @@ class Report:
     def add(self, header, seq, qual, record):
         self._chk(self.L.smr_report_add(self.h, header.encode(), seq.encode(), qual.encode() if qual else None, record, len(record)),
                   "smr_report_add")
+
+    def add_pair(self, mate1, mate2):
+        """mate = (header, seq, qual, record): routed like the reference's paired FASTX reports (-paired_in / -paired_out / -out2 / -sout)"""
+        (h1, s1, q1, r1), (h2, s2, q2, r2) = mate1, mate2
+        self._chk(self.L.smr_report_add_pair(self.h, h1.encode(), s1.encode(), q1.encode() if q1 else None, r1, len(r1),
+                                             h2.encode(), s2.encode(), q2.encode() if q2 else None, r2, len(r2)), "smr_report_add_pair")
 
     def close(self):
         if self.h:

@@ -74,6 +74,41 @@ def _check_case(exe, case, tmp_path):
         assert body(open(out2 / "aligned.log").read()) == body(open(os.path.join(r2, case + ".log.txt")).read())
 
 
+def _check_paired(exe, tmp_path):
+    """two mate files, -paired_in -out2: the files of tests/golden/paired (written by the reference) and its per-read records"""
+    import json
+    import struct
+    pd = os.path.join(paths.REPO, "tests", "golden", "paired")
+    g = json.load(open(os.path.join(pd, "paired.json")))
+    db = os.path.join(paths.REPO, "tests", "golden", "real_db.fasta")
+    log = g["two_files"]["log"]
+    for variant in ("paired_in_out2", "sout"):
+        out = tmp_path / variant
+        os.makedirs(out)
+        subprocess.check_call([exe, "--ref", db, "--gumbel", repr(log["lambda"][0]), repr(log["K"][0]), "--reads", os.path.join(pd, "paired_1.fastq"),
+                               "--reads", os.path.join(pd, "paired_2.fastq"), "--out", str(out), "--fastx", "--other"] + g[variant]["options"])
+        got = {fn: [l.split()[0][1:] for l in open(out / fn).readlines()[0::4]] for fn in sorted(os.listdir(out)) if fn.endswith(".fq")}
+        assert got == g[variant]["files"], variant
+    kv = refrun.parse_kvdb_dump(str(out / "records.bin"))
+    b = open(os.path.join(pd, "paired.records.bin"), "rb").read()
+    (n,) = struct.unpack_from("<I", b, 0)
+    o = 4
+    for k in range(n):
+        (l,) = struct.unpack_from("<I", b, o)
+        assert kv.get(b"%d_%d" % (k & 1, k >> 1), b"") == b[o + 4:o + 4 + l], k
+        o += 4 + l
+    assert "Total reads = %d" % n in open(out / "aligned.log").read()
+
+
+@pytest.mark.gpu
+def test_driver_paired_reads(tmp_path):
+    _check_paired(build_driver(), tmp_path)
+
+
+def test_driver_paired_reads_on_the_kernel_emulator(tmp_path):
+    _check_paired(_emu_driver(), tmp_path)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["syn_default", "syn_all", "two_db_default"])
 def test_driver_reproduces_reference_records(case, tmp_path):
@@ -83,9 +118,13 @@ def test_driver_reproduces_reference_records(case, tmp_path):
 @pytest.mark.parametrize("case", ["syn_default", "two_db_default"])
 def test_driver_on_the_kernel_emulator(case, tmp_path):
     """the same driver source linked with tests/emu's host build of the kernels (development aid, see tests/test_emu_kernels.py)"""
+    _check_case(_emu_driver(), case, tmp_path)
+
+
+def _emu_driver():
     from helpers import emu
     lib = emu.build()
     exe = os.path.join(os.path.dirname(lib), "smr_align_emu")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(paths.REPO, "examples", "smr_align.cpp"),
                            "-I", os.path.join(paths.REPO, "include"), lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
-    _check_case(exe, case, tmp_path)
+    return exe

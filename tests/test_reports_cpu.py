@@ -92,3 +92,52 @@ def test_pairwise_blast_sq_header_and_summary_equal_the_reference(case, tmp_path
                          [os.path.basename(rd)], rs["all_reads_count"], rs["num_aligned"], rs["all_reads_len"], rs["min_read_len"], rs["max_read_len"],
                          mismatch=mismatch, score_N=mismatch, sam_sq=True, threads=1, cmdline=lines[1][4:], pid="", timestamp=ts)
     assert open(tmp_path / "aligned.log").read() == log_exp
+
+
+PAIRED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "paired")
+
+
+def _paired_inputs():
+    import json
+    import struct
+    g = json.load(open(os.path.join(PAIRED, "paired.json")))
+    m1 = fastx.read_fastx(os.path.join(PAIRED, "paired_1.fastq"))
+    m2 = fastx.read_fastx(os.path.join(PAIRED, "paired_2.fastq"))
+    b = open(os.path.join(PAIRED, "paired.records.bin"), "rb").read()
+    (n,) = struct.unpack_from("<I", b, 0)
+    o, recs = 4, []
+    for _ in range(n):
+        (l,) = struct.unpack_from("<I", b, o)
+        recs.append(b[o + 4:o + 4 + l])
+        o += 4 + l
+    assert n == 2 * len(m1) == 2 * len(m2)
+    return g, m1, m2, recs
+
+
+@pytest.mark.parametrize("variant", ["two_files", "paired_in", "paired_out", "out2", "paired_in_out2", "paired_out_out2", "sout", "out2_sout"])
+def test_paired_fastx_reports_equal_the_reference(variant, tmp_path):
+    """two mate files with -paired_in / -paired_out / -out2 / -sout: smr_report_add_pair writes the files the unmodified reference writes
+    (names, which read goes where, order): ReportFastx::append report_fastx.cpp:57-133, ReportFxOther::append report_fx_other.cpp:49-113"""
+    g, m1, m2, recs = _paired_inputs()
+    opt = g[variant]["options"]
+    rep = report.Report(str(tmp_path), is_fastq=True, fastx=True, other=True, paired_in="-paired_in" in opt, paired_out="-paired_out" in opt,
+                        out2="-out2" in opt, sout="-sout" in opt)
+    for i in range(len(m1)):
+        rep.add_pair(m1[i] + (recs[2 * i],), m2[i] + (recs[2 * i + 1],))
+    rep.close()
+    got = {fn: [l.split()[0][1:] for l in open(tmp_path / fn).readlines()[0::4]] for fn in sorted(os.listdir(tmp_path)) if fn.endswith(".fq")}
+    assert got == g[variant]["files"]
+    # and the records themselves are copied verbatim
+    by_id = {r[0].split()[0][1:]: r for r in m1 + m2}
+    for fn, ids in got.items():
+        lines = open(tmp_path / fn).read().split("\n")
+        for k, rid in enumerate(ids[:20]):
+            h, s, q = by_id[rid]
+            assert lines[4 * k:4 * k + 4] == [h, s, "+", q]
+
+
+def test_invalid_pairing_options_are_rejected(tmp_path):
+    with pytest.raises(smr.SmrError):
+        report.Report(str(tmp_path), is_fastq=True, paired_in=True, paired_out=True)
+    with pytest.raises(smr.SmrError):
+        report.Report(str(tmp_path), is_fastq=True, paired_in=True, sout=True)
