@@ -100,11 +100,6 @@ def _check_paired(exe, tmp_path):
     assert "Total reads = %d" % n in open(out / "aligned.log").read()
 
 
-@pytest.mark.gpu
-def test_driver_paired_reads(tmp_path):
-    _check_paired(build_driver(), tmp_path)
-
-
 def test_driver_paired_reads_on_the_kernel_emulator(tmp_path):
     _check_paired(_emu_driver(), tmp_path)
 

@@ -74,3 +74,9 @@ def test_device_index_build_equals_the_host_build(engine, wl, tmp_path):
     recs_dev = engine.records()
     recs_host, _ = wl.gpu_records(engine)
     assert recs_dev == recs_host
+
+
+def test_cpp_driver_with_two_mate_files(tmp_path):
+    """examples/smr_align.cpp with two mate files (two resident batches) and -paired_in -out2 / -sout: the reference's output files and records"""
+    import test_cpp_driver as drv
+    drv._check_paired(drv.build_driver(), tmp_path)
