@@ -25,6 +25,7 @@ struct Db { std::string fasta, idx_prefix; double lambda = 0.618874, K = 0.34323
 int main(int argc, char** argv) {
   std::vector<Db> dbs;
   std::vector<std::string> reads_paths; std::string out_dir = ".";
+  int zip_out = -1;                                         // -1: like the reads file (options.hpp zip_out, report_fx_base.cpp:94)
   smr_params base; smr_params_default(&base);
   double evalue = 1.0;
   int device = 0;
@@ -59,6 +60,7 @@ int main(int argc, char** argv) {
     else if (a == "-paired_out" || a == "--paired_out") ro.paired_out = 1;
     else if (a == "-out2" || a == "--out2") ro.out2 = 1;
     else if (a == "-sout" || a == "--sout") ro.sout = 1;
+    else if (a == "-zip-out" || a == "--zip-out") { const std::string v = val(); zip_out = (v == "1" || v == "true" || v == "t" || v == "yes" || v == "y") ? 1 : 0; }
     else if (a == "-blast" || a == "--blast") {            // "1" = tabular, optionally followed by cigar / qcov / qstrand (options.cpp opt_blast)
       const std::string v = val();
       if (v == "0") { ro.blast_pairwise = 1; continue; }   // BLAST-like pairwise text
@@ -72,7 +74,7 @@ int main(int argc, char** argv) {
       printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq[.gz] [--reads MATES] [--out DIR]\n"
              "       [-e EVALUE] [-num_alignments N] [-no-best] [-min_lis N] [-num_seeds N] [-edges N] [-full_search] [-F|-R]\n"
              "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '0' | '1 cigar qcov qstrand'] [--sam [-SQ]]\n"
-             "       [-paired_in | -paired_out] [-out2] [-sout]     (two --reads files, or one interleaved file with -paired_in / -paired_out)\n");
+             "       [-zip-out 0|1] [-paired_in | -paired_out] [-out2] [-sout]     (two --reads files, or one interleaved file with -paired_in / -paired_out)\n");
       return 0;
     } else die("unknown option " + a);
   }
@@ -90,6 +92,12 @@ int main(int argc, char** argv) {
   }
   if (n == 0) min_len = 0;
   const bool is_fastq = smr_reads_is_fastq(rf[0]) != 0;
+  if (zip_out == -1) {                                      // gzip reports for a gzip reads file
+    unsigned char mg[2] = {0, 0};
+    if (FILE* fz = fopen(reads_paths[0].c_str(), "rb")) { if (fread(mg, 1, 2, fz) != 2) mg[0] = 0; fclose(fz); }
+    zip_out = (mg[0] == 0x1f && mg[1] == 0x8b) ? 1 : 0;
+  }
+  ro.zip_out = zip_out;
   const bool paired = rf.size() == 2 || ro.paired_in || ro.paired_out;
   if (rf.size() == 2 && smr_reads_count(rf[0]) != smr_reads_count(rf[1])) die("the two --reads files hold different numbers of reads");
   if (rf.size() == 1 && paired && (smr_reads_count(rf[0]) & 1)) die("-paired_in / -paired_out with one file: odd number of reads");

@@ -248,6 +248,7 @@ typedef struct {
   int paired_out;        /* -paired_out: ... goes to other.* entirely                              */
   int out2;              /* -out2: separate files for the mates: *_fwd / *_rev                     */
   int sout;              /* -sout: separate files for pairs and singletons: *_paired / *_singleton */
+  int zip_out;           /* gzip every report file, names + ".gz" (the reference does so for gzip reads files or -zip-out 1, report_fx_base.cpp:94-95) */
 } smr_report_opts;
 int smr_report_open(const char* out_dir, const smr_report_opts*, int is_fastq, smr_report** out, char* err, size_t errcap);
 /* per --ref: Gumbel parameters and the corrected sizes (smr_refstats_corrected); per (index, part): where its reference ids/sequences are */

@@ -27,7 +27,7 @@ class IndexInfo(C.Structure):
 
 class ReportOpts(C.Structure):
     _fields_ = [("fastx", C.c_int), ("other", C.c_int), ("blast_tabular", C.c_int), ("blast_cols", C.c_char * 64), ("sam", C.c_int),
-                ("blast_pairwise", C.c_int), ("sam_sq", C.c_int), ("paired_in", C.c_int), ("paired_out", C.c_int), ("out2", C.c_int), ("sout", C.c_int)]
+                ("blast_pairwise", C.c_int), ("sam_sq", C.c_int), ("paired_in", C.c_int), ("paired_out", C.c_int), ("out2", C.c_int), ("sout", C.c_int), ("zip_out", C.c_int)]
 
 
 class SummaryDb(C.Structure):

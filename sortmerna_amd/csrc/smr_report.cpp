@@ -19,9 +19,23 @@
 #include <string>
 #include <vector>
 
+#include <zlib.h>
+
 #include "smr_host.hpp"
 
 namespace {
+// one report file, plain or gzip (the reference deflates its reports when the reads file is gzip, or with -zip-out; the names get ".gz")
+struct Out {
+  FILE* f = nullptr; gzFile g = nullptr;
+  bool open(const std::string& path, bool zip) {
+    if (zip) { g = gzopen((path + ".gz").c_str(), "wb"); return g != nullptr; }
+    f = fopen(path.c_str(), "wb"); return f != nullptr;
+  }
+  bool is_open() const { return f || g; }
+  void put(const void* p, size_t n) { if (!n) return; if (g) gzwrite(g, p, (unsigned)n); else if (f) fwrite(p, 1, n, f); }
+  void put(const std::string& t) { put(t.data(), t.size()); }
+  void close() { if (g) gzclose(g); if (f) fclose(f); g = nullptr; f = nullptr; }
+};
 struct Aln {
   std::vector<uint32_t> cigar;
   uint32_t ref_num = 0; int32_t ref_begin1 = 0, ref_end1 = 0, read_begin1 = 0, read_end1 = 0; uint32_t readlen = 0;
@@ -65,7 +79,7 @@ std::string cigar_text(const Aln& a, size_t readlen) {        // soft clips as r
 
 struct smr_report {
   std::string dir; smr_report_opts o; bool fastq = false;
-  FILE* f_aligned[4] = {nullptr, nullptr, nullptr, nullptr}; FILE* f_other[4] = {nullptr, nullptr, nullptr, nullptr};
+  Out f_aligned[4], f_other[4];
   int num_out = 1;                                                     // ReportFxBase::set_num_out (report_fx_base.cpp:163-169)
   std::map<uint32_t, Db> dbs;
   std::map<std::pair<uint32_t, uint32_t>, const smr_index*> parts;
@@ -91,12 +105,12 @@ extern "C" int smr_report_open(const char* out_dir, const smr_report_opts* opts,
   };
   bool ok = true;
   for (int j = 0; j < r->num_out; j++) {
-    if (opts->fastx) { r->f_aligned[j] = fopen((r->dir + "/aligned" + sfx(j) + ext).c_str(), "wb"); ok = ok && r->f_aligned[j]; }
-    if (opts->other) { r->f_other[j] = fopen((r->dir + "/other" + sfx(j) + ext).c_str(), "wb"); ok = ok && r->f_other[j]; }
+    if (opts->fastx) ok = r->f_aligned[j].open(r->dir + "/aligned" + sfx(j) + ext, opts->zip_out != 0) && ok;
+    if (opts->other) ok = r->f_other[j].open(r->dir + "/other" + sfx(j) + ext, opts->zip_out != 0) && ok;
   }
   if (!ok) {
     if (err && errcap) snprintf(err, errcap, "cannot create report files in %s", out_dir);
-    for (int j = 0; j < 4; j++) { if (r->f_aligned[j]) fclose(r->f_aligned[j]); if (r->f_other[j]) fclose(r->f_other[j]); }
+    for (int j = 0; j < 4; j++) { r->f_aligned[j].close(); r->f_other[j].close(); }
     delete r; return SMR_ERR_IO;
   }
   *out = r;
@@ -117,10 +131,11 @@ extern "C" int smr_report_set_part(smr_report* r, uint32_t index_num, uint32_t p
 }
 
 namespace {
-void write_fx(const smr_report* r, FILE* f, const char* header, const char* seq, const char* qual) {      // the record as read (report_fx_base.cpp:176-181)
-  if (!f) return;
-  fprintf(f, "%s\n%s\n", header, seq);
-  if (r->fastq) fprintf(f, "+\n%s\n", qual ? qual : "");
+void write_fx(smr_report* r, Out& f, const char* header, const char* seq, const char* qual) {      // the record as read (report_fx_base.cpp:176-181)
+  if (!f.is_open()) return;
+  std::string t(header); t += '\n'; t += seq; t += '\n';
+  if (r->fastq) { t += "+\n"; t += qual ? qual : ""; t += '\n'; }
+  f.put(t);
 }
 int add_rows(smr_report* r, const char* header, const char* seq, const char* qual, const std::vector<Aln>& alns);
 }  // namespace
@@ -284,27 +299,27 @@ int add_rows(smr_report* r, const char* header, const char* seq, const char* qua
 extern "C" int smr_report_close(smr_report* r) {
   if (!r) return SMR_ERR_ARG;
   int rc = SMR_OK;
-  for (int j = 0; j < 4; j++) { if (r->f_aligned[j]) fclose(r->f_aligned[j]); if (r->f_other[j]) fclose(r->f_other[j]); }
+  for (int j = 0; j < 4; j++) { r->f_aligned[j].close(); r->f_other[j].close(); }
   if (r->o.blast_tabular || r->o.blast_pairwise) {
-    FILE* f = fopen((r->dir + "/aligned.blast").c_str(), "wb");
-    if (!f) rc = SMR_ERR_IO; else { for (auto& kv : r->blast) fwrite(kv.second.data(), 1, kv.second.size(), f); fclose(f); }
+    Out f;
+    if (!f.open(r->dir + "/aligned.blast", r->o.zip_out != 0)) rc = SMR_ERR_IO; else { for (auto& kv : r->blast) f.put(kv.second); f.close(); }
   }
   if (r->o.sam) {
-    FILE* f = fopen((r->dir + "/aligned.sam").c_str(), "wb");
-    if (!f) rc = SMR_ERR_IO;
+    Out f;
+    if (!f.open(r->dir + "/aligned.sam", r->o.zip_out != 0)) rc = SMR_ERR_IO;
     else {
-      fprintf(f, "@HD\tVN:1.0\tSO:unsorted\n");
+      f.put(std::string("@HD\tVN:1.0\tSO:unsorted\n"));
       if (r->o.sam_sq) {                                  // every sequence of every --ref, in --ref order (from <index>.stats)
         uint32_t last = 0xFFFFFFFFu;
         for (auto& kv : r->parts) {
           if (kv.first.first == last) continue;
           last = kv.first.first;
-          for (auto& sq : kv.second->sq_header) fprintf(f, "@SQ\tSN:%s\tLN:%u\n", sq.first.c_str(), sq.second);
+          for (auto& sq : kv.second->sq_header) f.put("@SQ\tSN:" + sq.first + "\tLN:" + std::to_string(sq.second) + "\n");
         }
       }
-      fprintf(f, "@PG\tID:sortmerna\tVN:1.0\tCL:%s\n", r->cmdline.c_str());
-      for (auto& kv : r->sam) fwrite(kv.second.data(), 1, kv.second.size(), f);
-      fclose(f);
+      f.put("@PG\tID:sortmerna\tVN:1.0\tCL:" + r->cmdline + "\n");
+      for (auto& kv : r->sam) f.put(kv.second);
+      f.close();
     }
   }
   delete r;

@@ -15,7 +15,7 @@ def corrected_sizes(K, info, all_reads_count, all_reads_len):
 
 class Report:
     def __init__(self, out_dir, is_fastq, fastx=True, other=True, blast_cols=None, sam=False, blast_pairwise=False, sam_sq=False, cmdline=None,
-                 paired_in=False, paired_out=False, out2=False, sout=False):
+                 paired_in=False, paired_out=False, out2=False, sout=False, zip_out=False):
         """blast_cols: None = no tabular BLAST report, else a list out of "cigar", "qcov", "qstrand" (output order);
         blast_pairwise: the `-blast 0` text instead; sam_sq: @SQ header lines (-SQ); cmdline: text of the SAM @PG CL: field"""
         self.L = capi.load()
@@ -25,6 +25,7 @@ class Report:
         o.blast_cols = " ".join(blast_cols or []).encode()
         o.blast_pairwise, o.sam_sq = int(blast_pairwise), int(sam_sq)
         o.paired_in, o.paired_out, o.out2, o.sout = int(paired_in), int(paired_out), int(out2), int(sout)
+        o.zip_out = int(zip_out)
         h = C.c_void_p()
         err = C.create_string_buffer(512)
         rc = self.L.smr_report_open(out_dir.encode(), C.byref(o), int(is_fastq), C.byref(h), err, 512)

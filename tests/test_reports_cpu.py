@@ -141,3 +141,28 @@ def test_invalid_pairing_options_are_rejected(tmp_path):
         report.Report(str(tmp_path), is_fastq=True, paired_in=True, paired_out=True)
     with pytest.raises(smr.SmrError):
         report.Report(str(tmp_path), is_fastq=True, paired_in=True, sout=True)
+
+
+def test_gzip_reports_hold_the_same_text(tmp_path):
+    """zip_out (the reference deflates its reports for gzip reads files / -zip-out 1 and appends .gz to the names): same text inside"""
+    import gzip
+    case = "syn_default"
+    g = golden.load()[case]
+    db, rd, _ = golden.inputs(case)
+    recs = golden.records(case)
+    reads = fastx.read_fastx(rd)
+    parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+    outs = {}
+    for z in (False, True):
+        d = tmp_path / ("z%d" % z)
+        os.makedirs(d)
+        rep = report.Report(str(d), is_fastq=False, fastx=True, other=True, blast_cols=["qstrand", "cigar"], sam=True, zip_out=z)
+        fr, fq = report.corrected_sizes(g["log"]["K"][0], parts[0].info(), g["readstats"]["all_reads_count"], g["readstats"]["all_reads_len"])
+        rep.set_db(0, g["log"]["lambda"][0], g["log"]["K"][0], fr, fq)
+        rep.set_part(0, 0, parts[0])
+        for (hdr, seq, qual), rec in zip(reads, recs):
+            rep.add(hdr, seq, qual, rec)
+        rep.close()
+        outs[z] = {fn: (gzip.open(d / fn).read() if z else open(d / fn, "rb").read()) for fn in sorted(os.listdir(d))}
+    assert sorted(outs[True]) == ["aligned.blast.gz", "aligned.fa.gz", "aligned.sam.gz", "other.fa.gz"]      # the reference's names
+    assert {k + ".gz": v for k, v in outs[False].items()} == outs[True]
