@@ -59,6 +59,19 @@ def main():
                     f.write(struct.pack("<I", len(r)))
                     f.write(r)
             G[name]["log"] = res.log
+    # one interleaved file (mate 1, mate 2, mate 1, ...) with -paired_in / -paired_out
+    inter = os.path.join(tmp, "interleaved.fastq")
+    a, b = open(rd[0]).readlines(), open(rd[1]).readlines()
+    with open(inter, "w") as f:
+        for i in range(N_PAIRS):
+            f.writelines(a[4 * i:4 * i + 4]); f.writelines(b[4 * i:4 * i + 4])
+    for name, extra in (("interleaved_paired_in", ["-paired_in"]), ("interleaved_paired_out_out2", ["-paired_out", "-out2"])):
+        res = refrun.run_reference([db], [inter], os.path.join(tmp, name), extra=extra + ["-fastx", "-other", "-v"], threads=1)
+        assert res.rc == 0, res.stdout[-2000:]
+        o = os.path.join(tmp, name, "out")
+        files = {fn: [l.split()[0][1:] for l in open(os.path.join(o, fn)).readlines()[0::4]] for fn in sorted(os.listdir(o)) if fn.endswith(".fq")}
+        G[name] = dict(options=extra, files=files)
+        print(name, {k: len(v) for k, v in files.items()})
     json.dump(G, open(os.path.join(out, "paired.json"), "w"), indent=0, sort_keys=True)
     shutil.rmtree(tmp, ignore_errors=True)
 

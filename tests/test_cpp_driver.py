@@ -89,6 +89,19 @@ def _check_paired(exe, tmp_path):
                                "--reads", os.path.join(pd, "paired_2.fastq"), "--out", str(out), "--fastx", "--other"] + g[variant]["options"])
         got = {fn: [l.split()[0][1:] for l in open(out / fn).readlines()[0::4]] for fn in sorted(os.listdir(out)) if fn.endswith(".fq")}
         assert got == g[variant]["files"], variant
+    # one interleaved file
+    inter = str(tmp_path / "interleaved.fastq")
+    a, b2 = open(os.path.join(pd, "paired_1.fastq")).readlines(), open(os.path.join(pd, "paired_2.fastq")).readlines()
+    with open(inter, "w") as f:
+        for i in range(len(a) // 4):
+            f.writelines(a[4 * i:4 * i + 4])
+            f.writelines(b2[4 * i:4 * i + 4])
+    for variant in ("interleaved_paired_in", "interleaved_paired_out_out2"):
+        o2 = tmp_path / variant
+        os.makedirs(o2)
+        subprocess.check_call([exe, "--ref", db, "--gumbel", repr(log["lambda"][0]), repr(log["K"][0]), "--reads", inter, "--out", str(o2), "--fastx", "--other"] + g[variant]["options"])
+        got = {fn: [l.split()[0][1:] for l in open(o2 / fn).readlines()[0::4]] for fn in sorted(os.listdir(o2)) if fn.endswith(".fq")}
+        assert got == g[variant]["files"], variant
     kv = refrun.parse_kvdb_dump(str(out / "records.bin"))
     b = open(os.path.join(pd, "paired.records.bin"), "rb").read()
     (n,) = struct.unpack_from("<I", b, 0)
