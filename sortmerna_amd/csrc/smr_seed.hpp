@@ -107,7 +107,7 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 // are applied exactly.
 //
 //   k_seed_keys         window -> forward and reverse (key, rank in bin, payload)  [9-mer hash, lookup probes, flip34 view]
-//   k_seed_scan         exclusive scan of the bin counts
+//   k_scan_tile/add     exclusive scan of the bin counts (tiled; smr_ibuild.hpp)
 //   k_seed_scatter      tuples to bin order
 //   k_seed_bfs<DIR>     the searches, work-queue formulation (smr_seed_bfs.hpp) -- the default
 //   k_seed_search<DIR>  the searches, per-lane DFS formulation (below): overflow redo + exact work counters
@@ -252,28 +252,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
   }
 }
 
-// one block of 1024 threads: exclusive scan of hist (tuple offsets of the bins)
-__global__ void __launch_bounds__(1024) k_seed_scan(SeedBufs sb) {
-  __shared__ uint32_t s_a[1024];
-  const uint32_t t = threadIdx.x;
-  const uint32_t per = (sb.nk + 1023) / 1024;
-  const uint32_t lo = t * per, hi = min(lo + per, sb.nk);
-  uint32_t a = 0;
-  for (uint32_t i = lo; i < hi; i++) a += sb.hist[i];
-  s_a[t] = a;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {
-    uint32_t va = 0;
-    if (t >= d) va = s_a[t - d];
-    __syncthreads();
-    s_a[t] += va;
-    __syncthreads();
-  }
-  uint32_t oa = s_a[t] - a;
-  for (uint32_t i = lo; i < hi; i++) { sb.bin_off[i] = oa; oa += sb.hist[i]; }
-  if (t == 1023) sb.bin_off[sb.nk] = s_a[1023];
-}
-
+// (the bin offsets = exclusive scan of hist are computed by k_scan_tile / k_scan_add of smr_ibuild.hpp, see launch_seed)
 __global__ void __launch_bounds__(256) k_seed_scatter(SeedBufs sb) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = min(sb.sn[SN_TUPLES], sb.cap_tuples);
