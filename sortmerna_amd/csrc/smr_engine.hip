@@ -214,6 +214,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
   const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
   sb.cap_tuples = (uint32_t)(2 * slots);
+  sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_bfs = (size_t)BFS_LDS_WORDS(c->hcap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
@@ -222,6 +223,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   // one counting sort for the forward and the reverse tuples of the stage
   HIPCHK(c, hipMemsetAsync(sb.hist, 0, ((size_t)sb.nk + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
+  if (slots) HIPCHK(c, hipMemsetAsync(sb.wseg, 0xFF, (size_t)slots * 4, c->stream));       // NONE: no window has hits yet
   hipLaunchKernelGGL(k_seed_keys, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
   {  // bin offsets = exclusive scan of the histogram (bin_off[nk] = number of tuples): tiles of 2048 bins, at most 2048 tiles (L <= 20)
     const uint64_t nscan = (uint64_t)sb.nk + 1;

@@ -146,11 +146,13 @@ struct SeedBufs {
   SeedTmp* tmp;              // unsorted tuples
   unsigned long long* tup;   // payloads in key order
   uint32_t* tkey;            // keys in key order
-  uint32_t* wseg;            // [n * maxwin] pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
+  uint32_t* wseg;            // [maxwin][n] (window-major: k_seed_finish's threads = reads read it coalesced) pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
   uint32_t* sn;              // SN_* counters
   uint32_t* redo;            // waves of k_seed_bfs to be searched again by k_seed_search
   uint32_t nk, nkh, maxwin, cap_tuples, cap_redo;     // nk = 2 * nkh bins: forward keys [0, nkh), reverse keys [nkh, 2 nkh)
+  uint32_t n;                // reads in the batch
 };
+__device__ __forceinline__ size_t wseg_slot(const SeedBufs& sb, uint32_t r, uint32_t k) { return (size_t)k * sb.n + r; }
 
 // nbits <= 40 bits starting at bit `bit0` of a little-endian word stream (reads up to 2 words past the first)
 __device__ __forceinline__ unsigned long long extract_bits(const uint32_t* w, uint32_t bit0, uint32_t nbits) {
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     bool mine = k < numwin;
     const uint32_t win_pos = k * stride;
     if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
-    if (active) sb.wseg[(size_t)r * sb.maxwin + k] = NONE;
+    // (wseg starts as NONE everywhere: launch_seed fills it)
     if (mine) {
       // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
       const uint32_t aval = w.is04 ? 0 : w.aval;
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     const Lookup lk = ix.lookup[sb.tkey[pos] - (DIR ? sb.nkh : 0u)];
     root = DIR == 0 ? lk.rootF : lk.rootR;
     r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
-    slot = (size_t)r * sb.maxwin + win_pos / P.skip[pass];
+    slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
     if (DIR == 1) {                                      // the window's list so far = the forward search's hits
       const uint32_t seg = sb.wseg[slot];
       if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
       uint32_t seeds = 0, total = 0, rlook = 0;
       for (uint32_t k = 0; k < numwin; k++) {
-        const uint32_t s = sb.wseg[(size_t)r * sb.maxwin + k];
+        const uint32_t s = sb.wseg[wseg_slot(sb, r, k)];
         bool searched = true;                                // windows of this pass: not searched by an earlier pass (:128-131)
         for (int q = 0; q < pass; q++) if ((k * stride) % P.skip[q] == 0) searched = false;
         if (searched && !(s != NONE && (s & SEED_ZERO_BIT))) rlook++;     // the reverse lookup happens unless the forward search hit exactly (:188-198)
@@ -565,7 +567,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       }
       uint32_t o = base;
       if (total) for (uint32_t k = 0; k < numwin; k++) {
-        const uint32_t s = sb.wseg[(size_t)r * sb.maxwin + k];
+        const uint32_t s = sb.wseg[wseg_slot(sb, r, k)];
         if (s == NONE) continue;
         const uint32_t sg = s & ~SEED_ZERO_BIT, c = pool[sg + 1];
         for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];

@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
     pat[lane] = (uint32_t)(pl >> 40);
-    slot = (size_t)r * sb.maxwin + win_pos / P.skip[pass];
+    slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
     if (DIR == 1) {                                      // the window's list so far = the forward search's hits
       const uint32_t seg = sb.wseg[slot];
       if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
