@@ -526,8 +526,8 @@ __global__ void __launch_bounds__(64) k_sw_selfcheck(uint32_t n_cases, uint32_t 
 extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uint32_t max_len, uint64_t* n_bad) {
   if (!c || !n_bad || max_len == 0 || max_len > 4000) return SMR_ERR_ARG;
   (void)hipSetDevice(c->device);
-  unsigned long long* d = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d, 3 * 8));
+  DevPool pool;
+  IB_GET(d, unsigned long long, 3);
   HIPCHK(c, hipMemsetAsync(d, 0, 3 * 8, c->stream));
   const uint32_t lm = (max_len + 15) & ~15u, ln = (max_len + max_len / 16 + 64 + 15) & ~15u;
   const size_t lds = (size_t)lm + ln + (size_t)2 * ln * 4;
@@ -538,7 +538,6 @@ extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uin
   unsigned long long h[3] = {0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(h, d, 3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d);
   if (h[0] != 2ull * n_cases) { c->err = "SW self-check did not run all cases"; return SMR_ERR_DEVICE; }
   *n_bad = h[1];
   return SMR_OK;
