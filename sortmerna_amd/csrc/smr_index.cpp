@@ -11,6 +11,7 @@
 //   minimal score       refstats.cpp:238-265
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -403,6 +404,18 @@ bool parse_fasta(const std::vector<uint8_t>& b, std::vector<SeqRec>& recs, std::
   return true;
 }
 
+// SMR_IB_TIMING=1: stage times of the index build on stderr
+struct StageTimer {
+  bool on = getenv("SMR_IB_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[smr index build] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
 template <class F> void parallel_for(uint32_t threads, size_t n, F f) {
   if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
   std::vector<std::thread> th;
@@ -577,6 +590,7 @@ int ib_part_host(void*, const smr::IBuildInput& in, smr_index& ix, std::string& 
     uint64_t N = occ_start.back();
     int occbits = 1; while ((1ull << occbits) < N) occbits++;
     if ((int)(2 * L) + occbits > 64) { why = "part too large for the builder (reduce -m)"; return SMR_ERR_ARG; }
+    StageTimer tm;
     std::vector<uint64_t> keys(N);
     std::vector<uint8_t> last_nt(N);     // nt at position p+L of occurrence (the 19th)
     parallel_for(threads, in.n_seqs, [&](size_t lo, size_t hi, uint32_t) {
@@ -593,47 +607,87 @@ int ib_part_host(void*, const smr::IBuildInput& in, smr_index& ix, std::string& 
         }
       }
     });
+    tm.lap("keys");
     bucket_sort_u64(keys, 2 * (int)L + occbits, threads);
+    tm.lap("sort");
     // ids, positions CSR, unique 19-mers
     const uint64_t occmask = (1ull << occbits) - 1;
     auto occ_to_seqpos = [&](uint64_t occ, uint32_t& seq, uint32_t& pos) {
       size_t m = std::upper_bound(occ_start.begin(), occ_start.end(), occ) - occ_start.begin() - 1;
       seq = (uint32_t)m; pos = (uint32_t)(occ - occ_start[m]);
     };
-    // F entries (keyF, tail, id) come out already sorted; R entries need regrouping by keyR
-    std::vector<uint64_t> fent;                       // (prefix19 code) kept implicit: we store key|tail|id in parallel arrays
-    std::vector<uint32_t> f_key; std::vector<uint64_t> f_tail_id;
-    std::vector<uint32_t> r_key; std::vector<uint64_t> r_tail_id;
-    ix.pos_off.assign(1, 0);
-    uint32_t id = 0;
-    for (uint64_t i = 0; i < N;) {
-      uint64_t pre = keys[i] >> occbits;
-      uint64_t j = i; uint32_t present = 0;
-      uint32_t stored = 0;
-      while (j < N && (keys[j] >> occbits) == pre) {
-        uint64_t occ = keys[j] & occmask;
-        present |= 1u << last_nt[occ];
-        if (max_pos == 0 || stored == 0 || stored < max_pos) {      // indexdb.cpp:318-349
-          uint32_t sq_, ps_; occ_to_seqpos(occ, sq_, ps_);
-          ix.pos_arr.push_back(ps_); ix.pos_arr.push_back(sq_); stored++;
-        }
-        j++;
-      }
-      ix.pos_off.push_back((uint32_t)(ix.pos_arr.size() / 2));
-      for (uint32_t c = 0; c < 4; c++) if (present & (1u << c)) {
-        uint64_t code19 = (pre << 2) | c;                         // 2W bits
-        uint32_t keyF = (uint32_t)(code19 >> (2 * T));            // first P nt
-        uint64_t tailF = code19 & ((1ull << (2 * T)) - 1);        // last T nt, MSB-first
-        f_key.push_back(keyF); f_tail_id.push_back((tailF << 32) | id);
-        uint32_t keyR = (uint32_t)(code19 & ((1ull << (2 * P)) - 1));   // last P nt
-        uint64_t head = code19 >> (2 * P);                        // first T nt, MSB-first
-        uint64_t tailR = 0;                                        // reversed head (indexdb.cpp:1441-1444)
-        for (uint32_t k = 0; k < T; k++) tailR = (tailR << 2) | ((head >> (2 * k)) & 3);
-        r_key.push_back(keyR); r_tail_id.push_back((tailR << 32) | id);
-      }
-      id++;
-      i = j;
+    // F entries (keyF, tail, id) come out already sorted; R entries need regrouping by keyR.
+    // The scan over the sorted windows runs in chunks that start at group heads: every chunk builds its ids (relative), position
+    // lists and entries locally, prefix sums give the chunk bases, then the pieces are copied to their final place.
+    struct Chunk {
+      uint64_t lo = 0, hi = 0; uint32_t n_ids = 0;
+      std::vector<uint32_t> pos_cnt, pos_arr, f_key, r_key; std::vector<uint64_t> f_tail_id, r_tail_id;
+    };
+    const size_t nchunk = std::max<size_t>(1, std::min<size_t>((size_t)threads * 4, N / 4096 + 1));
+    std::vector<Chunk> ch(nchunk);
+    for (size_t c = 0; c < nchunk; c++) {
+      uint64_t lo = N / nchunk * c;
+      while (c > 0 && lo < N && lo > 0 && (keys[lo] >> occbits) == (keys[lo - 1] >> occbits)) lo++;      // move to the next group head
+      ch[c].lo = lo;
     }
+    for (size_t c = 0; c < nchunk; c++) { ch[c].hi = c + 1 < nchunk ? ch[c + 1].lo : N; if (ch[c].hi < ch[c].lo) ch[c].hi = ch[c].lo; }
+    parallel_for(threads, nchunk, [&](size_t c0, size_t c1, uint32_t) {
+      for (size_t c = c0; c < c1; c++) {
+        Chunk& k = ch[c];
+        uint32_t id = 0;
+        for (uint64_t i = k.lo; i < k.hi;) {
+          const uint64_t pre = keys[i] >> occbits;
+          uint64_t j = i; uint32_t present = 0, stored = 0;
+          while (j < k.hi && (keys[j] >> occbits) == pre) {
+            const uint64_t occ = keys[j] & occmask;
+            present |= 1u << last_nt[occ];
+            if (max_pos == 0 || stored == 0 || stored < max_pos) {      // indexdb.cpp:318-349
+              uint32_t sq_, ps_; occ_to_seqpos(occ, sq_, ps_);
+              k.pos_arr.push_back(ps_); k.pos_arr.push_back(sq_); stored++;
+            }
+            j++;
+          }
+          k.pos_cnt.push_back(stored);
+          for (uint32_t cc = 0; cc < 4; cc++) if (present & (1u << cc)) {
+            const uint64_t code19 = (pre << 2) | cc;                       // 2W bits
+            const uint32_t keyF = (uint32_t)(code19 >> (2 * T));           // first P nt
+            const uint64_t tailF = code19 & ((1ull << (2 * T)) - 1);       // last T nt, MSB-first
+            k.f_key.push_back(keyF); k.f_tail_id.push_back((tailF << 32) | id);
+            const uint32_t keyR = (uint32_t)(code19 & ((1ull << (2 * P)) - 1));   // last P nt
+            const uint64_t head = code19 >> (2 * P);                       // first T nt, MSB-first
+            uint64_t tailR = 0;                                            // reversed head (indexdb.cpp:1441-1444)
+            for (uint32_t q = 0; q < T; q++) tailR = (tailR << 2) | ((head >> (2 * q)) & 3);
+            k.r_key.push_back(keyR); k.r_tail_id.push_back((tailR << 32) | id);
+          }
+          id++;
+          i = j;
+        }
+        k.n_ids = id;
+      }
+    });
+    std::vector<uint64_t> id_base(nchunk + 1, 0), pos_base(nchunk + 1, 0), ent_base(nchunk + 1, 0);
+    for (size_t c = 0; c < nchunk; c++) {
+      id_base[c + 1] = id_base[c] + ch[c].n_ids; pos_base[c + 1] = pos_base[c] + ch[c].pos_arr.size() / 2; ent_base[c + 1] = ent_base[c] + ch[c].f_key.size();
+    }
+    if (id_base[nchunk] > 0xFFFFFFF0ull || pos_base[nchunk] > 0xFFFFFFF0ull || ent_base[nchunk] > 0xFFFFFFF0ull) { why = "part too large for the builder (reduce -m)"; return SMR_ERR_ARG; }
+    std::vector<uint32_t> f_key(ent_base[nchunk]), r_key(ent_base[nchunk]); std::vector<uint64_t> f_tail_id(ent_base[nchunk]), r_tail_id(ent_base[nchunk]);
+    ix.pos_off.assign((size_t)id_base[nchunk] + 1, 0);
+    ix.pos_arr.resize((size_t)2 * pos_base[nchunk]);
+    parallel_for(threads, nchunk, [&](size_t c0, size_t c1, uint32_t) {
+      for (size_t c = c0; c < c1; c++) {
+        const Chunk& k = ch[c];
+        uint64_t po = pos_base[c];
+        for (uint32_t g = 0; g < k.n_ids; g++) { po += k.pos_cnt[g]; ix.pos_off[(size_t)id_base[c] + g + 1] = (uint32_t)po; }
+        if (!k.pos_arr.empty()) memcpy(ix.pos_arr.data() + 2 * pos_base[c], k.pos_arr.data(), k.pos_arr.size() * 4);
+        const size_t e0 = (size_t)ent_base[c];
+        for (size_t e = 0; e < k.f_key.size(); e++) {
+          f_key[e0 + e] = k.f_key[e]; r_key[e0 + e] = k.r_key[e];
+          f_tail_id[e0 + e] = k.f_tail_id[e] + id_base[c]; r_tail_id[e0 + e] = k.r_tail_id[e] + id_base[c];
+        }
+      }
+    });
+    ch.clear(); ch.shrink_to_fit();
+    tm.lap("ids, positions, entries");
     keys.clear(); keys.shrink_to_fit(); last_nt.clear(); last_nt.shrink_to_fit();
     const uint32_t NK = 1u << L;
     ix.lookup.assign(NK, Lookup{0, NONE, NONE, 0, 0});
@@ -649,6 +703,7 @@ int ib_part_host(void*, const smr::IBuildInput& in, smr_index& ix, std::string& 
     std::vector<size_t> fstart((size_t)NK + 1, 0);
     for (size_t i = 0; i < M; i++) fstart[f_key[i] + 1]++;
     for (uint32_t k = 0; k < NK; k++) fstart[k + 1] += fstart[k];
+    tm.lap("group reverse entries");
     // emit tries: size of every mini-trie (parallel) -> offsets -> layout (parallel); one function shared with the device builder
     const int burst_depth = (int)(W - P - 3);
     std::vector<uint64_t> toff((size_t)2 * NK + 1, 0);
@@ -685,6 +740,7 @@ int ib_part_host(void*, const smr::IBuildInput& in, smr_index& ix, std::string& 
         }
       }
     });
+    tm.lap("mini-tries");
   return SMR_OK;
 }
 
@@ -698,8 +754,10 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
   if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
   std::vector<uint8_t> file;
   if (!slurp(ref_fasta, file)) { set_err(err, errcap, std::string("cannot read ") + ref_fasta); return SMR_ERR_IO; }
+  StageTimer tmd;
   std::vector<SeqRec> recs; std::vector<uint8_t> raw; std::string why;
   if (!parse_fasta(file, recs, raw, why)) { set_err(err, errcap, why); return SMR_ERR_IO; }
+  tmd.lap("read + parse FASTA");
   const uint32_t W = L + 1;
   // STEP 1 statistics (indexdb.cpp:1198-1268)
   double bgc[4] = {0, 0, 0, 0}; uint64_t full_len = 0;
@@ -753,6 +811,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
       for (uint32_t k = 0; k < recs[s].len; k++) codes[o + k] = nt_index(raw[recs[s].seq_begin + k]);
       seq_off.push_back(codes.size());
     }
+    tmd.lap("statistics, refs, codes");
     smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
     const int rc = fn(user, in, *ix, why);
     if (rc != SMR_OK) { delete ix; set_err(err, errcap, why); return rc; }
