@@ -797,20 +797,20 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
     // sequences of this part (those skipped for size are not part of it); seq number = rank within the part
     std::vector<size_t> members;
     for (size_t s = pr[pi].s0; s < pr[pi].s1; s++) if ((double)(recs[s].len - W + 1) * 9.5e-6 <= max_mb) members.push_back(s);
-    // reference sequences for SW (nt_table)
-    ix->ref_off.assign(1, 0);
-    for (size_t s : members) {
-      for (uint32_t k = 0; k < recs[s].len; k++) ix->ref_seq.push_back(nt_sw(raw[recs[s].seq_begin + k]));
-      ix->ref_off.push_back(ix->ref_seq.size());
-    }
-    // nt codes of the index alphabet (map_nt) of the members, concatenated
-    std::vector<uint8_t> codes; std::vector<uint64_t> seq_off(1, 0);
-    for (size_t s : members) {
-      const size_t o = codes.size();
-      codes.resize(o + recs[s].len);
-      for (uint32_t k = 0; k < recs[s].len; k++) codes[o + k] = nt_index(raw[recs[s].seq_begin + k]);
-      seq_off.push_back(codes.size());
-    }
+    // reference sequences for SW (nt_table) and nt codes of the index alphabet (map_nt) of the members, concatenated
+    std::vector<uint64_t> seq_off(1, 0);
+    for (size_t s : members) seq_off.push_back(seq_off.back() + recs[s].len);
+    ix->ref_off = seq_off;
+    ix->ref_seq.resize(seq_off.back());
+    std::vector<uint8_t> codes(seq_off.back());
+    parallel_for(threads, members.size(), [&](size_t lo, size_t hi, uint32_t) {
+      for (size_t m = lo; m < hi; m++) {
+        const SeqRec& r = recs[members[m]];
+        const uint8_t* src = raw.data() + r.seq_begin;
+        uint8_t* d1 = ix->ref_seq.data() + seq_off[m]; uint8_t* d2 = codes.data() + seq_off[m];
+        for (uint32_t k = 0; k < r.len; k++) { d1[k] = nt_sw(src[k]); d2[k] = nt_index(src[k]); }
+      }
+    });
     tmd.lap("statistics, refs, codes");
     smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
     const int rc = fn(user, in, *ix, why);
