@@ -77,9 +77,20 @@ struct Block {                      // per host thread, reused for every block t
 };
 thread_local Block* tb = nullptr;
 
+// The running lane has blocked (or finished): hand the processor straight to the next runnable lane of its wave, if there is one
+// (half the context switches of going through the scheduler every time); the last one returns to the scheduler, which resolves.
 void yield_to_scheduler() {
   Block* b = tb;
-  Lane& l = b->lanes[b->running];
+  const int i = b->running;
+  Lane& l = b->lanes[i];
+  const int hi = std::min<int>((int)b->lanes.size(), (i | 63) + 1);
+  for (int j = i + 1; j < hi; j++) {
+    if (b->lanes[j].st != READY) continue;
+    b->running = j;
+    cur = b->base; cur.tid = b->lanes[j].tid;
+    emu_switch(&l.sp, b->lanes[j].sp);
+    return;
+  }
   emu_switch(&l.sp, b->sched_sp);
 }
 
