@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsmr_hip.so")
 SOURCES = ["smr_engine.hip", "smr_index.cpp", "smr_reads.cpp", "smr_report.cpp"]
-HEADERS = ["smr_kernels.hpp", "smr_seed.hpp", "smr_seed_bfs.hpp", "smr_chain.hpp", "smr_trace.hpp", "smr_host.hpp", os.path.join("..", "..", "include", "smr_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "smr_hip.h")]
 
 
 def _hipcc():
