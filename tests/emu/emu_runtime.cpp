@@ -284,14 +284,43 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   p->warpSize = 64; p->sharedMemPerBlock = 160 << 10;
   return hipSuccess;
 }
+// Device allocations end right before an inaccessible guard page (up to 255 bytes of slack for the 256-byte alignment) and start
+// after one: a kernel that runs past a buffer faults at once instead of corrupting a neighbour.  SMR_EMU_GUARD=0: plain malloc.
+namespace {
+struct GuardInfo { void* map; size_t map_n; };
+std::mutex g_guard_mu;
+std::vector<std::pair<void*, GuardInfo>> g_guard;
+bool guard_on() { static const bool on = !(getenv("SMR_EMU_GUARD") && atoi(getenv("SMR_EMU_GUARD")) == 0); return on; }
+}  // namespace
 hipError_t hipMalloc(void** p, size_t n) {
-  void* m = nullptr;
-  if (posix_memalign(&m, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
-  memset(m, 0xA5, n);           // fresh device memory is not zero: expose reads of uninitialised buffers
-  *p = m;
+  if (!guard_on()) {
+    void* m = nullptr;
+    if (posix_memalign(&m, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
+    memset(m, 0xA5, n);
+    *p = m;
+    return hipSuccess;
+  }
+  const size_t page = 4096, body = ((n ? n : 1) + 255 + page - 1) / page * page;
+  char* m = (char*)mmap(nullptr, body + 2 * page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (m == MAP_FAILED) return hipErrorOutOfMemory;
+  mprotect(m, page, PROT_NONE);
+  mprotect(m + page + body, page, PROT_NONE);
+  char* user = m + page + body - n;
+  user = (char*)((uintptr_t)user & ~(uintptr_t)255);
+  memset(user, 0xA5, n);           // fresh device memory is not zero: expose reads of uninitialised buffers
+  { std::lock_guard<std::mutex> g(g_guard_mu); g_guard.push_back({user, GuardInfo{m, body + 2 * page}}); }
+  *p = user;
   return hipSuccess;
 }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipFree(void* p) {
+  if (!p) return hipSuccess;
+  if (!guard_on()) { free(p); return hipSuccess; }
+  std::lock_guard<std::mutex> g(g_guard_mu);
+  for (size_t i = 0; i < g_guard.size(); i++)
+    if (g_guard[i].first == p) { munmap(g_guard[i].second.map, g_guard[i].second.map_n); g_guard[i] = g_guard.back(); g_guard.pop_back(); return hipSuccess; }
+  fprintf(stderr, "emu: hipFree of an unknown pointer %p\n", p);
+  abort();
+}
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }

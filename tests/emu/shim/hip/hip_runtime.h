@@ -8,7 +8,8 @@
 //   * a wave-level operation resolves when every unfinished lane of the wave has arrived at it -- and all of them
 //     must have arrived at the SAME call site: a shuffle/ballot executed by a divergent subset of a wave is
 //     reported as an error (on the hardware such lanes read 0 from the inactive ones, the bug class this catches);
-//   * blocks are distributed over host threads; atomics are real atomics; fresh device memory is filled with 0xA5.
+//   * blocks are distributed over host threads; atomics are real atomics; fresh device memory is filled with 0xA5 and lies
+//     between guard pages (an out-of-bounds access of a kernel faults at once).
 // Nothing under sortmerna_amd/ includes this file; libsmr_emu.so is built under tests/emu/_build only.
 #pragma once
 #include <chrono>
