@@ -693,16 +693,23 @@ int ib_part_host(void*, const smr::IBuildInput& in, smr_index& ix, std::string& 
     ix.lookup.assign(NK, Lookup{0, NONE, NONE, 0, 0});
     // group R by key (counting sort), sort each group by tail
     size_t M = f_key.size();
-    std::vector<size_t> rstart((size_t)NK + 1, 0);
-    for (size_t i = 0; i < M; i++) rstart[r_key[i] + 1]++;
-    for (uint32_t k = 0; k < NK; k++) rstart[k + 1] += rstart[k];
-    std::vector<uint64_t> rsorted(M);
-    { std::vector<size_t> cur(rstart.begin(), rstart.end() - 1); for (size_t i = 0; i < M; i++) rsorted[cur[r_key[i]]++] = r_tail_id[i]; }
-    r_tail_id.clear(); r_tail_id.shrink_to_fit(); r_key.clear(); r_key.shrink_to_fit();
+    std::vector<size_t> rstart((size_t)NK + 1, 0), fstart((size_t)NK + 1, 0);
+    {
+      std::vector<std::atomic<uint32_t>> cr(NK), cf(NK);            // value-initialised = 0
+      parallel_for(threads, M, [&](size_t lo, size_t hi, uint32_t) {
+        for (size_t i = lo; i < hi; i++) { cr[r_key[i]].fetch_add(1, std::memory_order_relaxed); cf[f_key[i]].fetch_add(1, std::memory_order_relaxed); }
+      });
+      for (uint32_t k = 0; k < NK; k++) { rstart[k + 1] = rstart[k] + cr[k].load(std::memory_order_relaxed); fstart[k + 1] = fstart[k] + cf[k].load(std::memory_order_relaxed); }
+      std::vector<uint64_t> rs(M);
+      for (uint32_t k = 0; k < NK; k++) cr[k].store(0, std::memory_order_relaxed);
+      parallel_for(threads, M, [&](size_t lo, size_t hi, uint32_t) {          // the order inside a key does not matter: every key is sorted next
+        for (size_t i = lo; i < hi; i++) rs[rstart[r_key[i]] + cr[r_key[i]].fetch_add(1, std::memory_order_relaxed)] = r_tail_id[i];
+      });
+      r_tail_id.swap(rs);
+    }
+    std::vector<uint64_t>& rsorted = r_tail_id;
+    r_key.clear(); r_key.shrink_to_fit();
     parallel_for(threads, NK, [&](size_t lo, size_t hi, uint32_t) { for (size_t k = lo; k < hi; k++) std::sort(rsorted.begin() + rstart[k], rsorted.begin() + rstart[k + 1]); });
-    std::vector<size_t> fstart((size_t)NK + 1, 0);
-    for (size_t i = 0; i < M; i++) fstart[f_key[i] + 1]++;
-    for (uint32_t k = 0; k < NK; k++) fstart[k + 1] += fstart[k];
     tm.lap("group reverse entries");
     // emit tries: size of every mini-trie (parallel) -> offsets -> layout (parallel); one function shared with the device builder
     const int burst_depth = (int)(W - P - 3);
