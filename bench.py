@@ -294,6 +294,17 @@ def main():
                 traffic = tj["seed_stage_bytes_per_launch"] * args.batch_reads / w["batch_reads"]
         except Exception:
             pass
+        # VALU model of the Smith-Waterman kernel: a wave64 VALU instruction occupies a SIMD for 4 cycles ->
+        # 256 CU x 4 SIMD x 2.4 GHz / 4 = 6.14e11 wave-instructions/s; one systolic step costs 13 R + 14 (packed, R = ceil(m/128) cell pairs)
+        # or 20 R + 15 (32-bit, R = ceil(m/64) cells) instructions and there are n + ceil(m/R) - 1 steps for an m x n problem
+        m_sw, n_sw = args.read_len, args.read_len + 8
+        if eng.sw_mode() == 1:
+            r_sw = (m_sw + 127) // 128
+            instr = (n_sw + (m_sw + r_sw - 1) // r_sw - 1) * (13 * r_sw + 14)
+        else:
+            r_sw = (m_sw + 63) // 64
+            instr = (n_sw + 63) * (20 * r_sw + 15)
+        sw_peak_gcups = m_sw * n_sw / (instr / 6.144e11) / 1e9
         out = {
             "metric": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "value": reads_timed / dt, "unit": "reads/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -313,7 +324,9 @@ def main():
                          "bytes_per_read": b_seed / reads_timed},
             "kernels": {"k_seed": {"ms": seed_ms / args.gpus, "launches": seed_l / args.gpus},
                         "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
-                                    "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6},
+                                    "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6,
+                                    "valu_model_peak_gcups": sw_peak_gcups * args.gpus,
+                                    "valu_model_frac": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6 / (sw_peak_gcups * args.gpus)},
                         "k_trace": {"ms": trace_ms / args.gpus, "launches": trace_l / args.gpus}},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -45,6 +45,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path):
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert out["counters"]["reads"] == 2 * 1500
+    assert out["kernels"]["k_chain"]["valu_model_peak_gcups"] > 0
     if baseline:
         cb = out["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["unit"] == "reads/s" and cb["cores"] == 2 and cb["value"] and cb["value"] > 0, cb
