@@ -43,6 +43,22 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
 
 
+def test_product_has_no_route_to_the_kernel_emulator():
+    """tests/emu is a development aid: the product's Python never loads it, the hipcc build never defines SMR_EMU (the few
+    `#ifdef SMR_EMU` lines in csrc/ only replace compiler intrinsics when tests/emu compiles the kernel sources for the host), and
+    libsmr_hip.so carries none of its symbols"""
+    import subprocess
+    for d, _, files in os.walk(os.path.join(paths.REPO, "sortmerna_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                t = open(os.path.join(d, f)).read()
+                assert "emu" not in t.replace("enumerate", ""), os.path.join(d, f)
+    from sortmerna_amd import build
+    assert "SMR_EMU" not in open(build.__file__).read()
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", build.LIB]).decode()
+    assert "emu" not in syms and "wave_exchange" not in syms
+
+
 def test_reads_pack_layout_and_ambiguity_mask():
     seqs = ["ACGTUacgtuNnRX", "", "A" * 33 + "N", "ACGT" * 40]
     r = smr.Reads.from_seqs(seqs)
