@@ -216,12 +216,13 @@ int smr_index_build_gpu(smr_ctx*, const char* ref_fasta, uint32_t lnwin, double 
 
 /* Device self-check: n_cases seeded random (read, reference window) pairs, 1..max_len nt, for two scoring schemes: the packed 16-bit
  * Smith-Waterman kernel against the 32-bit kernel (score, end cell; forward and reverse pass), both on the GPU.  smr_create runs it
- * (SMR_SW_SELFCHECK=<cases>, 0 = skip) and falls back to the 32-bit kernel if any case differs; SMR_SW_PACKED=0 disables the packed kernel. */
+ * (SMR_SW_SELFCHECK=<cases>, 0 = skip) and falls back to the 32-bit kernel if any case differs; SMR_SW_PACKED=0 disables the packed kernel,
+ * SMR_SW_PACKED=2 selects its wave_ror variant (the kernel checked is the selected one). */
 int smr_sw_selfcheck(smr_ctx*, uint32_t n_cases, uint32_t seed, uint32_t max_len, uint64_t* n_bad);
 int smr_sw_mode(smr_ctx*, int set_to);
 /* The SW kernels at the ssw.h seam: for n independent pairs (read / reference window in the 0..4 alphabet, pair i = bytes [off[i], off[i+1])),
  * what ssw_align(prof, ref, refLen, gapO, gapE, flag = 2, filters, 0, 0) returns without the CIGAR (ssw.h:118-140, ssw.c:834-941):
- * out[5 i ..] = {score1, ref_begin1, ref_end1, read_begin1, read_end1}, begins = -1 when score1 < filters.  mode 0 / 1 = 32-bit / packed kernel. */
+ * out[5 i ..] = {score1, ref_begin1, ref_end1, read_begin1, read_end1}, begins = -1 when score1 < filters.  mode 0 / 1 / 2 = 32-bit / packed / packed wave_ror kernel. */
 int smr_ssw_batch(smr_ctx*, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                   int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out);   /* set_to 0 / 1: use the 32-bit / the packed kernel; other values: query; returns the mode in use */
 int smr_prof_reset(smr_ctx*);

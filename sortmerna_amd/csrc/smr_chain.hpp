@@ -143,21 +143,24 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
 #include "smr_sw_pk.hpp"
 namespace smr {
 
-// mode 1: the packed 16-bit kernel (smr_sw_pk.hpp) where its preconditions hold; mode 0: always the 32-bit kernel
+// mode 1 / 2: the packed 16-bit kernel (smr_sw_pk.hpp; 2 = its wave_ror variant) where its preconditions hold; mode 0: always the 32-bit kernel
 __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                          int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
 #define SW_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge
-  if (mode == 1 && (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255) {
+  if (mode >= 1 && (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255) {
     bool hasn = false;
     for (int q = lane_id(); q < n; q += 64) hasn |= rfq[rf0 + rfstep * q] == 4;
-    if (__any(hasn)) {
-      if (m <= 128) return sw_wave_pk_r<1, true>(SW_ARGS);
-      if (m <= 256) return sw_wave_pk_r<2, true>(SW_ARGS);
-      return sw_wave_pk_r<4, true>(SW_ARGS);
+    const bool hn = __any(hasn);
+    if (mode == 2) {
+      if (hn) { if (m <= 128) return sw_wave_pk_r<1, true, true>(SW_ARGS); if (m <= 256) return sw_wave_pk_r<2, true, true>(SW_ARGS); return sw_wave_pk_r<4, true, true>(SW_ARGS); }
+      if (m <= 128) return sw_wave_pk_r<1, false, true>(SW_ARGS);
+      if (m <= 256) return sw_wave_pk_r<2, false, true>(SW_ARGS);
+      return sw_wave_pk_r<4, false, true>(SW_ARGS);
     }
-    if (m <= 128) return sw_wave_pk_r<1, false>(SW_ARGS);
-    if (m <= 256) return sw_wave_pk_r<2, false>(SW_ARGS);
-    return sw_wave_pk_r<4, false>(SW_ARGS);
+    if (hn) { if (m <= 128) return sw_wave_pk_r<1, true, false>(SW_ARGS); if (m <= 256) return sw_wave_pk_r<2, true, false>(SW_ARGS); return sw_wave_pk_r<4, true, false>(SW_ARGS); }
+    if (m <= 128) return sw_wave_pk_r<1, false, false>(SW_ARGS);
+    if (m <= 256) return sw_wave_pk_r<2, false, false>(SW_ARGS);
+    return sw_wave_pk_r<4, false, false>(SW_ARGS);
   }
   const bool small = (long long)m * match < 16384 && n < 65535 && match < 128 && mismatch > -128 && scoreN > -128 && scoreN < 128;
   if (small) {

@@ -475,7 +475,7 @@ __device__ __forceinline__ uint32_t sc_hash(uint32_t a, uint32_t b, uint32_t c) 
   return h;
 }
 __global__ void __launch_bounds__(64) k_sw_selfcheck(uint32_t n_cases, uint32_t seed, uint32_t max_m, uint32_t lds_m, uint32_t lds_n,
-                                                     int match, int mismatch, int scoreN, int go, int ge, unsigned long long* out) {
+                                                     int match, int mismatch, int scoreN, int go, int ge, int mode_b, unsigned long long* out) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   uint8_t* rdq = lds_raw;
   uint8_t* rfq = rdq + lds_m;
@@ -508,13 +508,13 @@ __global__ void __launch_bounds__(64) k_sw_selfcheck(uint32_t n_cases, uint32_t 
     const int n = s_n;
     const smr::SwRes a0 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, 0);
     __syncthreads();
-    const smr::SwRes a1 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, 1);
+    const smr::SwRes a1 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, mode_b);
     __syncthreads();
     bool bad = a0.score != a1.score || a0.end_ref != a1.end_ref || a0.end_read != a1.end_read;
     if (a0.score > 0 && a0.end_ref >= 0) {
       const smr::SwRes b0 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, 0);
       __syncthreads();
-      const smr::SwRes b1 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, 1);
+      const smr::SwRes b1 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, mode_b);
       __syncthreads();
       bad = bad || b0.score != b1.score || b0.end_ref != b1.end_ref || b0.end_read != b1.end_read;
     }
@@ -534,7 +534,7 @@ extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uin
   const int sc[2][3] = {{2, -3, -3}, {5, -4, -4}};
   for (int k = 0; k < 2 && n_cases; k++)
     hipLaunchKernelGGL(k_sw_selfcheck, dim3(std::min<uint32_t>(n_cases, (uint32_t)c->n_cu * 8u)), dim3(64), lds, c->stream, n_cases, seed + 7919u * (uint32_t)k, max_len, lm, ln,
-                       sc[k][0], sc[k][1], sc[k][2], 5, 2, d);
+                       sc[k][0], sc[k][1], sc[k][2], 5, 2, std::max(c->sw_mode, 1), d);
   unsigned long long h[3] = {0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(h, d, 3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(64) k_ssw_batch(uint32_t n_pairs, const uint8_
 
 extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                              int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out) {
-  if (!c || !read_off || !ref_off || !out || (mode != 0 && mode != 1)) return SMR_ERR_ARG;
+  if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 2) return SMR_ERR_ARG;
   if (n_pairs == 0) return SMR_OK;
   (void)hipSetDevice(c->device);
   uint64_t mx_m = 1, mx_n = 1;
@@ -605,7 +605,7 @@ extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads,
 
 extern "C" int smr_sw_mode(smr_ctx* c, int set_to) {      // set_to: 0 / 1 = select, anything else = query only; returns the mode in use
   if (!c) return SMR_ERR_ARG;
-  if (set_to == 0 || set_to == 1) c->sw_mode = set_to;
+  if (set_to >= 0 && set_to <= 2) c->sw_mode = set_to;
   return c->sw_mode;
 }
 
@@ -631,7 +631,7 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
   (void)hipMemset(c->b->d_ctr, 0, C_TOTAL * 8);
   c->b->used = true;
-  if (c->sw_mode == 1) {
+  if (c->sw_mode >= 1) {
     // the packed Smith-Waterman kernel must agree with the 32-bit kernel on this device, or it is not used
 #ifdef SMR_EMU
     uint32_t cases = 8;

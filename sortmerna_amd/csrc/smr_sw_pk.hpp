@@ -59,7 +59,12 @@ __device__ __forceinline__ pk16 pk_splat(int v) { return pk_from(((uint32_t)v & 
 __device__ __forceinline__ uint32_t pk_sel_of(int c) { return c < 4 ? (0x0C00u | (uint32_t)c) : PK_SEL_N; }
 __device__ __forceinline__ uint32_t pk_sel_to_hi(uint32_t s) { return (s & 0xFFu) < 4u ? s + 4u : s; }
 
-template <int R, bool HASN>
+// wave_ror:1 -- lane l reads lane l-1, lane 0 reads lane 63 (all lanes have a source, `old` is never used)
+__device__ __forceinline__ int dpp_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x13C /* wave_ror:1 */, 0xF, 0xF, false); }
+
+// ROR = true (sw mode 2): the hand-over from lane 63's low half to lane 0's high half stays in the vector unit (wave_ror + one
+// select per stream) instead of v_readlane -> SALU -> v_mov in front of a wave_shr; same values, shorter dependent chain per step.
+template <int R, bool HASN, bool ROR>
 __device__ __forceinline__ SwRes sw_wave_pk_r(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                               int* bound, int match, int mismatch, int scoreN, int go, int ge) {
   const int lane = lane_id();
@@ -112,13 +117,23 @@ __device__ __forceinline__ SwRes sw_wave_pk_r(const uint8_t* rdq, int m, int rd0
         const uint32_t inS = (uint32_t)__builtin_amdgcn_readlane((int)chS, tt);
         const uint32_t inY = (uint32_t)__builtin_amdgcn_readlane(chY, tt), inF = (uint32_t)__builtin_amdgcn_readlane(chF, tt);
         // virtual lane 64 (high half of lane 0) continues what lane 63's low half produced in the previous step
-        const uint32_t y63 = (uint32_t)__builtin_amdgcn_readlane((int)lastY, 63), f63 = (uint32_t)__builtin_amdgcn_readlane((int)lastF, 63),
-                       s63 = (uint32_t)__builtin_amdgcn_readlane((int)selcur, 63);
-        const uint32_t injY = (y63 << 16) | (inY & 0xFFFFu), injF = (f63 << 16) | (inF & 0xFFFFu),
-                       injS = (pk_sel_to_hi(s63 & 0xFFFFu) << 16) | inS;
-        const pk16 upY = pk_from((uint32_t)dpp_shr1((int)injY, (int)lastY));
-        const pk16 upF = pk_from((uint32_t)dpp_shr1((int)injF, (int)lastF));
-        selcur = (uint32_t)dpp_shr1((int)injS, (int)selcur);
+        pk16 upY, upF;
+        if (ROR) {
+          // lane 0: low half = the new input, high half = lane 63's low half (for the selector: moved to the high row's table, | 4)
+          const uint32_t rY = (uint32_t)dpp_ror1((int)lastY), rF = (uint32_t)dpp_ror1((int)lastF), rS = (uint32_t)dpp_ror1((int)selcur);
+          const bool first = lane == 0;
+          upY = pk_from(first ? ((rY << 16) | (inY & 0xFFFFu)) : rY);
+          upF = pk_from(first ? ((rF << 16) | (inF & 0xFFFFu)) : rF);
+          selcur = first ? ((rS << 16) | inS | 0x00040000u) : rS;
+        } else {
+          const uint32_t y63 = (uint32_t)__builtin_amdgcn_readlane((int)lastY, 63), f63 = (uint32_t)__builtin_amdgcn_readlane((int)lastF, 63),
+                         s63 = (uint32_t)__builtin_amdgcn_readlane((int)selcur, 63);
+          const uint32_t injY = (y63 << 16) | (inY & 0xFFFFu), injF = (f63 << 16) | (inF & 0xFFFFu),
+                         injS = (pk_sel_to_hi(s63 & 0xFFFFu) << 16) | inS;
+          upY = pk_from((uint32_t)dpp_shr1((int)injY, (int)lastY));
+          upF = pk_from((uint32_t)dpp_shr1((int)injF, (int)lastF));
+          selcur = (uint32_t)dpp_shr1((int)injS, (int)selcur);
+        }
         uint32_t nmask = 0;
         if (HASN) nmask = ((selcur >> 8) & 0x00010001u) * 0xFFFFu;               // 0xFFFF in the halves whose letter is N
         const uint32_t xhi = xlo + 127u;                                           // the high half is 64 columns behind, flag 0

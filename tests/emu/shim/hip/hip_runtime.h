@@ -98,13 +98,14 @@ __attribute__((noinline)) inline int all(int site, int p) {
   const uint64_t* res; const uint64_t m = wave_exchange(p ? 1 : 0, &res, site, EMU_RA);
   for (int l = 0; l < 64; l++) if (((m >> l) & 1) && !res[l]) return 0; return 1;
 }
-// DPP: only wave_shr:1 (0x138) with full row/bank masks and bound_ctrl = 0 is used: lane l reads lane l-1, lane 0 keeps `old`
+// DPP: wave_shr:1 (0x138: lane l reads lane l-1, lane 0 keeps `old`) and wave_ror:1 (0x13C: the same, lane 0 reads lane 63), with full
+// row/bank masks and bound_ctrl = 0
 __attribute__((noinline)) inline int update_dpp(int site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  if (ctrl != 0x138 || row_mask != 0xF || bank_mask != 0xF || bound_ctrl) { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+  if ((ctrl != 0x138 && ctrl != 0x13C) || row_mask != 0xF || bank_mask != 0xF || bound_ctrl) { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
   const uint64_t* res; const uint64_t m = wave_exchange((uint32_t)src, &res, site, EMU_RA);
-  const int l = EMU_LANE;
-  if (l == 0 || !((m >> (l - 1)) & 1)) return old;
-  return (int)(uint32_t)res[l - 1];
+  const int l = EMU_LANE, from = ctrl == 0x13C ? (l + 63) & 63 : l - 1;
+  if (from < 0 || !((m >> from) & 1)) return old;
+  return (int)(uint32_t)res[from];
 }
 __attribute__((noinline)) inline int readlane(int site, int v, int l) {          // v_readlane_b32: every lane gets lane l's value
   const uint64_t* res; const uint64_t m = wave_exchange((uint32_t)v, &res, site, EMU_RA);

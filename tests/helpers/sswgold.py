@@ -19,7 +19,7 @@ def load():
     return g["cases"]
 
 
-def check(engine, modes=(0, 1), max_pairs=None):
+def check(engine, modes=(0, 1, 2), max_pairs=None):
     """both SW kernels through smr_ssw_batch against the reference's answers; returns the number of pairs checked"""
     n = 0
     for c in load():

@@ -72,6 +72,9 @@ def test_packed_smith_waterman_equals_the_32bit_kernel(emulator):
     assert e.sw_mode() == 1                         # smr_create's own check passed
     for max_len, cases in ((100, 24), (250, 24), (700, 16), (1500, 8)):
         assert e.sw_selfcheck(cases, 11 + max_len, max_len) == 0
+    assert e.sw_mode(2) == 2                        # the wave_ror variant of the packed kernel
+    for max_len, cases in ((100, 24), (250, 24), (700, 16), (1500, 8)):
+        assert e.sw_selfcheck(cases, 11 + max_len, max_len) == 0
     e.close()
 
 
@@ -79,10 +82,10 @@ def test_packed_smith_waterman_equals_the_32bit_kernel(emulator):
 def test_both_smith_waterman_kernels_give_the_same_records(emulator, wl):
     e = smr.Engine(0)
     recs = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         assert e.sw_mode(mode) == mode
         recs[mode], _ = wl.gpu_records(e)
-    assert recs[0] == recs[1]
+    assert recs[0] == recs[1] == recs[2]
     e.close()
 
 

@@ -33,17 +33,22 @@ def test_packed_smith_waterman_selfcheck_on_the_device(engine):
     assert engine.sw_selfcheck(1000, 4, 1200) == 0
     assert engine.sw_selfcheck(200, 5, 3500) == 0
     assert engine.sw_mode() == 1
+    try:
+        assert engine.sw_mode(2) == 2               # the wave_ror variant
+        assert engine.sw_selfcheck(2000, 6, 300) == 0 and engine.sw_selfcheck(300, 7, 2000) == 0
+    finally:
+        engine.sw_mode(1)
 
 
 def test_both_smith_waterman_kernels_give_the_same_records(engine, wl):
     recs = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 2):
             assert engine.sw_mode(mode) == mode
             recs[mode], _ = wl.gpu_records(engine)
     finally:
         engine.sw_mode(1)
-    assert recs[0] == recs[1]
+    assert recs[0] == recs[1] == recs[2]
 
 
 def test_device_index_build_equals_the_host_build(engine, wl, tmp_path):

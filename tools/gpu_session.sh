@@ -15,8 +15,9 @@ tail -3 $OUT/pytest_gpu.log
 timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/bench_prof.json 2> $OLDPWD/$OUT/bench_prof.err )
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
-# A/B: 32-bit Smith-Waterman kernel only
-SMR_SW_PACKED=0 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_sw32.json 2> $OUT/bench_sw32.err; tail -c 300 $OUT/bench_sw32.json
+# A/B of the Smith-Waterman kernels on the bench workload, torch-free (20 s): packed, 32-bit, packed again; then the wave_ror variant
+timeout 200 python tools/hw_minibench.py > $OUT/minibench_modes_1_0_1.log 2>&1; tail -5 $OUT/minibench_modes_1_0_1.log
+SMR_SW_PACKED=2 timeout 200 python tools/hw_minibench.py > $OUT/minibench_ror.log 2>&1; grep "SW kernel" $OUT/minibench_ror.log
 # device vs host index build (14 Mnt and the bench DB size)
 timeout 600 python - > $OUT/index_build.log 2>&1 <<'PY'
 import os, sys, tempfile, time

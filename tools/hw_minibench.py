@@ -70,7 +70,8 @@ def step(b):
     smr.align_resident(eng, list(range(len(parts))), [params], with_cigar=True)
 
 
-for mode in (1, 0, 1):
+START = eng.sw_mode()                                  # 1, or 2 with SMR_SW_PACKED=2 (the wave_ror variant)
+for mode in (START, 0, START):
     eng.sw_mode(mode)
     step(0)
     eng.prof_reset()
@@ -82,7 +83,7 @@ for mode in (1, 0, 1):
     eng.select_batch(1)
     al = eng.counters(1)["num_aligned"]
     say("SW kernel %s: %.2f M reads/s (%.1f ms per 2 M-read step); seed stage %.2f ms/launch x %d, k_chain %.2f ms/launch x %d, k_trace %.2f ms x %d; aligned(batch 1) %d" % (
-        "packed" if mode == 1 else "32-bit", 2 * BATCH / dt / 1e6, dt / 2 * 1e3, p.seed_ms / max(p.seed_launches, 1), p.seed_launches,
+        {0: "32-bit", 1: "packed", 2: "packed (wave_ror)"}[mode], 2 * BATCH / dt / 1e6, dt / 2 * 1e3, p.seed_ms / max(p.seed_launches, 1), p.seed_launches,
         p.chain_ms / max(p.chain_launches, 1), p.chain_launches, p.trace_ms / max(p.trace_launches, 1), p.trace_launches, al))
 if os.environ.get("MB_HOST_BUILD"):
     t = time.time(); h2 = smr.Index.build(db, 18, 3072.0, 10000, 0); say("host index build: %.1f s" % (time.time() - t))
