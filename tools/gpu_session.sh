@@ -18,6 +18,12 @@ find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # A/B of the Smith-Waterman kernels on the bench workload, torch-free (20 s): packed, 32-bit, packed again; then the wave_ror variant
 timeout 200 python tools/hw_minibench.py > $OUT/minibench_modes_1_0_1.log 2>&1; tail -5 $OUT/minibench_modes_1_0_1.log
 SMR_SW_PACKED=2 timeout 200 python tools/hw_minibench.py > $OUT/minibench_ror.log 2>&1; grep "SW kernel" $OUT/minibench_ror.log
+# phase cycles of k_chain (library built in the container with -DSMR_CHAIN_PHASES: sortmerna_amd/lib/libsmr_hip_phases.so)
+if [ -f sortmerna_amd/lib/libsmr_hip_phases.so ]; then
+  cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp sortmerna_amd/lib/libsmr_hip_phases.so sortmerna_amd/lib/libsmr_hip.so
+  SMR_DEBUG_PHASES=1 timeout 200 python tools/hw_minibench.py > $OUT/minibench_phases.log 2>&1; grep -E "phase cycles|SW kernel" $OUT/minibench_phases.log | tail -8
+  cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
+fi
 # device vs host index build (14 Mnt and the bench DB size)
 timeout 600 python - > $OUT/index_build.log 2>&1 <<'PY'
 import os, sys, tempfile, time
