@@ -172,8 +172,16 @@ def main():
         os.replace(db + ".tmp", db)
     log("DB ready (%.1fs)" % (time.time() - t0))
     t0 = time.time()
+    eng = smr.Engine(local)
+    index_built = "loaded from rank 0's files"
     if rank == 0:
-        parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+        try:                                           # sorting / ids / positions / mini-tries on the device
+            parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)
+            index_built = "device (smr_index_build_gpu), %.1f s" % (time.time() - t0)
+        except smr.SmrError as e:
+            log("device index build failed (%s): host builder" % e)
+            parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+            index_built = "host (smr_index_build), %.1f s" % (time.time() - t0)
         if world > 1:
             smr.Index.write_files(parts, db, prefix)
     barrier()
@@ -188,7 +196,6 @@ def main():
         len(parts), sum(p.info().trie_words for p in parts) * 4 / 1e6, sum(p.info().n_pos for p in parts) * 8 / 1e6,
         info.numseq, time.time() - t0))
 
-    eng = smr.Engine(local)
     idx_slots = list(range(len(parts)))
     for s, ix in zip(idx_slots, parts):
         eng.upload_index(ix, s)
@@ -313,7 +320,7 @@ def main():
                                    "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); default options (--fastx, best 1)" % args.db_nt,
                        "batch_reads": args.batch_reads, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
                        "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
-                       "cigar": not args.no_cigar,
+                       "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": "packed 16-bit (v_pk, 128 virtual lanes)" if eng.sw_mode() == 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},

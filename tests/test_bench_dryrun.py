@@ -41,7 +41,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "reads/s" and out["value"] > 0
     assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
-    assert "workload" in out["config"] and "sw_kernel" in out["config"]
+    assert "workload" in out["config"] and "sw_kernel" in out["config"] and out["config"]["index_build"].startswith("device")
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert out["counters"]["reads"] == 2 * 1500
