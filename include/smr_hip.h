@@ -128,7 +128,7 @@ int smr_reads_pack(const char* seqs, const uint64_t* offs, uint32_t n_reads, smr
 /* FASTA/FASTQ (optionally multi-line FASTA), plain text; [first, first+count) selects a record range
  * (count = 0 => to the end): the host-side read shard of one rank. */
 int smr_reads_load_fastx(const char* path, uint64_t first, uint64_t count, smr_reads** out, char* err, size_t errcap);
-/* The whole file, parsed and packed by `threads` threads (0 = all cores) over byte ranges that start at record boundaries (the
+/* The whole file (plain or gzip, izlib.cpp:95-210), parsed and packed by `threads` threads (0 = all cores) over byte ranges that start at record boundaries (the
  * reference splits the read file the same way into one range per thread, readfeed.cpp:1253-1277).  Same result as
  * smr_reads_load_fastx(path, 0, 0, ...). */
 int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap);
