@@ -40,6 +40,7 @@ sys.path.insert(0, HERE)
 # computes them (refstats.cpp:194-233); inputs of smr_minimal_score.
 GUMBEL = (0.618874, 0.343238)
 HBM_PEAK_GBS = 8000.0
+MAX_RESIDENT = 14          # the engine holds 16 batch slots; slot 15 is the CPU-baseline sample's
 
 
 def log(msg):
@@ -57,7 +58,7 @@ def make_batch(synth, codes, offs, n, read_len, seed):
 
 
 def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_slots):
-    """Time the unmodified reference on a bounded sample; also compare its hit count with the GPU path's."""
+    """Time the unmodified reference on a bounded sample; also compare the set of read ids it aligns (aligned.fq) with the GPU path's."""
     ref_bin = os.path.join(HERE, "oracle", "_ref", "sortmerna_ref")
     strhash = os.path.join(HERE, "oracle", "_ref", "strhash")
     cores = os.cpu_count() or 1
@@ -93,14 +94,24 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
             ms = re.search(r"Minimal SW score based on E-value = (\d+)", t)
             na = re.search(r"Total reads passing E-value threshold = (\d+)", t)
             if ms and na:
-                # same sample through the GPU path with the reference's own minimal_score: hit counts must be equal
+                # same sample through the GPU path with the reference's own minimal_score: the SETS of aligned read ids must be equal
                 r = smr.Reads.from_seqs([bytes(x).decode() for x in letters[:n]])
                 eng.select_batch(15)
                 eng.upload_reads(r, 1)
                 p2 = smr.default_params(minimal_score=int(ms.group(1)))
                 smr.align_resident(eng, idx_slots, [p2], with_cigar=False)
+                gpu_ids = set(i for i in range(n) if eng.is_hit(i))
+                ref_ids = None
+                for nm in ("aligned.fq", "aligned.fastq"):
+                    fq = os.path.join(wd, "run", "out", nm)
+                    if os.path.isfile(fq):
+                        with open(fq, "rb") as f:
+                            ref_ids = set(int(l[2:].split()[0]) for k, l in enumerate(f) if k % 4 == 0)
                 res["parity"] = {"reference_aligned": int(na.group(1)), "gpu_aligned": int(eng.counters(1)["num_aligned"]),
-                                 "minimal_score": int(ms.group(1))}
+                                 "minimal_score": int(ms.group(1)),
+                                 "aligned_read_ids_equal": (ref_ids == gpu_ids) if ref_ids is not None else None,
+                                 "ids_only_reference": len(ref_ids - gpu_ids) if ref_ids is not None else None,
+                                 "ids_only_gpu": len(gpu_ids - ref_ids) if ref_ids is not None else None}
                 r.free()
         return res
     finally:
@@ -119,6 +130,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the reference CPU baseline (0 = min(host cores, 64))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cigar", action="store_true", help="skip the banded traceback (not the reference's behaviour)")
+    ap.add_argument("--resident-batches", type=int, default=8,
+                    help="distinct read batches kept resident in HBM (1..%d); step i runs on batch i %% this" % MAX_RESIDENT)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,8 +141,8 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
-    if args.warmup + args.steps > 15:
-        sys.exit("warmup + steps must be <= 15 (resident batches)")
+    args.steps = max(args.steps, 1)
+    args.warmup = max(args.warmup, 0)
 
     import numpy as np
     import torch
@@ -203,7 +216,8 @@ def main():
     # ---------------- reads: W + K different batches per rank, resident in HBM ----------------
     t0 = time.time()
     codes, offs = synth.load_db_codes(db)
-    nb = args.warmup + args.steps
+    n_total = args.warmup + args.steps              # step i (warmup first, then timed) runs on resident batch i % nb
+    nb = max(1, min(n_total, args.resident_batches, MAX_RESIDENT))
     batch0 = None
     tot_reads = 0
     tot_len = 0
@@ -239,33 +253,43 @@ def main():
         eng.reset_state()
         smr.align_resident(eng, idx_slots, [params], with_cigar=not args.no_cigar)
 
-    for b in range(args.warmup):
-        step(b)
-    # Algorithmic bytes of the timed batches: a workload property, counted by the per-lane DFS seed kernel whose work counters
-    # follow the reference's sequential scan exactly (untimed; the timed steps use the work-queue kernel, same results).
-    eng.prof_reset()
+    for i in range(args.warmup):
+        step(i % nb)
+    timed = [i % nb for i in range(args.warmup, n_total)]        # the resident batch of every timed step
+    uses = [timed.count(b) for b in range(nb)]
+    # Algorithmic bytes of the timed steps: a workload property, counted once per distinct batch by the per-lane DFS seed kernel whose
+    # work counters follow the reference's sequential scan exactly (untimed; the timed steps use the work-queue kernel, same results).
     eng.set_seed_mode(1)
-    for b in range(args.warmup, nb):
+    exact = [0] * 6
+    exact_aligned = 0
+    for b in range(nb):
+        if uses[b] == 0:
+            continue
+        eng.prof_reset()
         step(b)
+        pe = eng.prof()
+        for k, v in enumerate([pe.n_windows, pe.n_lookup, pe.n_node, pe.n_entry, pe.n_hit, pe.n_read_bytes]):
+            exact[k] += int(v) * uses[b]
+        exact_aligned += eng_counters_aligned(eng, b) * uses[b]
     eng.set_seed_mode(0)
-    pe = eng.prof()
-    exact = [pe.n_windows, pe.n_lookup, pe.n_node, pe.n_entry, pe.n_hit, pe.n_read_bytes]
-    exact_aligned = sum(eng_counters_aligned(eng, b) for b in range(args.warmup, nb))
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
-    for b in range(args.warmup, nb):
+    for b in timed:
         step(b)
     barrier()
     dt = time.perf_counter() - t0
     dt = shard.time_max(dt, device=cdev)
 
-    # C2: Readstats counters of the timed batches, summed over ranks (RCCL)
+    # C2: Readstats counters of the timed steps, summed over ranks (RCCL).  Every step starts from a reset state, so a batch's
+    # counter block holds the counts of its last step; a batch used u times contributes u times.
     ctr = np.zeros(3, dtype=np.int64)
-    for b in range(args.warmup, nb):
+    for b in range(nb):
+        if uses[b] == 0:
+            continue
         eng.select_batch(b)
         c = eng.counters(1)
-        ctr += np.array([c["num_aligned"], c["num_short"], c["reads_matched_per_db"][0]], dtype=np.int64)
+        ctr += uses[b] * np.array([c["num_aligned"], c["num_short"], c["reads_matched_per_db"][0]], dtype=np.int64)
     ctr_t = shard.reduce_counters(ctr.tolist(), device=cdev)
     pr = eng.prof()
     assert int(ctr[0]) == exact_aligned, "the two seed kernels disagree on num_aligned: %d vs %d" % (int(ctr[0]), exact_aligned)
@@ -318,7 +342,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32", "data": "synthetic",
             "config": {"workload": "synthetic 150-nt Illumina-like reads (10%% from DB, 90%% background) vs seeded synthetic rRNA-like DB "
                                    "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); default options (--fastx, best 1)" % args.db_nt,
-                       "batch_reads": args.batch_reads, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
+                       "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
                        "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
                        "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": "packed 16-bit (v_pk, 128 virtual lanes)" if eng.sw_mode() == 1 else "32-bit"},

@@ -15,8 +15,9 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "config", "roofline", "cpu_baseline"]
 
 
-def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path):
-    baseline = paths.have_ref_bin()               # with the reference binary at hand the CPU-baseline leg runs too
+@pytest.mark.parametrize("steps,warmup", [(2, 1), (20, 5)])          # (20, 5) = the driver's own command line of round 1, which aborted
+def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup):
+    baseline = paths.have_ref_bin() and steps == 2               # with the reference binary at hand the CPU-baseline leg runs too
     import torch
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -25,7 +26,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path):
     monkeypatch.setenv("SMR_BENCH_BACKEND", "gloo")          # the (world-size-1) reductions on CPU tensors
     import tempfile
     monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
-    argv = ["bench.py", "--steps", "2", "--warmup", "1", "--batch-reads", "1500", "--db-nt", "150000", "--cpu-sample-reads", "1500", "--cpu-threads", "2"]
+    argv = ["bench.py", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch-reads", "1500", "--db-nt", "150000", "--cpu-sample-reads", "1500", "--cpu-threads", "2"]
     if not baseline:
         argv.append("--no-cpu-baseline")
     monkeypatch.setattr(sys, "argv", argv)
@@ -39,15 +40,18 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path):
     out = json.loads(line)
     for k in KEYS:
         assert k in out, k
-    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["warmup"] == 1 and out["unit"] == "reads/s" and out["value"] > 0
+    assert out["n_gpus"] == 1 and out["steps"] == steps and out["warmup"] == warmup and out["unit"] == "reads/s" and out["value"] > 0
     assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
     assert "workload" in out["config"] and "sw_kernel" in out["config"] and out["config"]["index_build"].startswith("device")
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert out["counters"]["reads"] == 2 * 1500
+    assert out["counters"]["reads"] == steps * 1500
+    assert out["config"]["resident_batches"] == min(steps + warmup, 8)
+    assert abs(out["ms_per_step"] * steps / 1e3 * out["value"] - steps * 1500) < 1e-3
     assert out["kernels"]["k_chain"]["valu_model_peak_gcups"] > 0
     if baseline:
         cb = out["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["unit"] == "reads/s" and cb["cores"] == 2 and cb["value"] and cb["value"] > 0, cb
+        assert cb["parity"]["aligned_read_ids_equal"] is True and cb["parity"]["reference_aligned"] == cb["parity"]["gpu_aligned"] > 0, cb
     else:
         assert out["cpu_baseline"] is None
