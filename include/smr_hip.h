@@ -225,6 +225,13 @@ int smr_sw_mode(smr_ctx*, int set_to);
  * out[5 i ..] = {score1, ref_begin1, ref_end1, read_begin1, read_end1}, begins = -1 when score1 < filters.  mode 0 / 1 / 2 = 32-bit / packed / packed wave_ror kernel. */
 int smr_ssw_batch(smr_ctx*, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                   int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out);   /* set_to 0 / 1: use the 32-bit / the packed kernel; other values: query; returns the mode in use */
+/* The traceback kernels at the same seam: for n independent triples (read window, reference window -- both exactly the aligned spans
+ * [begin1, end1] -- and the alignment's score1) the CIGAR that banded_sw returns for them (ssw.c:577-773 as called from ssw_align,
+ * ssw.c:919-926): BAM-style u32 operations (length << 4 | op, op 0/1/2 = M/I/D), pair i at cigar_out[cigar_off_out[i] .. cigar_off_out[i+1]).
+ * Operations beyond cigar_cap are counted but not written.  Uses the same host logic and kernels as smr_traceback. */
+int smr_cigar_batch(smr_ctx*, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
+                    const uint16_t* scores, int match, int mismatch, int score_N, int gap_open, int gap_ext,
+                    uint32_t* cigar_out, uint64_t cigar_cap, uint64_t* cigar_off_out);
 int smr_prof_reset(smr_ctx*);
 int smr_prof_get(smr_ctx*, smr_prof* out);
 

@@ -6,7 +6,7 @@
 //   k_chain  : candidate histogram, LIS chaining, SW window geometry, Smith-Waterman score + begin position,
 //              accept/best-N bookkeeping, pass control (alignment.cpp:100-509, ssw.c:834-918,
 //              paralleltraversal.cpp:253-297)
-//   k_trace  : banded traceback -> CIGAR (ssw.c:577-773)
+//   k_trace_band / k_trace_wide : banded DP with lanes across the band (F by prefix scan) + walk back -> CIGAR (what ssw.c:577-773 yields)
 //
 // Design notes (DESIGN.md has the long form):
 //  * integer work, HBM/latency bound: no MFMA anywhere.
@@ -17,7 +17,7 @@
 //    varies by orders of magnitude).  Control flow is wave-uniform and follows the reference statement by
 //    statement; the data-parallel pieces (position-list walks, bitonic sorts, the SW anti-diagonal systolic
 //    array with lane = read row) use all 64 lanes.
-//  * k_trace: one thread per alignment, direction bytes interleaved by lane so a wave's stores coalesce.
+//  * k_trace_*: lanes across the band diagonals, one DP row per step; 4-bit direction flags in LDS (short reads) or a global tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -106,7 +106,7 @@ enum {
   C_NUM_ALIGNED = 0, C_NUM_SHORT = 1, C_PER_DB = 2,           // C_PER_DB .. C_PER_DB+63
   C_WINDOWS = 66, C_LOOKUP, C_NODE, C_ENTRY, C_HIT, C_READ_BYTES, C_SW_FWD, C_SW_REV, C_SW_CELLS,
   C_ERR_HITCAP, C_ERR_POOL, C_ERR_SLOTS, C_ERR_PAIRS, C_ERR_CIGAR, C_ERR_TRACE, C_POOL_CURSOR, C_WORK_NEXT,
-  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_COUNT = 96,
+  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_COUNT = 96,
   // Work counters and the pool cursor are sharded 64 ways (by block id): one address would serialise ~10 ns per
   // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k at C_SHARDS + 16*s + k; the host folds them.
   C_NSHARD = 64, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + 16 * C_NSHARD, C_TOTAL = C_PCUR + C_NSHARD

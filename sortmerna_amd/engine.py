@@ -251,6 +251,21 @@ class Engine:
                                        gap_open, gap_ext, filters, mode, out.ctypes.data), "smr_ssw_batch")
         return out
 
+    def cigar_batch(self, reads, refs, scores, match=2, mismatch=-3, score_N=-3, gap_open=5, gap_ext=2):
+        """reads / refs: the aligned spans (byte strings in the 0..4 alphabet), scores: their score1; -> list of u32 CIGAR arrays (len << 4 | op),
+        what the reference's banded_sw returns for each triple (the traceback kernels behind smr_traceback)"""
+        n = len(reads)
+        ro = np.zeros(n + 1, dtype=np.uint64); fo = np.zeros(n + 1, dtype=np.uint64)
+        ro[1:] = np.cumsum([len(x) for x in reads]); fo[1:] = np.cumsum([len(x) for x in refs])
+        rb = np.frombuffer(b"".join(reads) + b"\0", dtype=np.uint8).copy(); fb = np.frombuffer(b"".join(refs) + b"\0", dtype=np.uint8).copy()
+        sc = np.asarray(scores, dtype=np.uint16)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        cap = int(ro[-1] + fo[-1]) + 4 * n + 16
+        out = np.zeros(cap, dtype=np.uint32)
+        self._chk(self.L.smr_cigar_batch(self.h, n, rb.ctypes.data, ro.ctypes.data, fb.ctypes.data, fo.ctypes.data, sc.ctypes.data, match, mismatch, score_N,
+                                         gap_open, gap_ext, out.ctypes.data, cap, off.ctypes.data), "smr_cigar_batch")
+        return [out[int(off[i]):int(off[i + 1])].copy() for i in range(n)]
+
     def upload_reads(self, reads, max_alignments_per_read=1):
         self._chk(self.L.smr_reads_upload(self.h, reads.h, max_alignments_per_read), "smr_reads_upload")
         self.n_reads = reads.count

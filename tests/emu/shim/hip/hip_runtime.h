@@ -98,13 +98,31 @@ __attribute__((noinline)) inline int all(int site, int p) {
   const uint64_t* res; const uint64_t m = wave_exchange(p ? 1 : 0, &res, site, EMU_RA);
   for (int l = 0; l < 64; l++) if (((m >> l) & 1) && !res[l]) return 0; return 1;
 }
-// DPP: wave_shr:1 (0x138: lane l reads lane l-1, lane 0 keeps `old`) and wave_ror:1 (0x13C: the same, lane 0 reads lane 63), with full
-// row/bank masks and bound_ctrl = 0
+// DPP (gfx9 encodings of dpp_ctrl): quad_perm 0x00-0xFF, row_shl:n 0x101-0x10F (lane l reads l+n of its row of 16), row_shr:n 0x111-0x11F,
+// row_ror:n 0x121-0x12F, wave_shl:1 0x130, wave_rol:1 0x134, wave_shr:1 0x138, wave_ror:1 0x13C, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast:15 0x142 (lane 15 of a row to every lane of the next row), row_bcast:31 0x143 (lane 31 to rows 2 and 3).  A lane whose row
+// (row_mask) or bank of 4 (bank_mask) is masked off, or whose source lane does not exist / does not participate, keeps `old`
+// (bound_ctrl = 1: a non-existent source writes 0 instead).
 __attribute__((noinline)) inline int update_dpp(int site, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
-  if ((ctrl != 0x138 && ctrl != 0x13C) || row_mask != 0xF || bank_mask != 0xF || bound_ctrl) { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
   const uint64_t* res; const uint64_t m = wave_exchange((uint32_t)src, &res, site, EMU_RA);
-  const int l = EMU_LANE, from = ctrl == 0x13C ? (l + 63) & 63 : l - 1;
-  if (from < 0 || !((m >> from) & 1)) return old;
+  const int l = EMU_LANE, row = l >> 4, rl = l & 15;
+  if (!((row_mask >> row) & 1) || !((bank_mask >> ((l >> 2) & 3)) & 1)) return old;
+  int from = -1; bool exists = true;
+  if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+  else if (ctrl >= 0x101 && ctrl <= 0x10F) { const int s = rl + (ctrl & 15); exists = s <= 15; from = (row << 4) | (s & 15); }
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int s = rl - (ctrl & 15); exists = s >= 0; from = (row << 4) | (s & 15); }
+  else if (ctrl >= 0x121 && ctrl <= 0x12F) from = (row << 4) | ((rl - (ctrl & 15)) & 15);
+  else if (ctrl == 0x130) { exists = l < 63; from = (l + 1) & 63; }
+  else if (ctrl == 0x134) from = (l + 1) & 63;
+  else if (ctrl == 0x138) { exists = l > 0; from = (l + 63) & 63; }
+  else if (ctrl == 0x13C) from = (l + 63) & 63;
+  else if (ctrl == 0x140) from = (row << 4) | (15 - rl);
+  else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));
+  else if (ctrl == 0x142) { exists = row > 0; from = ((row - 1) << 4) | 15; }
+  else if (ctrl == 0x143) { exists = row >= 2; from = 31; }
+  else { fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); abort(); }
+  if (!exists) return bound_ctrl ? 0 : old;
+  if (!((m >> from) & 1)) return old;
   return (int)(uint32_t)res[from];
 }
 __attribute__((noinline)) inline int readlane(int site, int v, int l) {          // v_readlane_b32: every lane gets lane l's value

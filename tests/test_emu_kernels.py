@@ -130,3 +130,15 @@ def test_sw_kernels_equal_the_reference_ssw_c(emulator):
     e = smr.Engine(0)
     assert sswgold.check(e) == 320
     e.close()
+
+
+def test_traceback_kernels_equal_the_reference_banded_sw(emulator):
+    """smr_cigar_batch (k_trace_band<8>, <16>, k_trace_wide: band doubling, several strips, gap_open < gap_ext) against
+    tests/golden/trace_pairs.json.gz = CIGARs of the reference's own banded_sw for seeded pairs"""
+    from helpers import tracegold
+    e = smr.Engine(0)
+    n = tracegold.check(e, kinds=["short", "tiny", "indels"])
+    n += tracegold.check(e, kinds=["long"], max_pairs=3)
+    assert n > 1700
+    assert tracegold.check_variants(e) > 150
+    e.close()

@@ -27,6 +27,14 @@ def test_sw_kernels_equal_the_reference_ssw_c(engine):
     assert sswgold.check(engine) == 320
 
 
+def test_traceback_kernels_equal_the_reference_banded_sw(engine):
+    """smr_cigar_batch (k_trace_band<8>, <16>, k_trace_wide) against the CIGARs of the reference's own banded_sw (tests/golden/trace_pairs.json.gz):
+    gapless / single-indel short reads, multi-indel reads, windows narrower than their band, 0.7-3 kb noisy reads with long gaps, four scoring schemes"""
+    from helpers import tracegold
+    assert tracegold.check(engine) > 1800
+    assert tracegold.check_variants(engine) > 150
+
+
 def test_packed_smith_waterman_selfcheck_on_the_device(engine):
     """the packed 16-bit SW kernel against the 32-bit kernel, both on the GPU (smr_sw_selfcheck), and smr_create's own check passed"""
     assert engine.sw_selfcheck(2000, 3, 300) == 0
