@@ -14,14 +14,15 @@ import sortmerna_amd as smr
 from helpers import emu
 from helpers.workload import Workload
 
-from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_index, test_longer_reads, test_empty_batch)  # noqa: F401
+from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_index, test_longer_reads, test_empty_batch,  # noqa: F401
+                             test_seed_work_counters_match_oracle)
 from test_gpu_parity import test_align_records_match_oracle as _align_body
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 
 FULL = os.environ.get("SMR_EMU_FULL", "0") == "1"
 if FULL:
     from test_gpu_parity import (test_align_records_match_oracle, test_other_seed_lengths, test_non_default_strides,  # noqa: F401
-                                 test_long_noisy_reads, test_long_reads_with_large_gaps)
+                                 test_long_noisy_reads, test_long_reads_with_large_gaps, test_very_long_reads)
     from test_gpu_sw_and_index_build import test_device_index_build_equals_the_host_build as test_device_index_build_gpu_test_body  # noqa: F401
 else:
     @pytest.mark.parametrize("opts", [{}, {"is_reverse": 0}], ids=["default", "F"])

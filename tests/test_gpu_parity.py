@@ -205,6 +205,65 @@ def test_long_reads_with_large_gaps(engine, tmp_path, scoring):
     assert max(a["read_end1"] - a["read_begin1"] for a in spans) > 2500          # alignments really span the gap
 
 
+def test_seed_work_counters_match_oracle(wl):
+    """The numerator of bench.py's roofline: the device work counters of the per-lane DFS seed kernel (smr_prof_get in seed mode 1:
+    windows searched, 9-mer lookups, trie nodes visited, bucket entries compared, seed hits) equal the oracle's counters of the
+    reference's sequential scan (oracle/smr_oracle.c, counters next to traversetrie_align) on the same workload -- and the
+    Smith-Waterman call counts of k_chain equal the oracle's ssw_align calls."""
+    e = smr.Engine(0)
+    try:
+        e.set_seed_mode(1)
+        _, ctr_o = wl.oracle_records()
+        e.prof_reset()
+        wl.gpu_records(e)
+        p = e.prof()
+        got = dict(n_windows=p.n_windows, n_lookup=p.n_lookup, n_node=p.n_node, n_entry=p.n_entry, n_hit=p.n_hit, n_sw_fwd=p.n_sw_fwd, n_sw_rev=p.n_sw_rev)
+        exp = {k: ctr_o[k] for k in got}
+        assert got == exp
+        assert exp["n_entry"] > exp["n_windows"] > 0 and exp["n_node"] > 0 and p.n_read_bytes > 0
+    finally:
+        e.close()
+
+
+def test_very_long_reads(engine, tmp_path):
+    """8-12.5 kb reads (BASELINE config 5 is 5 kb PacBio; this is beyond it): k_chain needs more than 64 KB of dynamic LDS per
+    workgroup (hipFuncSetAttribute), the packed SW kernel runs 512-row strips up to ~8 kb and the 32-bit kernel beyond, the
+    traceback takes the wide kernel with bands of hundreds of diagonals"""
+    import numpy as np
+    from sortmerna_amd import synth
+    w = Workload(str(tmp_path), db_nt=400_000, n_reads=20, seed=43, family_size=4, mean_len=14000)
+    codes, offs = synth.load_db_codes(w.db)
+    rng = np.random.Generator(np.random.PCG64(7))
+    seqs = []
+    for i in range(6):
+        sq = int(rng.integers(0, len(offs) - 1))
+        full = int(offs[sq + 1] - offs[sq])
+        ln = min(full, [8000, 9000, 10000, 11000, 12500, 6000][i])
+        st = int(offs[sq] + rng.integers(0, full - ln + 1))
+        out = []
+        for c in codes[st:st + ln]:
+            u = rng.random()
+            if u < 0.03:
+                continue
+            if u < 0.06:
+                out.append(int(rng.integers(0, 4)))
+            out.append(int((c + rng.integers(1, 4)) & 3) if u > 0.96 else int(c))
+        s = "".join("ACGT"[c] for c in out)
+        if i % 2:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        seqs.append(s)
+    assert max(map(len, seqs)) > 11000
+    w.seqs = seqs
+    w.reads = smr.Reads.from_seqs(seqs)
+    w.minimal_score = smr.minimal_score(0.618874, 0.343238, w.parts[0].info(), len(seqs), sum(map(len, seqs)))
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "8-12.5 kb reads")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 5
+    spans = [refrun.parse_record(r)["alignv"][0] for r in recs_o if r]
+    assert max(a["read_end1"] - a["read_begin1"] for a in spans) > 8000
+
+
 def test_empty_batch(engine, wl):
     r = smr.Reads.from_seqs([])
     p = smr.default_params(minimal_score=wl.minimal_score)
