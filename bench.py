@@ -317,12 +317,18 @@ def main():
         b_seed = n_read_bytes + 12 * n_lookup + 16 * n_node + 8 * n_entry + 8 * n_hit
         # per-rank kernel time: ranks run concurrently, the sums above are over ranks
         ach = (b_seed / args.gpus) / (seed_ms / args.gpus * 1e-3) / 1e9 if seed_ms > 0 else 0.0
-        traffic = None                                      # PMC HBM bytes per seed-stage launch, measured with rocprofv3 in separate counter passes
+        # PMC HBM bytes per seed-stage launch: measured with rocprofv3 in separate counter passes (tools/pmc_traffic.py), used only when it
+        # was measured on THESE kernel sources at THIS batch size / read length / DB size (otherwise null: never rescaled)
+        traffic = None
+        traffic_note = "no PMC measurement for these kernel sources and this workload (profiles/hbm_traffic.json)"
         try:
+            sys.path.insert(0, os.path.join(HERE, "tools"))
+            import pmc_traffic
             tj = json.load(open(os.path.join(HERE, "profiles", "hbm_traffic.json")))
             w = tj["workload"]
-            if (w["read_len"], w["db_nt"]) == (args.read_len, args.db_nt):    # measured per 1 M-read launch; per-read traffic scales with the batch
-                traffic = tj["seed_stage_bytes_per_launch"] * args.batch_reads / w["batch_reads"]
+            if (w["read_len"], w["db_nt"], w["batch_reads"]) == (args.read_len, args.db_nt, args.batch_reads) and tj.get("kernel_src_sha") == pmc_traffic.kernel_src_sha():
+                traffic = tj["seed_stage_bytes_per_launch"]
+                traffic_note = "rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE per seed-stage launch, kernel sources %s" % tj["kernel_src_sha"]
         except Exception:
             pass
         # VALU model of the Smith-Waterman kernel: a wave64 VALU instruction occupies a SIMD for 4 cycles ->
@@ -351,7 +357,7 @@ def main():
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,
                               "entries": n_entry / reads_timed, "hits": n_hit / reads_timed},
             "roofline": {"kernel": "k_seed", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": b_seed / max(seed_l, 1), "avg_launch_ms": seed_ms / max(seed_l, 1),
+                         "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_seed / max(seed_l, 1), "avg_launch_ms": seed_ms / max(seed_l, 1),
                          "bytes_per_read": b_seed / reads_timed},
             "kernels": {"k_seed": {"ms": seed_ms / args.gpus, "launches": seed_l / args.gpus},
                         "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
