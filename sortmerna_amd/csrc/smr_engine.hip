@@ -677,7 +677,8 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   d.lnwin = ix->lnwin; d.n_refs = ix->n_refs(); d.n_ids = ix->n_ids(); d.trie_words = ix->trie.size(); d.n_pos = ix->pos_arr.size() / 2; d.ref_bytes = ix->ref_seq.size();
   int rc;
   {
-    // the bit-sliced second layout of the tries (host transform, cached in the smr_index)
+    // the bit-sliced second layout of the tries: a host transform cached in the smr_index, built once under its mutex (the loaders and
+    // builders already do it; this call only covers indexes made before that) -- concurrent uploads of one host index are safe
     std::string why;
     if (!smr_build_bitsliced(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
   }

@@ -3,6 +3,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/smr_hip.h"
@@ -61,6 +62,7 @@ struct smr_index {
   uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
   std::vector<uint32_t> trie2;          // bit-sliced arena (built on demand by smr_build_bitsliced)
   std::vector<uint32_t> root2;          // 2 * 4^(L/2): root word offset in trie2 of the forward / reverse mini-trie of key k at [2k], [2k+1]
+  std::mutex bs_mutex;                  // smr_build_bitsliced runs once, whichever thread / context asks first (several smr_ctx may upload the same host index)
   // whole-DB statistics (.stats)
   double bg[4] = {0.25, 0.25, 0.25, 0.25};
   uint64_t full_len = 0, numseq = 0, filesize = 0;

@@ -537,6 +537,7 @@ bool bs_emit_node(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t pat
 }  // namespace
 
 bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why) {
+  std::lock_guard<std::mutex> once(ix.bs_mutex);
   if (!ix.root2.empty()) return true;
   if (const char* e = getenv("SMR_BS_COLLAPSE")) g_bs_collapse = std::min(255u, std::max(1u, (uint32_t)atoi(e)));
   const size_t nk = ix.lookup.size();

@@ -1,5 +1,5 @@
 """profiles/hbm_traffic.json from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected SEPARATELY, as
-/opt/skills/guides/MI355X_MICROARCH.md prescribes) of `bench.py --steps 1 --warmup 0 --resident-batches 1 --no-cpu-baseline`.
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) of `bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run`.
 
     python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <batch_reads> <read_len> <db_nt> <out.json>
 
@@ -54,7 +54,7 @@ def main():
     seed = [k for k in kern if k.startswith("k_seed") or k.startswith("k_scan")]
     fb = sum(kern[k]["fetch_bytes"] for k in seed)
     wb = sum(kern[k]["write_bytes"] for k in seed)
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 --resident-batches 1; KiB x 1024; "
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run; KiB x 1024; "
                      "corrected = 2 x FETCH + WRITE (gfx950: FETCH_SIZE counts 64 B per 128-B request, MI355X_MICROARCH.md)",
            "kernel_src_sha": kernel_src_sha(),
            "workload": {"batch_reads": int(batch), "read_len": int(read_len), "db_nt": int(db_nt)},
