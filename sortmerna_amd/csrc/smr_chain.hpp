@@ -187,21 +187,49 @@ struct ChainScratch {
 #define CH_PAIRS_LDS 256
 #define CH_HITS_LDS 128
 
-// find_lis (alignment.cpp:58-98) over a[0..n): keys = ref_pos<<32 | read_pos ; compares read_pos (.second).
-// executed redundantly by every lane (uniform control flow); b,p hold indices.
-__device__ uint32_t find_lis_dev(const unsigned long long* a, uint32_t n, uint32_t* b, uint32_t* p) {
+// Longest strictly increasing subsequence of the read positions (low 32 bits) of a[0..n), n <= 64: its length and the index of the
+// FIRST element of the particular subsequence that the reference's find_lis (alignment.cpp:58-98) reconstructs -- the only two things
+// compute_lis_alignment uses (alignment.cpp:263-279).  The patience piles live across the lanes: lane c holds the smallest tail of an
+// increasing run of length c+1 and the index of the element that run started with.  Placing element i is one ballot (how many tails are
+// smaller = its pile) and two lane reads; the predecessor links of find_lis are not needed because the start of a run is inherited from
+// the pile to the left at the moment the element is placed, exactly where find_lis records p[i] = b[u-1].
+__device__ __forceinline__ uint32_t wave_lis_first(const unsigned long long* a, uint32_t n, uint32_t& first) {
+  const int lane = lane_id();
+  const uint32_t mine = (uint32_t)lane < n ? (uint32_t)a[lane] : 0u;
+  uint32_t tail = 0, root = 0, nb = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t ai = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+    const uint32_t u = (uint32_t)__popcll(__ballot((uint32_t)lane < nb && tail < ai));          // tails are increasing: the piles with a smaller tail
+    bool place = u == nb;
+    if (!place) place = ai < (uint32_t)__builtin_amdgcn_readlane((int)tail, (int)u);              // equal: nothing changes (find_lis :87)
+    if (place) {
+      const uint32_t r = u > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)root, (int)(u - 1)) : i;
+      if ((uint32_t)lane == u) { tail = ai; root = r; }
+      if (u == nb) nb++;
+    }
+  }
+  first = nb ? (uint32_t)__builtin_amdgcn_readlane((int)root, (int)(nb - 1)) : 0u;
+  return nb;
+}
+
+// The same for n > 64 (more piles than lanes can occur): the textbook O(n log k) form with explicit pile and predecessor arrays
+// b, p (2 x capacity n), executed uniformly by the wave; b[0] ends up as the first element of the subsequence.
+__device__ uint32_t serial_lis_first(const unsigned long long* a, uint32_t n, uint32_t* b, uint32_t* p, uint32_t& first) {
+  first = 0;
   if (n == 0) return 0;
   uint32_t nb = 0;
   for (uint32_t i = 0; i < n; i++) p[i] = 0;
   b[nb++] = 0;
   for (uint32_t i = 1; i < n; i++) {
-    uint32_t ai = (uint32_t)a[i];
-    if ((uint32_t)a[b[nb - 1]] < ai) { p[i] = b[nb - 1]; b[nb++] = i; continue; }
-    uint32_t u = 0, v = nb - 1;
-    while (u < v) { uint32_t c = (u + v) / 2; if ((uint32_t)a[b[c]] < ai) u = c + 1; else v = c; }
-    if (ai < (uint32_t)a[b[u]]) { if (u > 0) p[i] = b[u - 1]; b[u] = i; }
+    const uint32_t ai = (uint32_t)a[i];
+    uint32_t lo = 0, hi = nb;                                  // first pile whose tail is >= ai
+    while (lo < hi) { const uint32_t mid = (lo + hi) / 2; if ((uint32_t)a[b[mid]] < ai) lo = mid + 1; else hi = mid; }
+    if (lo == nb) { p[i] = b[nb - 1]; b[nb++] = i; }
+    else if (ai < (uint32_t)a[b[lo]]) { if (lo > 0) p[i] = b[lo - 1]; b[lo] = i; }
   }
-  for (uint32_t u = nb, v = b[nb - 1]; u--; v = p[v]) b[u] = v;
+  uint32_t v = b[nb - 1];
+  for (uint32_t c = nb; c-- > 1;) v = p[v];
+  first = v;
   return nb;
 }
 
@@ -431,10 +459,11 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
             if (!push && is_aligned) skip_to_pop = 1;        // heuristic 1 (:243-246)
             else is_aligned = 0;
             if (!skip_to_pop && (ms_hi - ms_lo) >= (uint32_t)P.num_seeds) {
-              uint32_t nl = find_lis_dev(pairs + ms_lo, ms_hi - ms_lo, lisb, lisp);
+              uint32_t lis0;
+              const uint32_t nl = ms_hi - ms_lo <= 64 ? wave_lis_first(pairs + ms_lo, ms_hi - ms_lo, lis0) : serial_lis_first(pairs + ms_lo, ms_hi - ms_lo, lisb, lisp, lis0);
               if (nl >= (uint32_t)P.min_lis) {
-                const uint32_t lcs_ref_start = (uint32_t)(pairs[ms_lo + lisb[0]] >> 32);
-                const uint32_t lcs_que_start = (uint32_t)pairs[ms_lo + lisb[0]];
+                const uint32_t lcs_ref_start = (uint32_t)(pairs[ms_lo + lis0] >> 32);
+                const uint32_t lcs_que_start = (uint32_t)pairs[ms_lo + lis0];
                 uint64_t head = 0, tail = 0, align_ref_start = 0, align_que_start = 0, align_length = 0;
                 const uint64_t rlen = len;
                 uint32_t edges;
