@@ -337,7 +337,7 @@ def main():
         # 256 CU x 4 SIMD x 2.4 GHz / 4 = 6.14e11 wave-instructions/s; one systolic step costs 13 R + 14 (packed, R = ceil(m/128) cell pairs)
         # or 20 R + 15 (32-bit, R = ceil(m/64) cells) instructions and there are n + ceil(m/R) - 1 steps for an m x n problem
         m_sw, n_sw = args.read_len, args.read_len + 8
-        if eng.sw_mode() == 1:
+        if eng.sw_mode() >= 1:
             r_sw = (m_sw + 127) // 128
             instr = (n_sw + (m_sw + r_sw - 1) // r_sw - 1) * (13 * r_sw + 14)
         else:
@@ -353,7 +353,7 @@ def main():
                        "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
                        "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
                        "cigar": not args.no_cigar, "index_build": index_built,
-                       "sw_kernel": "packed 16-bit (v_pk, 128 virtual lanes)" if eng.sw_mode() == 1 else "32-bit"},
+                       "sw_kernel": "packed 16-bit (v_pk): candidate windows scored ahead four per wave, single problems on 128 virtual lanes" if eng.sw_mode() >= 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,

@@ -206,7 +206,8 @@ typedef struct {
   double   trace_ms; uint64_t trace_launches;  /* banded traceback kernel */
   /* exact work counters of the seed-scan kernel (SURVEY.md 8d byte formula) */
   uint64_t n_windows, n_lookup, n_node, n_entry, n_hit, n_read_bytes;
-  uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;
+  uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;     /* ssw_align calls of the sequential walk (forward / reverse passes) and their DP cells */
+  uint64_t n_sw_spec, n_sw_spec_used;          /* forward passes scored ahead of the walk in four-problem batches, and how many of them the walk then asked for */
 } smr_prof;
 /* smr_index_build with the per-occurrence work (sorting all (L+1)-mers, ids, position lists, mini-trie layout) done
  * on the device: same arguments (threads does not apply), same smr_index objects, byte-identical index files

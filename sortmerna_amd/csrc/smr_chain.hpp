@@ -243,7 +243,10 @@ __device__ uint32_t serial_lis_first(const unsigned long long* a, uint32_t n, ui
 // open-addressing set S.  Most background reads leave S empty and are done.  Walk 2 counts exactly, for the
 // references in S only, and records their (pos, win) tuples; candidates are the members of S with count >= num_seeds,
 // and each candidate's (ref_pos, read_pos) pairs are a filter over the tuples instead of per-hit binary searches.
-__global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
+#ifndef SMR_CHAIN_WAVES_PER_SIMD
+#define SMR_CHAIN_WAVES_PER_SIMD 3
+#endif
+__global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
                                               RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
@@ -275,7 +278,7 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
   uint32_t* gl = g_lis + (size_t)blockIdx.x * 2 * pairs_cap;
   uint2* gh = g_hits + (size_t)blockIdx.x * hits_cap;
 
-  unsigned long long n_fwd = 0, n_rev = 0, n_cells = 0;   // flushed once per block (lane 0)
+  unsigned long long n_fwd = 0, n_rev = 0, n_cells = 0, n_spec = 0, n_spec_used = 0;   // flushed once per block (lane 0)
 #ifdef SMR_CHAIN_PHASES                                   // per-phase cycle accounting (build with -DSMR_CHAIN_PHASES, run with SMR_DEBUG_PHASES=1)
   unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define TPH(i) { const unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; }
@@ -405,29 +408,58 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
         TPH(3)
         const uint32_t ntup = min(s_nt, pairs_cap);
 
-        // 2. candidate loop (:150-508)
-        int is_aligned = 0;
-        int is_search_candidates = 1;
-        for (uint32_t k = 0; k < ncand && is_search_candidates && !cap_err; k++) {
-          const unsigned long long ck = keys[k];
+        // 2. candidate loop (:150-508), organised as a GENERATOR of Smith-Waterman tasks.
+        // The reference walks the candidates and, inside each, a sliding window over its (ref_pos, read_pos) pairs; every window
+        // whose LIS is long enough costs one ssw_align, and what happens next depends on its result.  Most results are "no
+        // alignment" (spurious candidates of background reads come 40 at a time and never align), so the walk is run AHEAD on a
+        // copy of its state under that assumption to collect up to four tasks, which one pass of the four-problem SW kernel
+        // (sw_wave_x4) scores together.  The real walk then consumes the results in its own order, looking each task up by its
+        // geometry; a result that did align changes the real walk's course (heuristic 1, best, termination), tasks predicted
+        // past that point simply go unused, and the walk asks for a new batch when it reaches a task that is not in the cache.
+        // The results a read ends up with are those of the sequential walk; only the order of evaluation differs.
+        struct Walk {                        // where the walk stands: candidate k, window iterators over its sorted pairs
+          uint32_t k, np, it, ms_lo, ms_hi, begin_ref, begin_read;
+          int is_aligned, best, go_on;       // go_on = is_search_candidates
+          int started, pending_pop, buf;     // buf: which pairs buffer holds candidate k (0/1: halves of l_pairs, 2: all of l_pairs, 3: global)
+        };
+        struct SwTask { uint32_t max_ref; uint64_t rf_start, align_ref_start, head, align_que_start; int m, nref; };
+        uint32_t buf_tag[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, buf_np[2] = {0, 0};
+        int real_buf = 0;                                                     // the buffer the real walk's current candidate lives in
+        const uint64_t rlen = len;
+        auto pairs_of = [&](int bufid) -> unsigned long long* { return bufid == 0 ? l_pairs : bufid == 1 ? l_pairs + CH_PAIRS_LDS / 2 : bufid == 2 ? l_pairs : gp; };
+
+        // candidate wk.k: termination rules (:156-169), its hits (:181-201) into a pairs buffer, sorted; false = the candidate loop ends here
+        auto load_candidate = [&](Walk& wk, bool real) -> bool {
+          if (wk.k >= ncand || !wk.go_on || cap_err) return false;
+          const unsigned long long ck = keys[wk.k];
           const uint32_t max_ref = (uint32_t)ck;
           const uint32_t max_occur = 0xFFFFFFFFu - (uint32_t)(ck >> 32);
-          if (max_occur < (uint32_t)P.num_seeds) break;
-          if (is_aligned && P.min_lis > 0 && k > 0 && max_occur < (0xFFFFFFFFu - (uint32_t)(keys[k - 1] >> 32))) {   // :165-169
-            --w.best;
-            if (w.best < 1) break;
+          if (max_occur < (uint32_t)P.num_seeds) return false;
+          if (wk.is_aligned && P.min_lis > 0 && wk.k > 0 && max_occur < (0xFFFFFFFFu - (uint32_t)(keys[wk.k - 1] >> 32))) {   // :165-169
+            --wk.best;
+            if (wk.best < 1) return false;
           }
-          // 3. hits on this reference (:181-201): the tuples recorded for its slot in S
-          uint32_t cslot = (max_ref * 0x9E3779B1u >> 7) & s_mask;
-          while (skey[cslot] != max_ref + 1) cslot = (cslot + 1) & s_mask;
-          uint32_t np = 0;
-          for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            np += (uint32_t)__popcll(__ballot(t < ntup && (uint32_t)((gt[t] >> 16) & 0xFFFFu) == cslot));
-          }
-          if (np > pairs_cap && np > CH_PAIRS_LDS) cap_err = true;
-          if (!cap_err) {
-            unsigned long long* pw_ = np <= CH_PAIRS_LDS ? l_pairs : gp;
+          if (real && buf_tag[0] == wk.k) { wk.buf = 0; wk.np = buf_np[0]; }
+          else if (real && buf_tag[1] == wk.k) { wk.buf = 1; wk.np = buf_np[1]; }
+          else {
+            uint32_t cslot = (max_ref * 0x9E3779B1u >> 7) & s_mask;
+            while (skey[cslot] != max_ref + 1) cslot = (cslot + 1) & s_mask;
+            uint32_t np = 0;
+            for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
+              const uint32_t t = t0 + lane;
+              np += (uint32_t)__popcll(__ballot(t < ntup && (uint32_t)((gt[t] >> 16) & 0xFFFFu) == cslot));
+            }
+            int bufid;
+            if (!real) {                                                      // the look-ahead never touches the buffer the real walk stands on,
+              if (np > CH_PAIRS_LDS / 2 || real_buf == 2) return false;       // and leaves a large candidate to the real walk
+              bufid = real_buf == 0 ? 1 : 0;
+            }
+            else if (np <= CH_PAIRS_LDS / 2) bufid = 0;
+            else if (np <= CH_PAIRS_LDS) bufid = 2;
+            else if (np <= pairs_cap) bufid = 3;
+            else { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; return false; }
+            unsigned long long* pw_ = pairs_of(bufid);
+            __syncthreads();
             uint32_t run = 0;
             for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
               const uint32_t t = t0 + lane;
@@ -438,151 +470,234 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
               if (mt) pw_[run + (uint32_t)__popcll(mm & ((1ull << lane) - 1))] = (tv & 0xFFFFFFFF00000000ull) | (tv & 0xFFFFull);
               run += (uint32_t)__popcll(mm);
             }
+            __syncthreads();
+            if (np > 1) wave_sort_u64(pw_, np);
+            __syncthreads();
+            if (bufid >= 2) { buf_tag[0] = buf_tag[1] = 0xFFFFFFFFu; }
+            else { buf_tag[bufid] = wk.k; buf_np[bufid] = np; }
+            wk.buf = bufid; wk.np = np;
           }
-          if (cap_err) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); break; }
-          unsigned long long* pairs = np <= CH_PAIRS_LDS ? l_pairs : gp;
-          uint32_t* lisb = np <= CH_PAIRS_LDS ? l_lis : gl;
-          uint32_t* lisp = lisb + (np <= CH_PAIRS_LDS ? CH_PAIRS_LDS : pairs_cap);
-          __syncthreads();
-          if (np > 1) wave_sort_u64(pairs, np);
-          __syncthreads();
-          TPH(4)
-          // 4. sliding window of read length along the reference (:203-506)
-          uint32_t it = 0, ms_lo = 0, ms_hi = 0;
-          uint32_t begin_ref = (uint32_t)(pairs[0] >> 32), begin_read = (uint32_t)pairs[0];
-          const uint64_t reflen = ix.ref_off[max_ref + 1] - ix.ref_off[max_ref];
-          while (it != np && is_search_candidates) {
-            const uint64_t end_ref_max = (uint64_t)begin_ref + len - begin_read - P.lnwin + 1;
-            int push = 0;
-            while (it != np && (uint64_t)(uint32_t)(pairs[it] >> 32) <= end_ref_max) { ms_hi = ++it; push = 1; }
-            int skip_to_pop = 0;
-            if (!push && is_aligned) skip_to_pop = 1;        // heuristic 1 (:243-246)
-            else is_aligned = 0;
-            if (!skip_to_pop && (ms_hi - ms_lo) >= (uint32_t)P.num_seeds) {
-              uint32_t lis0;
-              const uint32_t nl = ms_hi - ms_lo <= 64 ? wave_lis_first(pairs + ms_lo, ms_hi - ms_lo, lis0) : serial_lis_first(pairs + ms_lo, ms_hi - ms_lo, lisb, lisp, lis0);
-              if (nl >= (uint32_t)P.min_lis) {
-                const uint32_t lcs_ref_start = (uint32_t)(pairs[ms_lo + lis0] >> 32);
-                const uint32_t lcs_que_start = (uint32_t)pairs[ms_lo + lis0];
-                uint64_t head = 0, tail = 0, align_ref_start = 0, align_que_start = 0, align_length = 0;
-                const uint64_t rlen = len;
-                uint32_t edges;
-                if (P.is_as_percent) edges = (uint32_t)((P.edges / 100.0) * (double)rlen);
-                else edges = (uint32_t)P.edges;
-                if (lcs_ref_start < lcs_que_start) {                         // :287-325
-                  align_ref_start = 0; align_que_start = lcs_que_start - lcs_ref_start; head = 0;
-                  if (reflen < rlen) {
-                    tail = 0;
-                    if (align_que_start > (rlen - reflen)) align_length = reflen - (align_que_start - (rlen - reflen));
-                    else align_length = reflen;
-                  } else {
-                    tail = reflen - align_ref_start - rlen;
-                    if (tail > (uint64_t)(uint32_t)(edges - 1)) tail = edges;
-                    align_length = rlen + head + tail - align_que_start;
-                  }
-                } else {                                                     // :326-357
-                  align_ref_start = lcs_ref_start - lcs_que_start; align_que_start = 0;
-                  if (align_ref_start > (uint64_t)(uint32_t)(edges - 1)) head = edges;
-                  if (align_ref_start + rlen > reflen) { tail = 0; align_length = reflen - align_ref_start - head; }
-                  else {
-                    tail = reflen - align_ref_start - rlen;
-                    if (tail > (uint64_t)(uint32_t)(edges - 1)) tail = edges;
-                    align_length = rlen + head + tail;
-                  }
-                }
-                // read.flip34() to the 0..4 alphabet before SSW (:360-361)
-                // (is03/is04 only toggle when the read has ambiguous letters; aval tracks the stored value)
-                if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; }
-                const int m = (int)(align_length - head - tail);
-                const int nref = (int)align_length;
-                const uint64_t rf_start = ix.ref_off[max_ref] + align_ref_start - head;
-                SwRes fw; fw.score = 0; fw.end_ref = -1; fw.end_read = m - 1;
-                bool sw_ok = (m > 0 && nref > 0 && (uint32_t)m <= lds_ml && (uint32_t)nref <= lds_rf);
-                if (!sw_ok && (m > 0 && nref > 0)) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
-                if (sw_ok) {
-                  for (int q = lane; q < m; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, (uint32_t)align_que_start + q, w.reversed, w.aval);
-                  for (int q = lane; q < nref; q += 64) rfq[q] = ix.ref_seq[rf_start + q];
-                  __syncthreads();
-                  TPH(5)
-                  fw = sw_wave(rdq, m, 0, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
-                  TPH(6)
-                  n_fwd++; n_cells += (unsigned long long)m * nref;
-                }
-                int score1 = fw.score > 65535 ? 65535 : fw.score;
-                int ref_begin1 = -1, read_begin1 = -1;
-                const int ref_end1 = fw.end_ref, read_end1 = fw.end_read;
-                if (sw_ok && (uint32_t)score1 >= (P.minimal_score & 0xFFFFu)) {   // ssw_align: flag==2 && score1 < filters -> no begin
-                  // reverse pass (ssw.c:900-918) on the prefixes ending at (read_end1, ref_end1)
-                  TPH(5)
-                  SwRes bw = sw_wave(rdq, read_end1 + 1, read_end1, -1, rfq, ref_end1 + 1, ref_end1, -1, bound,
-                                     P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
-                  ref_begin1 = ref_end1 - bw.end_ref;
-                  read_begin1 = read_end1 - bw.end_read;
-                  TPH(6)
-                  n_rev++; n_cells += (unsigned long long)(read_end1 + 1) * (ref_end1 + 1);
-                }
-                is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
-                if (is_aligned) {
-                  if ((uint32_t)score1 == max_SW_score) ++st.max_SW_count;
-                  AlignRec al;
-                  al.ref_begin1 = ref_begin1 + (int32_t)(align_ref_start - head);
-                  al.ref_end1 = ref_end1 + (int32_t)(align_ref_start - head);
-                  al.read_begin1 = read_begin1 + (int32_t)align_que_start;
-                  al.read_end1 = read_end1 + (int32_t)align_que_start;
-                  al.readlen = len; al.ref_num = max_ref;
-                  al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
-                  al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
-                  al.has_cigar = 0; al.cigar_off = 0; al.cigar_len = 0;
-                  AlignRec* slots = work_aln + (size_t)r * P.slots;
-                  if (!st.is_hit) {                                              // :411-416
-                    st.is_hit = 1;
-                    if (lane == 0) { atomicAdd(&ctr[C_NUM_ALIGNED], 1ull); atomicAdd(&ctr[C_PER_DB + P.index_num], 1ull); }
-                  }
-                  if (P.num_alignments == 0 || !P.is_best || (P.is_best && st.n_align < P.num_alignments)) {
-                    if (st.n_align < P.slots) { if (lane == 0) slots[st.n_align] = al; st.n_align++; w.is_new_hit = 1; }
-                    else { if (lane == 0) atomicAdd(&ctr[C_ERR_SLOTS], 1ull); }
-                  } else if (P.is_best && st.n_align == P.num_alignments) {
-                    __syncthreads();
-                    if (slots[st.min_index].score1 < (uint16_t)score1) {         // :425-459
-                      if (P.num_alignments > 1 && st.max_index == 0 && st.min_index == 0) {
-                        uint32_t mn = 0, mx = 0;
-                        for (uint32_t q = 1; q < st.n_align; q++) { if (slots[q].score1 < slots[mn].score1) mn = q; if (slots[q].score1 > slots[mx].score1) mx = q; }
-                        st.min_index = mn; st.max_index = mx;
-                      }
-                      const uint32_t mn = st.min_index, mx = st.max_index;
-                      const uint16_t mx_score = slots[mx].score1;
-                      __syncthreads();
-                      if (lane == 0) slots[mn] = al;
-                      __threadfence_block();
-                      __syncthreads();
-                      w.is_new_hit = 1;
-                      if ((uint16_t)score1 > (mn == mx ? (uint16_t)score1 : mx_score) && st.n_align > 1) {
-                        st.max_index = mn;
-                        uint32_t m2 = 0;
-                        for (uint32_t q = 1; q < st.n_align; q++) if (slots[q].score1 < slots[m2].score1) m2 = q;
-                        st.min_index = m2;
-                      }
-                      // :454-457 decrement/increment of reads_matched_per_db cancel (both use the NEW alignment's index)
+          if (real) real_buf = wk.buf;
+          const unsigned long long* pairs = pairs_of(wk.buf);
+          wk.it = 0; wk.ms_lo = 0; wk.ms_hi = 0;
+          wk.begin_ref = (uint32_t)(pairs[0] >> 32); wk.begin_read = (uint32_t)pairs[0];
+          wk.pending_pop = 0;
+          return true;
+        };
+
+        // the sliding window of read length along candidate wk.k (:203-506), up to its next window that calls for ssw_align
+        auto next_task = [&](Walk& wk, SwTask& tk) -> bool {
+          const unsigned long long* pairs = pairs_of(wk.buf);
+          const uint32_t np = wk.np;
+          const uint32_t max_ref = (uint32_t)keys[wk.k];
+          while (wk.it != np && wk.go_on) {
+            if (!wk.pending_pop) {
+              wk.pending_pop = 1;
+              const uint64_t end_ref_max = (uint64_t)wk.begin_ref + len - wk.begin_read - P.lnwin + 1;
+              int push = 0;
+              while (wk.it != np && (uint64_t)(uint32_t)(pairs[wk.it] >> 32) <= end_ref_max) { wk.ms_hi = ++wk.it; push = 1; }
+              int skip_to_pop = 0;
+              if (!push && wk.is_aligned) skip_to_pop = 1;        // heuristic 1 (:243-246)
+              else wk.is_aligned = 0;
+              if (!skip_to_pop && (wk.ms_hi - wk.ms_lo) >= (uint32_t)P.num_seeds) {
+                uint32_t lis0;
+                const uint32_t nw = wk.ms_hi - wk.ms_lo;
+                uint32_t* lisb = nw <= CH_PAIRS_LDS ? l_lis : gl;
+                const uint32_t nl = nw <= 64 ? wave_lis_first(pairs + wk.ms_lo, nw, lis0) : serial_lis_first(pairs + wk.ms_lo, nw, lisb, lisb + (nw <= CH_PAIRS_LDS ? CH_PAIRS_LDS : pairs_cap), lis0);
+                if (nl >= (uint32_t)P.min_lis) {
+                  const uint32_t lcs_ref_start = (uint32_t)(pairs[wk.ms_lo + lis0] >> 32);
+                  const uint32_t lcs_que_start = (uint32_t)pairs[wk.ms_lo + lis0];
+                  const uint64_t reflen = ix.ref_off[max_ref + 1] - ix.ref_off[max_ref];
+                  uint64_t head = 0, tail = 0, align_ref_start = 0, align_que_start = 0, align_length = 0;
+                  uint32_t edges;
+                  if (P.is_as_percent) edges = (uint32_t)((P.edges / 100.0) * (double)rlen);
+                  else edges = (uint32_t)P.edges;
+                  if (lcs_ref_start < lcs_que_start) {                         // :287-325
+                    align_ref_start = 0; align_que_start = lcs_que_start - lcs_ref_start; head = 0;
+                    if (reflen < rlen) {
+                      tail = 0;
+                      if (align_que_start > (rlen - reflen)) align_length = reflen - (align_que_start - (rlen - reflen));
+                      else align_length = reflen;
+                    } else {
+                      tail = reflen - align_ref_start - rlen;
+                      if (tail > (uint64_t)(uint32_t)(edges - 1)) tail = edges;
+                      align_length = rlen + head + tail - align_que_start;
+                    }
+                  } else {                                                     // :326-357
+                    align_ref_start = lcs_ref_start - lcs_que_start; align_que_start = 0;
+                    if (align_ref_start > (uint64_t)(uint32_t)(edges - 1)) head = edges;
+                    if (align_ref_start + rlen > reflen) { tail = 0; align_length = reflen - align_ref_start - head; }
+                    else {
+                      tail = reflen - align_ref_start - rlen;
+                      if (tail > (uint64_t)(uint32_t)(edges - 1)) tail = edges;
+                      align_length = rlen + head + tail;
                     }
                   }
-                  __syncthreads();
-                  if (P.num_alignments > 0) {                                    // :462-469
-                    if (P.is_best) { if (P.num_alignments == st.max_SW_count) is_search_candidates = 0; }
-                    else if (P.num_alignments == st.n_align) is_search_candidates = 0;
-                  }
-                  search = 0;
+                  tk.max_ref = max_ref; tk.align_ref_start = align_ref_start; tk.head = head; tk.align_que_start = align_que_start;
+                  tk.m = (int)(align_length - head - tail); tk.nref = (int)align_length;
+                  tk.rf_start = ix.ref_off[max_ref] + align_ref_start - head;
+                  return true;
                 }
               }
             }
             // pop (:486-506)
-            if (ms_hi > ms_lo) ms_lo++;
-            if (ms_hi == ms_lo) {
-              if (it != np) { begin_ref = (uint32_t)(pairs[it] >> 32); begin_read = (uint32_t)pairs[it]; }
+            wk.pending_pop = 0;
+            if (wk.ms_hi > wk.ms_lo) wk.ms_lo++;
+            if (wk.ms_hi == wk.ms_lo) {
+              if (wk.it != np) { wk.begin_ref = (uint32_t)(pairs[wk.it] >> 32); wk.begin_read = (uint32_t)pairs[wk.it]; }
               else break;
-            } else { begin_ref = (uint32_t)(pairs[ms_lo] >> 32); begin_read = (uint32_t)pairs[ms_lo]; }
+            } else { wk.begin_ref = (uint32_t)(pairs[wk.ms_lo] >> 32); wk.begin_read = (uint32_t)pairs[wk.ms_lo]; }
           }
-          __syncthreads();
+          return false;
+        };
+
+        auto advance = [&](Walk& wk, bool real, SwTask& tk) -> bool {
+          for (;;) {
+            if (!wk.started) {
+              if (!load_candidate(wk, real)) return false;
+              wk.started = 1;
+            }
+            if (next_task(wk, tk)) return true;
+            wk.k++; wk.started = 0;
+            __syncthreads();
+          }
+        };
+
+        Walk R;
+        R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0;
+        R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.buf = 0;
+        SwTask ctk[4]; SwRes cfw[4]; int n_cached = 0;
+        bool rdq_staged = false;
+        const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
+        for (;;) {
+          SwTask tk;
+          if (!advance(R, true, tk)) break;
+          // read.flip34() to the 0..4 alphabet before SSW (:360-361)
+          // (is03/is04 only toggle when the read has ambiguous letters; aval tracks the stored value)
+          if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; rdq_staged = false; }
+          const int m = tk.m, nref = tk.nref;
+          const bool sw_ok = (m > 0 && nref > 0 && (uint32_t)m <= lds_ml && (uint32_t)nref <= lds_rf);
+          if (!sw_ok && (m > 0 && nref > 0)) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
+          SwRes fw; fw.score = 0; fw.end_ref = -1; fw.end_read = m - 1;
+          int ce = -1;
+          if (sw_ok) {
+            for (int e = 0; e < n_cached; e++)
+              if (ctk[e].max_ref == tk.max_ref && ctk[e].rf_start == tk.rf_start && ctk[e].align_que_start == tk.align_que_start && ctk[e].m == m && ctk[e].nref == nref) { ce = e; break; }
+            if (ce < 0) {
+              // a new batch: this task, and the tasks the walk would reach next if this one and they do not align
+              ctk[0] = tk; n_cached = 1;
+              if (x4_ok) {
+                Walk L = R; L.is_aligned = 0;
+                while (n_cached < 4) {
+                  SwTask t2;
+                  if (!advance(L, false, t2)) break;
+                  if (!(t2.m > 0 && t2.nref > 0 && (uint32_t)t2.m <= lds_ml && (uint32_t)t2.nref <= lds_rf)) break;
+                  ctk[n_cached++] = t2; L.is_aligned = 0;
+                }
+              }
+              __syncthreads();
+              if (!rdq_staged) { for (uint32_t q = lane; q < len; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, w.aval); rdq_staged = true; }
+              bool hasn = false;
+              for (int e = 0; e < n_cached; e++) {
+                uint8_t* dst = rfq + (size_t)e * lds_rf;                    // windows 1..3 overlay the strip-boundary array, which single-strip problems do not use
+                for (int q = lane; q < ctk[e].nref; q += 64) { const uint8_t ch = ix.ref_seq[ctk[e].rf_start + q]; dst[q] = ch; hasn |= ch == 4; }
+              }
+              __syncthreads();
+              TPH(5)
+              if (n_cached >= 2) {
+                const int g = lane >> 4;
+                const bool mine = g < n_cached;
+                const int gm = mine ? (g == 0 ? ctk[0].m : g == 1 ? ctk[1].m : g == 2 ? ctk[2].m : ctk[3].m) : 0;
+                const int gn = mine ? (g == 0 ? ctk[0].nref : g == 1 ? ctk[1].nref : g == 2 ? ctk[2].nref : ctk[3].nref) : 0;
+                const int gq = mine ? (int)(g == 0 ? ctk[0].align_que_start : g == 1 ? ctk[1].align_que_start : g == 2 ? ctk[2].align_que_start : ctk[3].align_que_start) : 0;
+                int mm = gm;
+                for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
+                const SwRes r4 = sw_wave_x4(rdq, gm, gq, 1, rfq + (size_t)g * lds_rf, gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
+                for (int e = 0; e < n_cached; e++) {
+                  cfw[e].score = __builtin_amdgcn_readlane(r4.score, 16 * e); cfw[e].end_ref = __builtin_amdgcn_readlane(r4.end_ref, 16 * e);
+                  cfw[e].end_read = __builtin_amdgcn_readlane(r4.end_read, 16 * e);
+                }
+                if (n_cached > 1) n_spec += (unsigned long long)(n_cached - 1);
+              } else {
+                cfw[0] = sw_wave(rdq, m, (int)tk.align_que_start, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+              }
+              __syncthreads();
+              TPH(6)
+              ce = 0;
+            }
+            else n_spec_used++;
+            fw = cfw[ce];
+            n_fwd++; n_cells += (unsigned long long)m * nref;
+          }
+          const uint64_t align_ref_start = tk.align_ref_start, head = tk.head, align_que_start = tk.align_que_start;
+          const uint32_t max_ref = tk.max_ref;
+          int score1 = fw.score > 65535 ? 65535 : fw.score;
+          int ref_begin1 = -1, read_begin1 = -1;
+          const int ref_end1 = fw.end_ref, read_end1 = fw.end_read;
+          if (sw_ok && (uint32_t)score1 >= (P.minimal_score & 0xFFFFu)) {   // ssw_align: flag==2 && score1 < filters -> no begin
+            // reverse pass (ssw.c:900-918) on the prefixes ending at (read_end1, ref_end1)
+            TPH(5)
+            SwRes bw = sw_wave(rdq, read_end1 + 1, (int)align_que_start + read_end1, -1, rfq + (size_t)ce * lds_rf, ref_end1 + 1, ref_end1, -1, bound,
+                               P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+            ref_begin1 = ref_end1 - bw.end_ref;
+            read_begin1 = read_end1 - bw.end_read;
+            __syncthreads();
+            TPH(6)
+            n_rev++; n_cells += (unsigned long long)(read_end1 + 1) * (ref_end1 + 1);
+          }
+          R.is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
+          if (R.is_aligned) {
+            if ((uint32_t)score1 == max_SW_score) ++st.max_SW_count;
+            AlignRec al;
+            al.ref_begin1 = ref_begin1 + (int32_t)(align_ref_start - head);
+            al.ref_end1 = ref_end1 + (int32_t)(align_ref_start - head);
+            al.read_begin1 = read_begin1 + (int32_t)align_que_start;
+            al.read_end1 = read_end1 + (int32_t)align_que_start;
+            al.readlen = len; al.ref_num = max_ref;
+            al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
+            al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
+            al.has_cigar = 0; al.cigar_off = 0; al.cigar_len = 0;
+            AlignRec* slots = work_aln + (size_t)r * P.slots;
+            if (!st.is_hit) {                                              // :411-416
+              st.is_hit = 1;
+              if (lane == 0) { atomicAdd(&ctr[C_NUM_ALIGNED], 1ull); atomicAdd(&ctr[C_PER_DB + P.index_num], 1ull); }
+            }
+            if (P.num_alignments == 0 || !P.is_best || (P.is_best && st.n_align < P.num_alignments)) {
+              if (st.n_align < P.slots) { if (lane == 0) slots[st.n_align] = al; st.n_align++; w.is_new_hit = 1; }
+              else { if (lane == 0) atomicAdd(&ctr[C_ERR_SLOTS], 1ull); }
+            } else if (P.is_best && st.n_align == P.num_alignments) {
+              __syncthreads();
+              if (slots[st.min_index].score1 < (uint16_t)score1) {         // :425-459
+                if (P.num_alignments > 1 && st.max_index == 0 && st.min_index == 0) {
+                  uint32_t mn = 0, mx = 0;
+                  for (uint32_t q = 1; q < st.n_align; q++) { if (slots[q].score1 < slots[mn].score1) mn = q; if (slots[q].score1 > slots[mx].score1) mx = q; }
+                  st.min_index = mn; st.max_index = mx;
+                }
+                const uint32_t mn = st.min_index, mx = st.max_index;
+                const uint16_t mx_score = slots[mx].score1;
+                __syncthreads();
+                if (lane == 0) slots[mn] = al;
+                __threadfence_block();
+                __syncthreads();
+                w.is_new_hit = 1;
+                if ((uint16_t)score1 > (mn == mx ? (uint16_t)score1 : mx_score) && st.n_align > 1) {
+                  st.max_index = mn;
+                  uint32_t m2 = 0;
+                  for (uint32_t q = 1; q < st.n_align; q++) if (slots[q].score1 < slots[m2].score1) m2 = q;
+                  st.min_index = m2;
+                }
+                // :454-457 decrement/increment of reads_matched_per_db cancel (both use the NEW alignment's index)
+              }
+            }
+            __syncthreads();
+            if (P.num_alignments > 0) {                                    // :462-469
+              if (P.is_best) { if (P.num_alignments == st.max_SW_count) R.go_on = 0; }
+              else if (P.num_alignments == st.n_align) R.go_on = 0;
+            }
+            search = 0;
+          }
         }
+        w.best = R.best;
       }
     }
     TPH(5)
@@ -611,6 +726,8 @@ __global__ void __launch_bounds__(64, 4) k_chain(DReads rd, DIndex ix, DParams P
     if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
     if (n_rev) ctr_add(ctr, C_SW_REV, n_rev);
     if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
+    if (n_spec) atomicAdd(&ctr[C_SW_SPEC], n_spec);
+    if (n_spec_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_spec_used);
 #ifdef SMR_CHAIN_PHASES
     for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
 #endif

@@ -67,7 +67,7 @@ struct smr_ctx {
   uint32_t chain_blocks = 0;
   unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
   size_t chain_lds_attr = 0;
-  int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 1;   // 1: packed 16-bit Smith-Waterman kernel (smr_sw_pk.hpp) where it applies
+  int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 2;   // 1 / 2: packed 16-bit Smith-Waterman kernels (smr_sw_pk.hpp; 2 = lane hand-over by wave_ror, measured faster) where they apply
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
@@ -577,9 +577,41 @@ __global__ void __launch_bounds__(64) k_ssw_batch(uint32_t n_pairs, const uint8_
   }
 }
 
+// the same through the four-problems-per-wave kernel (sw_wave_x4): row g of the wave takes pair 4 b + g; forward pass, then the reverse
+// pass of the rows whose score passed the filter (the others idle)
+__global__ void __launch_bounds__(64) k_ssw_batch_x4(uint32_t n_pairs, const uint8_t* __restrict__ reads, const unsigned long long* __restrict__ read_off,
+                                                     const uint8_t* __restrict__ refs, const unsigned long long* __restrict__ ref_off, uint32_t lds_m, uint32_t lds_n,
+                                                     int match, int mismatch, int scoreN, int go, int ge, uint32_t filters, int* __restrict__ out) {
+  SMR_DYN_LDS(unsigned char, lds_raw);
+  const int lane = smr::lane_id(), g = lane >> 4, gl = lane & 15;
+  uint8_t* rdq = lds_raw + (size_t)g * lds_m;
+  uint8_t* rfq = lds_raw + (size_t)4 * lds_m + (size_t)g * lds_n;
+  for (uint32_t p0 = blockIdx.x * 4; p0 < n_pairs; p0 += gridDim.x * 4) {
+    const uint32_t pi = p0 + g;
+    const bool have = pi < n_pairs;
+    int m = have ? (int)(read_off[pi + 1] - read_off[pi]) : 0, n = have ? (int)(ref_off[pi + 1] - ref_off[pi]) : 0;
+    if (n == 0) m = 0;
+    __syncthreads();
+    bool hasn = false;
+    for (int q = gl; q < m; q += 16) rdq[q] = reads[read_off[pi] + q];
+    for (int q = gl; q < n; q += 16) { const uint8_t ch = refs[ref_off[pi] + q]; rfq[q] = ch; hasn |= ch == 4; }
+    __syncthreads();
+    int mm = m;
+    for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
+    const bool hn = __any(hasn);
+    int res[5] = {0, -1, -1, -1, m - 1};
+    const smr::SwRes fw = smr::sw_wave_x4(rdq, m, 0, 1, rfq, n, 0, 1, match, mismatch, scoreN, go, ge, mm, hn);
+    res[0] = fw.score > 65535 ? 65535 : fw.score; res[2] = fw.end_ref; res[4] = fw.end_read;
+    const bool rev = m > 0 && (uint32_t)res[0] >= filters && fw.score > 0;
+    const smr::SwRes bw = smr::sw_wave_x4(rdq, rev ? fw.end_read + 1 : 0, fw.end_read, -1, rfq, rev ? fw.end_ref + 1 : 0, fw.end_ref, -1, match, mismatch, scoreN, go, ge, mm, hn);
+    if (rev) { res[1] = fw.end_ref - bw.end_ref; res[3] = fw.end_read - bw.end_read; }
+    if (have && gl < 5) out[(size_t)pi * 5 + gl] = res[gl];
+  }
+}
+
 extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                              int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out) {
-  if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 2) return SMR_ERR_ARG;
+  if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 3) return SMR_ERR_ARG;
   if (n_pairs == 0) return SMR_OK;
   (void)hipSetDevice(c->device);
   uint64_t mx_m = 1, mx_n = 1;
@@ -595,6 +627,16 @@ extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads,
   if (ref_off[n_pairs]) HIPCHK(c, hipMemcpyAsync(d_refs, refs, ref_off[n_pairs], hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_ro, read_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d_fo, ref_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  if (mode == 3) {          // four pairs per wave (the kernel k_chain batches candidate windows with): spans up to SW_X4_MAX_ROWS, numbers within the packed range
+    for (uint32_t i = 0; i < n_pairs; i++) {
+      const uint64_t m = read_off[i + 1] - read_off[i], n = ref_off[i + 1] - ref_off[i];
+      if (m > SW_X4_MAX_ROWS || !((long long)m * match + 255 < 32768 && n + 128 <= 8191 && gap_open + mismatch >= 0 && gap_open + score_N >= 0 && match + gap_open <= 255 && score_N + gap_open <= 255)) {
+        c->err = "smr_ssw_batch mode 3: a pair is outside the range of the four-problem kernel"; return SMR_ERR_ARG;
+      }
+    }
+    hipLaunchKernelGGL(k_ssw_batch_x4, dim3(std::min<uint32_t>((n_pairs + 3) / 4, (uint32_t)c->n_cu * 8u)), dim3(64), (size_t)4 * (lm + ln), c->stream, n_pairs, (const uint8_t*)d_reads,
+                       (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, d_out);
+  } else
   hipLaunchKernelGGL(k_ssw_batch, dim3(std::min<uint32_t>(n_pairs, (uint32_t)c->n_cu * 8u)), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
                      (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, mode, d_out);
   HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n_pairs * 5 * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1179,6 +1221,7 @@ extern "C" int smr_prof_reset(smr_ctx* c) {
   for (int k = 0; k < SMR_MAX_BATCHES; k++)
     if (c->bt[k].d_ctr) {
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SW_SPEC], 0, 2 * 8, c->stream));
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SHARDS], 0, 16 * C_NSHARD * 8, c->stream));
     }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1204,5 +1247,6 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
   o->seed_ms = c->seed_ms; o->seed_launches = c->seed_l; o->chain_ms = c->chain_ms; o->chain_launches = c->chain_l; o->trace_ms = c->trace_ms; o->trace_launches = c->trace_l;
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];
+  o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED];
   return SMR_OK;
 }

@@ -183,4 +183,120 @@ __device__ __forceinline__ SwRes sw_wave_pk_r(const uint8_t* rdq, int m, int rd0
   return rr;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Four independent problems per wave: each DPP row of 16 lanes is its own systolic array of 32 virtual lanes (low halves =
+// virtual lanes 0..15, high halves 16..31, R consecutive read rows each: reads up to 32 R rows, one strip).  A single 150-nt
+// problem keeps 75 of the 128 virtual lanes of sw_wave_pk_r busy for n + 74 steps; four of them side by side fill 120 virtual
+// lanes for n + 29 steps, i.e. ~2.7 x fewer wave instructions per problem.  Same recurrence, same representation, same end-cell
+// rule as sw_wave_pk_r (whose results it must equal bit for bit).  Differences: the hand-over between neighbouring virtual lanes is
+// row_ror:1 (lane 0 of a row takes lane 15's low half into its high half), and the reference letters of a row's problem enter at
+// its lane 0 from a 16-column register window that moves down by one lane per step (row_shl:1) and is reloaded every 16 steps.
+// Every lane passes ITS row's problem: read rdq[rd0 + rdstep * row], m rows; reference rfq[rf0 + rfstep * col], n columns
+// (m = 0: the row idles).  The result of a row's problem is returned in all 16 lanes of that row.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpp_row_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x121 /* row_ror:1 */, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_row_shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x101 /* row_shl:1 */, 0xF, 0xF, false); }
+
+template <int R, bool HASN>
+__device__ __forceinline__ SwRes sw_wave_pk_x4(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                               int match, int mismatch, int scoreN, int go, int ge) {
+  const int gl = lane_id() & 15;
+  const pk16 GE = pk_splat(ge), GO = pk_splat(go), ZERO = pk_splat(0);
+  const uint32_t TN = (((uint32_t)(scoreN + go)) & 0xFFFFu) * 0x00010001u;
+  uint32_t tlo[R], thi[R];
+  pk16 Y[R], E[R];
+  uint32_t key[R];
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    uint32_t t2[2];
+    for (int hf = 0; hf < 2; hf++) {
+      const int row = (gl + 16 * hf) * R + j;
+      uint32_t t = 0;
+      if (row < m) {
+        const int c = rdq[rd0 + rdstep * row];
+        for (int b = 0; b < 4; b++) t |= (uint32_t)((c == 4 ? scoreN : (c == b ? match : mismatch)) + go) << (8 * b);
+      }
+      t2[hf] = t;
+    }
+    tlo[j] = t2[0]; thi[j] = t2[1];
+    Y[j] = pk_splat(-go); E[j] = ZERO; key[j] = 0;
+  }
+  int steps = m > 0 ? n + (m + R - 1) / R - 1 : 0;
+  for (int d = 32; d > 0; d >>= 1) steps = max(steps, __shfl_xor(steps, d, 64));
+  uint32_t lastY = pk_bits(pk_splat(-go)), lastF = 0, selcur = PK_SEL_NONE * 0x00010001u;
+  pk16 diag0 = pk_splat(-go);
+  const uint32_t in_y = (uint32_t)(-go) & 0xFFFFu;                  // what enters virtual lane 0 from above: H = 0 (Y = -gap_open), F = 0
+  uint32_t xlo = ((uint32_t)(0x3FFF + gl) << 1) | 1u;               // column term of the running-maximum key, as in sw_wave_pk_r
+  uint32_t win = PK_SEL_NONE;
+  const bool first = gl == 0;
+  for (int t = 0; t < steps; t++) {
+    if ((t & 15) == 0) { const int cq = t + gl; win = cq < n ? pk_sel_of(rfq[rf0 + rfstep * cq]) : PK_SEL_NONE; }
+    const uint32_t rY = (uint32_t)dpp_row_ror1((int)lastY), rF = (uint32_t)dpp_row_ror1((int)lastF), rS = (uint32_t)dpp_row_ror1((int)selcur);
+    const pk16 upY = pk_from(first ? ((rY << 16) | in_y) : rY);
+    const pk16 upF = pk_from(first ? (rF << 16) : rF);
+    selcur = first ? ((rS << 16) | win | 0x00040000u) : rS;
+    win = (uint32_t)dpp_row_shl1((int)win);
+    uint32_t nmask = 0;
+    if (HASN) nmask = ((selcur >> 8) & 0x00010001u) * 0xFFFFu;
+    const uint32_t xhi = xlo + 31u;                                 // the high half is 16 columns behind, flag 0
+    pk16 diag = diag0, uy = upY, uf = upF;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+      uint32_t T = perm_b32(thi[j], tlo[j], selcur);
+      if (HASN) T = (T & ~nmask) | (TN & nmask);
+      const pk16 a = pk_add(diag, pk_from(T));
+      const pk16 e = pk_max(pk_sub(E[j], GE), Y[j]);
+      const pk16 f = pk_max(pk_sub(uf, GE), uy);
+      const pk16 h = pk_max(pk_max(a, e), pk_max(f, ZERO));
+      diag = Y[j];
+      const pk16 y = pk_sub(h, GO);
+      Y[j] = y; E[j] = e;
+      const uint32_t hu = pk_bits(h);
+      key[j] = max(key[j], max((hu << 16) | xlo, (hu & 0xFFFF0000u) | xhi));
+      uy = y; uf = f;
+    }
+    diag0 = upY;
+    lastY = pk_bits(uy); lastF = pk_bits(uf);
+    xlo -= 2u;
+  }
+  int bestH = 0, bestcol = 0x1FFFFF, bestrow = 0x1FFFFF;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const int h = (int)(key[j] >> 16);
+    const int hf = (key[j] & 1u) ? 0 : 1;
+    const int col = 0x3FFF - (int)((key[j] >> 1) & 0x7FFFu);
+    const int row = (gl + 16 * hf) * R + j;
+    if (h > bestH || (h == bestH && h > 0 && (col < bestcol || (col == bestcol && row < bestrow)))) { bestH = h; bestcol = col; bestrow = row; }
+  }
+  unsigned long long k64 = bestH > 0 ? (((unsigned long long)bestH << 42) | ((unsigned long long)(0x1FFFFF - bestcol) << 21) |
+                                        (unsigned long long)(0x1FFFFF - bestrow)) : 0ull;
+  for (int d = 8; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(k64, d, 16); k64 = o > k64 ? o : k64; }
+  SwRes rr;
+  if (k64 == 0) { rr.score = 0; rr.end_ref = -1; rr.end_read = m - 1; return rr; }
+  rr.score = (int)(k64 >> 42);
+  rr.end_ref = 0x1FFFFF - (int)((k64 >> 21) & 0x1FFFFF);
+  rr.end_read = 0x1FFFFF - (int)(k64 & 0x1FFFFF);
+  return rr;
+}
+
+// the largest read span the four-problem kernel takes, and whether a problem's numbers fit the packed representation at all
+#define SW_X4_MAX_ROWS 256
+__device__ __forceinline__ bool sw_pk_fits(int m, int n, int match, int mismatch, int scoreN, int go) {
+  return (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255;
+}
+// max_m: the longest read span among the wave's problems (wave-uniform), hasn: some reference window holds an N (wave-uniform)
+__device__ __attribute__((noinline)) SwRes sw_wave_x4(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                                      int match, int mismatch, int scoreN, int go, int ge, int max_m, bool hasn) {
+#define X4_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, match, mismatch, scoreN, go, ge
+  if (hasn) {
+    if (max_m <= 96) return sw_wave_pk_x4<3, true>(X4_ARGS);
+    if (max_m <= 160) return sw_wave_pk_x4<5, true>(X4_ARGS);
+    return sw_wave_pk_x4<8, true>(X4_ARGS);
+  }
+  if (max_m <= 96) return sw_wave_pk_x4<3, false>(X4_ARGS);
+  if (max_m <= 160) return sw_wave_pk_x4<5, false>(X4_ARGS);
+  return sw_wave_pk_x4<8, false>(X4_ARGS);
+#undef X4_ARGS
+}
+
 }  // namespace smr

@@ -34,3 +34,19 @@ def check(engine, modes=(0, 1, 2), max_pairs=None):
                 mode, sc, bad.size, k, bad[0], len(c["reads_b"][bad[0]]), len(c["refs_b"][bad[0]]), got[bad[0]].tolist(), exp[bad[0]].tolist())
         n += k
     return n
+
+
+def check_x4(engine):
+    """the four-problems-per-wave kernel (smr_ssw_batch mode 3) on the pairs it takes (read spans <= 256, any four of them per wave)"""
+    n = 0
+    for c in load():
+        sc = c["scoring"]
+        idx = [i for i in range(len(c["reads_b"])) if len(c["reads_b"][i]) <= 256]
+        got = engine.ssw_batch([c["reads_b"][i] for i in idx], [c["refs_b"][i] for i in idx], match=sc["match"], mismatch=sc["mismatch"], score_N=sc["score_N"],
+                               gap_open=sc["gap_open"], gap_ext=sc["gap_ext"], filters=sc["filters"], mode=3)
+        exp = c["expected_a"][idx]
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        assert bad.size == 0, "x4 kernel, scoring %s: %d of %d pairs differ from ssw.c; first pair %d (m=%d, n=%d): got %s, ssw.c %s" % (
+            sc, bad.size, len(idx), idx[bad[0]], len(c["reads_b"][idx[bad[0]]]), len(c["refs_b"][idx[bad[0]]]), got[bad[0]].tolist(), exp[bad[0]].tolist())
+        n += len(idx)
+    return n

@@ -70,10 +70,10 @@ def test_packed_smith_waterman_equals_the_32bit_kernel(emulator):
     systolic kernel on seeded random pairs -- single strip (<= 128 / 256 rows), several strips, N in read and reference,
     two scoring schemes, forward and reverse pass."""
     e = smr.Engine(0)
-    assert e.sw_mode() == 1                         # smr_create's own check passed
+    assert e.sw_mode() == 2                         # smr_create's own check passed (default: the wave_ror variant)
     for max_len, cases in ((100, 24), (250, 24), (700, 16), (1500, 8)):
         assert e.sw_selfcheck(cases, 11 + max_len, max_len) == 0
-    assert e.sw_mode(2) == 2                        # the wave_ror variant of the packed kernel
+    assert e.sw_mode(1) == 1                        # the readlane variant of the packed kernel
     for max_len, cases in ((100, 24), (250, 24), (700, 16), (1500, 8)):
         assert e.sw_selfcheck(cases, 11 + max_len, max_len) == 0
     e.close()
@@ -130,6 +130,7 @@ def test_sw_kernels_equal_the_reference_ssw_c(emulator):
     from helpers import sswgold
     e = smr.Engine(0)
     assert sswgold.check(e) == 320
+    assert sswgold.check_x4(e) > 150
     e.close()
 
 

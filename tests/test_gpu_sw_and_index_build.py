@@ -25,6 +25,7 @@ def test_sw_kernels_equal_the_reference_ssw_c(engine):
     """smr_ssw_batch (32-bit and packed kernel) against the answers of the reference's own ssw.c (tests/golden/ssw_pairs.json)"""
     from helpers import sswgold
     assert sswgold.check(engine) == 320
+    assert sswgold.check_x4(engine) > 150          # the four-problems-per-wave kernel that k_chain batches candidate windows with
 
 
 def test_traceback_kernels_equal_the_reference_banded_sw(engine):
@@ -40,12 +41,12 @@ def test_packed_smith_waterman_selfcheck_on_the_device(engine):
     assert engine.sw_selfcheck(2000, 3, 300) == 0
     assert engine.sw_selfcheck(1000, 4, 1200) == 0
     assert engine.sw_selfcheck(200, 5, 3500) == 0
-    assert engine.sw_mode() == 1
+    assert engine.sw_mode() == 2                    # the default: packed kernel, lane hand-over by wave_ror
     try:
-        assert engine.sw_mode(2) == 2               # the wave_ror variant
+        assert engine.sw_mode(1) == 1               # the readlane variant
         assert engine.sw_selfcheck(2000, 6, 300) == 0 and engine.sw_selfcheck(300, 7, 2000) == 0
     finally:
-        engine.sw_mode(1)
+        engine.sw_mode(2)
 
 
 def test_both_smith_waterman_kernels_give_the_same_records(engine, wl):
@@ -55,7 +56,7 @@ def test_both_smith_waterman_kernels_give_the_same_records(engine, wl):
             assert engine.sw_mode(mode) == mode
             recs[mode], _ = wl.gpu_records(engine)
     finally:
-        engine.sw_mode(1)
+        engine.sw_mode(2)
     assert recs[0] == recs[1] == recs[2]
 
 

@@ -40,6 +40,13 @@ phases)
 ab)
   # the wave_ror variant of the packed SW kernel against the default (same workload, torch-free)
   SMR_SW_PACKED=2 timeout 300 python tools/hw_minibench.py > $OUT/minibench_ror.log 2>&1; grep "SW kernel" $OUT/minibench_ror.log ;;
+alt)
+  # an alternative build of the library (sortmerna_amd/lib/libsmr_hip_alt.so, made in the container with other -D flags) on the same mini bench
+  if [ -f sortmerna_amd/lib/libsmr_hip_alt.so ]; then
+    cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp sortmerna_amd/lib/libsmr_hip_alt.so sortmerna_amd/lib/libsmr_hip.so
+    timeout 300 python tools/hw_minibench.py > $OUT/minibench_alt.log 2>&1; grep -E "SW kernel" $OUT/minibench_alt.log | tail -4
+    cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
+  fi ;;
 mini)
   timeout 300 python tools/hw_minibench.py > $OUT/minibench.log 2>&1; tail -6 $OUT/minibench.log ;;
 esac; done

@@ -82,7 +82,7 @@ for mode in (START, 0, START):
     p = eng.prof()
     eng.select_batch(1)
     al = eng.counters(1)["num_aligned"]
-    say("SW kernel %s: %.2f M reads/s (%.1f ms per 2 M-read step); seed stage %.2f ms/launch x %d, k_chain %.2f ms/launch x %d, k_trace %.2f ms x %d; aligned(batch 1) %d" % (
+    say("spec SW issued %d used %d; " % (p.n_sw_spec, p.n_sw_spec_used) + "SW kernel %s: %.2f M reads/s (%.1f ms per 2 M-read step); seed stage %.2f ms/launch x %d, k_chain %.2f ms/launch x %d, k_trace %.2f ms x %d; aligned(batch 1) %d" % (
         {0: "32-bit", 1: "packed", 2: "packed (wave_ror)"}[mode], 2 * BATCH / dt / 1e6, dt / 2 * 1e3, p.seed_ms / max(p.seed_launches, 1), p.seed_launches,
         p.chain_ms / max(p.chain_launches, 1), p.chain_launches, p.trace_ms / max(p.trace_launches, 1), p.trace_launches, al))
 if os.environ.get("MB_HOST_BUILD"):
