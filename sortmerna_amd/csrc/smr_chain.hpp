@@ -256,8 +256,13 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
   const int lane = lane_id();
+  // rdq: read slot 0 (lds_ml bytes: the read being walked) + 4 slots of lds_mq = min(lds_ml, SW_X4_MAX_ROWS) bytes (the parked reads);
+  // rfq: 9 reference-window slots of lds_rf bytes
+  // (0..3: the batch of the read being walked, 4..7: the parked tasks) of which slots 1..8 share their memory with `bound`, the
+  // strip-boundary array that only reads of more than SW_X4_MAX_ROWS letters need (nothing is ever parked while such a read is walked)
   uint8_t* rdq = lds_raw;
-  uint8_t* rfq = rdq + lds_ml;
+  const uint32_t lds_mq = min(lds_ml, (uint32_t)SW_X4_MAX_ROWS);
+  uint8_t* rfq = rdq + (size_t)lds_ml + 4 * (size_t)lds_mq;
   int* bound = (int*)(rfq + lds_rf);
   unsigned long long* l_keys = (unsigned long long*)(bound + 2 * lds_rf);
   // region R: [pairs | lis] during the candidate loop, [bloom | scnt] while the candidate set is built (dead afterwards)
@@ -285,17 +290,104 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 #else
 #define TPH(i)
 #endif
-  uint32_t chunk_next = 0, chunk_end = 0;                 // reads are claimed 16 at a time (one atomic per chunk)
-  for (;;) {
-    if (chunk_next == chunk_end) {
-      __syncthreads();
-      if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 16ull);
-      __syncthreads();
-      chunk_next = s_next; chunk_end = min(chunk_next + 16u, rd.n);
-      if (chunk_next >= rd.n) break;
+  // end of traverse() for one read: pass control (paralleltraversal.cpp:253-277), state write-back
+  auto finish_read = [&](uint32_t r, RState& st, RWork& w, int search, bool writer) {
+    uint32_t pass_n = w.pass_n;
+    if (search) {
+      if (pass_n == 2) search = 0;
+      else {
+        while (pass_n < 2 && P.skip[pass_n] == P.skip[pass_n + 1]) ++pass_n;
+        if (++pass_n > 2) search = 0;
+        else w.win_shift = P.skip[pass_n];
+      }
     }
-    __syncthreads();
-    const uint32_t r = chunk_next++;
+    w.pass_n = (uint8_t)pass_n; w.search = (uint8_t)search;
+    if (!search) {
+      // end of traverse() (:279-297)
+      st.lastIndex = P.index_num; st.lastPart = P.part;
+      if (P.num_alignments > 0) {
+        if ((P.is_best && P.num_alignments == st.max_SW_count) || (!P.is_best && st.n_align == P.num_alignments)) st.is_done = 1;
+      } else if (P.is_last_index_part && is_last_strand && st.n_align > 0) st.is_done = 1;
+      w.strand_active = 0;
+    }
+    if (writer) { work[r] = st; rw[r] = w; }
+  };
+  // Reads whose walk meets exactly ONE Smith-Waterman task (the usual case for a background read with a spurious candidate) are PARKED:
+  // task and sequences go into one of four LDS slots, nothing is written back, the wave moves on to its next read.  Four parked tasks
+  // of four different reads are scored by one pass of the four-problem kernel.  A result that is "no alignment" -- what the walk was
+  // run ahead under -- completes its read exactly as the sequential walk would have; any other result sends the read through the
+  // walk again from the start, in immediate mode, with this result already in its cache.
+  __shared__ uint32_t q_r[4], q_max_ref[4], q_aq[4], q_m[4], q_nref[4], q_ars[4], q_head[4];
+  __shared__ unsigned long long q_rf[4];
+  __shared__ int q_score[4], q_eref[4], q_eread[4];
+  uint32_t q_n = 0, n_redo = 0, redo_slots = 0;          // parked tasks; parked reads to walk again (bit mask of their slots)
+  bool q_hasn = false, need_flush = false, out_of_reads = false;
+  uint32_t chunk_base = 0, chunk_todo = 0;                // reads are claimed 16 at a time (one atomic per chunk); bit i: read chunk_base + i is still to be walked
+  for (;;) {
+    uint32_t r;
+    int mode = 0, seed_slot = -1;                         // mode 1: immediate (sequential walk), possibly seeded with the parked task's result
+    if (n_redo > 0) {
+      seed_slot = __ffs((int)redo_slots) - 1; redo_slots &= redo_slots - 1; n_redo--;
+      r = q_r[seed_slot]; mode = 1;
+    } else if (need_flush || (out_of_reads && q_n > 0)) {
+      // ---- score the parked tasks together ----
+      __syncthreads();
+      TPH(5)
+      if (q_n >= 2) {
+        const int g = lane >> 4;
+        const bool mine = (uint32_t)g < q_n;
+        const int gm = mine ? (int)q_m[g] : 0, gn = mine ? (int)q_nref[g] : 0, gq = mine ? (int)q_aq[g] : 0;
+        int mm = gm;
+        for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
+        const SwRes r4 = sw_wave_x4(rdq + (size_t)lds_ml + (size_t)g * lds_mq, gm, gq, 1, rfq + (size_t)(4 + g) * lds_rf, gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, q_hasn);
+        if ((lane & 15) == 0 && mine) { q_score[g] = r4.score; q_eref[g] = r4.end_ref; q_eread[g] = r4.end_read; }
+      } else {
+        const SwRes r1 = sw_wave(rdq + lds_ml, (int)q_m[0], (int)q_aq[0], 1, rfq + (size_t)4 * lds_rf, (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+        if (lane == 0) { q_score[0] = r1.score; q_eref[0] = r1.end_ref; q_eread[0] = r1.end_read; }
+      }
+      __syncthreads();
+      TPH(6)
+      for (uint32_t e = 0; e < q_n; e++) {
+        const int score1 = q_score[e] > 65535 ? 65535 : q_score[e];
+        if ((uint32_t)score1 > P.minimal_score) { redo_slots |= 1u << e; n_redo++; continue; }
+        // no alignment: the read ends as the sequential walk ends it -- one ssw_align call, nothing recorded
+        const uint32_t rr = q_r[e];
+        RWork w2 = rw[rr];
+        RState st2 = work[rr];
+        if (w2.has_amb && !w2.is04) { w2.is04 = 1; w2.aval = 4; }          // read.flip34() before SSW (:360-361)
+        n_fwd++; n_cells += (unsigned long long)q_m[e] * q_nref[e]; n_spec++; n_spec_used++;
+        finish_read(rr, st2, w2, 1, lane == 0);
+      }
+      q_n = 0; q_hasn = false; need_flush = false;
+      __syncthreads();
+      continue;
+    } else {
+      if (out_of_reads) break;
+      if (chunk_todo == 0) {
+        // claim the next 16 reads.  Lane i looks at read i of the chunk: not in this (strand, pass) -> nothing to do; in it but without the
+        // seeds for compute_lis_alignment (:103-108) -> only the pass control, done by that lane on its own; the others are walked one by one
+        __syncthreads();
+        if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 16ull);
+        __syncthreads();
+        chunk_base = s_next;
+        if (chunk_base >= rd.n) { out_of_reads = true; continue; }
+        bool todo = false;
+        const uint32_t ri = chunk_base + (uint32_t)lane;
+        if (lane < 16 && ri < rd.n) {
+          RWork wi = rw[ri];
+          if (wi.strand_active && wi.search && wi.pass_n == (uint32_t)pass) {
+            RState si = work[ri];
+            if (si.hit_seeds >= (uint32_t)P.num_seeds && wi.hit_total > 0) todo = true;
+            else finish_read(ri, si, wi, 1, true);
+          }
+        }
+        chunk_todo = (uint32_t)__ballot(todo);
+        if (chunk_todo == 0) continue;
+      }
+      __syncthreads();
+      r = chunk_base + (uint32_t)(__ffs((int)chunk_todo) - 1);
+      chunk_todo &= chunk_todo - 1;
+    }
     RWork w = rw[r];
     if (!(w.strand_active && w.search && w.pass_n == (uint32_t)pass)) continue;
     RState st = work[r];
@@ -303,6 +395,9 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     const uint32_t* rec = rd.words + rd.rec_off[r];
     int search = 1;
     const uint32_t max_SW_score = len * (uint32_t)P.match;
+    const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
+    if (!x4_ok && q_n > 0) { need_flush = true; chunk_todo |= 1u << (r - chunk_base); continue; }        // its strip boundaries would overwrite the parked windows: score those first
+    bool parked = false;
 
     if (st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0) {
       // ---------------- compute_lis_alignment (alignment.cpp:100-509) ----------------
@@ -428,16 +523,17 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         const uint64_t rlen = len;
         auto pairs_of = [&](int bufid) -> unsigned long long* { return bufid == 0 ? l_pairs : bufid == 1 ? l_pairs + CH_PAIRS_LDS / 2 : bufid == 2 ? l_pairs : gp; };
 
-        // candidate wk.k: termination rules (:156-169), its hits (:181-201) into a pairs buffer, sorted; false = the candidate loop ends here
-        auto load_candidate = [&](Walk& wk, bool real) -> bool {
-          if (wk.k >= ncand || !wk.go_on || cap_err) return false;
+        // candidate wk.k: termination rules (:156-169), its hits (:181-201) into a pairs buffer, sorted.
+        // 1 = loaded, 0 = the candidate loop ends here, 2 = (look-ahead only) this candidate has to be left to the real walk
+        auto load_candidate = [&](Walk& wk, bool real) -> int {
+          if (wk.k >= ncand || !wk.go_on || cap_err) return 0;
           const unsigned long long ck = keys[wk.k];
           const uint32_t max_ref = (uint32_t)ck;
           const uint32_t max_occur = 0xFFFFFFFFu - (uint32_t)(ck >> 32);
-          if (max_occur < (uint32_t)P.num_seeds) return false;
+          if (max_occur < (uint32_t)P.num_seeds) return 0;
           if (wk.is_aligned && P.min_lis > 0 && wk.k > 0 && max_occur < (0xFFFFFFFFu - (uint32_t)(keys[wk.k - 1] >> 32))) {   // :165-169
             --wk.best;
-            if (wk.best < 1) return false;
+            if (wk.best < 1) return 0;
           }
           if (real && buf_tag[0] == wk.k) { wk.buf = 0; wk.np = buf_np[0]; }
           else if (real && buf_tag[1] == wk.k) { wk.buf = 1; wk.np = buf_np[1]; }
@@ -451,13 +547,13 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
             }
             int bufid;
             if (!real) {                                                      // the look-ahead never touches the buffer the real walk stands on,
-              if (np > CH_PAIRS_LDS / 2 || real_buf == 2) return false;       // and leaves a large candidate to the real walk
+              if (np > CH_PAIRS_LDS / 2 || real_buf == 2) return 2;           // and leaves a large candidate to the real walk
               bufid = real_buf == 0 ? 1 : 0;
             }
             else if (np <= CH_PAIRS_LDS / 2) bufid = 0;
             else if (np <= CH_PAIRS_LDS) bufid = 2;
             else if (np <= pairs_cap) bufid = 3;
-            else { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; return false; }
+            else { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; return 0; }
             unsigned long long* pw_ = pairs_of(bufid);
             __syncthreads();
             uint32_t run = 0;
@@ -482,7 +578,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           wk.it = 0; wk.ms_lo = 0; wk.ms_hi = 0;
           wk.begin_ref = (uint32_t)(pairs[0] >> 32); wk.begin_read = (uint32_t)pairs[0];
           wk.pending_pop = 0;
-          return true;
+          return 1;
         };
 
         // the sliding window of read length along candidate wk.k (:203-506), up to its next window that calls for ssw_align
@@ -551,27 +647,66 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           return false;
         };
 
-        auto advance = [&](Walk& wk, bool real, SwTask& tk) -> bool {
+        // 1 = the walk stands at a task, 0 = the walk is over, 2 = (look-ahead only) cannot look further
+        auto advance = [&](Walk& wk, bool real, SwTask& tk) -> int {
           for (;;) {
             if (!wk.started) {
-              if (!load_candidate(wk, real)) return false;
+              const int lc = load_candidate(wk, real);
+              if (lc != 1) return lc;
               wk.started = 1;
             }
-            if (next_task(wk, tk)) return true;
+            if (next_task(wk, tk)) return 1;
             wk.k++; wk.started = 0;
             __syncthreads();
           }
         };
+        auto task_fits = [&](const SwTask& t) -> bool { return t.m > 0 && t.nref > 0 && (uint32_t)t.m <= lds_ml && (uint32_t)t.nref <= lds_rf; };
 
         Walk R;
         R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0;
         R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.buf = 0;
-        SwTask ctk[4]; SwRes cfw[4]; int n_cached = 0;
+        SwTask ctk[4]; SwRes cfw[4]; int cslot[4] = {0, 1, 2, 3}; int n_cached = 0;     // the batch cache: task, forward result, LDS slot of its reference window
         bool rdq_staged = false;
-        const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
+        bool immediate = mode == 1 || !x4_ok;
+        if (mode == 1 && seed_slot >= 0) {
+          ctk[0].max_ref = q_max_ref[seed_slot]; ctk[0].rf_start = q_rf[seed_slot]; ctk[0].align_ref_start = q_ars[seed_slot]; ctk[0].head = q_head[seed_slot];
+          ctk[0].align_que_start = q_aq[seed_slot]; ctk[0].m = (int)q_m[seed_slot]; ctk[0].nref = (int)q_nref[seed_slot];
+          cfw[0].score = q_score[seed_slot]; cfw[0].end_ref = q_eref[seed_slot]; cfw[0].end_read = q_eread[seed_slot];
+          cslot[0] = 4 + seed_slot; n_cached = 1;
+        }
+        if (!immediate) {
+          // run the walk ahead assuming that nothing aligns: no task -> the read is finished; exactly one -> park it; more -> walk it now
+          Walk L = R;
+          SwTask t1, t2;
+          const int c1 = advance(L, false, t1);
+          if (c1 == 1) {
+            L.is_aligned = 0;
+            const int c2 = advance(L, false, t2);
+            if (c2 == 0 && task_fits(t1)) {
+              const uint32_t e = q_n;
+              const uint32_t aval = (w.has_amb && !w.is04) ? 4u : (uint32_t)w.aval;             // read.flip34() before SSW (:360-361)
+              __syncthreads();
+              uint8_t* rq = rdq + (size_t)lds_ml + (size_t)e * lds_mq;
+              uint8_t* fq = rfq + (size_t)(4 + e) * lds_rf;
+              for (uint32_t q = lane; q < len; q += 64) rq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, aval);
+              bool hn = false;
+              for (int q = lane; q < t1.nref; q += 64) { const uint8_t ch = ix.ref_seq[t1.rf_start + q]; fq[q] = ch; hn |= ch == 4; }
+              if (__any(hn)) q_hasn = true;
+              if (lane == 0) {
+                q_r[e] = r; q_max_ref[e] = t1.max_ref; q_rf[e] = t1.rf_start; q_ars[e] = (uint32_t)t1.align_ref_start; q_head[e] = (uint32_t)t1.head;
+                q_aq[e] = (uint32_t)t1.align_que_start; q_m[e] = (uint32_t)t1.m; q_nref[e] = (uint32_t)t1.nref;
+              }
+              __syncthreads();
+              q_n++;
+              if (q_n == 4) need_flush = true;
+              parked = true;
+            } else immediate = true;
+          } else if (c1 == 2) immediate = true;
+        }
+        if (immediate)
         for (;;) {
           SwTask tk;
-          if (!advance(R, true, tk)) break;
+          if (advance(R, true, tk) != 1) break;
           // read.flip34() to the 0..4 alphabet before SSW (:360-361)
           // (is03/is04 only toggle when the read has ambiguous letters; aval tracks the stored value)
           if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; rdq_staged = false; }
@@ -581,22 +716,23 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           SwRes fw; fw.score = 0; fw.end_ref = -1; fw.end_read = m - 1;
           int ce = -1;
           if (sw_ok) {
+            if (!rdq_staged) { __syncthreads(); for (uint32_t q = lane; q < len; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, w.aval); rdq_staged = true; __syncthreads(); }
             for (int e = 0; e < n_cached; e++)
               if (ctk[e].max_ref == tk.max_ref && ctk[e].rf_start == tk.rf_start && ctk[e].align_que_start == tk.align_que_start && ctk[e].m == m && ctk[e].nref == nref) { ce = e; break; }
             if (ce < 0) {
               // a new batch: this task, and the tasks the walk would reach next if this one and they do not align
               ctk[0] = tk; n_cached = 1;
+              for (int e = 0; e < 4; e++) cslot[e] = e;
               if (x4_ok) {
                 Walk L = R; L.is_aligned = 0;
                 while (n_cached < 4) {
                   SwTask t2;
-                  if (!advance(L, false, t2)) break;
-                  if (!(t2.m > 0 && t2.nref > 0 && (uint32_t)t2.m <= lds_ml && (uint32_t)t2.nref <= lds_rf)) break;
+                  if (advance(L, false, t2) != 1) break;
+                  if (!task_fits(t2)) break;
                   ctk[n_cached++] = t2; L.is_aligned = 0;
                 }
               }
               __syncthreads();
-              if (!rdq_staged) { for (uint32_t q = lane; q < len; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, w.aval); rdq_staged = true; }
               bool hasn = false;
               for (int e = 0; e < n_cached; e++) {
                 uint8_t* dst = rfq + (size_t)e * lds_rf;                    // windows 1..3 overlay the strip-boundary array, which single-strip problems do not use
@@ -637,7 +773,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           if (sw_ok && (uint32_t)score1 >= (P.minimal_score & 0xFFFFu)) {   // ssw_align: flag==2 && score1 < filters -> no begin
             // reverse pass (ssw.c:900-918) on the prefixes ending at (read_end1, ref_end1)
             TPH(5)
-            SwRes bw = sw_wave(rdq, read_end1 + 1, (int)align_que_start + read_end1, -1, rfq + (size_t)ce * lds_rf, ref_end1 + 1, ref_end1, -1, bound,
+            SwRes bw = sw_wave(rdq, read_end1 + 1, (int)align_que_start + read_end1, -1, rfq + (size_t)cslot[ce] * lds_rf, ref_end1 + 1, ref_end1, -1, bound,
                                P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
             ref_begin1 = ref_end1 - bw.end_ref;
             read_begin1 = read_end1 - bw.end_read;
@@ -701,26 +837,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
       }
     }
     TPH(5)
-    // ---------------- pass control (paralleltraversal.cpp:253-277) ----------------
-    uint32_t pass_n = w.pass_n;
-    if (search) {
-      if (pass_n == 2) search = 0;
-      else {
-        while (pass_n < 2 && P.skip[pass_n] == P.skip[pass_n + 1]) ++pass_n;
-        if (++pass_n > 2) search = 0;
-        else w.win_shift = P.skip[pass_n];
-      }
-    }
-    w.pass_n = (uint8_t)pass_n; w.search = (uint8_t)search;
-    if (!search) {
-      // end of traverse() (:279-297)
-      st.lastIndex = P.index_num; st.lastPart = P.part;
-      if (P.num_alignments > 0) {
-        if ((P.is_best && P.num_alignments == st.max_SW_count) || (!P.is_best && st.n_align == P.num_alignments)) st.is_done = 1;
-      } else if (P.is_last_index_part && is_last_strand && st.n_align > 0) st.is_done = 1;
-      w.strand_active = 0;
-    }
-    if (lane == 0) { work[r] = st; rw[r] = w; }
+    if (!parked) finish_read(r, st, w, search, lane == 0);
   }
   if (lane == 0) {
     if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);

@@ -260,7 +260,7 @@ void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, s
   uint32_t edges = P.is_as_percent ? (uint32_t)((P.edges / 100.0) * c->b->max_len) + 1 : (uint32_t)std::max(P.edges, 0);
   ml = (c->b->max_len + 15) & ~15u;
   rf = (c->b->max_len + 2 * edges + 16 + 15) & ~15u;
-  bytes = (size_t)ml + rf + (size_t)2 * rf * 4 + (size_t)CH_KEYS_LDS * 8 + (size_t)std::max<uint32_t>(4u * CH_PAIRS_LDS, 2u * c->chain_scap) * 4 +
+  bytes = (size_t)ml + 4 * (size_t)std::min<uint32_t>(ml, SW_X4_MAX_ROWS) + rf + (size_t)2 * rf * 4 + (size_t)CH_KEYS_LDS * 8 + (size_t)std::max<uint32_t>(4u * CH_PAIRS_LDS, 2u * c->chain_scap) * 4 +
           (size_t)CH_HITS_LDS * 8 + (size_t)(CH_HITS_LDS + 8) * 4 + (size_t)c->chain_scap * 4;
 }
 
