@@ -19,7 +19,7 @@
 
 namespace {
 [[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR: %s\n", m.c_str()); exit(EXIT_FAILURE); }
-struct Db { std::string fasta, idx_prefix; double lambda = 0.618874, K = 0.343238; std::vector<smr_index*> parts; };
+struct Db { std::string fasta, idx_prefix; double lambda = 0, K = 0; bool has_gumbel = false; std::vector<smr_index*> parts; };
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
     auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value after " + a); return argv[++i]; };
     if (a == "-ref" || a == "--ref") { Db d; d.fasta = val(); dbs.push_back(d); }
     else if (a == "-idx" || a == "--idx") { if (dbs.empty()) die("--idx before --ref"); dbs.back().idx_prefix = val(); }   // reference-format index files
-    else if (a == "-gumbel" || a == "--gumbel") { if (dbs.empty()) die("--gumbel before --ref"); dbs.back().lambda = atof(val().c_str()); dbs.back().K = atof(val().c_str()); }
+    else if (a == "-gumbel" || a == "--gumbel") { if (dbs.empty()) die("--gumbel before --ref"); dbs.back().lambda = atof(val().c_str()); dbs.back().K = atof(val().c_str()); dbs.back().has_gumbel = true; }
     else if (a == "-reads" || a == "--reads") { if (reads_paths.size() == 2) die("at most two --reads files (mates)"); reads_paths.push_back(val()); }
     else if (a == "-out" || a == "--out") out_dir = val();
     else if (a == "-e") evalue = atof(val().c_str());
@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
       strcpy(ro.blast_cols, cols.c_str());
     }
     else if (a == "-h" || a == "--help") {
-      printf("usage: smr_align --ref DB.fasta [--idx PREFIX] [--gumbel LAMBDA K] [--ref ...] --reads READS.fa|fq[.gz] [--reads MATES] [--out DIR]\n"
+      printf("usage: smr_align --ref DB.fasta --gumbel LAMBDA K [--idx PREFIX] [--ref ...] --reads READS.fa|fq[.gz] [--reads MATES] [--out DIR]\n"
              "       [-e EVALUE] [-num_alignments N] [-no-best] [-min_lis N] [-num_seeds N] [-edges N] [-full_search] [-F|-R]\n"
              "       [-match N -mismatch N -gap_open N -gap_ext N] [-device K] [--fastx] [--other] [--blast '0' | '1 cigar qcov qstrand'] [--sam [-SQ]]\n"
              "       [-zip-out 0|1] [-paired_in | -paired_out] [-out2] [-sout]     (two --reads files, or one interleaved file with -paired_in / -paired_out)\n");
@@ -79,6 +79,11 @@ int main(int argc, char** argv) {
     } else die("unknown option " + a);
   }
   if (dbs.empty() || reads_paths.empty()) die("--ref and --reads are required (see --help)");
+  // minimal_score (which reads count as aligned) and the e-values / bit scores of the BLAST report depend on the Gumbel parameters of the
+  // (scoring scheme, DB background) pair.  The reference computes them per DB with its vendored NCBI ALP library (refstats.cpp:194-233),
+  // which is outside this library: they must be given -- from the reference's log ("Gumbel lambda = ..", "Gumbel K = ..") for the same DB
+  // and the same -match/-mismatch/-gap_open/-gap_ext.  No default is assumed: a silent guess would classify a different set of reads.
+  for (auto& d : dbs) if (!d.has_gumbel) die("--gumbel LAMBDA K is required after every --ref (see --help): the values of the reference's log for this DB and scoring scheme");
   char err[512] = "";
   // reads (Readfeed::next -> Read::init, readfeed.hpp:124 / read.cpp:264-347)
   // (all cores parse and 2-bit pack the FASTA / FASTQ / .gz file; the text stays mapped for the report writers)

@@ -1,0 +1,316 @@
+// smr_align_mgpu.cpp -- the C++17 multi-GPU host over the C ABI of libsmr_hip (include/smr_hip.h): one process, one host thread
+// and one smr_ctx per GPU, reads sharded by record range, every GPU holds a full index replica (uploaded from ONE host copy of
+// the index), no collective on the data path.  What the reference's semantics need across the shards are two tiny reductions,
+// and both are RCCL all-reduces over xGMI issued from this C++ host:
+//   C1 (before aligning)  sum of (reads, letters) over the shards -> the same minimal_score on every GPU
+//                         (Readstats is built from the whole read file, main.cpp:77-78; refstats.cpp:247-265)
+//   C2 (after aligning)   element-wise sum of the Readstats counter block, IN PLACE on the device memory that
+//                         smr_counters_device hands out (readstats.hpp:77-85)
+// It replaces the reference's thread fan-out over one read file (processor.cpp:248-256, split of the file into one range
+// per thread readfeed.cpp:1253-1277) by a fan-out over GPUs.
+//
+// Output:  <out>/records.bin (same format as examples/smr_align.cpp: KVDB key "0_<global read number>" / Read::toBinString value,
+//          shards concatenated in rank order), <out>/summary.txt (the reduced counters), and one "[timing]" line per stage.
+// Build:   hipcc -std=c++17 -O2 examples/smr_align_mgpu.cpp -Iinclude -Lsortmerna_amd/lib -lsmr_hip -lrccl -Wl,-rpath,$PWD/sortmerna_amd/lib -o smr_align_mgpu
+// Options: --ref DB.fasta [--idx PREFIX] --gumbel LAMBDA K  [--ref ...]  --reads READS[.gz]  --out DIR
+//          --gpus N            ranks (default: all visible devices)
+//          --devices a,b,..    device of every rank (default 0,1,..,N-1)
+//          --reduce rccl|host  how C1 / C2 are reduced; `host` (a mutex-protected sum between the rank threads) exists for dry
+//                              runs of the N-rank path on fewer GPUs than ranks -- RCCL needs one device per rank
+//          --chunk-reads M     per rank: upload / align in chunks of M reads, chunk k+1 uploaded while chunk k is aligned (0 = one batch)
+//          -num_alignments N, -no-best, -e EVALUE as in smr_align
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "smr_hip.h"
+
+namespace {
+[[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR: %s\n", m.c_str()); exit(EXIT_FAILURE); }
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Db { std::string fasta, idx_prefix; double lambda = 0, K = 0; bool has_gumbel = false; std::vector<smr_index*> parts; };
+
+// contiguous record range of a rank (sortmerna_amd/shard.py: shard_range)
+void shard_range(uint64_t n, int rank, int world, uint64_t& first, uint64_t& count) {
+  const uint64_t base = n / world, rem = n % world;
+  first = rank * base + std::min<uint64_t>(rank, rem);
+  count = base + ((uint64_t)rank < rem ? 1 : 0);
+}
+
+struct Barrier {                       // reusable barrier for the rank threads (host reduction and stage timing)
+  std::mutex m; std::condition_variable cv; int n, waiting = 0; uint64_t gen = 0;
+  explicit Barrier(int n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> l(m);
+    const uint64_t g = gen;
+    if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(l, [&] { return gen != g; });
+  }
+};
+
+struct Shared {
+  int world = 1;
+  bool use_rccl = true;
+  std::vector<int> devices;
+  std::vector<ncclComm_t> comms;
+  Barrier* bar = nullptr;
+  std::mutex m;
+  std::vector<uint64_t> acc;           // host reduction scratch
+};
+
+// element-wise sum over the ranks of n u64 values that live in DEVICE memory at dptr (in place)
+void all_reduce_sum_u64(Shared& S, int rank, void* dptr, size_t n, hipStream_t stream) {
+  if (S.world == 1 && !S.use_rccl) return;
+  if (S.use_rccl) {
+    if (ncclAllReduce(dptr, dptr, n, ncclUint64, ncclSum, S.comms[rank], stream) != ncclSuccess) die("ncclAllReduce failed");
+    if (hipStreamSynchronize(stream) != hipSuccess) die("hipStreamSynchronize after ncclAllReduce failed");
+    return;
+  }
+  std::vector<uint64_t> h(n);
+  if (hipMemcpy(h.data(), dptr, n * 8, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy D2H (host reduction) failed");
+  S.bar->wait();
+  { std::lock_guard<std::mutex> l(S.m); if (S.acc.size() != n) S.acc.assign(n, 0); for (size_t i = 0; i < n; i++) S.acc[i] += h[i]; }
+  S.bar->wait();
+  h = S.acc;
+  S.bar->wait();
+  if (rank == 0) S.acc.clear();
+  S.bar->wait();
+  if (hipMemcpy(dptr, h.data(), n * 8, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy H2D (host reduction) failed");
+}
+
+struct RankOut {
+  std::vector<uint8_t> records;        // concatenated (u64 klen, key, u64 vlen, value) entries of the shard
+  uint64_t n_records = 0;
+  std::vector<uint64_t> counters;      // reduced: identical on every rank
+  double t_upload = 0, t_align = 0, t_fetch = 0;
+  uint32_t minimal_score0 = 0;
+};
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::vector<Db> dbs;
+  std::string reads_path, out_dir = ".", reduce = "rccl", devlist;
+  smr_params base; smr_params_default(&base);
+  double evalue = 1.0;
+  int world = 0;
+  uint64_t chunk_reads = 0;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value after " + a); return argv[++i]; };
+    if (a == "-ref" || a == "--ref") { Db d; d.fasta = val(); dbs.push_back(d); }
+    else if (a == "-idx" || a == "--idx") { if (dbs.empty()) die("--idx before --ref"); dbs.back().idx_prefix = val(); }
+    else if (a == "-gumbel" || a == "--gumbel") { if (dbs.empty()) die("--gumbel before --ref"); dbs.back().lambda = atof(val().c_str()); dbs.back().K = atof(val().c_str()); dbs.back().has_gumbel = true; }
+    else if (a == "-reads" || a == "--reads") reads_path = val();
+    else if (a == "-out" || a == "--out") out_dir = val();
+    else if (a == "-e") evalue = atof(val().c_str());
+    else if (a == "-num_alignments" || a == "--num_alignments") base.num_alignments = (uint32_t)atoi(val().c_str());
+    else if (a == "-no-best" || a == "--no-best") base.is_best = 0;
+    else if (a == "--gpus" || a == "-gpus") world = atoi(val().c_str());
+    else if (a == "--devices" || a == "-devices") devlist = val();
+    else if (a == "--reduce" || a == "-reduce") reduce = val();
+    else if (a == "--chunk-reads" || a == "-chunk-reads") chunk_reads = strtoull(val().c_str(), nullptr, 10);
+    else die("unknown option " + a);
+  }
+  if (dbs.empty() || reads_path.empty()) die("--ref and --reads are required");
+  for (auto& d : dbs) if (!d.has_gumbel) die("--gumbel LAMBDA K is required for every --ref (the reference computes them with its vendored ALP library, refstats.cpp:194-233; minimal_score depends on them)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) die("no HIP device (libsmr_hip has no CPU fallback)");
+  if (world <= 0) world = ndev;
+  Shared S; S.world = world;
+  if (devlist.empty()) for (int r = 0; r < world; r++) S.devices.push_back(r % ndev);
+  else { size_t p = 0; while (p <= devlist.size()) { size_t q = devlist.find(',', p); if (q == std::string::npos) q = devlist.size(); S.devices.push_back(atoi(devlist.substr(p, q - p).c_str())); p = q + 1; } }
+  if ((int)S.devices.size() != world) die("--devices must list one device per rank");
+  S.use_rccl = reduce == "rccl";
+  if (!S.use_rccl && reduce != "host") die("--reduce rccl|host");
+  if (S.use_rccl) {
+    for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (S.devices[a] == S.devices[b]) die("RCCL needs one device per rank: use --reduce host for a dry run with shared devices");
+    S.comms.resize(world);
+    if (ncclCommInitAll(S.comms.data(), world, S.devices.data()) != ncclSuccess) die("ncclCommInitAll failed");
+  }
+  Barrier bar(world); S.bar = &bar;
+  char err[512] = "";
+
+  // ---- host side, once: the reads (all cores parse and pack), the index parts (one host copy shared by all ranks) ----
+  const double t0 = now_s();
+  smr_reads* all = nullptr;
+  if (smr_reads_load_fastx_mt(reads_path.c_str(), 0, &all, err, sizeof err) != SMR_OK) die(err);
+  const uint64_t n = smr_reads_count(all);
+  const double t_reads = now_s() - t0;
+  for (auto& d : dbs) {
+    if (!d.idx_prefix.empty()) {
+      smr_index* p0 = nullptr;
+      if (smr_index_load_files(d.idx_prefix.c_str(), 0, d.fasta.c_str(), &p0, err, sizeof err) != SMR_OK) die(err);
+      smr_index_info info; smr_index_get_info(p0, &info);
+      d.parts.push_back(p0);
+      for (uint32_t k = 1; k < info.n_parts; k++) {
+        smr_index* pk = nullptr;
+        if (smr_index_load_files(d.idx_prefix.c_str(), k, d.fasta.c_str(), &pk, err, sizeof err) != SMR_OK) die(err);
+        d.parts.push_back(pk);
+      }
+    } else {
+      smr_index* arr[256]; uint32_t np = 0;
+      if (smr_index_build(d.fasta.c_str(), 18, 3072.0, 10000, 0, arr, 256, &np, err, sizeof err) != SMR_OK) die(err);
+      d.parts.assign(arr, arr + np);
+    }
+  }
+  const double t_index = now_s() - t0 - t_reads;
+  size_t total_parts = 0;
+  for (auto& d : dbs) total_parts += d.parts.size();
+  if (total_parts > 64) die("more than 64 index parts in total");
+
+  std::vector<RankOut> outs(world);
+  const double t_start = now_s();
+  auto rank_main = [&](int rank) {
+    RankOut& O = outs[rank];
+    const int dev = S.devices[rank];
+    if (hipSetDevice(dev) != hipSuccess) die("hipSetDevice failed");
+    hipStream_t cstream;
+    if (hipStreamCreate(&cstream) != hipSuccess) die("hipStreamCreate failed");
+    char e2[512] = "";
+    smr_ctx* gpu = nullptr;
+    if (smr_create(dev, &gpu, e2, sizeof e2) != SMR_OK) die(e2);
+    // the read shard of this rank, in chunks (each chunk is one resident batch of the engine)
+    uint64_t first = 0, count = 0;
+    shard_range(n, rank, world, first, count);
+    const uint64_t chunk = chunk_reads ? chunk_reads : std::max<uint64_t>(count, 1);
+    const size_t n_chunks = (size_t)((count + chunk - 1) / chunk);
+    if (n_chunks > 14) die("--chunk-reads: more than 14 chunks per rank (the engine keeps 16 batches resident)");
+    // C1: global read totals (this rank only knows its shard)
+    uint64_t* d_tot = nullptr;
+    if (hipMalloc((void**)&d_tot, 2 * 8) != hipSuccess) die("hipMalloc failed");
+    {
+      smr_reads* mine = nullptr;
+      if (smr_reads_slice(all, first, count, &mine) != SMR_OK) die("smr_reads_slice failed");
+      const uint64_t loc[2] = {smr_reads_count(mine), smr_reads_total_len(mine)};
+      smr_reads_free(mine);
+      if (hipMemcpy(d_tot, loc, 16, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy failed");
+    }
+    all_reduce_sum_u64(S, rank, d_tot, 2, cstream);
+    uint64_t tot[2];
+    if (hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy failed");
+    (void)hipFree(d_tot);
+    // index replica: every part stays resident in its own slot
+    double t = now_s();
+    std::vector<std::vector<int>> slot(dbs.size());
+    int next_slot = 0;
+    for (size_t k = 0; k < dbs.size(); k++)
+      for (size_t part = 0; part < dbs[k].parts.size(); part++) {
+        if (smr_index_upload(gpu, dbs[k].parts[part], next_slot) != SMR_OK) die(smr_last_error(gpu));
+        slot[k].push_back(next_slot++);
+      }
+    const uint32_t slots_per_read = base.num_alignments > 0 ? base.num_alignments : 256;
+    std::vector<smr_params> pk(dbs.size(), base);
+    for (size_t k = 0; k < dbs.size(); k++) {
+      smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
+      pk[k].minimal_score = smr_minimal_score(dbs[k].lambda, dbs[k].K, info.bg, info.full_len, info.numseq, tot[0], tot[1], evalue);
+      pk[k].index_num = (uint32_t)k;
+    }
+    O.minimal_score0 = pk[0].minimal_score;
+    O.t_upload += now_s() - t;
+    // upload chunk c+1 on a helper thread while chunk c is aligned (smr_reads_upload works on its own stream and only touches its batch)
+    std::vector<smr_reads*> cr(n_chunks, nullptr);
+    auto upload = [&](size_t c) {
+      const uint64_t f = first + c * chunk, cnt = std::min<uint64_t>(chunk, first + count - f);
+      if (smr_reads_slice(all, f, cnt, &cr[c]) != SMR_OK) die("smr_reads_slice failed");
+      if (smr_reads_upload_batch(gpu, (int)c, cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu));
+    };
+    t = now_s();
+    if (n_chunks) upload(0);
+    O.t_upload += now_s() - t;
+    for (size_t c = 0; c < n_chunks; c++) {
+      std::thread up;
+      if (c + 1 < n_chunks) up = std::thread(upload, c + 1);
+      t = now_s();
+      if (smr_batch_select(gpu, (int)c) != SMR_OK) die(smr_last_error(gpu));
+      for (size_t k = 0; k < dbs.size(); k++)
+        for (size_t part = 0; part < dbs[k].parts.size(); part++) {
+          smr_params p = pk[k];
+          p.part = (uint32_t)part;
+          p.is_last_index_part = (k + 1 == dbs.size() && part + 1 == dbs[k].parts.size());
+          if (smr_align_part(gpu, slot[k][part], &p) != SMR_OK || smr_traceback(gpu, slot[k][part], &p) != SMR_OK) die(smr_last_error(gpu));
+        }
+      O.t_align += now_s() - t;
+      if (up.joinable()) up.join();
+    }
+    // C2: the Readstats counters of all chunks of this rank summed into chunk 0's block, then reduced over the ranks IN PLACE on the device
+    t = now_s();
+    void* dctr0 = nullptr; uint32_t nctr = 0;
+    if (n_chunks == 0) { if (smr_batch_select(gpu, 0) != SMR_OK) die(smr_last_error(gpu)); }
+    if (smr_batch_select(gpu, 0) != SMR_OK || smr_counters_device(gpu, &dctr0, &nctr) != SMR_OK) die(smr_last_error(gpu));
+    for (size_t c = 1; c < n_chunks; c++) {
+      std::vector<uint64_t> a(nctr), b(nctr);
+      void* dc = nullptr; uint32_t nc = 0;
+      if (smr_batch_select(gpu, (int)c) != SMR_OK || smr_counters_device(gpu, &dc, &nc) != SMR_OK) die(smr_last_error(gpu));
+      if (hipMemcpy(a.data(), dctr0, nctr * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(b.data(), dc, nctr * 8, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy failed");
+      for (uint32_t q = 0; q < nctr; q++) a[q] += b[q];
+      if (hipMemcpy(dctr0, a.data(), nctr * 8, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy failed");
+    }
+    all_reduce_sum_u64(S, rank, dctr0, nctr, cstream);
+    O.counters.assign(2 + dbs.size(), 0);
+    if (smr_batch_select(gpu, 0) != SMR_OK || smr_counters(gpu, O.counters.data(), (uint32_t)dbs.size()) != SMR_OK) die(smr_last_error(gpu));
+    // results of the shard (kvdb.put(read.id, read.toBinString()), processor.cpp:150-155), keys carry the GLOBAL read number
+    std::vector<uint8_t> rec;
+    for (size_t c = 0; c < n_chunks; c++) {
+      if (smr_batch_select(gpu, (int)c) != SMR_OK || smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
+      const uint32_t cnt = smr_reads_count(cr[c]);
+      for (uint32_t i = 0; i < cnt; i++) {
+        const size_t len = smr_result_record(gpu, i, nullptr, 0);
+        if (!len) continue;
+        rec.resize(len);
+        smr_result_record(gpu, i, rec.data(), len);
+        const std::string key = "0_" + std::to_string(first + c * chunk + i);
+        const uint64_t kl = key.size(), vl = len;
+        const size_t o = O.records.size();
+        O.records.resize(o + 16 + kl + vl);
+        memcpy(&O.records[o], &kl, 8); memcpy(&O.records[o + 8], key.data(), kl); memcpy(&O.records[o + 8 + kl], &vl, 8); memcpy(&O.records[o + 16 + kl], rec.data(), vl);
+        O.n_records++;
+      }
+      smr_reads_free(cr[c]);
+    }
+    O.t_fetch = now_s() - t;
+    smr_destroy(gpu);
+    (void)hipStreamDestroy(cstream);
+  };
+  std::vector<std::thread> th;
+  for (int r = 0; r < world; r++) th.emplace_back(rank_main, r);
+  for (auto& t : th) t.join();
+  const double t_ranks = now_s() - t_start;
+  if (S.use_rccl) for (auto& c : S.comms) ncclCommDestroy(c);
+
+  // ---- rank 0's view of the reduced counters is everybody's; shards concatenate in rank order ----
+  for (int r = 1; r < world; r++) if (outs[r].counters != outs[0].counters) die("the ranks disagree on the reduced counters");
+  const std::string rp = out_dir + "/records.bin", sp = out_dir + "/summary.txt";
+  FILE* f = fopen(rp.c_str(), "wb");
+  if (!f) die("cannot write " + rp);
+  uint64_t nrec = 0;
+  for (auto& o : outs) nrec += o.n_records;
+  fwrite(&nrec, 8, 1, f);
+  for (auto& o : outs) if (!o.records.empty()) fwrite(o.records.data(), 1, o.records.size(), f);
+  fclose(f);
+  f = fopen(sp.c_str(), "w");
+  if (!f) die("cannot write " + sp);
+  const auto& ctr = outs[0].counters;
+  fprintf(f, "Total reads = %llu\nTotal reads passing E-value threshold = %llu\nToo short reads (last part) = %llu\n", (unsigned long long)n,
+          (unsigned long long)ctr[0], (unsigned long long)ctr[1]);
+  for (size_t k = 0; k < dbs.size(); k++) fprintf(f, "%s\t%llu\n", dbs[k].fasta.c_str(), (unsigned long long)ctr[2 + k]);
+  fclose(f);
+  double tu = 0, ta = 0, tf = 0;
+  for (auto& o : outs) { tu = std::max(tu, o.t_upload); ta = std::max(ta, o.t_align); tf = std::max(tf, o.t_fetch); }
+  const double t_all = now_s() - t0;
+  printf("[timing] ranks %d (%s reduction), reads %llu: parse+pack %.3f s, index load/build %.3f s, per-rank max: index+first upload %.3f s, align+traceback %.3f s "
+         "(uploads of later chunks overlapped), counters+records %.3f s; rank stage %.3f s; end to end %.3f s = %.0f reads/s (rank stage alone: %.0f reads/s)\n",
+         world, S.use_rccl ? "RCCL" : "host", (unsigned long long)n, t_reads, t_index, tu, ta, tf, t_ranks, t_all, n / t_all, n / t_ranks);
+  printf("%llu reads, %llu aligned, %llu records, minimal_score %u -> %s\n", (unsigned long long)n, (unsigned long long)ctr[0], (unsigned long long)nrec, outs[0].minimal_score0, rp.c_str());
+  for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
+  smr_reads_free(all);
+  return 0;
+}

@@ -133,6 +133,9 @@ int smr_reads_load_fastx(const char* path, uint64_t first, uint64_t count, smr_r
  * smr_reads_load_fastx(path, 0, 0, ...). */
 int smr_reads_load_fastx_mt(const char* path, uint32_t threads, smr_reads** out, char* err, size_t errcap);
 void smr_reads_free(smr_reads*);
+/* records [first, first + count) of a packed batch as a batch of their own (no text): the host-side split of the reads into one shard per
+ * GPU (the reference splits the read file into one range per thread, readfeed.cpp:1253-1277) or into the chunks of an upload/align pipeline */
+int smr_reads_slice(const smr_reads*, uint64_t first, uint64_t count, smr_reads** out);
 /* like smr_reads_load_fastx_mt, and keeps the file text so that smr_reads_record_text can hand out every record's header line (as in the
  * file, with '>' / '@'), letters (line breaks removed) and quality line for the report writers; lens = {header, letters, quality} lengths;
  * a NULL / too small buffer is skipped / filled as far as it goes (always NUL-terminated) */
@@ -170,6 +173,11 @@ int smr_set_seed_mode(smr_ctx*, int exact_counters);
 /* Copy a read batch to HBM (into the selected batch) and allocate its persistent per-read state (what the reference keeps in
  * the KVDB between index parts, read.cpp:429-539).  Resets all state and counters. */
 int smr_reads_upload(smr_ctx*, const smr_reads*, uint32_t max_alignments_per_read);
+/* The same into batch `batch` (0..15) WITHOUT selecting it, on the context's second (upload) stream: a second host thread may call this
+ * while the first one is inside smr_align_part / smr_traceback / smr_results_fetch of another batch -- upload of batch k+1 overlaps the
+ * alignment of batch k (the reference's Readfeed/Processor overlap file reading with alignment the same way, readfeed.cpp, processor.cpp:248-256).
+ * Fails with SMR_ERR_STATE when `batch` is the selected batch. */
+int smr_reads_upload_batch(smr_ctx*, int batch, const smr_reads*, uint32_t max_alignments_per_read);
 /* Forget all per-read results/counters of the resident batch (reads stay resident). */
 int smr_state_reset(smr_ctx*);
 

@@ -47,6 +47,8 @@ struct Batch {
   std::vector<RState> h_state; std::vector<AlignRec> h_aln; std::vector<uint32_t> h_cigar;
   uint32_t last_num_alignments = 1;
   bool fetched = false;
+  // capacities of the device arrays above (grow-only: a re-upload into the same batch allocates nothing unless it is larger)
+  size_t cap_words = 0, cap_reads = 0, cap_aln = 0;
 };
 
 struct smr_ctx {
@@ -75,7 +77,9 @@ struct smr_ctx {
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
   int* d_trrows = nullptr; uint64_t trrows_ints = 0;                   // its DP rows when the band does not fit LDS
   // profiling
-  std::vector<EvPair> events;
+  std::vector<EvPair> events, ev_pool;
+  hipStream_t upload_stream = nullptr;     // smr_reads_upload_batch: H2D of batch k+1 while batch k is aligned on `stream`
+  unsigned long long* d_ctr_snap = nullptr; // counters of the selected batch at the start of smr_align_part (restored when an attempt is redone)
   double seed_ms = 0, chain_ms = 0, trace_ms = 0; uint64_t seed_l = 0, chain_l = 0, trace_l = 0;
 };
 
@@ -156,9 +160,11 @@ int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
   return SMR_OK;
 }
 
-void ev_begin(smr_ctx* c, int kind) {
-  EvPair e; e.kind = kind;
-  (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+void ev_begin(smr_ctx* c, int kind) {            // event pairs are pooled: created once, reused for every launch
+  EvPair e;
+  if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+  else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+  e.kind = kind;
   (void)hipEventRecord(e.a, c->stream);
   c->events.push_back(e);
 }
@@ -169,7 +175,7 @@ void ev_collect(smr_ctx* c) {
     if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
       if (e.kind == 0) { c->seed_ms += ms; c->seed_l++; } else if (e.kind == 1) { c->chain_ms += ms; c->chain_l++; } else { c->trace_ms += ms; c->trace_l++; }
     }
-    (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+    c->ev_pool.push_back(e);
   }
   c->events.clear();
 }
@@ -662,7 +668,8 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   if (device < 0 || device >= ndev) { if (err && errcap) snprintf(err, errcap, "device %d out of range (%d devices)", device, ndev); return SMR_ERR_ARG; }
   auto c = new smr_ctx();
   c->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->upload_stream) != hipSuccess ||
+      hipMalloc((void**)&c->d_ctr_snap, C_TOTAL * 8) != hipSuccess) {
     if (err && errcap) snprintf(err, errcap, "cannot initialise device %d", device);
     delete c; return SMR_ERR_DEVICE;
   }
@@ -705,6 +712,9 @@ extern "C" void smr_destroy(smr_ctx* c) {
   dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
+  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  dev_free(&c->d_ctr_snap);
+  (void)hipStreamDestroy(c->upload_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -772,40 +782,79 @@ extern "C" int smr_set_seed_mode(smr_ctx* c, int exact_counters) {
   return SMR_OK;
 }
 
+namespace {
+int reset_batch(smr_ctx* c, Batch& B, hipStream_t st) {
+  HIPCHK(c, hipMemsetAsync(B.d_saved, 0, (size_t)B.n * sizeof(RState), st));
+  HIPCHK(c, hipMemsetAsync(B.d_saved_aln, 0, (size_t)B.n * B.slots * sizeof(AlignRec), st));
+  HIPCHK(c, hipMemsetAsync(B.d_ctr, 0, C_TOTAL * 8, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  B.fetched = false;
+  return SMR_OK;
+}
+template <class T> int grow(smr_ctx* c, T** p, size_t& cap, size_t need) {        // grow-only device array
+  if (*p && cap >= need) return SMR_OK;
+  int rc = dev_alloc(c, p, need); if (rc) return rc;
+  cap = need;
+  return SMR_OK;
+}
+// the packed reads of r into batch B (+ its per-read state, reset), all work on stream st; touches nothing but B
+int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipStream_t st) {
+  if (max_aln == 0) max_aln = 1;
+  int rc;
+  if (!B.d_ctr) { HIPCHK(c, hipMalloc((void**)&B.d_ctr, C_TOTAL * 8)); }
+  const size_t nw = r->words.size() + 4, nr = (size_t)r->n + 1, na = std::max<size_t>((size_t)r->n * max_aln, 1);     // + slack: window extraction reads 2 words ahead
+  if (B.cap_words < nw) { if ((rc = dev_alloc(c, &B.d_words, nw))) return rc; B.cap_words = nw; }
+  if (B.cap_reads < nr) {
+    if ((rc = dev_alloc(c, &B.d_rec_off, nr))) return rc;
+    if ((rc = dev_alloc(c, &B.d_len, nr))) return rc;
+    if ((rc = dev_alloc(c, &B.d_saved, nr))) return rc;
+    if ((rc = dev_alloc(c, &B.d_work, nr))) return rc;
+    if ((rc = dev_alloc(c, &B.d_rw, nr))) return rc;
+    B.cap_reads = nr;
+  }
+  if (B.cap_aln < na) {
+    if ((rc = dev_alloc(c, &B.d_saved_aln, na))) return rc;
+    if ((rc = dev_alloc(c, &B.d_work_aln, na))) return rc;
+    B.cap_aln = na;
+  }
+  B.n = r->n; B.max_len = r->max_len; B.slots = max_aln; B.used = true;
+  HIPCHK(c, hipMemcpyAsync(B.d_words, r->words.data(), r->words.size() * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(B.d_rec_off, r->rec_off.data(), r->rec_off.size() * 8, hipMemcpyHostToDevice, st));
+  if (r->n) HIPCHK(c, hipMemcpyAsync(B.d_len, r->len.data(), r->len.size() * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(B.d_rw, 0, (size_t)B.n * sizeof(RWork), st));
+  HIPCHK(c, hipMemsetAsync(B.d_work, 0, (size_t)B.n * sizeof(RState), st));
+  B.cigar_words = 0; dev_free(&B.d_cigar);
+  return reset_batch(c, B, st);
+}
+}  // namespace
+
 extern "C" int smr_state_reset(smr_ctx* c) {
   if (!c || !c->b->d_saved) return SMR_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemsetAsync(c->b->d_saved, 0, (size_t)c->b->n * sizeof(RState), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->b->d_saved_aln, 0, (size_t)c->b->n * c->b->slots * sizeof(AlignRec), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->b->d_ctr, 0, C_TOTAL * 8, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->b->fetched = false;
-  return SMR_OK;
+  return reset_batch(c, *c->b, c->stream);
 }
 
 extern "C" int smr_reads_upload(smr_ctx* c, const smr_reads* r, uint32_t max_aln) {
   if (!c || !r) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  if (max_aln == 0) max_aln = 1;
-  c->b->n = r->n; c->b->max_len = r->max_len; c->b->slots = max_aln;
-  int rc;
-  if ((rc = dev_alloc(c, &c->b->d_words, r->words.size() + 4))) return rc;     // + slack: window extraction reads 2 words ahead
-  if ((rc = dev_alloc(c, &c->b->d_rec_off, r->rec_off.size()))) return rc;
-  if ((rc = dev_alloc(c, &c->b->d_len, r->len.size()))) return rc;
-  if ((rc = dev_alloc(c, &c->b->d_saved, (size_t)c->b->n))) return rc;
-  if ((rc = dev_alloc(c, &c->b->d_work, (size_t)c->b->n))) return rc;
-  if ((rc = dev_alloc(c, &c->b->d_rw, (size_t)c->b->n))) return rc;
-  if ((rc = dev_alloc(c, &c->b->d_saved_aln, (size_t)c->b->n * c->b->slots))) return rc;
-  if ((rc = dev_alloc(c, &c->b->d_work_aln, (size_t)c->b->n * c->b->slots))) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->b->d_words, r->words.data(), r->words.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->b->d_rec_off, r->rec_off.data(), r->rec_off.size() * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->b->d_len, r->len.data(), r->len.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->b->d_rw, 0, (size_t)c->b->n * sizeof(RWork), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->b->d_work, 0, (size_t)c->b->n * sizeof(RState), c->stream));
-  uint64_t want_pool = std::max<uint64_t>((uint64_t)c->b->n * 64 + (1u << 20), 1u << 22);
-  if (c->pool_words < want_pool) { if ((rc = dev_alloc(c, &c->d_pool, want_pool))) return rc; c->pool_words = want_pool; }
-  c->b->cigar_words = 0; dev_free(&c->b->d_cigar);
-  return smr_state_reset(c);
+  return upload_into(c, *c->b, r, max_aln, c->stream);
+}
+
+// The same into batch `batch`, without selecting it, on the context's UPLOAD stream: may be called from a second host thread while the
+// first one is inside smr_align_part / smr_traceback / smr_results_fetch of ANOTHER batch (the two calls share no device buffer: each
+// batch owns its reads, per-read state, counters and CIGAR pool; the scratch of the kernels is sized inside smr_align_part).
+extern "C" int smr_reads_upload_batch(smr_ctx* c, int batch, const smr_reads* r, uint32_t max_aln) {
+  if (!c || !r || batch < 0 || batch >= SMR_MAX_BATCHES) return SMR_ERR_ARG;
+  if (&c->bt[batch] == c->b) { c->err = "smr_reads_upload_batch: the batch is the selected one (use smr_reads_upload)"; return SMR_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  return upload_into(c, c->bt[batch], r, max_aln, c->upload_stream);
+}
+
+__global__ void k_ctr_begin(unsigned long long* __restrict__ ctr, const unsigned long long* __restrict__ snap) {
+  for (int k = threadIdx.x; k < C_TOTAL; k += blockDim.x) {
+    const bool zero = k == C_NUM_SHORT || (k >= C_ERR_HITCAP && k <= C_ERR_TRACE) || k == C_ERR_SCAP || k == C_ERR_REDO || k == C_POOL_CURSOR || k == C_WORK_NEXT || k >= C_PCUR;
+    ctr[k] = zero ? 0ull : snap[k];
+  }
 }
 
 extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
@@ -821,8 +870,13 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   c->b->last_num_alignments = p->num_alignments;
   c->b->fetched = false;
   if (c->b->n == 0) return SMR_OK;
-  std::vector<unsigned long long> snap, h;
-  if ((rc = read_ctr(c, snap))) return rc;
+  {
+    const uint64_t want_pool = std::max<uint64_t>((uint64_t)c->b->n * 64 + (1u << 20), 1u << 22);      // seed-hit pool: scratch shared by all batches
+    if (c->pool_words < want_pool) { if ((rc = dev_alloc(c, &c->d_pool, want_pool))) return rc; c->pool_words = want_pool; }
+  }
+  std::vector<unsigned long long> h;
+  // the counters as they stand now stay on the device; an attempt that has to be redone starts from them again (one read-back per attempt, none before)
+  HIPCHK(c, hipMemcpyAsync(c->d_ctr_snap, c->b->d_ctr, C_TOTAL * 8, hipMemcpyDeviceToDevice, c->stream));
   const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   const int single = (p->is_forward != 0) ^ (p->is_reverse != 0);
   const int num_strands = single ? 1 : 2;
@@ -830,13 +884,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if ((rc = ensure_chain_scratch(c, di))) return rc;
     const double t_seed0 = c->seed_ms, t_chain0 = c->chain_ms; const uint64_t l_seed0 = c->seed_l, l_chain0 = c->chain_l;
     // restore counters (retry) and clear the per-part ones (processor.cpp:230 resets num_short per part)
-    std::vector<unsigned long long> init = snap;
-    init[C_NUM_SHORT] = 0;
-    for (int k = C_ERR_HITCAP; k <= C_ERR_TRACE; k++) init[k] = 0;
-    init[C_ERR_SCAP] = 0; init[C_ERR_REDO] = 0;
-    init[C_POOL_CURSOR] = 0; init[C_WORK_NEXT] = 0;
-    for (int q = 0; q < C_NSHARD; q++) init[C_PCUR + q] = 0;
-    HIPCHK(c, hipMemcpyAsync(c->b->d_ctr, init.data(), C_TOTAL * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_ctr_begin, dim3(1), dim3(256), 0, c->stream, c->b->d_ctr, (const unsigned long long*)c->d_ctr_snap);
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     for (int count = 0; count < num_strands; count++) {
       hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, count, c->b->d_work, c->b->d_rw);

@@ -316,6 +316,23 @@ extern "C" int smr_reads_record_text(const smr_reads* r, uint32_t i, char* hdr, 
 }
 
 extern "C" void smr_reads_free(smr_reads* r) { delete r; }
+
+// records [first, first + count) of a packed batch as a batch of their own: the host-side read shard of one rank / one pipeline chunk
+extern "C" int smr_reads_slice(const smr_reads* r, uint64_t first, uint64_t count, smr_reads** out) {
+  if (!r || !out || first > r->n || count > r->n - first) return SMR_ERR_ARG;
+  auto s = new smr_reads();
+  s->n = (uint32_t)count;
+  s->len.assign(r->len.begin() + (size_t)first, r->len.begin() + (size_t)(first + count));
+  const uint64_t w0 = r->rec_off[(size_t)first], w1 = r->rec_off[(size_t)(first + count)];
+  s->words.assign(r->words.begin() + (size_t)w0, r->words.begin() + (size_t)w1);
+  s->rec_off.resize((size_t)count + 1);
+  for (uint64_t i = 0; i <= count; i++) s->rec_off[(size_t)i] = r->rec_off[(size_t)(first + i)] - w0;
+  s->min_len = count ? 0xFFFFFFFFu : 0; s->max_len = 0; s->total_len = 0;
+  for (uint32_t l : s->len) { s->total_len += l; s->min_len = std::min(s->min_len, l); s->max_len = std::max(s->max_len, l); }
+  s->fastq = r->fastq;
+  *out = s;
+  return SMR_OK;
+}
 // FNV-1a over lengths, record offsets and packed words: two batches with the same digest hold the same reads in the same order
 extern "C" uint64_t smr_reads_digest(const smr_reads* r) {
   if (!r) return 0;

@@ -149,6 +149,14 @@ class Reads:
             raise SmrError("smr_reads_load_fastx_text: %s (rc=%d)" % (err.value.decode(), rc))
         return Reads(h)
 
+    def slice(self, first, count):
+        """records [first, first+count) as a batch of their own (the read shard of one rank / one pipeline chunk)"""
+        h = C.c_void_p()
+        rc = capi.load().smr_reads_slice(self.h, first, count, C.byref(h))
+        if rc != 0:
+            raise SmrError("smr_reads_slice rc=%d" % rc)
+        return Reads(h)
+
     @property
     def is_fastq(self):
         return bool(capi.load().smr_reads_is_fastq(self.h))

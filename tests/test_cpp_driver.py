@@ -29,6 +29,8 @@ def test_driver_builds_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip("a GPU is present")
     db, rd, _ = golden.inputs("syn_default")
     p = subprocess.run([exe, "--ref", db, "--reads", rd, "--out", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode != 0 and b"--gumbel LAMBDA K is required" in p.stderr          # no silent default for the Gumbel parameters
+    p = subprocess.run([exe, "--ref", db, "--gumbel", "0.6", "0.33", "--reads", rd, "--out", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode != 0 and b"no CPU fallback" in p.stderr
 
 
@@ -136,3 +138,57 @@ def _emu_driver():
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(paths.REPO, "examples", "smr_align.cpp"),
                            "-I", os.path.join(paths.REPO, "include"), lib, "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     return exe
+
+
+# ---- the multi-GPU C++ host (examples/smr_align_mgpu.cpp): one thread + one smr_ctx per rank, RCCL all-reduces for the read totals and the counters ----
+MGPU = os.path.join(paths.REPO, "examples", "build", "smr_align_mgpu")
+
+
+def build_mgpu():
+    lib = os.path.join(paths.REPO, "sortmerna_amd", "lib")
+    import sortmerna_amd.capi as capi
+    capi.load()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-std=c++17", "-O2", os.path.join(paths.REPO, "examples", "smr_align_mgpu.cpp"), "-I", os.path.join(paths.REPO, "include"),
+                           "-L", lib, "-lsmr_hip", "-lrccl", "-Wl,-rpath," + lib, "-o", MGPU])
+    return MGPU
+
+
+def _check_mgpu(case, tmp_path, extra):
+    g = golden.load()[case]
+    dbs, rd, seqs = golden.inputs(case)
+    if not isinstance(dbs, list):
+        dbs = [dbs]
+    cmd = [build_mgpu(), "--reads", rd, "--out", str(tmp_path)] + extra
+    for k, db in enumerate(dbs):
+        cmd += ["--ref", db, "--gumbel", repr(g["log"]["lambda"][k]), repr(g["log"]["K"][k])]
+    if "num_alignments" in g["params"]:
+        cmd += ["-num_alignments", str(g["params"]["num_alignments"])]
+    out = subprocess.check_output(cmd).decode()
+    assert "[timing]" in out
+    kv = refrun.parse_kvdb_dump(str(tmp_path / "records.bin"))
+    got = [kv.get(b"0_%d" % i, b"") for i in range(len(seqs))]
+    exp = golden.records(case)
+    bad = [i for i in range(len(seqs)) if got[i] != exp[i]]
+    assert not bad, "%d records differ, first %d" % (len(bad), bad[0])
+    summary = open(tmp_path / "summary.txt").read()
+    assert "Total reads passing E-value threshold = %d" % g["readstats"]["num_aligned"] in summary
+    for k, db in enumerate(dbs):
+        assert "%s\t%d" % (db, g["readstats"]["reads_matched_per_db"][k]) in summary
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["syn_default", "two_db_default"])
+def test_mgpu_host_one_rank_rccl(case, tmp_path):
+    """world size 1 through the real RCCL path: ncclCommInitAll, the all-reduce of the read totals, the in-place all-reduce on the device counter block"""
+    out = _check_mgpu(case, tmp_path, ["--gpus", "1", "--reduce", "rccl"])
+    assert "RCCL reduction" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,ranks,chunk", [("syn_default", 2, 0), ("syn_all", 3, 40), ("two_db_default", 2, 64)])
+def test_mgpu_host_shards_and_chunks_on_one_device(case, ranks, chunk, tmp_path):
+    """the N-rank path on one GPU (every rank thread gets device 0; the two reductions go through the host because RCCL needs a device per rank):
+    record-range shards, chunked upload overlapped with alignment, counters summed over chunks and ranks, records concatenated in rank order"""
+    _check_mgpu(case, tmp_path, ["--gpus", str(ranks), "--devices", ",".join(["0"] * ranks), "--reduce", "host", "--chunk-reads", str(chunk)])
