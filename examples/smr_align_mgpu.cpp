@@ -221,7 +221,9 @@ int main(int argc, char** argv) {
     auto upload = [&](size_t c) {
       const uint64_t f = first + c * chunk, cnt = std::min<uint64_t>(chunk, first + count - f);
       if (smr_reads_slice(all, f, cnt, &cr[c]) != SMR_OK) die("smr_reads_slice failed");
-      if (smr_reads_upload_batch(gpu, (int)c, cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu));
+      // chunk 0 goes into the selected batch (nothing is running yet); later chunks go into their own batch on the upload stream while the previous one is aligned
+      if (c == 0) { if (smr_batch_select(gpu, 0) != SMR_OK || smr_reads_upload(gpu, cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu)); }
+      else if (smr_reads_upload_batch(gpu, (int)c, cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu));
     };
     t = now_s();
     if (n_chunks) upload(0);

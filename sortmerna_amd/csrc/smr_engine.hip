@@ -850,6 +850,14 @@ extern "C" int smr_reads_upload_batch(smr_ctx* c, int batch, const smr_reads* r,
   return upload_into(c, c->bt[batch], r, max_aln, c->upload_stream);
 }
 
+namespace {
+int ensure_pool(smr_ctx* c) {          // seed-hit pool: scratch shared by all batches, sized for the selected one before its kernels run
+  const uint64_t want_pool = std::max<uint64_t>((uint64_t)c->b->n * 64 + (1u << 20), 1u << 22);
+  if (c->pool_words < want_pool) { int rc = dev_alloc(c, &c->d_pool, want_pool); if (rc) return rc; c->pool_words = want_pool; }
+  return SMR_OK;
+}
+}  // namespace
+
 __global__ void k_ctr_begin(unsigned long long* __restrict__ ctr, const unsigned long long* __restrict__ snap) {
   for (int k = threadIdx.x; k < C_TOTAL; k += blockDim.x) {
     const bool zero = k == C_NUM_SHORT || (k >= C_ERR_HITCAP && k <= C_ERR_TRACE) || k == C_ERR_SCAP || k == C_ERR_REDO || k == C_POOL_CURSOR || k == C_WORK_NEXT || k >= C_PCUR;
@@ -870,10 +878,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   c->b->last_num_alignments = p->num_alignments;
   c->b->fetched = false;
   if (c->b->n == 0) return SMR_OK;
-  {
-    const uint64_t want_pool = std::max<uint64_t>((uint64_t)c->b->n * 64 + (1u << 20), 1u << 22);      // seed-hit pool: scratch shared by all batches
-    if (c->pool_words < want_pool) { if ((rc = dev_alloc(c, &c->d_pool, want_pool))) return rc; c->pool_words = want_pool; }
-  }
+  if ((rc = ensure_pool(c))) return rc;
   std::vector<unsigned long long> h;
   // the counters as they stand now stay on the device; an attempt that has to be redone starts from them again (one read-back per attempt, none before)
   HIPCHK(c, hipMemcpyAsync(c->d_ctr_snap, c->b->d_ctr, C_TOTAL * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1214,6 +1219,7 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
   int rc = check_params(c, p); if (rc) return rc;
   const DevIndex& di = c->idx[slot];
   DParams P = make_dparams(c, di, p);
+  if ((rc = ensure_pool(c))) return rc;
   const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   std::vector<unsigned long long> h;
   for (int attempt = 0; attempt < 8; attempt++) {

@@ -1,0 +1,75 @@
+"""The drop-in boundary, compiled and run: oracle/_ref/sortmerna_gpu is the REFERENCE -- its CLI, option parsing, indexer,
+Readfeed, Refstats with the ALP Gumbel parameters, KVDB, summary and report writers, compiled from its sources where they lie -- with
+align() (processor.cpp:173-285) replaced by the INTEGRATION.md binding over include/smr_hip.h (oracle/dropin/align_gpu.cpp), built by
+`make -C oracle dropin`.  It must write the same files as the unmodified binary (oracle/_ref/sortmerna_ref) for the same command line:
+aligned/other FASTX, BLAST, SAM, the KVDB values, and aligned.log except the lines that hold the command line, pid and time.
+On the GPU box both prebuilt binaries are run (`-m gpu`); without a GPU the same objects are linked against the kernel emulator's build
+of the library (needs /root/reference for the objects)."""
+import os
+import subprocess
+
+import pytest
+
+from helpers import paths, refrun
+
+REF_GPU = os.path.join(paths.ORACLE_DIR, "_ref", "sortmerna_gpu")
+CASES = {
+    "t0": dict(refs=["t0_ref.fasta"], reads=["t0_read.fasta"], extra=["-fastx", "-other", "-blast", "1 cigar qcov qstrand", "-sam", "-SQ"]),
+    "t9": dict(refs=["t9_ref.fasta"], reads=["t9_reads.fasta"], extra=["-fastx", "-blast", "1", "-sam", "-num_alignments", "3"]),
+    "real_two_db": dict(refs=["syn_db.fasta", "real_db.fasta"], reads=["two_db_reads.fasta"], extra=["-fastx", "-other", "-blast", "1 cigar", "-sam"]),
+    "paired": dict(refs=["real_db.fasta"], reads=["paired/paired_1.fastq", "paired/paired_2.fastq"], extra=["-fastx", "-other", "-paired_in", "-out2", "-blast", "1", "-sam"]),
+}
+
+
+def run_binary(exe, case, wd):
+    c = CASES[case]
+    cmd = [exe]
+    for r in c["refs"]:
+        cmd += ["-ref", os.path.join(paths.GOLDEN, r)]
+    for r in c["reads"]:
+        cmd += ["-reads", os.path.join(paths.GOLDEN, r)]
+    cmd += ["-workdir", str(wd), "-threads", "1"] + c["extra"]
+    env = dict(os.environ)
+    env["SMR_KVDB_DUMP"] = os.path.join(str(wd), "kvdb_dump.bin")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
+    assert p.returncode == 0, p.stdout.decode("latin-1")[-3000:]
+    out = {}
+    od = os.path.join(str(wd), "out")
+    for fn in sorted(os.listdir(od)):
+        b = open(os.path.join(od, fn), "rb").read()
+        if fn.endswith(".log"):           # without the command line, the process id and the time stamps
+            b = b"\n".join(l for l in b.split(b"\n") if not (b"Command:" in l or b"Process pid" in l or b"sortmerna" in l.lower() or b"20" in l[:24] and b":" in l[:24])
+                           and str(wd).encode() not in l)
+        if fn.endswith(".sam"):
+            b = b"\n".join(l for l in b.split(b"\n") if not l.startswith(b"@PG"))
+        out[fn] = b
+    return out, refrun.parse_kvdb_dump(env["SMR_KVDB_DUMP"]), p.stdout.decode("latin-1")
+
+
+def compare(exe_gpu, case, tmp_path):
+    ref_files, ref_kv, _ = run_binary(paths.REF_BIN, case, tmp_path / "ref")
+    gpu_files, gpu_kv, log = run_binary(exe_gpu, case, tmp_path / "gpu")
+    assert "Starting alignment (libsmr_hip)" in log
+    assert sorted(ref_files) == sorted(gpu_files)
+    assert any(fn.startswith("aligned") and fn.endswith(".blast") for fn in ref_files)
+    for fn in ref_files:
+        assert gpu_files[fn] == ref_files[fn], "%s: %s differs from the reference's (%d vs %d bytes)" % (case, fn, len(gpu_files[fn]), len(ref_files[fn]))
+    rk = {k: v for k, v in ref_kv.items() if k[:1].isdigit()}
+    gk = {k: v for k, v in gpu_kv.items() if k[:1].isdigit()}
+    assert rk == gk and len(rk) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_reference_cli_with_the_gpu_in_the_middle(case, tmp_path):
+    assert os.path.isfile(REF_GPU) and os.path.isfile(paths.REF_BIN), "make -C oracle ref dropin (in the build container)"
+    compare(REF_GPU, case, tmp_path)
+
+
+@pytest.mark.skipif(not (paths.have_reference() and paths.have_ref_bin()), reason="needs /root/reference and `make -C oracle ref`")
+@pytest.mark.parametrize("case", ["t0", "paired"])
+def test_reference_cli_with_the_kernel_emulator_in_the_middle(case, tmp_path):
+    from helpers import emu
+    lib = emu.build()
+    subprocess.check_call(["make", "-s", "-j8", "-C", paths.ORACLE_DIR, "dropin", "SMRLIB=" + os.path.dirname(lib), "SMRNAME=smr_emu", "DROPIN_BIN=sortmerna_gpu_emu"])
+    compare(os.path.join(paths.ORACLE_DIR, "_ref", "sortmerna_gpu_emu"), case, tmp_path)
