@@ -1,0 +1,76 @@
+"""End-to-end number of the C++ host (examples/smr_align_mgpu.cpp) on the bench workload: N synthetic 150-nt reads in a FASTQ FILE against
+the 140 Mnt synthetic DB -- parse + 2-bit pack (all cores), H2D in chunks overlapped with alignment, both strands / all passes, traceback,
+counters all-reduce (RCCL, world 1), result fetch and KVDB-record serialisation.  Prints the driver's [timing] line; everything
+before it (DB, index files, FASTQ) is preparation and not timed.
+
+    python tools/e2e_cpp.py [--reads 10000000] [--chunk 2000000]        (on the GPU box, through gpurun)
+"""
+import argparse
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sortmerna_amd as smr  # noqa: E402
+from sortmerna_amd import synth  # noqa: E402
+
+
+def write_fastq_fast(path, letters, first_id):
+    n, L = letters.shape
+    ids = np.char.zfill((np.arange(n) + first_id).astype(str), 9)
+    hdr = np.frombuffer("".join(ids).encode(), dtype=np.uint8).reshape(n, 9)
+    rec = np.empty((n, 2 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2:11] = hdr; rec[:, 11] = 10
+    rec[:, 12:12 + L] = letters
+    rec[:, 12 + L] = 10; rec[:, 13 + L] = ord("+"); rec[:, 14 + L] = 10
+    rec[:, 15 + L:15 + 2 * L] = ord("I"); rec[:, 15 + 2 * L] = 10
+    with open(path, "ab") as f:
+        f.write(rec.tobytes())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--chunk", type=int, default=2_000_000)
+    ap.add_argument("--db-nt", type=int, default=140_000_000)
+    a = ap.parse_args()
+    d = tempfile.mkdtemp(prefix="smr_e2e_")
+    t = time.time()
+    db = os.path.join(d, "db.fasta")
+    synth.make_db(db, a.db_nt, seed=42)
+    eng = smr.Engine(0)
+    parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)
+    prefix = os.path.join(d, "idx")
+    smr.Index.write_files(parts, db, prefix)
+    info = parts[0].info()
+    eng.close()
+    print("[prep] DB + device index build + index files: %.1f s" % (time.time() - t), flush=True)
+    t = time.time()
+    codes, offs = synth.load_db_codes(db)
+    fq = os.path.join(d, "reads.fastq")
+    done = 0
+    while done < a.reads:
+        k = min(2_000_000, a.reads - done)
+        letters = synth.make_reads(codes, offs, k, read_len=150, frac_db=0.10, seed=1234 + done, sub=0.005, indel=0.0001, n_rate=0.001)
+        write_fastq_fast(fq, letters, done)
+        done += k
+    print("[prep] %d reads -> %s (%.2f GB): %.1f s" % (a.reads, fq, os.path.getsize(fq) / 1e9, time.time() - t), flush=True)
+    exe = os.path.join(ROOT, "examples", "build", "smr_align_mgpu")
+    out = os.path.join(d, "out")
+    os.makedirs(out)
+    for rep in range(2):                       # second run: page cache warm, like a file that was just written by the sequencer pipeline
+        t = time.time()
+        p = subprocess.run([exe, "--ref", db, "--idx", prefix, "--gumbel", "0.618874", "0.343238", "--reads", fq, "--out", out, "--gpus", "1",
+                            "--chunk-reads", str(a.chunk)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        print("[run %d] wall %.1f s (includes loading the index files, %.1f GB)" % (rep, time.time() - t, sum(os.path.getsize(prefix + s) for s in (".kmer_0.dat", ".bursttrie_0.dat", ".pos_0.dat")) / 1e9))
+        print(p.stdout.decode(), flush=True)
+        assert p.returncode == 0
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,8 @@ alt)
     timeout 300 python tools/hw_minibench.py > $OUT/minibench_alt.log 2>&1; grep -E "SW kernel" $OUT/minibench_alt.log | tail -4
     cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
   fi ;;
+e2e)
+  timeout 900 python tools/e2e_cpp.py > $OUT/e2e_cpp.log 2>&1; tail -12 $OUT/e2e_cpp.log ;;
 mini)
   timeout 300 python tools/hw_minibench.py > $OUT/minibench.log 2>&1; tail -6 $OUT/minibench.log ;;
 esac; done
