@@ -296,7 +296,7 @@ def main():
     pr = eng.prof()
     assert exact_aligned is None or int(ctr[0]) == exact_aligned, "the two seed kernels disagree on num_aligned: %d vs %d" % (int(ctr[0]), exact_aligned)
     prof = torch.tensor([pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.seed_launches, pr.chain_launches, pr.trace_launches] +
-                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells], dtype=torch.float64, device=cdev)
+                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells, pr.n_sw_spec, pr.n_sw_spec_used], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(prof)
     prof = [float(x) for x in prof.cpu()]
@@ -344,6 +344,10 @@ def main():
             r_sw = (m_sw + 63) // 64
             instr = (n_sw + 63) * (20 * r_sw + 15)
         sw_peak_gcups = m_sw * n_sw / (instr / 6.144e11) / 1e9
+        # the four-problem kernel (sw_wave_x4): 32 virtual lanes per problem, R = 3 / 5 / 8 rows each, n + ceil(m/R) - 1 steps of 13 R + 13 instructions for FOUR problems
+        r4 = 3 if m_sw <= 96 else (5 if m_sw <= 160 else 8)
+        instr4 = (n_sw + (m_sw + r4 - 1) // r4 - 1) * (13 * r4 + 13)
+        sw4_peak_gcups = 4 * m_sw * n_sw / (instr4 / 6.144e11) / 1e9 if m_sw <= 256 else None
         out = {
             "metric": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "value": reads_timed / dt, "unit": "reads/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -365,7 +369,11 @@ def main():
                         "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
                                     "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6,
                                     "valu_model_peak_gcups": sw_peak_gcups * args.gpus,
-                                    "valu_model_frac": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6 / (sw_peak_gcups * args.gpus)},
+                                    "valu_model_frac": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6 / (sw_peak_gcups * args.gpus),
+                                    "valu_model_x4_peak_gcups": sw4_peak_gcups * args.gpus if sw4_peak_gcups else None,
+                                    "sw_scored_ahead": prof[15], "sw_scored_ahead_used": prof[16],
+                                    "note": "gcups = DP cells of the sequential walk's ssw_align calls / whole k_chain time (candidate search, LIS, bookkeeping included); "
+                                            "valu_model_* = what the single-problem / four-problem packed kernel alone could do at one VALU op per SIMD per 4 cycles"},
                         "k_trace": {"ms": trace_ms / args.gpus, "launches": trace_l / args.gpus}},
         }
         if args.gpus == 1 and not args.no_cpu_baseline and not args.profile_run:

@@ -233,6 +233,110 @@ __device__ uint32_t serial_lis_first(const unsigned long long* a, uint32_t n, ui
   return nb;
 }
 
+// end of traverse() for one read: pass control (paralleltraversal.cpp:253-277), state write-back by the lane(s) with writer = true
+__device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_strand, uint32_t r, RState& st, RWork& w, int search, bool writer,
+                                                  RState* __restrict__ work, RWork* __restrict__ rw) {
+  uint32_t pass_n = w.pass_n;
+  if (search) {
+    if (pass_n == 2) search = 0;
+    else {
+      while (pass_n < 2 && P.skip[pass_n] == P.skip[pass_n + 1]) ++pass_n;
+      if (++pass_n > 2) search = 0;
+      else w.win_shift = P.skip[pass_n];
+    }
+  }
+  w.pass_n = (uint8_t)pass_n; w.search = (uint8_t)search;
+  if (!search) {
+    // end of traverse() (:279-297)
+    st.lastIndex = P.index_num; st.lastPart = P.part;
+    if (P.num_alignments > 0) {
+      if ((P.is_best && P.num_alignments == st.max_SW_count) || (!P.is_best && st.n_align == P.num_alignments)) st.is_done = 1;
+    } else if (P.is_last_index_part && is_last_strand && st.n_align > 0) st.is_done = 1;
+    w.strand_active = 0;
+  }
+  if (writer) { work[r] = st; rw[r] = w; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cand: the cheap majority first.  Most reads that reach compute_lis_alignment (alignment.cpp:100-148) have no candidate reference
+// at all: no reference sequence occurs twice among the positions of their seed hits.  That is decided here for every read of the
+// (strand, pass), 16 lanes per read and four reads per wave: the position lists of the read's hits are walked with one lane per
+// POSITION and every reference number sets one bit of a Bloom bitmap in LDS (2 KB per read).  No bit set twice -> no reference seen
+// twice -> no candidate (for num_seeds >= 2): the read's pass ends here, exactly as the candidate loop would end it without a single
+// ssw_align (pass control + write-back by one lane).  Anything else -- a collision, more hits than the group holds, num_seeds < 2 --
+// only marks the read (RWork::pad_[0]) for k_chain, which does the exact work.  k_chain then walks the marked reads only.
+// ------------------------------------------------------------------------------------------------
+#define CAND_HITS 64u                 // seed hits per read handled here
+#define CAND_BLOOM_WORDS 512u         // 16 384 bits per read
+__global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
+                                              const uint32_t* __restrict__ pool) {
+  __shared__ uint32_t s_bloom[16][CAND_BLOOM_WORDS];
+  __shared__ uint32_t s_hp[16][CAND_HITS + 1], s_lo[16][CAND_HITS];
+  const int lane = lane_id(), gl = lane & 15, g = (int)(threadIdx.x >> 4);
+  const uint32_t r = blockIdx.x * 16u + (uint32_t)g;
+  bool have = r < rd.n;
+  RWork w; RState st;
+  bool eligible = false;
+  if (have) {
+    w = rw[r];
+    have = w.strand_active && w.search && w.pass_n == (uint32_t)pass;
+    if (have) {
+      st = work[r];
+      eligible = st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0;
+      if (!eligible) { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+    }
+  }
+  const uint32_t nh = eligible ? w.hit_total : 0u;
+  bool mark = eligible && (nh > CAND_HITS || P.num_seeds < 2);
+  const bool scan = eligible && !mark;
+  // the group's hits: list start and length of each, prefix over the lengths (row-wise, 16 hits per round)
+  uint32_t npos = 0;
+  if (scan) { for (uint32_t q = gl; q < CAND_BLOOM_WORDS; q += 16) s_bloom[g][q] = 0; }
+  for (uint32_t h0 = 0; h0 < CAND_HITS; h0 += 16) {
+    const uint32_t h = h0 + (uint32_t)gl;
+    uint32_t lo = 0, ln = 0;
+    if (scan && h < nh) {
+      uint32_t o = h, id = 0;
+      for (uint32_t pp = 0; pp < 3; pp++) {                // the hit blocks of the passes run so far on this strand, concatenated
+        const uint32_t c = w.blk_cnt[pp];
+        if (o < c) { id = pool[w.blk_off[pp] + 2 * o]; break; }
+        o -= c;
+      }
+      lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
+    }
+    uint32_t inc = ln;                                     // inclusive prefix inside the row of 16 lanes (row_shr:1/2/4/8)
+    uint32_t v;
+    v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, false); inc += v;
+    v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, false); inc += v;
+    v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, false); inc += v;
+    v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, false); inc += v;
+    if (scan && h < nh) { s_hp[g][h] = npos + inc - ln; s_lo[g][h] = lo; }
+    npos += (uint32_t)__shfl((int)inc, 15, 16);
+  }
+  if (scan && gl == 0) s_hp[g][nh] = npos;
+  __syncthreads();
+  uint32_t rounds = scan ? (npos + 15u) / 16u : 0u;
+  for (int d = 32; d > 0; d >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d, 64));
+  bool hit = false;
+  for (uint32_t it = 0; it < rounds; it++) {
+    const uint32_t p = it * 16u + (uint32_t)gl;
+    if (scan && p < npos) {
+      uint32_t h = 0;
+      for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && s_hp[g][t] <= p) h = t; }
+      const uint32_t seq = ix.pos_arr[s_lo[g][h] + (p - s_hp[g][h])].y;
+      const uint32_t hb = (seq * 2654435761u) >> 18;                    // 14 bits
+      const uint32_t old = atomicOr(&s_bloom[g][hb >> 5], 1u << (hb & 31u));
+      hit |= ((old >> (hb & 31u)) & 1u) != 0;
+    }
+  }
+  const unsigned long long hm = __ballot(hit);
+  if (scan && ((hm >> (lane & 48)) & 0xFFFFull)) mark = true;
+  if (eligible) {
+    if (mark) { if (gl == 0) rw[r].pad_[0] = 1; }
+    else { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+  }
+}
+
 // One block (64 threads = one wave) per read, persistent.  Dynamic LDS layout (bytes), ML = max_len rounded:
 //   rdq[ML] | rfq[ML+2*edges_max+64] | bound[2*(ML+...)] ints | keys[CH_KEYS_LDS] u64 | pairs[CH_PAIRS_LDS] u64 |
 //   lis[2*CH_PAIRS_LDS] u32 | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS+8] u32 | bloom[s_cap] u32 | skey[s_cap] u32 | scnt[s_cap] u32
@@ -290,28 +394,13 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 #else
 #define TPH(i)
 #endif
-  // end of traverse() for one read: pass control (paralleltraversal.cpp:253-277), state write-back
-  auto finish_read = [&](uint32_t r, RState& st, RWork& w, int search, bool writer) {
-    uint32_t pass_n = w.pass_n;
-    if (search) {
-      if (pass_n == 2) search = 0;
-      else {
-        while (pass_n < 2 && P.skip[pass_n] == P.skip[pass_n + 1]) ++pass_n;
-        if (++pass_n > 2) search = 0;
-        else w.win_shift = P.skip[pass_n];
-      }
-    }
-    w.pass_n = (uint8_t)pass_n; w.search = (uint8_t)search;
-    if (!search) {
-      // end of traverse() (:279-297)
-      st.lastIndex = P.index_num; st.lastPart = P.part;
-      if (P.num_alignments > 0) {
-        if ((P.is_best && P.num_alignments == st.max_SW_count) || (!P.is_best && st.n_align == P.num_alignments)) st.is_done = 1;
-      } else if (P.is_last_index_part && is_last_strand && st.n_align > 0) st.is_done = 1;
-      w.strand_active = 0;
-    }
-    if (writer) { work[r] = st; rw[r] = w; }
-  };
+#ifdef SMR_CHAIN_STATS                                    // read-class census in the same seven debug slots (build with -DSMR_CHAIN_STATS instead)
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0};
+#define TST(i) { tph[i]++; }
+#else
+#define TST(i) {}
+#endif
+  auto finish_read = [&](uint32_t r, RState& st, RWork& w, int search, bool writer) { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, search, writer, work, rw); };
   // Reads whose walk meets exactly ONE Smith-Waterman task (the usual case for a background read with a spurious candidate) are PARKED:
   // task and sequences go into one of four LDS slots, nothing is written back, the wave moves on to its next read.  Four parked tasks
   // of four different reads are scored by one pass of the four-problem kernel.  A result that is "no alignment" -- what the walk was
@@ -377,7 +466,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           RWork wi = rw[ri];
           if (wi.strand_active && wi.search && wi.pass_n == (uint32_t)pass) {
             RState si = work[ri];
-            if (si.hit_seeds >= (uint32_t)P.num_seeds && wi.hit_total > 0) todo = true;
+            if (si.hit_seeds >= (uint32_t)P.num_seeds && wi.hit_total > 0) todo = wi.pad_[0] != 0;      // marked by k_cand (the others ended their pass there)
             else finish_read(ri, si, wi, 1, true);
           }
         }
@@ -402,6 +491,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     if (st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0) {
       // ---------------- compute_lis_alignment (alignment.cpp:100-509) ----------------
       TPH(0)
+      if (mode == 0) TST(0)
       // gather this strand's hits (all passes so far) into a flat array
       const uint32_t nh = w.hit_total;
       uint2* hits = nh <= CH_HITS_LDS ? l_hits : gh;
@@ -458,6 +548,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         unsigned long long* keys = l_keys;
         if (s_ns > 0 && !cap_err) {
           TPH(2)
+          if (mode == 0) TST(1)
           // walk 2: exact counts for the members of S, and their (pos, win) tuples
           for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
             const uint32_t p = p0 + lane;
@@ -501,6 +592,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           __syncthreads();
         }
         TPH(3)
+        if (mode == 0 && ncand > 0) TST(2)
         const uint32_t ntup = min(s_nt, pairs_cap);
 
         // 2. candidate loop (:150-508), organised as a GENERATOR of Smith-Waterman tasks.
@@ -700,9 +792,12 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               q_n++;
               if (q_n == 4) need_flush = true;
               parked = true;
+              TST(3)
             } else immediate = true;
           } else if (c1 == 2) immediate = true;
         }
+        if (immediate && mode == 0) TST(4)
+        if (mode == 1) TST(5)
         if (immediate)
         for (;;) {
           SwTask tk;
@@ -845,7 +940,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
     if (n_spec) atomicAdd(&ctr[C_SW_SPEC], n_spec);
     if (n_spec_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_spec_used);
-#ifdef SMR_CHAIN_PHASES
+#if defined(SMR_CHAIN_PHASES) || defined(SMR_CHAIN_STATS)
     for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
 #endif
   }

@@ -145,7 +145,7 @@ DIndex dindex(const DevIndex& d) {
 DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off = c->b->d_rec_off; r.len = c->b->d_len; r.n = c->b->n; r.max_len = c->b->max_len; return r; }
 
 int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
-  if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * (getenv("SMR_CHAIN_WPC") ? atoi(getenv("SMR_CHAIN_WPC")) : 15);
+  if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * (getenv("SMR_CHAIN_WPC") ? atoi(getenv("SMR_CHAIN_WPC")) : 12);     // k_chain: 3 waves per SIMD by registers
   (void)di;
   uint32_t need_keys = std::max(c->chain_scap, 1024u);
   if (c->keys_cap < need_keys) { int rc = dev_alloc(c, &c->d_keys, (size_t)c->chain_blocks * need_keys); if (rc) return rc; c->keys_cap = need_keys; }
@@ -280,6 +280,8 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   }
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
   ev_begin(c, 1);
+  // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
+  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool);
   hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
                      c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap);
   ev_end(c);
