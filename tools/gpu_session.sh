@@ -14,10 +14,14 @@ tests)
   tail -15 $OUT/pytest_gpu.log ;;
 bench)
   timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 900 $OUT/bench_default.json ;;
+bench20)
+  # the driver's own command line
+  ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_steps20_warmup5.json 2> $OUT/bench_steps20_warmup5.err; tail -c 1200 $OUT/bench_steps20_warmup5.json; tail -4 $OUT/bench_steps20_warmup5.err ;;
 prof)
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $ROOT/$OUT/bench_prof.json 2> $ROOT/$OUT/bench_prof.err )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --profile-run > $ROOT/$OUT/bench_prof.json 2> $ROOT/$OUT/bench_prof.err )
   find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
-  head -12 $OUT/kernel_stats.csv | cut -c1-160 ;;
+  head -14 $OUT/kernel_stats.csv | cut -c1-60,150-260
+  rm -rf $OUT/prof ;;
 pmc)
   # HBM traffic of the seed stage: one counter per pass (FETCH_SIZE, WRITE_SIZE), at the bench's own batch size
   for CTR in FETCH_SIZE WRITE_SIZE; do

@@ -6,7 +6,7 @@
 Per kernel: sum of the counter over its dispatches and the dispatch count.  Unit of FETCH_SIZE / WRITE_SIZE: KiB.  gfx950 correction of the
 guide: FETCH_SIZE reports half of the bytes of wide coalesced reads -> the corrected figure doubles it (upper bound for the narrow accesses
 of the trie walk); both are stored.  The seed stage of one launch = keys + scan + scatter + bfs<0> + bfs<1> + finish (+ the redo launches of
-k_seed_search), summed per launch of k_seed_keys.  The file is stamped with a hash of the kernel sources: bench.py only uses it when the
+k_seed_search), summed per launch of k_seed_keys.  The file is stamped with a hash of the seed-stage kernel sources (SEED_SOURCES): bench.py only uses it when the
 hash, the batch size, the read length and the DB size are the ones of its own run."""
 import collections
 import csv
@@ -18,13 +18,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+SEED_SOURCES = ["smr_seed.hpp", "smr_seed_bfs.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
+
+
 def kernel_src_sha():
     h = hashlib.sha1()
     d = os.path.join(ROOT, "sortmerna_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hpp", ".hip")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in SEED_SOURCES:
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
