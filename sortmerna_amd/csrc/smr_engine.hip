@@ -788,7 +788,11 @@ namespace {
 int reset_batch(smr_ctx* c, Batch& B, hipStream_t st) {
   HIPCHK(c, hipMemsetAsync(B.d_saved, 0, (size_t)B.n * sizeof(RState), st));
   HIPCHK(c, hipMemsetAsync(B.d_saved_aln, 0, (size_t)B.n * B.slots * sizeof(AlignRec), st));
-  HIPCHK(c, hipMemsetAsync(B.d_ctr, 0, C_TOTAL * 8, st));
+  // the Readstats counters, error flags and cursors start over; the profiling work counters (windows .. SW cells, scored-ahead counts and
+  // their shards) keep accumulating until smr_prof_reset, like the kernel times do
+  HIPCHK(c, hipMemsetAsync(B.d_ctr, 0, (size_t)C_WINDOWS * 8, st));
+  HIPCHK(c, hipMemsetAsync(B.d_ctr + C_ERR_HITCAP, 0, (size_t)(C_SW_SPEC - C_ERR_HITCAP) * 8, st));
+  HIPCHK(c, hipMemsetAsync(B.d_ctr + C_PCUR, 0, (size_t)C_NSHARD * 8, st));
   HIPCHK(c, hipStreamSynchronize(st));
   B.fetched = false;
   return SMR_OK;
@@ -803,7 +807,7 @@ template <class T> int grow(smr_ctx* c, T** p, size_t& cap, size_t need) {      
 int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipStream_t st) {
   if (max_aln == 0) max_aln = 1;
   int rc;
-  if (!B.d_ctr) { HIPCHK(c, hipMalloc((void**)&B.d_ctr, C_TOTAL * 8)); }
+  if (!B.d_ctr) { HIPCHK(c, hipMalloc((void**)&B.d_ctr, C_TOTAL * 8)); HIPCHK(c, hipMemsetAsync(B.d_ctr, 0, C_TOTAL * 8, st)); }
   const size_t nw = r->words.size() + 4, nr = (size_t)r->n + 1, na = std::max<size_t>((size_t)r->n * max_aln, 1);     // + slack: window extraction reads 2 words ahead
   if (B.cap_words < nw) { if ((rc = dev_alloc(c, &B.d_words, nw))) return rc; B.cap_words = nw; }
   if (B.cap_reads < nr) {
