@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   uint32_t* gl = g_lis + (size_t)blockIdx.x * 2 * pairs_cap;
   uint2* gh = g_hits + (size_t)blockIdx.x * hits_cap;
 
-  unsigned long long n_fwd = 0, n_rev = 0, n_cells = 0, n_spec = 0, n_spec_used = 0;   // flushed once per block (lane 0)
+  unsigned long long n_fwd = 0, n_cells = 0, n_spec = 0, n_spec_used = 0;   // flushed once per block (lane 0)
 #ifdef SMR_CHAIN_PHASES                                   // per-phase cycle accounting (build with -DSMR_CHAIN_PHASES, run with SMR_DEBUG_PHASES=1)
   unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define TPH(i) { const unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; }
@@ -863,31 +863,22 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           const uint64_t align_ref_start = tk.align_ref_start, head = tk.head, align_que_start = tk.align_que_start;
           const uint32_t max_ref = tk.max_ref;
           int score1 = fw.score > 65535 ? 65535 : fw.score;
-          int ref_begin1 = -1, read_begin1 = -1;
           const int ref_end1 = fw.end_ref, read_end1 = fw.end_read;
-          if (sw_ok && (uint32_t)score1 >= (P.minimal_score & 0xFFFFu)) {   // ssw_align: flag==2 && score1 < filters -> no begin
-            // reverse pass (ssw.c:900-918) on the prefixes ending at (read_end1, ref_end1)
-            TPH(5)
-            SwRes bw = sw_wave(rdq, read_end1 + 1, (int)align_que_start + read_end1, -1, rfq + (size_t)cslot[ce] * lds_rf, ref_end1 + 1, ref_end1, -1, bound,
-                               P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
-            ref_begin1 = ref_end1 - bw.end_ref;
-            read_begin1 = read_end1 - bw.end_read;
-            __syncthreads();
-            TPH(6)
-            n_rev++; n_cells += (unsigned long long)(read_end1 + 1) * (ref_end1 + 1);
-          }
+          // The begin cell (ssw_align's reverse pass, ssw.c:900-918) does not influence the walk -- it is only stored -- so it is not
+          // computed here: an accepted alignment is recorded with the START OF ITS WINDOW in ref_begin1 / read_begin1 and has_cigar = 2
+          // ("begin pending"), and k_begins computes the begins of the alignments that are still stored when the part is done, four per wave.
           R.is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
           if (R.is_aligned) {
             if ((uint32_t)score1 == max_SW_score) ++st.max_SW_count;
             AlignRec al;
-            al.ref_begin1 = ref_begin1 + (int32_t)(align_ref_start - head);
+            al.ref_begin1 = (int32_t)(align_ref_start - head);
             al.ref_end1 = ref_end1 + (int32_t)(align_ref_start - head);
-            al.read_begin1 = read_begin1 + (int32_t)align_que_start;
+            al.read_begin1 = (int32_t)align_que_start;
             al.read_end1 = read_end1 + (int32_t)align_que_start;
             al.readlen = len; al.ref_num = max_ref;
             al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
             al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
-            al.has_cigar = 0; al.cigar_off = 0; al.cigar_len = 0;
+            al.has_cigar = 2; al.cigar_off = 0; al.cigar_len = 0;
             AlignRec* slots = work_aln + (size_t)r * P.slots;
             if (!st.is_hit) {                                              // :411-416
               st.is_hit = 1;
@@ -936,7 +927,6 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   }
   if (lane == 0) {
     if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
-    if (n_rev) ctr_add(ctr, C_SW_REV, n_rev);
     if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
     if (n_spec) atomicAdd(&ctr[C_SW_SPEC], n_spec);
     if (n_spec_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_spec_used);
@@ -944,6 +934,82 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
 #endif
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// k_begins: the begin cells of the stored alignments (ssw_align's reverse pass, ssw.c:900-918: the same recurrence on the reversed
+// prefixes that end in the forward end cell; first column reaching the maximum, smallest row).  k_chain records an accepted alignment
+// with the start of its SW window in ref_begin1 / read_begin1 and has_cigar = 2; best-N bookkeeping may replace it before the part is
+// done, so only the survivors cost a reverse pass (43 % of the accepted ones on the bench workload), and they are independent problems:
+// four per wave through the four-problem kernel (reads <= SW_X4_MAX_ROWS), else one per wave through sw_wave.
+// k_begins_collect lists the pending slots of the reads with a new hit; k_begins claims them four at a time.
+// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4), or 1 + 1 + the strip-boundary array.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __restrict__ work, const RWork* __restrict__ rw, const AlignRec* __restrict__ work_aln,
+                                 uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * slots) return;
+  const uint32_t r = i / slots, k = i % slots;
+  if (!rw[r].is_new_hit || k >= work[r].n_align) return;
+  if (work_aln[i].has_cigar != 2) return;
+  tasks[atomicAdd(&ctr[C_BEGIN_N], 1ull)] = i;
+}
+
+__global__ void __launch_bounds__(64) k_begins(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, AlignRec* __restrict__ work_aln,
+                                               unsigned long long* __restrict__ ctr, uint32_t lds_m, uint32_t lds_n, int x4) {
+  SMR_DYN_LDS(unsigned char, lds_raw);
+  __shared__ uint32_t s_t0;
+  const int lane = lane_id();
+  const uint32_t n_tasks = (uint32_t)ctr[C_BEGIN_N];
+  const int per = x4 ? 4 : 1;
+  const int g = x4 ? lane >> 4 : 0;
+  uint8_t* rdq = lds_raw + (size_t)g * lds_m;
+  uint8_t* rfq = lds_raw + (size_t)per * lds_m + (size_t)g * lds_n;
+  int* bound = (int*)(lds_raw + (size_t)lds_m + lds_n);          // single-problem mode only
+  unsigned long long n_rev = 0, n_cells = 0;
+  for (;;) {
+    __syncthreads();
+    if (lane == 0) s_t0 = (uint32_t)atomicAdd(&ctr[C_BEGIN_NEXT], (unsigned long long)per);
+    __syncthreads();
+    const uint32_t t0 = s_t0;
+    if (t0 >= n_tasks) break;
+    const uint32_t t = t0 + (uint32_t)g;
+    const bool have = t < n_tasks;
+    uint32_t slot = 0;
+    AlignRec al;
+    int m = 0, n = 0;
+    if (have) {
+      slot = tasks[t]; al = work_aln[slot];
+      m = al.read_end1 - al.read_begin1 + 1; n = al.ref_end1 - al.ref_begin1 + 1;       // the window prefixes that end in the forward end cell
+      const uint32_t r = slot / P.slots, len = rd.len[r];
+      const uint32_t* rec = rd.words + rd.rec_off[r];
+      const uint8_t* ref = ix.ref_seq + ix.ref_off[al.ref_num] + al.ref_begin1;
+      const int l0 = x4 ? (lane & 15) : lane, ls = x4 ? 16 : 64;
+      for (int q = l0; q < m; q += ls) rdq[q] = (uint8_t)read_nt(rec, len, (uint32_t)(al.read_begin1 + q), al.strand ? 0u : 1u, 4u);
+      for (int q = l0; q < n; q += ls) rfq[q] = ref[q];
+    }
+    bool hasn = false;
+    __syncthreads();
+    if (have) { const int l0 = x4 ? (lane & 15) : lane, ls = x4 ? 16 : 64; for (int q = l0; q < n; q += ls) hasn |= rfq[q] == 4; }
+    SwRes bw;
+    if (x4) {
+      int mm = m;
+      for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
+      bw = sw_wave_x4(rdq, m, m - 1, -1, rfq, n, n - 1, -1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
+    } else {
+      bw = sw_wave(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+    }
+    if (have && (x4 ? (lane & 15) == 0 : lane == 0)) {
+      al.ref_begin1 = al.ref_end1 - bw.end_ref;
+      al.read_begin1 = al.read_end1 - bw.end_read;
+      al.has_cigar = 0;
+      work_aln[slot] = al;
+    }
+    if (have) { n_rev += (x4 ? (lane & 15) == 0 : lane == 0) ? 1 : 0; n_cells += (x4 ? (lane & 15) == 0 : lane == 0) ? (unsigned long long)m * n : 0; }
+  }
+  for (int d = 32; d > 0; d >>= 1) { n_rev += __shfl_xor(n_rev, d, 64); n_cells += __shfl_xor(n_cells, d, 64); }
+  if (lane == 0) { if (n_rev) ctr_add(ctr, C_SW_REV, n_rev); if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells); }
 }
 
 }  // namespace smr

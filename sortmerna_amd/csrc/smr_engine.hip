@@ -68,7 +68,7 @@ struct smr_ctx {
   uint32_t* sb_scan_sums = nullptr; uint32_t* sb_scan_pre = nullptr;   // tile sums / prefixes of the bin-offset scan
   uint32_t chain_blocks = 0;
   unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
-  size_t chain_lds_attr = 0;
+  size_t chain_lds_attr = 0, begins_lds_attr = 0;
   int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 2;   // 1 / 2: packed 16-bit Smith-Waterman kernels (smr_sw_pk.hpp; 2 = lane hand-over by wave_ror, measured faster) where they apply
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
@@ -926,10 +926,32 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if (h[C_ERR_SLOTS]) { c->err = "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"; return SMR_ERR_CAPACITY; }
     if (retry) { c->seed_ms = t_seed0; c->chain_ms = t_chain0; c->seed_l = l_seed0; c->chain_l = l_chain0; }   // timings of a discarded attempt
     if (!retry) {
+      // the begin cells of the alignments that are still stored (k_chain records the accepted ones "begin pending"): four reverse passes per wave
+      {
+        const uint64_t ntot = (uint64_t)c->b->n * c->b->slots;
+        if (c->tasks_cap < ntot) { if ((rc = dev_alloc(c, &c->d_tasks, 2 * ntot))) return rc; c->tasks_cap = ntot; }
+        uint32_t ml, rf; size_t chain_bytes;
+        chain_lds(c, P, ml, rf, chain_bytes);
+        const int x4 = (P.sw_mode >= 1 && c->b->max_len <= SW_X4_MAX_ROWS &&
+                        (long long)c->b->max_len * P.match + 255 < 32768 && rf + 128 <= 8191 && P.gap_open + P.mismatch >= 0 && P.gap_open + P.score_N >= 0 &&
+                        P.match + P.gap_open <= 255 && P.score_N + P.gap_open <= 255) ? 1 : 0;
+        const size_t lds_b = x4 ? (size_t)4 * (ml + rf) : (size_t)ml + rf + (size_t)2 * rf * 4;
+        if (lds_b > 64 * 1024 && lds_b > c->begins_lds_attr) {
+          HIPCHK(c, hipFuncSetAttribute((const void*)k_begins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          c->begins_lds_attr = lds_b;
+        }
+        HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_BEGIN_N], 0, 16, c->stream));       // C_BEGIN_N, C_BEGIN_NEXT
+        ev_begin(c, 1);
+        hipLaunchKernelGGL(k_begins_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->b->n, c->b->slots, (const RState*)c->b->d_work, (const RWork*)c->b->d_rw,
+                           (const AlignRec*)c->b->d_work_aln, c->d_tasks, c->b->d_ctr);
+        hipLaunchKernelGGL(k_begins, dim3((uint32_t)c->n_cu * 8u), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4);
+        ev_end(c);
+      }
       // only a clean attempt is committed to the persistent per-read state (kvdb.put, processor.cpp:150-155)
       hipLaunchKernelGGL(k_commit_part, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      ev_collect(c);
       return SMR_OK;
     }
   }
