@@ -198,14 +198,16 @@ def main():
             parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
             index_built = "host (smr_index_build), %.1f s" % (time.time() - t0)
         if world > 1:
+            import glob
+            for old in glob.glob(prefix + ".*"):         # nothing of an earlier build may survive next to the new files
+                os.remove(old)
             smr.Index.write_files(parts, db, prefix)
     barrier()
     if rank != 0:
-        parts = []
-        k = 0
-        while os.path.isfile("%s.kmer_%d.dat" % (prefix, k)):
+        # exactly the parts of THIS build: the number is in the .stats file rank 0 has just written (files of an earlier run in the cache are ignored)
+        parts = [smr.Index.load_files(prefix, 0, db)]
+        for k in range(1, int(parts[0].info().n_parts)):
             parts.append(smr.Index.load_files(prefix, k, db))
-            k += 1
     info = parts[0].info()
     log("index ready: %d part(s), trie %.0f MB, positions %.0f MB, %d refs (%.1fs)" % (
         len(parts), sum(p.info().trie_words for p in parts) * 4 / 1e6, sum(p.info().n_pos for p in parts) * 8 / 1e6,

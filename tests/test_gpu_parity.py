@@ -164,6 +164,44 @@ def test_long_noisy_reads(engine, tmp_path):
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 40
 
 
+def test_percent_edges_on_kilobase_reads(engine, tmp_path):
+    """`-edges 8%` on 1-2 kb reads: the SW window grows by a share of the read length on both sides (alignment.cpp:283-286), so reference
+    spans exceed max_len + a constant -- the LDS windows of k_chain / k_begins and the scratch of the traceback are sized from the same
+    percentage (round 1 sized the traceback from the absolute value and could fail on such runs)"""
+    import numpy as np
+    from sortmerna_amd import synth
+    w = Workload(str(tmp_path), db_nt=200_000, n_reads=20, seed=77, family_size=4, mean_len=4000)
+    codes, offs = synth.load_db_codes(w.db)
+    rng = np.random.Generator(np.random.PCG64(5))
+    seqs = []
+    for i in range(24):
+        sq = int(rng.integers(0, len(offs) - 1))
+        full = int(offs[sq + 1] - offs[sq])
+        ln = int(min(full - 400, rng.integers(1000, 2000)))
+        st = int(offs[sq] + 200 + rng.integers(0, full - ln - 400 + 1))
+        out = []
+        for c in codes[st:st + ln]:
+            u = rng.random()
+            if u < 0.02:
+                continue
+            if u < 0.04:
+                out.append(int(rng.integers(0, 4)))
+            out.append(int((c + rng.integers(1, 4)) & 3) if u > 0.97 else int(c))
+        # soft-clipped ends: random letters around the homologous part, so that the window really extends into the edges
+        s = "".join("ACGT"[c] for c in list(rng.integers(0, 4, size=30)) + out + list(rng.integers(0, 4, size=30)))
+        if i % 2:
+            s = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+        seqs.append(s)
+    w.seqs = seqs
+    w.reads = smr.Reads.from_seqs(seqs)
+    w.minimal_score = smr.minimal_score(0.618874, 0.343238, w.parts[0].info(), len(seqs), sum(map(len, seqs)))
+    opts = {"edges": 8, "is_as_percent": 1}
+    recs_o, ctr_o = w.oracle_records(**opts)
+    recs_g, ctr_g = w.gpu_records(engine, **opts)
+    _compare(recs_g, recs_o, "-edges 8%")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 20
+
+
 @pytest.mark.parametrize("scoring", [{}, {"match": 5, "mismatch": -4, "score_N": -4}], ids=["2_-3", "5_-4"])
 def test_long_reads_with_large_gaps(engine, tmp_path, scoring):
     """3-5 kb reads with one 120-400 nt deletion or insertion: 16-bit SW range, >= 12 SW strips, traceback bands of
