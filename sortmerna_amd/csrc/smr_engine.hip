@@ -44,7 +44,8 @@ struct Batch {
   unsigned long long* d_ctr = nullptr;
   uint32_t* d_cigar = nullptr; uint64_t cigar_words = 0;
   // host copies of results
-  std::vector<RState> h_state; std::vector<AlignRec> h_aln; std::vector<uint32_t> h_cigar;
+  std::vector<RState> h_state; std::vector<AlignRec> h_aln; std::vector<uint32_t> h_cigar;       // of the reads with alignments, packed
+  std::vector<uint32_t> h_idx, h_map;                                                            // packed position -> read, read -> packed position (or ~0)
   uint32_t last_num_alignments = 1;
   bool fetched = false;
   // capacities of the device arrays above (grow-only: a re-upload into the same batch allocates nothing unless it is larger)
@@ -69,6 +70,7 @@ struct smr_ctx {
   uint32_t chain_blocks = 0;
   unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
   size_t chain_lds_attr = 0, begins_lds_attr = 0;
+  uint32_t* d_fidx = nullptr; RState* d_fstate = nullptr; AlignRec* d_faln = nullptr; size_t fetch_cap_r = 0, fetch_cap_a = 0;   // staging of smr_results_fetch
   int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 2;   // 1 / 2: packed 16-bit Smith-Waterman kernels (smr_sw_pk.hpp; 2 = lane hand-over by wave_ror, measured faster) where they apply
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
@@ -715,7 +717,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-  dev_free(&c->d_ctr_snap);
+  dev_free(&c->d_ctr_snap); dev_free(&c->d_fidx); dev_free(&c->d_fstate); dev_free(&c->d_faln);
   (void)hipStreamDestroy(c->upload_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1178,30 +1180,62 @@ extern "C" int smr_counters_device(smr_ctx* c, void** dptr, uint32_t* n_u64) {
   return SMR_OK;
 }
 
+// the reads that have alignments, packed: read number, state, alignment slots (order = whatever the atomics hand out)
+__global__ void k_results_compact(uint32_t n, uint32_t slots, const RState* __restrict__ saved, const AlignRec* __restrict__ saved_aln,
+                                  uint32_t* __restrict__ out_idx, RState* __restrict__ out_state, AlignRec* __restrict__ out_aln, unsigned long long* __restrict__ ctr) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const RState s = saved[r];
+  if (s.n_align == 0) return;
+  const uint32_t p = (uint32_t)atomicAdd(&ctr[C_FETCH_N], 1ull);
+  out_idx[p] = r; out_state[p] = s;
+  for (uint32_t k = 0; k < s.n_align && k < slots; k++) out_aln[(size_t)p * slots + k] = saved_aln[(size_t)r * slots + k];
+}
+
+// Only the reads that have alignments cross the bus (a tenth of the batch on the bench workload): compacted on the device, then
+// read number -> packed position on the host.
 extern "C" int smr_results_fetch(smr_ctx* c) {
   if (!c || !c->b->d_saved) return SMR_ERR_STATE;
   HIPCHK(c, hipSetDevice(c->device));
-  c->b->h_state.resize(c->b->n); c->b->h_aln.resize((size_t)c->b->n * c->b->slots);
-  std::vector<unsigned long long> h;
-  int rc = read_ctr(c, h); if (rc) return rc;
-  uint64_t cw = std::min<uint64_t>(h[C_CIGAR_CURSOR], c->b->cigar_words);
-  c->b->h_cigar.resize(cw);
-  if (c->b->n) {
-    HIPCHK(c, hipMemcpyAsync(c->b->h_state.data(), c->b->d_saved, (size_t)c->b->n * sizeof(RState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->b->h_aln.data(), c->b->d_saved_aln, (size_t)c->b->n * c->b->slots * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  Batch& B = *c->b;
+  int rc;
+  const size_t need_r = std::max<size_t>(B.n, 1), need_a = std::max<size_t>((size_t)B.n * B.slots, 1);
+  if (c->fetch_cap_r < need_r) {
+    if ((rc = dev_alloc(c, &c->d_fidx, need_r))) return rc;
+    if ((rc = dev_alloc(c, &c->d_fstate, need_r))) return rc;
+    c->fetch_cap_r = need_r;
   }
-  if (cw) HIPCHK(c, hipMemcpyAsync(c->b->h_cigar.data(), c->b->d_cigar, cw * 4, hipMemcpyDeviceToHost, c->stream));
+  if (c->fetch_cap_a < need_a) { if ((rc = dev_alloc(c, &c->d_faln, need_a))) return rc; c->fetch_cap_a = need_a; }
+  HIPCHK(c, hipMemsetAsync(&B.d_ctr[C_FETCH_N], 0, 8, c->stream));
+  if (B.n) hipLaunchKernelGGL(k_results_compact, dim3((B.n + 255) / 256), dim3(256), 0, c->stream, B.n, B.slots, (const RState*)B.d_saved, (const AlignRec*)B.d_saved_aln,
+                              c->d_fidx, c->d_fstate, c->d_faln, B.d_ctr);
+  std::vector<unsigned long long> h;
+  rc = read_ctr(c, h); if (rc) return rc;
+  const uint64_t cw = std::min<uint64_t>(h[C_CIGAR_CURSOR], B.cigar_words);
+  const size_t nhit = (size_t)std::min<unsigned long long>(h[C_FETCH_N], B.n);
+  B.h_cigar.resize(cw);
+  B.h_idx.resize(nhit); B.h_state.resize(nhit); B.h_aln.resize(nhit * B.slots);
+  if (nhit) {
+    HIPCHK(c, hipMemcpyAsync(B.h_idx.data(), c->d_fidx, nhit * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.h_state.data(), c->d_fstate, nhit * sizeof(RState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(B.h_aln.data(), c->d_faln, nhit * B.slots * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
+  }
+  if (cw) HIPCHK(c, hipMemcpyAsync(B.h_cigar.data(), B.d_cigar, cw * 4, hipMemcpyDeviceToHost, c->stream));
+  B.h_map.assign(B.n, 0xFFFFFFFFu);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->b->fetched = true;
+  for (size_t j = 0; j < nhit; j++) B.h_map[B.h_idx[j]] = (uint32_t)j;
+  B.fetched = true;
   return SMR_OK;
 }
 
 // Read::toBinString read.cpp:429-462 (+ alignment_struct2::toString, s_align2::toString ssw.hpp:106-140)
 extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, size_t cap) {
   if (!c || !c->b->fetched || i >= c->b->n) return 0;
-  const RState& s = c->b->h_state[i];
+  const uint32_t j = c->b->h_map[i];
+  if (j == 0xFFFFFFFFu) return 0;
+  const RState& s = c->b->h_state[j];
   if (s.n_align == 0) return 0;
-  const AlignRec* al = c->b->h_aln.data() + (size_t)i * c->b->slots;
+  const AlignRec* al = c->b->h_aln.data() + (size_t)j * c->b->slots;
   size_t need = 24 + 3 + 2 + 4 + 4 + 8 + 4 + 4 + 8;
   for (uint32_t k = 0; k < s.n_align; k++) need += 8 + 8 + (size_t)(al[k].has_cigar ? al[k].cigar_len : 0) * 4 + 24 + 6 + 1;
   if (!buf || cap < need) return need;
@@ -1227,7 +1261,10 @@ extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, 
   }
   return (size_t)(p - buf);
 }
-extern "C" int smr_result_is_hit(const smr_ctx* c, uint32_t i) { return (c && c->b->fetched && i < c->b->n) ? c->b->h_state[i].is_hit : 0; }
+extern "C" int smr_result_is_hit(const smr_ctx* c, uint32_t i) {
+  if (!c || !c->b->fetched || i >= c->b->n || c->b->h_map[i] == 0xFFFFFFFFu) return 0;
+  return c->b->h_state[c->b->h_map[i]].is_hit;
+}
 
 // ---- standalone seed scan (kernel-level parity and the seed-scan roofline bench) ------------------
 __global__ void k_force_pass(uint32_t n, DParams P, int pass, const uint32_t* __restrict__ len, RWork* __restrict__ rw) {

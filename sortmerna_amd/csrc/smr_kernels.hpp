@@ -106,7 +106,7 @@ enum {
   C_NUM_ALIGNED = 0, C_NUM_SHORT = 1, C_PER_DB = 2,           // C_PER_DB .. C_PER_DB+63
   C_WINDOWS = 66, C_LOOKUP, C_NODE, C_ENTRY, C_HIT, C_READ_BYTES, C_SW_FWD, C_SW_REV, C_SW_CELLS,
   C_ERR_HITCAP, C_ERR_POOL, C_ERR_SLOTS, C_ERR_PAIRS, C_ERR_CIGAR, C_ERR_TRACE, C_POOL_CURSOR, C_WORK_NEXT,
-  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_SW_SPEC, C_SW_SPEC_USED, C_COUNT = 96,
+  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_FETCH_N, C_SW_SPEC, C_SW_SPEC_USED, C_COUNT = 96,
   // Work counters and the pool cursor are sharded 64 ways (by block id): one address would serialise ~10 ns per
   // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k at C_SHARDS + 16*s + k; the host folds them.
   C_NSHARD = 64, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + 16 * C_NSHARD, C_TOTAL = C_PCUR + C_NSHARD
