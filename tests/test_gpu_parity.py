@@ -111,6 +111,24 @@ def test_longer_reads(engine, tmp_path):
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 50
 
 
+def test_mixed_read_lengths(engine, tmp_path):
+    """60-400 nt reads in one batch: reads up to 256 nt are parked / scored four per wave, longer ones take the single-problem kernels
+    (and force the parked tasks to be scored first, because their strip boundaries share LDS with the parked windows); k_begins runs
+    in its one-problem-per-wave mode because the batch's longest read exceeds the four-problem kernel"""
+    import numpy as np
+    w = Workload(str(tmp_path), db_nt=250_000, n_reads=1800, read_len=400, seed=91, frac_db=0.5)
+    rng = np.random.Generator(np.random.PCG64(17))
+    w.seqs = [s[: int(rng.integers(60, 401))] if len(s) > 60 else s for s in w.seqs]
+    w.reads = smr.Reads.from_seqs(w.seqs)
+    w.minimal_score = smr.minimal_score(0.618874, 0.343238, w.parts[0].info(), len(w.seqs), sum(map(len, w.seqs)))
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "mixed read lengths")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 300
+    lens = [len(s) for s, r in zip(w.seqs, recs_o) if r]
+    assert min(lens) < 200 and max(lens) > 300
+
+
 @pytest.mark.parametrize("lnwin", [12, 14, 16])
 def test_other_seed_lengths(engine, tmp_path, lnwin):
     """-L 12/14/16: other window lengths (partialwin 6/7/8), their trie depth limits and automaton tail tables"""
