@@ -204,14 +204,24 @@ int main(int argc, char** argv) {
       if (rep && smr_report_add(rep, m1.h.data(), m1.s.data(), is_fastq ? m1.q.data() : nullptr, m1.rec.data(), m1.rec.size()) != SMR_OK) die(smr_report_last_error(rep));
     }
   }
-  fseek(f, 0, SEEK_SET); fwrite(&nrec, 8, 1, f); fclose(f);
-  if (rep && smr_report_close(rep) != SMR_OK) die("cannot write the report files");
   std::vector<uint64_t> ctr(2 + dbs.size(), 0), cb(2 + dbs.size());
   for (size_t b = 0; b < rf.size(); b++) {
     smr_batch_select(gpu, (int)b);
     smr_counters(gpu, cb.data(), (uint32_t)dbs.size());
     for (size_t k = 0; k < ctr.size(); k++) ctr[k] += cb[k];
   }
+  {  // readstats.store_to_db(kvdb) (processor.cpp:283-284): one more KVDB entry, key = hash of the read files' names
+    const char* rfn[2] = {reads_paths[0].c_str(), reads_paths.size() > 1 ? reads_paths[1].c_str() : nullptr};
+    char key[32];
+    const uint64_t kl = smr_readstats_key(rfn, (uint32_t)reads_paths.size(), key, sizeof key);
+    std::vector<uint8_t> rs(smr_readstats_record(n, total_len, min_len, max_len, ctr[0], ctr[1], ctr.data() + 2, (uint32_t)dbs.size(), nullptr, 0));
+    smr_readstats_record(n, total_len, min_len, max_len, ctr[0], ctr[1], ctr.data() + 2, (uint32_t)dbs.size(), rs.data(), rs.size());
+    const uint64_t vl = rs.size();
+    fwrite(&kl, 8, 1, f); fwrite(key, 1, kl, f); fwrite(&vl, 8, 1, f); fwrite(rs.data(), 1, vl, f);
+    nrec++;
+  }
+  fseek(f, 0, SEEK_SET); fwrite(&nrec, 8, 1, f); fclose(f);
+  if (rep && smr_report_close(rep) != SMR_OK) die("cannot write the report files");
   f = fopen(sp.c_str(), "w");
   if (!f) die("cannot write " + sp);
   fprintf(f, "Total reads = %llu\nTotal reads passing E-value threshold = %llu\nToo short reads (last part) = %llu\n", (unsigned long long)n,

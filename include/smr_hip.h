@@ -111,7 +111,11 @@ int smr_index_get_info(const smr_index*, smr_index_info* out);
 
 /* Refstats::load arithmetic (refstats.cpp:238-265): minimal SW score for E-value `evalue` given the
  * Gumbel parameters of the (scoring scheme, background) pair and the GLOBAL read totals
- * (all_reads_count / all_reads_len are sums over every rank when reads are sharded). */
+ * (all_reads_count / all_reads_len are sums over every rank when reads are sharded).
+ * lambda and K are INPUTS and there is no default: the reference computes them per DB and scoring scheme (-match / -mismatch / -gap_open /
+ * -gap_ext, background frequencies) with its vendored NCBI ALP library (refstats.cpp:194-233) and prints them in its log ("Gumbel lambda",
+ * "Gumbel K").  A different pair gives a different minimal_score, i.e. a different set of reads passes -- take them from the reference
+ * (the compiled drop-in, oracle/dropin/align_gpu.cpp, uses the reference's own Refstats object). */
 uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq,
                            uint64_t all_reads_count, uint64_t all_reads_len, double evalue);
 
@@ -297,6 +301,13 @@ typedef struct {
   const smr_summary_db* dbs; uint32_t n_dbs;
 } smr_summary;
 int smr_summary_write(const char* path, const smr_summary*);
+
+/* Readstats persistence: the value Readstats::store_to_db puts into the KVDB after the alignment stage = Readstats::toBstring()
+ * (readstats.cpp:133-174, 291-295) and its key = decimal std::hash of the '_'-joined basenames of the read files (readstats.cpp:82-91,
+ * util.cpp:216-222).  Both return the size needed; the buffer is filled when it is large enough (the key NUL-terminated). */
+size_t smr_readstats_record(uint64_t all_reads_count, uint64_t all_reads_len, uint32_t min_read_len, uint32_t max_read_len, uint64_t num_aligned,
+                            uint64_t num_short, const uint64_t* reads_matched_per_db, uint32_t n_db, uint8_t* buf, size_t cap);
+size_t smr_readstats_key(const char* const* reads_files, uint32_t n_files, char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -61,7 +61,7 @@ EXPORTS = [
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_sw_selfcheck", "smr_sw_mode", "smr_ssw_batch", "smr_cigar_batch", "smr_prof_reset", "smr_prof_get", "smr_refstats_corrected", "smr_report_open",
     "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_add_pair", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
-    "smr_summary_write",
+    "smr_summary_write", "smr_readstats_record", "smr_readstats_key",
 ]
 
 _lib = None
@@ -160,6 +160,10 @@ def bind(L):
     L.smr_sw_selfcheck.argtypes = [vp, u32, u32, u32, C.POINTER(u64)]
     L.smr_ssw_batch.restype = i32
     L.smr_ssw_batch.argtypes = [vp, u32, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, i32, vp]
+    L.smr_readstats_record.restype = C.c_size_t
+    L.smr_readstats_record.argtypes = [u64, u64, u32, u32, u64, u64, vp, u32, vp, C.c_size_t]
+    L.smr_readstats_key.restype = C.c_size_t
+    L.smr_readstats_key.argtypes = [vp, u32, vp, C.c_size_t]
     L.smr_reads_upload_batch.restype = i32
     L.smr_reads_upload_batch.argtypes = [vp, i32, vp, u32]
     L.smr_reads_slice.restype = i32

@@ -16,6 +16,7 @@
 #include <iomanip>
 #include <map>
 #include <sstream>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -372,3 +373,41 @@ extern "C" int smr_summary_write(const char* path, const smr_summary* s) {
 }
 
 extern "C" const char* smr_report_last_error(const smr_report* r) { return r ? r->err.c_str() : "null report"; }
+
+
+// ------------------------------------------------------------------------------------------------
+// Readstats persistence: what the reference keeps in its KVDB next to the per-read records after the alignment stage --
+// Readstats::store_to_db (readstats.cpp:291-295) puts Readstats::toBstring() (:133-174) under the decimal std::hash of the '_'-joined
+// basenames of the read files (:82-91, util.cpp:216-222).  The identity / coverage counters and is_stats_calc belong to later stages of
+// the reference and are zero / false here; is_set_aligned_id_cov stays false because n_yid_ycov is 0 (readstats.cpp:199-203).
+// ------------------------------------------------------------------------------------------------
+extern "C" size_t smr_readstats_record(uint64_t all_reads_count, uint64_t all_reads_len, uint32_t min_read_len, uint32_t max_read_len, uint64_t num_aligned,
+                                       uint64_t num_short, const uint64_t* reads_matched_per_db, uint32_t n_db, uint8_t* buf, size_t cap) {
+  const size_t need = 8 + 8 + 4 + 4 + 6 * 8 + 8 + (size_t)n_db * 8 + 2;
+  if (!buf || cap < need) return need;
+  uint8_t* p = buf;
+  auto put = [&](const void* v, size_t n) { memcpy(p, v, n); p += n; };
+  const uint64_t zero = 0, ndb = n_db;
+  put(&all_reads_count, 8); put(&all_reads_len, 8); put(&min_read_len, 4); put(&max_read_len, 4);
+  put(&num_aligned, 8);
+  put(&zero, 8); put(&zero, 8); put(&zero, 8); put(&zero, 8);          // n_yid_ncov, n_nid_ycov, n_yid_ycov, num_denovo
+  put(&num_short, 8);
+  put(&ndb, 8);
+  for (uint32_t i = 0; i < n_db; i++) put(&reads_matched_per_db[i], 8);
+  const uint8_t f = 0;
+  put(&f, 1); put(&f, 1);                                              // is_stats_calc, is_set_aligned_id_cov
+  return need;
+}
+
+extern "C" size_t smr_readstats_key(const char* const* reads_files, uint32_t n_files, char* buf, size_t cap) {
+  std::string joined;
+  for (uint32_t i = 0; i < n_files; i++) {
+    std::string f = reads_files[i] ? reads_files[i] : "";
+    const size_t sl = f.find_last_of('/');
+    if (sl != std::string::npos) f = f.substr(sl + 1);
+    joined += (i ? "_" : "") + f;
+  }
+  const std::string key = std::to_string(std::hash<std::string>{}(joined));
+  if (buf && cap > key.size()) memcpy(buf, key.c_str(), key.size() + 1);
+  return key.size();
+}

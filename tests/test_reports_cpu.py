@@ -166,3 +166,37 @@ def test_gzip_reports_hold_the_same_text(tmp_path):
         outs[z] = {fn: (gzip.open(d / fn).read() if z else open(d / fn, "rb").read()) for fn in sorted(os.listdir(d))}
     assert sorted(outs[True]) == ["aligned.blast.gz", "aligned.fa.gz", "aligned.sam.gz", "other.fa.gz"]      # the reference's names
     assert {k + ".gz": v for k, v in outs[False].items()} == outs[True]
+
+
+def test_readstats_record_equals_the_reference_blob(tmp_path):
+    """smr_readstats_record / smr_readstats_key = the KVDB entry of Readstats::store_to_db (readstats.cpp:133-174, 82-91, 291-295): parsed
+    fields equal the golden Readstats of every case; with the reference binary at hand the key and every byte of a live run"""
+    import ctypes as C
+    import sortmerna_amd.capi as capi
+    from helpers import golden, paths, refrun
+    L = capi.load()
+
+    def blob(rs):
+        per = (C.c_uint64 * len(rs["reads_matched_per_db"]))(*rs["reads_matched_per_db"])
+        n = L.smr_readstats_record(rs["all_reads_count"], rs["all_reads_len"], rs["min_read_len"], rs["max_read_len"], rs["num_aligned"], rs["num_short"], per, len(per), None, 0)
+        buf = C.create_string_buffer(n)
+        assert L.smr_readstats_record(rs["all_reads_count"], rs["all_reads_len"], rs["min_read_len"], rs["max_read_len"], rs["num_aligned"], rs["num_short"], per, len(per), buf, n) == n
+        return buf.raw
+
+    for case, g in golden.load().items():
+        rs = g.get("readstats")
+        if rs:
+            assert refrun.parse_readstats(blob(rs)) == rs, case
+    if not (paths.have_reference() and paths.have_ref_bin()):
+        return
+    db, rd, _ = golden.inputs("t9")
+    res = refrun.run_reference([db], [rd], str(tmp_path / "wd"), threads=1)
+    assert res.rc == 0
+    entries = {k: v for k, v in res.kvdb.items() if b"_" not in k}
+    assert len(entries) == 1
+    key, val = next(iter(entries.items()))
+    files = (C.c_char_p * 1)(rd.encode())
+    kb = C.create_string_buffer(32)
+    L.smr_readstats_key(files, 1, kb, 32)
+    assert kb.value == key
+    assert blob(refrun.parse_readstats(val)) == val
