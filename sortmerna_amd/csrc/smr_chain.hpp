@@ -183,6 +183,7 @@ struct ChainScratch {
   uint32_t keys_cap, pairs_cap, hits_cap;
 };
 
+#define CH_EXT_CAP 65536u          // slots of the global candidate-set table of a block (tuples carry the slot in 16 bits)
 #define CH_KEYS_LDS 128
 #define CH_PAIRS_LDS 256
 #define CH_HITS_LDS 128
@@ -337,6 +338,120 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The exact candidate set of one read (alignment.cpp:117-148) in a hash table of `cap` slots -- bl: 32 * cap Bloom bits, sk: keys
+// (reference number + 1), sc: exact counts.  Walk 1 over all positions of the read's hits: a reference whose Bloom bit is already set may
+// occur twice and becomes a member of S.  Walk 2: exact counts of the members and their (pos, slot, win) tuples.  Candidates = members
+// with count >= num_seeds, keyed (~count, ref) and sorted: count descending, reference ascending (:134-148).  false = the table overflowed
+// (nothing usable was produced).  k_chain<false> runs it on the wave's LDS table, k_chain<true> on the block's global table.
+// ------------------------------------------------------------------------------------------------
+struct SetArgs {
+  const uint2* pos_arr; const uint2* hits; const uint32_t* hp; uint32_t nh, npos, num_seeds;
+  unsigned long long* gt; uint32_t pairs_cap, keys_cap; unsigned long long* l_keys; unsigned long long* gk; unsigned long long* ctr;
+  uint32_t* s_ns; uint32_t* s_nt; uint32_t* s_ncand;
+};
+__device__ __forceinline__ bool chain_build_set(const SetArgs& A, uint32_t* bl, uint32_t* sk, uint32_t* sc, const uint32_t cap,
+                                                bool& cap_err, uint32_t& ncand, unsigned long long*& keys) {
+  const int lane = lane_id();
+  const uint32_t mask = cap - 1, bshift = 32 - (5 + __ffs((int)cap) - 1);     // 32 * cap Bloom bits
+  const uint32_t nh = A.nh, npos = A.npos;
+  if (lane == 0) { *A.s_ns = 0; *A.s_nt = 0; *A.s_ncand = 0; }
+  for (uint32_t q = lane; q < cap; q += 64) { bl[q] = 0; sk[q] = 0; sc[q] = 0; }
+  __syncthreads();
+  // walk 1: Bloom bitmap -> set S of references that may occur more than once
+  bool s_over = false;
+  for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
+    const uint32_t p = p0 + lane;
+    if (p < npos) {
+      uint32_t h = 0;
+      for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
+      const uint32_t seq = A.pos_arr[A.hits[h].x + (p - A.hp[h])].y;
+      const uint32_t hb = (seq * 2654435761u) >> bshift;
+      const uint32_t old = atomicOr(&bl[hb >> 5], 1u << (hb & 31u));
+      if (((old >> (hb & 31u)) & 1u) || A.num_seeds < 2) {
+        uint32_t sl = (seq * 0x9E3779B1u >> 7) & mask;
+        for (uint32_t tries = 0; tries < cap; tries++) {
+          const uint32_t o = atomicCAS(&sk[sl], 0u, seq + 1);
+          if (o == 0) { if (atomicAdd(A.s_ns, 1u) + 1 > (cap * 3) / 4) s_over = true; break; }
+          if (o == seq + 1) break;
+          sl = (sl + 1) & mask;
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (__any(s_over)) return false;
+  if (*A.s_ns > 0) {
+    // walk 2: exact counts for the members of S, and their (pos, win) tuples
+    for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
+      const uint32_t p = p0 + lane;
+      if (p < npos) {
+        uint32_t h = 0;
+        for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
+        const uint2 pa = A.pos_arr[A.hits[h].x + (p - A.hp[h])];
+        uint32_t sl = (pa.y * 0x9E3779B1u >> 7) & mask;
+        for (;;) {
+          const uint32_t o = sk[sl];
+          if (o == pa.y + 1) {
+            atomicAdd(&sc[sl], 1u);
+            const uint32_t t = atomicAdd(A.s_nt, 1u);
+            if (t < A.pairs_cap) A.gt[t] = ((unsigned long long)pa.x << 32) | ((unsigned long long)sl << 16) | A.hits[h].y;
+            break;
+          }
+          if (o == 0) break;
+          sl = (sl + 1) & mask;
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (*A.s_nt > A.pairs_cap) { if (lane == 0) atomicAdd(&A.ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
+    // candidates: members of S with count >= num_seeds
+    for (uint32_t q0 = 0; q0 < cap; q0 += 64) {
+      const uint32_t q = q0 + lane;
+      ncand += (uint32_t)__popcll(__ballot(sk[q] != 0 && sc[q] >= A.num_seeds));
+    }
+    if (ncand > A.keys_cap) { if (lane == 0) atomicAdd(&A.ctr[C_ERR_PAIRS], 1ull); ncand = 0; cap_err = true; }
+    keys = ncand <= CH_KEYS_LDS ? A.l_keys : A.gk;
+    if (!cap_err) for (uint32_t q0 = 0; q0 < cap; q0 += 64) {
+      const uint32_t q = q0 + lane;
+      if (sk[q] != 0 && sc[q] >= A.num_seeds) {
+        const uint32_t c = atomicAdd(A.s_ncand, 1u);
+        keys[c] = ((unsigned long long)(0xFFFFFFFFu - sc[q]) << 32) | (sk[q] - 1);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (ncand > 1) wave_sort_u64(keys, ncand);
+    __syncthreads();
+  }
+  return true;
+}
+// group the tuples by member of S: exclusive prefix of the exact counts (so[] = where a member's tuples start), then every tuple to its
+// member's next free place; a candidate's (ref_pos, read_pos) pairs are then a slice instead of a filter over all tuples
+__device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* sc, uint32_t* so, uint32_t cap, unsigned long long* gt2) {
+  const int lane = lane_id();
+  const uint32_t per = cap / 64;
+  uint32_t loc = 0;
+  for (uint32_t q = 0; q < per; q++) loc += sc[lane * per + q];
+  uint32_t tot; uint32_t run = wave_excl_scan_u32(loc, tot);
+  for (uint32_t q = 0; q < per; q++) { const uint32_t cnt = sc[lane * per + q]; so[lane * per + q] = run; sc[lane * per + q] = run; run += cnt; }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t nt_ = min(*A.s_nt, A.pairs_cap);
+  for (uint32_t t0 = 0; t0 < nt_; t0 += 64) {
+    const uint32_t t = t0 + lane;
+    if (t < nt_) {
+      const unsigned long long tv = A.gt[t];
+      const uint32_t p = atomicAdd(&sc[(uint32_t)((tv >> 16) & 0xFFFFu)], 1u);
+      gt2[p] = (tv & 0xFFFFFFFF00000000ull) | (tv & 0xFFFFull);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
 // One block (64 threads = one wave) per read, persistent.  Dynamic LDS layout (bytes), ML = max_len rounded:
 //   rdq[ML] | rfq[ML+2*edges_max+64] | bound[2*(ML+...)] ints | keys[CH_KEYS_LDS] u64 | pairs[CH_PAIRS_LDS] u64 |
 //   lis[2*CH_PAIRS_LDS] u32 | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS+8] u32 | bloom[s_cap] u32 | skey[s_cap] u32 | scnt[s_cap] u32
@@ -350,12 +465,13 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
 #ifndef SMR_CHAIN_WAVES_PER_SIMD
 #define SMR_CHAIN_WAVES_PER_SIMD 3
 #endif
+template <bool EXT>
 __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
                                               RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
-                                              uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap) {
+                                              uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
@@ -379,9 +495,14 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   uint32_t* l_hp = (uint32_t*)(l_hits + CH_HITS_LDS);
   uint32_t* skey = l_hp + CH_HITS_LDS + 8;
   __shared__ uint32_t s_ns, s_nt;
-  const uint32_t s_mask = s_cap - 1, bloom_shift = 32 - (5 + __ffs((int)s_cap) - 1);     // 32 * s_cap bits
+  const uint32_t s_mask = s_cap - 1;
 
   unsigned long long* gt = g_tuples + (size_t)blockIdx.x * pairs_cap;
+  // a read whose set S outgrows the LDS table (thousands of references sharing seeds with it) builds it again in this block's global table
+  // of CH_EXT_CAP slots (Bloom words | keys | counts | tuple offsets); its tuples are then grouped by member in gt2 (g_stab / g_tuples2 are
+  // only allocated after a first overflow, see smr_align_part)
+  uint32_t* xt = g_stab ? g_stab + (size_t)blockIdx.x * 4 * CH_EXT_CAP : nullptr;
+  unsigned long long* gt2 = g_tuples2 ? g_tuples2 + (size_t)blockIdx.x * pairs_cap : nullptr;
   unsigned long long* gk = g_keys + (size_t)blockIdx.x * keys_cap;
   unsigned long long* gp = g_pairs + (size_t)blockIdx.x * pairs_cap;
   uint32_t* gl = g_lis + (size_t)blockIdx.x * 2 * pairs_cap;
@@ -466,7 +587,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           RWork wi = rw[ri];
           if (wi.strand_active && wi.search && wi.pass_n == (uint32_t)pass) {
             RState si = work[ri];
-            if (si.hit_seeds >= (uint32_t)P.num_seeds && wi.hit_total > 0) todo = wi.pad_[0] != 0;      // marked by k_cand (the others ended their pass there)
+            if (si.hit_seeds >= (uint32_t)P.num_seeds && wi.hit_total > 0) todo = wi.pad_[0] == (EXT ? 2 : 1);      // marked by k_cand (the others ended their pass there); 2 = left to the EXT launch by the first one
             else finish_read(ri, si, wi, 1, true);
           }
         }
@@ -517,80 +638,29 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           if (h < nh) { hp[h] = npos + ex; hits[h].x = lo; }
           npos += tot;
         }
-        if (lane == 0) { hp[nh] = npos; s_ns = 0; s_nt = 0; s_ncand = 0; }
-        for (uint32_t q = lane; q < s_cap; q += 64) { bloom[q] = 0; skey[q] = 0; scnt[q] = 0; }
-        __syncthreads();
-        TPH(1)
-        // walk 1: Bloom bitmap -> set S of references that may occur more than once
-        bool s_over = false;
-        for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
-          const uint32_t p = p0 + lane;
-          if (p < npos) {
-            uint32_t h = 0;
-            for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp[t] <= p) h = t; }
-            const uint32_t seq = ix.pos_arr[hits[h].x + (p - hp[h])].y;
-            const uint32_t hb = (seq * 2654435761u) >> bloom_shift;
-            const uint32_t old = atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
-            if (((old >> (hb & 31u)) & 1u) || P.num_seeds < 2) {
-              uint32_t sl = (seq * 0x9E3779B1u >> 7) & s_mask;
-              for (uint32_t tries = 0; tries < s_cap; tries++) {
-                const uint32_t o = atomicCAS(&skey[sl], 0u, seq + 1);
-                if (o == 0) { if (atomicAdd(&s_ns, 1u) + 1 > (s_cap * 3) / 4) s_over = true; break; }
-                if (o == seq + 1) break;
-                sl = (sl + 1) & s_mask;
-              }
-            }
-          }
-        }
-        __syncthreads();
-        if (__any(s_over)) { if (lane == 0) atomicAdd(&ctr[C_ERR_SCAP], 1ull); cap_err = true; }
+        if (lane == 0) hp[nh] = npos;
         uint32_t ncand = 0;
         unsigned long long* keys = l_keys;
-        if (s_ns > 0 && !cap_err) {
-          TPH(2)
-          if (mode == 0) TST(1)
-          // walk 2: exact counts for the members of S, and their (pos, win) tuples
-          for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
-            const uint32_t p = p0 + lane;
-            if (p < npos) {
-              uint32_t h = 0;
-              for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp[t] <= p) h = t; }
-              const uint2 pa = ix.pos_arr[hits[h].x + (p - hp[h])];
-              uint32_t sl = (pa.y * 0x9E3779B1u >> 7) & s_mask;
-              for (;;) {
-                const uint32_t o = skey[sl];
-                if (o == pa.y + 1) {
-                  atomicAdd(&scnt[sl], 1u);
-                  const uint32_t t = atomicAdd(&s_nt, 1u);
-                  if (t < pairs_cap) gt[t] = ((unsigned long long)pa.x << 32) | ((unsigned long long)sl << 16) | hits[h].y;
-                  break;
-                }
-                if (o == 0) break;
-                sl = (sl + 1) & s_mask;
-              }
-            }
+        SetArgs sa;
+        sa.pos_arr = ix.pos_arr; sa.hits = hits; sa.hp = hp; sa.nh = nh; sa.npos = npos; sa.num_seeds = (uint32_t)P.num_seeds;
+        sa.gt = gt; sa.pairs_cap = pairs_cap; sa.keys_cap = keys_cap; sa.l_keys = l_keys; sa.gk = gk; sa.ctr = ctr;
+        sa.s_ns = &s_ns; sa.s_nt = &s_nt; sa.s_ncand = &s_ncand;
+        // EXT = false: the set in the wave's LDS table; a read that overflows it is marked for the EXT = true launch of this kernel, which
+        // keeps the set in the block's global table (CH_EXT_CAP slots) and groups the tuples by member
+        uint32_t* const t_bloom = EXT ? xt : bloom;
+        uint32_t* const t_skey = EXT ? xt + CH_EXT_CAP : skey;
+        uint32_t* const t_scnt = EXT ? xt + 2 * CH_EXT_CAP : scnt;
+        const uint32_t t_cap = EXT ? CH_EXT_CAP : s_cap, t_mask = t_cap - 1;
+        const bool set_ok = chain_build_set(sa, t_bloom, t_skey, t_scnt, t_cap, cap_err, ncand, keys);
+        if (!set_ok) {
+          if (!EXT && xt) {                                  // leave the read to the EXT launch: nothing of it is written but the mark
+            if (lane == 0) rw[r].pad_[0] = 2;
+            continue;
           }
-          __threadfence_block();
-          __syncthreads();
-          if (s_nt > pairs_cap) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
-          // candidates: members of S with count >= num_seeds; key = (~count, ref): ascending == count desc, ref asc (:134-148)
-          for (uint32_t q0 = 0; q0 < s_cap; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            ncand += (uint32_t)__popcll(__ballot(skey[q] != 0 && scnt[q] >= (uint32_t)P.num_seeds));
-          }
-          if (ncand > keys_cap) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); ncand = 0; cap_err = true; }
-          keys = ncand <= CH_KEYS_LDS ? l_keys : gk;
-          if (!cap_err) for (uint32_t q0 = 0; q0 < s_cap; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            if (skey[q] != 0 && scnt[q] >= (uint32_t)P.num_seeds) {
-              const uint32_t c = atomicAdd(&s_ncand, 1u);
-              keys[c] = ((unsigned long long)(0xFFFFFFFFu - scnt[q]) << 32) | (skey[q] - 1);
-            }
-          }
-          __syncthreads();
-          if (ncand > 1) wave_sort_u64(keys, ncand);
-          __syncthreads();
+          if (lane == 0) atomicAdd(&ctr[C_ERR_SCAP], 1ull);
+          cap_err = true; ncand = 0;
         }
+        if (EXT && set_ok && ncand > 0 && !cap_err) chain_group_tuples(sa, t_scnt, xt + 3 * CH_EXT_CAP, t_cap, gt2);
         TPH(3)
         if (mode == 0 && ncand > 0) TST(2)
         const uint32_t ntup = min(s_nt, pairs_cap);
@@ -630,13 +700,9 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           if (real && buf_tag[0] == wk.k) { wk.buf = 0; wk.np = buf_np[0]; }
           else if (real && buf_tag[1] == wk.k) { wk.buf = 1; wk.np = buf_np[1]; }
           else {
-            uint32_t cslot = (max_ref * 0x9E3779B1u >> 7) & s_mask;
-            while (skey[cslot] != max_ref + 1) cslot = (cslot + 1) & s_mask;
-            uint32_t np = 0;
-            for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
-              const uint32_t t = t0 + lane;
-              np += (uint32_t)__popcll(__ballot(t < ntup && (uint32_t)((gt[t] >> 16) & 0xFFFFu) == cslot));
-            }
+            uint32_t cslot = (max_ref * 0x9E3779B1u >> 7) & t_mask;
+            while (t_skey[cslot] != max_ref + 1) cslot = (cslot + 1) & t_mask;
+            const uint32_t np = max_occur;                                    // the exact count of the member = the number of its tuples
             int bufid;
             if (!real) {                                                      // the look-ahead never touches the buffer the real walk stands on,
               if (np > CH_PAIRS_LDS / 2 || real_buf == 2) return 2;           // and leaves a large candidate to the real walk
@@ -648,15 +714,20 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
             else { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; return 0; }
             unsigned long long* pw_ = pairs_of(bufid);
             __syncthreads();
-            uint32_t run = 0;
-            for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
-              const uint32_t t = t0 + lane;
-              unsigned long long tv = 0;
-              bool mt = false;
-              if (t < ntup) { tv = gt[t]; mt = (uint32_t)((tv >> 16) & 0xFFFFu) == cslot; }
-              const unsigned long long mm = __ballot(mt);
-              if (mt) pw_[run + (uint32_t)__popcll(mm & ((1ull << lane) - 1))] = (tv & 0xFFFFFFFF00000000ull) | (tv & 0xFFFFull);
-              run += (uint32_t)__popcll(mm);
+            if (EXT) {                                                        // grouped tuples: the candidate's pairs are a slice
+              const uint32_t start = xt[3 * CH_EXT_CAP + cslot];
+              for (uint32_t q = lane; q < np; q += 64) pw_[q] = gt2[start + q];
+            } else {
+              uint32_t run = 0;
+              for (uint32_t t0 = 0; t0 < ntup; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                unsigned long long tv = 0;
+                bool mt = false;
+                if (t < ntup) { tv = gt[t]; mt = (uint32_t)((tv >> 16) & 0xFFFFu) == cslot; }
+                const unsigned long long mm = __ballot(mt);
+                if (mt) pw_[run + (uint32_t)__popcll(mm & ((1ull << lane) - 1))] = (tv & 0xFFFFFFFF00000000ull) | (tv & 0xFFFFull);
+                run += (uint32_t)__popcll(mm);
+              }
             }
             __syncthreads();
             if (np > 1) wave_sort_u64(pw_, np);

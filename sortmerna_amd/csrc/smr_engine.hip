@@ -69,6 +69,9 @@ struct smr_ctx {
   uint32_t* sb_scan_sums = nullptr; uint32_t* sb_scan_pre = nullptr;   // tile sums / prefixes of the bin-offset scan
   uint32_t chain_blocks = 0;
   unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
+  uint32_t keys_need = 0;
+  bool chain_ext = false;                                              // a read's candidate set has outgrown the LDS table once: global tables are on
+  uint32_t* d_stab = nullptr; unsigned long long* d_tuples2 = nullptr; // per block: CH_EXT_CAP-slot table (4 arrays), tuples grouped by member
   size_t chain_lds_attr = 0, begins_lds_attr = 0;
   uint32_t* d_fidx = nullptr; RState* d_fstate = nullptr; AlignRec* d_faln = nullptr; size_t fetch_cap_r = 0, fetch_cap_a = 0;   // staging of smr_results_fetch
   int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 2;   // 1 / 2: packed 16-bit Smith-Waterman kernels (smr_sw_pk.hpp; 2 = lane hand-over by wave_ror, measured faster) where they apply
@@ -149,13 +152,17 @@ DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off =
 int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
   if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * (getenv("SMR_CHAIN_WPC") ? atoi(getenv("SMR_CHAIN_WPC")) : 12);     // k_chain: 3 waves per SIMD by registers
   (void)di;
-  uint32_t need_keys = std::max(c->chain_scap, 1024u);
+  uint32_t need_keys = std::max(std::max(c->chain_scap, 1024u), c->keys_need);
   if (c->keys_cap < need_keys) { int rc = dev_alloc(c, &c->d_keys, (size_t)c->chain_blocks * need_keys); if (rc) return rc; c->keys_cap = need_keys; }
   if (c->pairs_cap == 0) c->pairs_cap = 4096;
   if (!c->d_pairs) {
     int rc = dev_alloc(c, &c->d_pairs, (size_t)c->chain_blocks * c->pairs_cap); if (rc) return rc;
     rc = dev_alloc(c, &c->d_lis, (size_t)c->chain_blocks * 2 * c->pairs_cap); if (rc) return rc;
     rc = dev_alloc(c, &c->d_tuples, (size_t)c->chain_blocks * c->pairs_cap); if (rc) return rc;
+  }
+  if (c->chain_ext) {
+    if (!c->d_stab) { int rc = dev_alloc(c, &c->d_stab, (size_t)c->chain_blocks * 4 * CH_EXT_CAP); if (rc) return rc; }
+    if (!c->d_tuples2) { int rc = dev_alloc(c, &c->d_tuples2, (size_t)c->chain_blocks * c->pairs_cap); if (rc) return rc; }
   }
   if (c->hits_cap == 0) c->hits_cap = 4096;
   if (!c->d_hits) { int rc = dev_alloc(c, &c->d_hits, (size_t)c->chain_blocks * c->hits_cap); if (rc) return rc; }
@@ -277,15 +284,24 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   chain_lds(c, P, ml, rf, lds);
   HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
   if (lds > 64 * 1024 && lds > c->chain_lds_attr) {     // reads beyond ~5.6 kb: more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     c->chain_lds_attr = lds;
   }
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
   ev_begin(c, 1);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool);
-  hipLaunchKernelGGL(k_chain, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
-                     c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap);
+  hipLaunchKernelGGL(k_chain<false>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
+                     c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap,
+                     c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr);
+  if (c->chain_ext) {
+    // the reads whose candidate set outgrew the LDS table of the first launch: same walk, set in the block's global table
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
+    hipLaunchKernelGGL(k_chain<true>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
+                       c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap,
+                       c->d_stab, c->d_tuples2);
+  }
   ev_end(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
@@ -714,7 +730,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   }
   dev_free(&c->sb.hist); dev_free(&c->sb.bin_off); dev_free(&c->sb.tmp); dev_free(&c->sb_scan_sums); dev_free(&c->sb_scan_pre);
   dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
-  dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
+  dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   dev_free(&c->d_ctr_snap); dev_free(&c->d_fidx); dev_free(&c->d_fstate); dev_free(&c->d_faln);
@@ -916,14 +932,19 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0x7FFFFFF0ull) { c->err = "seed-hit pool exceeds 8 GiB"; return SMR_ERR_CAPACITY; }
       if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (h[C_ERR_PAIRS]) {
-      c->pairs_cap *= 4; c->hits_cap *= 4; dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits); dev_free(&c->d_tuples);
+      c->pairs_cap *= 4; c->hits_cap *= 4; dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits); dev_free(&c->d_tuples); dev_free(&c->d_tuples2);
       if (c->pairs_cap > (1u << 22)) { c->err = "per-read candidate scratch exceeds capacity"; return SMR_ERR_CAPACITY; }
       retry = true;
     }
     if (h[C_ERR_REDO]) { c->seed_exact = 1; retry = true; }     // too many overflowing waves for the redo list: use the DFS kernel throughout
     if (h[C_ERR_SCAP]) {
-      c->chain_scap *= 4; retry = true;
-      if (c->chain_scap > 4096) { c->err = "more than 3072 references share seeds with one read (candidate set capacity)"; return SMR_ERR_CAPACITY; }
+      // a read shares seeds with more references than the LDS table of its wave holds (384): from now on such reads build their set in a
+      // per-block table in global memory; the candidate keys need room for as many members
+      if (c->chain_ext) { c->err = "more than 49152 references share seeds with one read (candidate set capacity)"; return SMR_ERR_CAPACITY; }
+      c->chain_ext = true; retry = true;
+      if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: a read shares seeds with more references than its wave's LDS table holds: per-block global candidate tables enabled (%.1f GB)\n",
+                                         (double)c->chain_blocks * (4.0 * CH_EXT_CAP * 4 + (double)c->pairs_cap * 8 + (double)CH_EXT_CAP * 8) / 1e9);
+      if (c->keys_cap < CH_EXT_CAP) { dev_free(&c->d_keys); c->keys_cap = 0; c->keys_need = CH_EXT_CAP; }
     }
     if (h[C_ERR_SLOTS]) { c->err = "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"; return SMR_ERR_CAPACITY; }
     if (retry) { c->seed_ms = t_seed0; c->chain_ms = t_chain0; c->seed_l = l_seed0; c->chain_l = l_chain0; }   // timings of a discarded attempt

@@ -17,11 +17,11 @@ GUMBEL_UNIFORM = (0.618874, 0.343238)
 
 class Workload:
     def __init__(self, tmpdir, db_nt=300_000, n_reads=4000, read_len=150, frac_db=0.4, seed=5, max_mb=3072.0,
-                 n_rate=0.002, family_size=40, lnwin=18, mean_len=1500):
+                 n_rate=0.002, family_size=40, lnwin=18, mean_len=1500, db_kw=None):
         self.lnwin = lnwin
         self.dir = tmpdir
         self.db = os.path.join(tmpdir, "db_%d_%d.fasta" % (db_nt, seed))
-        synth.make_db(self.db, db_nt, seed=seed, family_size=family_size, mean_len=mean_len)
+        synth.make_db(self.db, db_nt, seed=seed, family_size=family_size, mean_len=mean_len, **(db_kw or {}))
         codes, offs = synth.load_db_codes(self.db)
         self.letters = synth.make_reads(codes, offs, n_reads, read_len=read_len, frac_db=frac_db, seed=seed + 1, n_rate=n_rate)
         # ragged lengths, a too-short read and an empty read to cover the edge cases

@@ -111,6 +111,22 @@ def test_longer_reads(engine, tmp_path):
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 50
 
 
+def test_reads_sharing_seeds_with_thousands_of_references(engine, tmp_path):
+    """a DB of 1 500 near-identical sequences (one family, 0.5-2 % divergence): every read from it shares seeds with up to all of them, far
+    beyond the 384 members the LDS candidate-set table of a wave holds -- such reads build their set in the block's global table and get
+    their tuples grouped by member (round 1: SMR_ERR_CAPACITY beyond 3 072 references)"""
+    w = Workload(str(tmp_path), db_nt=600_000, n_reads=160, read_len=150, frac_db=0.7, seed=123, family_size=1500, mean_len=400,
+                 db_kw=dict(sub_lo=0.005, sub_hi=0.02))
+    assert w.parts[0].info().numseq >= 1400
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "1500-member family")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 80
+    recs_o, ctr_o = w.oracle_records(num_alignments=5)
+    recs_g, ctr_g = w.gpu_records(engine, num_alignments=5)
+    _compare(recs_g, recs_o, "1500-member family, best 5")
+
+
 def test_mixed_read_lengths(engine, tmp_path):
     """60-400 nt reads in one batch: reads up to 256 nt are parked / scored four per wave, longer ones take the single-problem kernels
     (and force the parked tasks to be scored first, because their strip boundaries share LDS with the parked windows); k_begins runs
