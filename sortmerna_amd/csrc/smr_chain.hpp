@@ -173,16 +173,6 @@ __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, in
 #undef SW_ARGS
 }
 
-// per-block (= per persistent wave slot) scratch in global memory
-struct ChainScratch {
-  uint32_t* cnt;                    // n_refs counters, all zero between reads
-  unsigned long long* keys;         // candidate keys, capacity keys_cap (>= pow2(n_refs))
-  unsigned long long* pairs;        // hits on one reference, capacity pairs_cap (pow2)
-  uint32_t* lis;                    // 2 * pairs_cap (b and p arrays of find_lis)
-  uint2* hits;                      // gathered (id,win) of the read, capacity hits_cap
-  uint32_t keys_cap, pairs_cap, hits_cap;
-};
-
 #define CH_EXT_CAP 65536u          // slots of the global candidate-set table of a block (tuples carry the slot in 16 bits)
 #define CH_KEYS_LDS 128
 #define CH_PAIRS_LDS 256
@@ -452,16 +442,16 @@ __device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* s
   __syncthreads();
 }
 
-// One block (64 threads = one wave) per read, persistent.  Dynamic LDS layout (bytes), ML = max_len rounded:
-//   rdq[ML] | rfq[ML+2*edges_max+64] | bound[2*(ML+...)] ints | keys[CH_KEYS_LDS] u64 | pairs[CH_PAIRS_LDS] u64 |
-//   lis[2*CH_PAIRS_LDS] u32 | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS+8] u32 | bloom[s_cap] u32 | skey[s_cap] u32 | scnt[s_cap] u32
-//
-// Candidate references (alignment.cpp:117-148) without a per-reference counter array: the position lists of all hits
-// are walked twice with one lane per POSITION (prefix sum over the list lengths).  Walk 1 sets one bit per reference
-// in a Bloom bitmap in LDS; a reference seen with its bit already set may occur twice and goes into a small
-// open-addressing set S.  Most background reads leave S empty and are done.  Walk 2 counts exactly, for the
-// references in S only, and records their (pos, win) tuples; candidates are the members of S with count >= num_seeds,
-// and each candidate's (ref_pos, read_pos) pairs are a filter over the tuples instead of per-hit binary searches.
+// k_chain<EXT>: compute_lis_alignment (alignment.cpp:100-509) for the reads k_cand marked.  One block = one wave, persistent: chunks of
+// 16 reads are claimed with one atomic, their flags fetched by 16 lanes at once, the marked ones walked one by one.
+// Dynamic LDS (bytes), ML = max_len rounded to 16, MQ = min(ML, SW_X4_MAX_ROWS), RF = ML + 2 * edges + 16 rounded:
+//   read slots    ML + 4 MQ     the read being walked | four parked reads
+//   window slots  9 RF          0..3: batch of the read being walked, 4..7: parked tasks; slots 1..8 share their memory with the strip
+//                               boundaries (2 RF ints) that only reads longer than SW_X4_MAX_ROWS need
+//   keys[CH_KEYS_LDS] u64 | region R = max(4 CH_PAIRS_LDS, 2 s_cap) u32: pairs (two halves) + serial-LIS arrays during the candidate loop,
+//   Bloom words + counts while the candidate set is built | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS + 8] u32 | skey[s_cap] u32
+// Candidate references (alignment.cpp:117-148) without a per-reference counter array: see chain_build_set.  EXT = true is the second
+// instantiation for the reads whose set outgrew the LDS table (global table of the block, tuples grouped by member).
 #ifndef SMR_CHAIN_WAVES_PER_SIMD
 #define SMR_CHAIN_WAVES_PER_SIMD 3
 #endif
