@@ -3,20 +3,20 @@
 //   k_begin_part / k_begin_strand / k_commit_part : per-read state bookkeeping (processor.cpp:104-161)
 //   k_seed   : window scan (9-mer hash + lookup probe) + burst-trie descent with the LEV(1) automaton
 //              (paralleltraversal.cpp:124-249, traverse_bursttrie.cpp:100-298, bitvector.cpp:57-132)
-//   k_chain  : candidate histogram, LIS chaining, SW window geometry, Smith-Waterman score + begin position,
-//              accept/best-N bookkeeping, pass control (alignment.cpp:100-509, ssw.c:834-918,
-//              paralleltraversal.cpp:253-297)
+//   k_cand   : per read "is there any candidate reference at all?" (Bloom bitmap over the references of all seed positions); the
+//              reads without one end their pass here (alignment.cpp:117-148, paralleltraversal.cpp:253-297)
+//   k_chain  : exact candidate set, candidate walk as a task generator (LIS, SW window geometry), Smith-Waterman four problems per
+//              wave, accept/best-N bookkeeping, pass control (alignment.cpp:100-509, ssw.c:834-899, paralleltraversal.cpp:253-297)
+//   k_begins : begin cells of the alignments that are still stored (reverse SW passes, ssw.c:900-918), four per wave
 //   k_trace_band / k_trace_wide : banded DP with lanes across the band (F by prefix scan) + walk back -> CIGAR (what ssw.c:577-773 yields)
 //
 // Design notes (DESIGN.md has the long form):
-//  * integer work, HBM/latency bound: no MFMA anywhere.
-//  * k_seed: a wave is split into groups of `gw` lanes (gw = pow2 >= windows per read in this pass); each
-//    group owns one read, each lane one window.  Lane-local hit lists live in LDS (k*64+lane layout, conflict
-//    free); per-group compaction uses a segmented wave prefix sum and ONE atomic on the global hit pool.
-//  * k_chain: one wave per read (persistent blocks pull reads from an atomic counter because per-read work
-//    varies by orders of magnitude).  Control flow is wave-uniform and follows the reference statement by
-//    statement; the data-parallel pieces (position-list walks, bitonic sorts, the SW anti-diagonal systolic
-//    array with lane = read row) use all 64 lanes.
+//  * integer work, VALU-issue / latency bound: no MFMA anywhere.
+//  * seed stage: the windows of the whole batch are binned by 9-mer key (counting sort) and searched in key order, 64 searches per
+//    wave taken apart into node / bucket work items (k_seed_bfs); lane-local hit lists in LDS.
+//  * k_cand: 16 lanes per read, four reads per wave.  k_chain: one wave per marked read, persistent blocks pulling chunks of 16 reads
+//    from an atomic counter (per-read work varies by orders of magnitude); the data-parallel pieces (position-list walks, bitonic
+//    sorts, LIS as patience piles across lanes, the SW systolic arrays) use all 64 lanes, control flow is wave-uniform.
 //  * k_trace_*: lanes across the band diagonals, one DP row per step; 4-bit direction flags in LDS (short reads) or a global tile.
 #pragma once
 #include <hip/hip_runtime.h>
