@@ -115,7 +115,7 @@ int smr_index_get_info(const smr_index*, smr_index_info* out);
  * lambda and K are INPUTS and there is no default: the reference computes them per DB and scoring scheme (-match / -mismatch / -gap_open /
  * -gap_ext, background frequencies) with its vendored NCBI ALP library (refstats.cpp:194-233) and prints them in its log ("Gumbel lambda",
  * "Gumbel K").  A different pair gives a different minimal_score, i.e. a different set of reads passes -- take them from the reference
- * (the compiled drop-in, oracle/dropin/align_gpu.cpp, uses the reference's own Refstats object). */
+ * (the compiled drop-in of INTEGRATION.md uses the reference's own Refstats object). */
 uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq,
                            uint64_t all_reads_count, uint64_t all_reads_len, double evalue);
 
