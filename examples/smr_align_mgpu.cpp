@@ -157,8 +157,13 @@ int main(int argc, char** argv) {
         d.parts.push_back(pk);
       }
     } else {
+      // no index files: build the index, on the first rank's GPU (sorting / ids / positions / mini-tries as device kernels: seconds for a
+      // 140 Mnt DB, build_index of the reference takes minutes, indexdb.cpp:1119-2095); the host copy then serves every rank
+      smr_ctx* bctx = nullptr;
+      if (smr_create(S.devices[0], &bctx, err, sizeof err) != SMR_OK) die(err);
       smr_index* arr[256]; uint32_t np = 0;
-      if (smr_index_build(d.fasta.c_str(), 18, 3072.0, 10000, 0, arr, 256, &np, err, sizeof err) != SMR_OK) die(err);
+      if (smr_index_build_gpu(bctx, d.fasta.c_str(), 18, 3072.0, 10000, arr, 256, &np, err, sizeof err) != SMR_OK) die(err);
+      smr_destroy(bctx);
       d.parts.assign(arr, arr + np);
     }
   }
