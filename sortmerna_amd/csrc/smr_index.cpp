@@ -282,6 +282,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   if (!load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix)) {
     delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO;
   }
+  if (!smr_build_bitsliced(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the second device layout, once, here: smr_index_upload only reads
   *out = ix;
   return SMR_OK;
 }
@@ -823,6 +824,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
     smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
     const int rc = fn(user, in, *ix, why);
     if (rc != SMR_OK) { delete ix; set_err(err, errcap, why); return rc; }
+    if (!smr_build_bitsliced(*ix, threads, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }     // the second device layout, once, here: smr_index_upload only reads
     parts_out[pi] = ix;
   }
   *n_parts_out = (uint32_t)pr.size();
