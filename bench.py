@@ -176,38 +176,27 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- workload: DB + index (rank 0 builds, the others load its files) ----------------
+    # ---------------- workload: DB (rank 0 writes the FASTA) + index (every rank builds its replica on its own GPU) ----------------
     cache = os.path.join(tempfile.gettempdir(), "smr_bench_%d" % args.db_nt)
     os.makedirs(cache, exist_ok=True)
     db = os.path.join(cache, "synth_rrna_db_%d.fasta" % args.db_nt)
-    prefix = os.path.join(cache, "index")
     t0 = time.time()
     if rank == 0 and not os.path.isfile(db):
         synth.make_db(db + ".tmp", args.db_nt, seed=42)
         os.replace(db + ".tmp", db)
     log("DB ready (%.1fs)" % (time.time() - t0))
+    barrier()
     t0 = time.time()
     eng = smr.Engine(local)
-    index_built = "loaded from rank 0's files"
-    if rank == 0:
-        try:                                           # sorting / ids / positions / mini-tries on the device
-            parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)
-            index_built = "device (smr_index_build_gpu), %.1f s" % (time.time() - t0)
-        except smr.SmrError as e:
-            log("device index build failed (%s): host builder" % e)
-            parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
-            index_built = "host (smr_index_build), %.1f s" % (time.time() - t0)
-        if world > 1:
-            import glob
-            for old in glob.glob(prefix + ".*"):         # nothing of an earlier build may survive next to the new files
-                os.remove(old)
-            smr.Index.write_files(parts, db, prefix)
-    barrier()
-    if rank != 0:
-        # exactly the parts of THIS build: the number is in the .stats file rank 0 has just written (files of an earlier run in the cache are ignored)
-        parts = [smr.Index.load_files(prefix, 0, db)]
-        for k in range(1, int(parts[0].info().n_parts)):
-            parts.append(smr.Index.load_files(prefix, k, db))
+    # sorting / ids / positions / mini-tries as device kernels (seconds for 140 Mnt).  With several ranks every rank builds
+    # the same index from the same FASTA on its own GPU, concurrently: no index files, no N-fold host parsing of them
+    try:
+        parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)
+        index_built = "device (smr_index_build_gpu), %.1f s" % (time.time() - t0)
+    except smr.SmrError as e:
+        log("device index build failed (%s): host builder" % e)
+        parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+        index_built = "host (smr_index_build), %.1f s" % (time.time() - t0)
     info = parts[0].info()
     log("index ready: %d part(s), trie %.0f MB, positions %.0f MB, %d refs (%.1fs)" % (
         len(parts), sum(p.info().trie_words for p in parts) * 4 / 1e6, sum(p.info().n_pos for p in parts) * 8 / 1e6,
