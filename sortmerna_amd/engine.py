@@ -279,6 +279,12 @@ class Engine:
         self.n_reads = reads.count
         self._batch_n[self._cur] = reads.count
 
+    def upload_reads_batch(self, batch, reads, max_alignments_per_read=1):
+        """smr_reads_upload_batch: into batch `batch` without selecting it, on the context's upload stream (may run on a second host thread
+        while the selected batch is being aligned)"""
+        self._chk(self.L.smr_reads_upload_batch(self.h, batch, reads.h, max_alignments_per_read), "smr_reads_upload_batch")
+        self._batch_n[batch] = reads.count
+
     def reset_state(self):
         self._chk(self.L.smr_state_reset(self.h), "smr_state_reset")
 

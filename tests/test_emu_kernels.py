@@ -144,3 +144,45 @@ def test_traceback_kernels_equal_the_reference_banded_sw(emulator):
     assert n > 1700
     assert tracegold.check_variants(e) > 150
     e.close()
+
+
+def test_chunked_pipeline_equals_one_batch(emulator, wl):
+    """the host-side streaming pattern of INTEGRATION.md / examples/smr_align_mgpu.cpp: the reads in chunks (smr_reads_slice), chunk k+1 uploaded
+    by a second thread into its own batch (smr_reads_upload_batch, upload stream) while chunk k is aligned; per-chunk records and counters
+    add up to those of the whole batch"""
+    import threading
+    e = smr.Engine(0)
+    for s, ix in enumerate(wl.parts):
+        e.upload_index(ix, s)
+    p = smr.default_params(minimal_score=wl.minimal_score)
+    slots = list(range(len(wl.parts)))
+    e.select_batch(0)
+    e.upload_reads(wl.reads, 1)
+    smr.align_resident(e, slots, [p])
+    whole = e.records()
+    whole_ctr = e.counters(1)
+    n = wl.reads.count
+    cuts = [0, n // 3, n // 3 + 1, 2 * n // 3, n]                   # four chunks, one of them a single read
+    chunks = [wl.reads.slice(cuts[i], cuts[i + 1] - cuts[i]) for i in range(4)]
+    assert sum(c.count for c in chunks) == n and chunks[1].count == 1
+    e.select_batch(1)
+    e.upload_reads(chunks[0], 1)
+    got, aligned = [], 0
+    for k in range(4):
+        t = None
+        if k + 1 < 4:
+            t = threading.Thread(target=e.upload_reads_batch, args=(2 + k, chunks[k + 1], 1))
+            t.start()
+        e.select_batch(1 + k)
+        smr.align_resident(e, slots, [p])
+        e.n_reads = chunks[k].count
+        got += e.records()
+        aligned += e.counters(1)["num_aligned"]
+        if t:
+            t.join()
+    assert got == whole and aligned == whole_ctr["num_aligned"]
+    with pytest.raises(smr.SmrError):
+        e.upload_reads_batch(4, chunks[0], 1)                       # the selected batch must go through smr_reads_upload
+    for c in chunks:
+        c.free()
+    e.close()
