@@ -220,6 +220,7 @@ typedef struct {
   uint64_t n_windows, n_lookup, n_node, n_entry, n_hit, n_read_bytes;
   uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;     /* ssw_align calls of the sequential walk (forward / reverse passes) and their DP cells */
   uint64_t n_sw_spec, n_sw_spec_used;          /* forward passes scored ahead of the walk in four-problem batches, and how many of them the walk then asked for */
+  uint64_t n_seed_redo;                        /* waves (64 searches) of the fast seed kernel whose candidate pool overflowed and that the per-lane DFS kernel searched again */
 } smr_prof;
 /* smr_index_build with the per-occurrence work (sorting all (L+1)-mers, ids, position lists, mini-trie layout) done
  * on the device: same arguments (threads does not apply), same smr_index objects, byte-identical index files

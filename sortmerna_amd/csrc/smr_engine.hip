@@ -20,7 +20,7 @@ namespace {
 struct DevIndex {
   bool used = false;
   Lookup* lookup = nullptr; uint32_t* trie = nullptr; uint32_t* pos_off = nullptr; uint2* pos_arr = nullptr;
-  uint32_t* trie2 = nullptr; uint32_t* root2 = nullptr;
+  uint32_t* trie2 = nullptr; uint32_t* root2 = nullptr; uint32_t* pg = nullptr; uint32_t* root3 = nullptr;
   uint8_t* ref_seq = nullptr; uint64_t* ref_off = nullptr;
   uint32_t n_refs = 0, n_ids = 0, lnwin = 0;
   uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0;
@@ -47,6 +47,7 @@ struct Batch {
   std::vector<RState> h_state; std::vector<AlignRec> h_aln; std::vector<uint32_t> h_cigar;       // of the reads with alignments, packed
   std::vector<uint32_t> h_idx, h_map;                                                            // packed position -> read, read -> packed position (or ~0)
   uint32_t last_num_alignments = 1;
+  unsigned long long redo_seen = 0, win_seen = 0;        // C_SEED_REDO / C_WINDOWS at the end of the previous part (smr_align_part sizes k_seed_pg's candidate pool from the increments)
   bool fetched = false;
   // capacities of the device arrays above (grow-only: a re-upload into the same batch allocates nothing unless it is larger)
   size_t cap_words = 0, cap_reads = 0, cap_aln = 0;
@@ -63,7 +64,9 @@ struct smr_ctx {
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 4;                      // lane-local hit list capacity; doubles (and the part is redone) on overflow
-  int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_bfs (+ redo)
+  int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_pg (+ redo)
+  uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
+  int seed_bfs = 0;                       // SMR_SEED_BFS=1: k_seed_bfs instead of k_seed_pg (comparison runs)
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t* sb_scan_sums = nullptr; uint32_t* sb_scan_pre = nullptr;   // tile sums / prefixes of the bin-offset scan
@@ -143,7 +146,7 @@ int check_params(smr_ctx* c, const smr_params* p) {
 }
 
 DIndex dindex(const DevIndex& d) {
-  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.trie2 = d.trie2; x.root2 = d.root2; x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
+  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.trie2 = d.trie2; x.root2 = d.root2; x.pg = d.pg; x.root3 = reinterpret_cast<const uint2*>(d.root3); x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
   x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2;
   return x;
 }
@@ -230,7 +233,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.cap_tuples = (uint32_t)(2 * slots);
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_bfs = (size_t)BFS_LDS_WORDS(c->hcap) * 4;
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_bfs = (size_t)BFS_LDS_WORDS(c->hcap) * 4, lds_pg = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024), gs = (uint32_t)((2 * slots + 255) / 256);
   ev_begin(c, 0);
@@ -257,10 +260,12 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
       HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       if (dir == 0) {
-        hipLaunchKernelGGL(k_seed_bfs<0>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+        if (c->seed_bfs) hipLaunchKernelGGL(k_seed_bfs<0>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+        else hipLaunchKernelGGL(k_seed_pg<0>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       } else {
-        hipLaunchKernelGGL(k_seed_bfs<1>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+        if (c->seed_bfs) hipLaunchKernelGGL(k_seed_bfs<1>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
+        else hipLaunchKernelGGL(k_seed_pg<1>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       }
     }
@@ -694,6 +699,7 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
     delete c; return SMR_ERR_DEVICE;
   }
   if (const char* e = getenv("SMR_SEED_EXACT")) c->seed_exact = atoi(e) != 0;
+  if (const char* e = getenv("SMR_SEED_BFS")) c->seed_bfs = atoi(e) != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
@@ -752,8 +758,12 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
     // the bit-sliced second layout of the tries: a host transform cached in the smr_index, built once under its mutex (the loaders and
     // builders already do it; this call only covers indexes made before that) -- concurrent uploads of one host index are safe
     std::string why;
-    if (!smr_build_bitsliced(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
+    if (!smr_build_bitsliced(*const_cast<smr_index*>(ix), 0, why) || !smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
   }
+  if ((rc = dev_alloc(c, &d.pg, ix->pg.size()))) return rc;
+  if ((rc = dev_alloc(c, &d.root3, ix->root3.size()))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d.pg, ix->pg.data(), ix->pg.size() * 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d.root3, ix->root3.data(), ix->root3.size() * 4, hipMemcpyHostToDevice, c->stream));
   if ((rc = dev_alloc(c, &d.trie2, ix->trie2.size()))) return rc;
   if ((rc = dev_alloc(c, &d.root2, ix->root2.size()))) return rc;
   HIPCHK(c, hipMemcpyAsync(d.trie2, ix->trie2.data(), ix->trie2.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -778,7 +788,7 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
 extern "C" int smr_index_unload(smr_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
   DevIndex& d = c->idx[slot];
-  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.trie2); dev_free(&d.root2); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
+  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.trie2); dev_free(&d.root2); dev_free(&d.pg); dev_free(&d.root3); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
   d = DevIndex();
   return SMR_OK;
 }
@@ -937,6 +947,17 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       retry = true;
     }
     if (h[C_ERR_REDO]) { c->seed_exact = 1; retry = true; }     // too many overflowing waves for the redo list: use the DFS kernel throughout
+    {
+      // k_seed_pg's candidate pool: when more than 1/64 of this part's waves overflowed it (they were searched again by the DFS kernel:
+      // right, but slow), the next launches get twice the pool
+      if (h[C_SEED_REDO] < c->b->redo_seen || h[C_WINDOWS] < c->b->win_seen) c->b->redo_seen = c->b->win_seen = 0;       // counters were reset
+      const unsigned long long redo = h[C_SEED_REDO] - c->b->redo_seen, waves = (h[C_WINDOWS] - c->b->win_seen) / 32;   // forward + reverse search per window
+      c->b->redo_seen = h[C_SEED_REDO]; c->b->win_seen = h[C_WINDOWS];
+      if (!retry && !c->seed_bfs && redo * 64 > waves && c->ccap < PG_CAND_CAP_MAX) {
+        c->ccap *= 2;
+        if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: %llu of ~%llu seed-search waves overflowed their candidate pool: %u records per wave from now on\n", redo, waves, c->ccap);
+      }
+    }
     if (h[C_ERR_SCAP]) {
       // a read shares seeds with more references than the LDS table of its wave holds (384): from now on such reads build their set in a
       // per-block table in global memory; the candidate keys need room for as many members
@@ -1361,7 +1382,7 @@ extern "C" int smr_prof_reset(smr_ctx* c) {
   for (int k = 0; k < SMR_MAX_BATCHES; k++)
     if (c->bt[k].d_ctr) {
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
-      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SW_SPEC], 0, 2 * 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SW_SPEC], 0, 3 * 8, c->stream));
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SHARDS], 0, 16 * C_NSHARD * 8, c->stream));
     }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1379,7 +1400,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
       unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
       for (int s2 = 0; s2 < C_NSHARD; s2++) for (int q = 0; q < 7; q++) ph[q] += t[C_SHARDS + 16 * s2 + 9 + q];
       fprintf(stderr, "[smr] phase cycles (batch %d): %llu %llu %llu %llu %llu %llu %llu  (-DSMR_CHAIN_PHASES: claim, gather+prefix, walk1, walk2+cands, pairs+sort, "
-              "window/lis/book, sw; -DSMR_SEED_PHASES: setup, node walk, flatten, stage A, stage B, output, -)\n", k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+              "window/lis/book, sw; -DSMR_SEED_PHASES (k_seed_bfs): setup, node steps, bucket batches, queue compaction, candidate selection, output, steps + batches<<32)\n", k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
     }
     fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
@@ -1387,6 +1408,6 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
   o->seed_ms = c->seed_ms; o->seed_launches = c->seed_l; o->chain_ms = c->chain_ms; o->chain_launches = c->chain_l; o->trace_ms = c->trace_ms; o->trace_launches = c->trace_l;
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];
-  o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED];
+  o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED]; o->n_seed_redo = h[C_SEED_REDO];
   return SMR_OK;
 }

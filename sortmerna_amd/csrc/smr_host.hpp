@@ -43,6 +43,32 @@ static constexpr uint32_t BS_UNIT = 32;
 __host__ __device__ inline uint32_t bs_plane_words(uint32_t pw) { return (2 * (pw + 1) + 3) & ~3u; }
 __host__ __device__ inline uint32_t bs_unit_words(uint32_t pw) { return bs_plane_words(pw) + BS_UNIT; }
 
+// Third device layout, used by the pigeonhole seed search (k_seed_pg): per mini-trie a flat block of its complete candidate strings.
+// A string within LEV(1) of a pattern P either agrees with P on its first h = pw/2 chars, or -- the one edit being among those -- on
+// chars h..pw-1 with P[h..], P[h-1..] or P[h+1..] (smr_seed_pg.hpp), so only the entries under a handful of exact keys can match:
+//   dirA  4^cA + 1 offsets into EA: entries whose first cA chars (first char most significant) are < key
+//   dirB  4^cB + 1 offsets into EB: the same over chars h..h+cB-1
+//   EA    n x {string, DFS rank, id} sorted by string (first char most significant)
+//   EB    the same entries sorted by chars h..pw-1
+// "DFS rank" = the entry's position in the reference's traversal order of the mini-trie (A<C<G<T, bucket order), which is the order the
+// reference meets -- and de-duplicates -- the hits in.  cA = min(h, log4 n), cB = min(pw-h, log4 2n); a block with n <= PG_SCAN entries
+// has no directories and one array in DFS order (the search looks at every entry).  Blocks are 16-byte aligned;
+// root3[2k + d] = {block offset / 4 words, n | cA << 24 | cB << 28} for the forward / reverse mini-trie of key k.
+static constexpr uint32_t PG_SCAN = 4;
+__host__ __device__ inline void pg_chars(uint32_t n, uint32_t pw, uint32_t& cA, uint32_t& cB) {
+  cA = cB = 0;
+  if (n <= PG_SCAN) return;
+  const uint32_t h = pw / 2;
+  while (cA < h && (4u << (2 * cA)) <= n) cA++;                   // floor(log4 n)
+  while (cB < pw - h && (4u << (2 * cB)) <= 2 * n) cB++;          // floor(log4 2n)
+}
+// chars from..from+cnt-1 of a 2-bit packed string (char j at bits 2j) as a number, first char most significant
+__host__ __device__ inline uint32_t pg_key(uint32_t T, uint32_t from, uint32_t cnt) {
+  uint32_t k = 0;
+  for (uint32_t q = 0; q < cnt; q++) k = (k << 2) | ((T >> (2 * (from + q))) & 3u);
+  return k;
+}
+
 struct PartStats {
   uint64_t start_part = 0, seq_part_size = 0;
   uint32_t numseq_part = 0;
@@ -62,6 +88,9 @@ struct smr_index {
   uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
   std::vector<uint32_t> trie2;          // bit-sliced arena (built on demand by smr_build_bitsliced)
   std::vector<uint32_t> root2;          // 2 * 4^(L/2): root word offset in trie2 of the forward / reverse mini-trie of key k at [2k], [2k+1]
+  std::vector<uint32_t> pg;             // pigeonhole arena (smr_build_pigeonhole)
+  std::vector<uint32_t> root3;          // 2 * 2 * 4^(L/2) words: {block offset / 4, n | cA << 24 | cB << 28} of the forward / reverse mini-trie of key k at [2k], [2k+1]
+  std::mutex pg_mutex;
   std::mutex bs_mutex;                  // smr_build_bitsliced runs once, whichever thread / context asks first (several smr_ctx may upload the same host index)
   // whole-DB statistics (.stats)
   double bg[4] = {0.25, 0.25, 0.25, 0.25};
@@ -83,6 +112,8 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
 
 // builds trie2/root2 from trie/lookup (idempotent); false + message when a mini-trie does not fit the element encoding
 bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why);
+// builds pg/root3 from trie/lookup (idempotent)
+bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why);
 
 // Packed read batch.  Record i = ceil(len/16) words of 2-bit codes (nt k in bits 2*(k%16) of word k/16)
 // followed by ceil(len/32) words of ambiguity mask (bit k%32 of word k/32 set when the input letter

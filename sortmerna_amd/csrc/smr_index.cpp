@@ -282,7 +282,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   if (!load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix)) {
     delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO;
   }
-  if (!smr_build_bitsliced(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the second device layout, once, here: smr_index_upload only reads
+  if (!smr_build_bitsliced(*ix, 0, why) || !smr_build_pigeonhole(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the other device layouts, once, here: smr_index_upload only reads
   *out = ix;
   return SMR_OK;
 }
@@ -338,6 +338,45 @@ extern "C" int smr_index_selfcheck(smr_index* ix, char* err, size_t errcap) {
       bool same = a.size() == b.size();
       for (size_t i = 0; same && i < a.size(); i++) same = a[i].str == b[i].str && a[i].id == b[i].id;
       if (!same) { set_err(err, errcap, "bit-sliced layout: entries differ at key " + std::to_string(k)); return SMR_ERR_STATE; }
+    }
+  // pigeonhole layout: both arrays of a block hold exactly the reference's entries (rank r = the r-th entry of the DFS), sorted by
+  // their keys, and the directories bound the keys
+  if (!smr_build_pigeonhole(*ix, 0, why)) { set_err(err, errcap, why); return SMR_ERR_CAPACITY; }
+  const uint32_t h = pw / 2;
+  std::vector<uint8_t> seen;
+  for (size_t k = 0; k < ix->lookup.size(); k++)
+    for (int d = 0; d < 2; d++) {
+      const uint32_t r1 = d == 0 ? ix->lookup[k].rootF : ix->lookup[k].rootR, r3 = ix->root3[2 * (2 * k + d)], meta = ix->root3[2 * (2 * k + d) + 1];
+      const std::string at = " at key " + std::to_string(k);
+      if ((r1 == NONE) != (r3 == NONE)) { set_err(err, errcap, "pigeonhole layout: root presence differs" + at); return SMR_ERR_STATE; }
+      if (r1 == NONE) continue;
+      a.clear();
+      sc_walk_ref(ix->trie.data() + r1, 0, 0, 0, a);
+      const uint32_t n = meta & 0xFFFFFFu, cA = (meta >> 24) & 15u, cB = meta >> 28;
+      uint32_t wA, wB;
+      pg_chars(n, pw, wA, wB);
+      if (n != a.size() || cA != wA || cB != wB) { set_err(err, errcap, "pigeonhole layout: block header wrong" + at); return SMR_ERR_STATE; }
+      const uint32_t* blk = ix->pg.data() + (size_t)r3 * 4;
+      const uint32_t nA = cA ? (1u << (2 * cA)) + 1 : 0, nB = cA ? (1u << (2 * cB)) + 1 : 0;
+      for (int o = 0; o < (cA ? 2 : 1); o++) {
+        const uint32_t* E = blk + nA + nB + (o ? 3 * (size_t)n : 0);
+        const uint32_t* dir = o ? blk + nA : blk;
+        const uint32_t c = o ? cB : cA, from = o ? h : 0;
+        seen.assign(n, 0);
+        uint64_t prev = 0;
+        for (uint32_t i = 0; i < n; i++) {
+          const uint32_t T = E[3 * i], r = E[3 * i + 1];
+          if (r >= n || seen[r] || a[r].str != T || a[r].id != E[3 * i + 2]) { set_err(err, errcap, "pigeonhole layout: entries differ" + at); return SMR_ERR_STATE; }
+          seen[r] = 1;
+          if (!cA) { if (r != i) { set_err(err, errcap, "pigeonhole layout: scan block not in DFS order" + at); return SMR_ERR_STATE; } continue; }
+          const uint64_t key = o ? pg_key(T, h, pw - h) : pg_key(T, 0, pw + 1);
+          if (i && key < prev) { set_err(err, errcap, "pigeonhole layout: array not sorted" + at); return SMR_ERR_STATE; }
+          prev = key;
+          const uint32_t kk = pg_key(T, from, c);
+          if (!(dir[kk] <= i && i < dir[kk + 1])) { set_err(err, errcap, "pigeonhole layout: directory wrong" + at); return SMR_ERR_STATE; }
+        }
+        if (cA && (dir[0] != 0 || dir[(1u << (2 * c))] != n)) { set_err(err, errcap, "pigeonhole layout: directory ends wrong" + at); return SMR_ERR_STATE; }
+      }
     }
   return SMR_OK;
 }
@@ -579,6 +618,84 @@ bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why) {
     }
   });
   ix.root2.swap(root2);
+  return true;
+}
+
+// ---- pigeonhole arena (smr_host.hpp) -------------------------------------------------------------
+bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
+  std::lock_guard<std::mutex> once(ix.pg_mutex);
+  if (!ix.root3.empty()) return true;
+  const size_t nk = ix.lookup.size();
+  const uint32_t pw = ix.lnwin / 2, h = pw / 2;
+  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  threads = std::min<uint32_t>(threads, 64);
+  std::vector<std::vector<uint32_t>> local(threads);
+  std::vector<uint32_t> root3(4 * nk, 0);
+  for (size_t i = 0; i < 2 * nk; i++) root3[2 * i] = NONE;
+  std::vector<size_t> t_lo(threads, 0), t_hi(threads, 0);
+  bool ok = true;
+  parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
+    t_lo[tid] = lo; t_hi[tid] = hi;
+    std::vector<uint32_t>& out = local[tid];
+    std::vector<BsEnt> v;
+    std::vector<uint64_t> ord;
+    for (size_t k = lo; k < hi; k++) {
+      for (int d = 0; d < 2; d++) {
+        const uint32_t root = d == 0 ? ix.lookup[k].rootF : ix.lookup[k].rootR;
+        if (root == NONE) continue;
+        v.clear();
+        bs_collect(ix.trie.data() + root, 0, 0, 0, v);          // complete strings (char j at bits 2j) in DFS order
+        const uint32_t n = (uint32_t)v.size();
+        if (n > 0xFFFFFFu) { ok = false; return; }
+        uint32_t cA, cB;
+        pg_chars(n, pw, cA, cB);
+        const size_t base = out.size();
+        if (base / 4 > 0xFFFFFFF0ull) { ok = false; return; }
+        root3[2 * (2 * k + d)] = (uint32_t)(base / 4);         // thread-local for now
+        root3[2 * (2 * k + d) + 1] = n | (cA << 24) | (cB << 28);
+        if (cA == 0) {
+          for (uint32_t r = 0; r < n; r++) { out.push_back(v[r].tail); out.push_back(r); out.push_back(v[r].id); }
+        } else {
+          const uint32_t nA = (1u << (2 * cA)) + 1, nB = (1u << (2 * cB)) + 1;
+          out.resize(base + nA + nB + 6 * (size_t)n);
+          uint32_t* dirA = out.data() + base; uint32_t* dirB = dirA + nA; uint32_t* EA = dirB + nB; uint32_t* EB = EA + 3 * (size_t)n;
+          for (int o = 0; o < 2; o++) {
+            ord.resize(n);
+            for (uint32_t r = 0; r < n; r++) {
+              const uint64_t key = o == 0 ? pg_key(v[r].tail, 0, pw + 1) : (((uint64_t)pg_key(v[r].tail, h, pw - h) << 32) | r);
+              ord[r] = o == 0 ? ((key << 32) | r) : key;
+            }
+            std::sort(ord.begin(), ord.end());
+            uint32_t* E = o == 0 ? EA : EB; uint32_t* dir = o == 0 ? dirA : dirB;
+            const uint32_t c = o == 0 ? cA : cB, from = o == 0 ? 0 : h, nd = o == 0 ? nA : nB;
+            uint32_t next = 0;                                  // next directory slot to fill
+            for (uint32_t i = 0; i < n; i++) {
+              const uint32_t r = (uint32_t)(ord[i] & 0xFFFFFFFFull);
+              E[3 * i] = v[r].tail; E[3 * i + 1] = r; E[3 * i + 2] = v[r].id;
+              const uint32_t kk = pg_key(v[r].tail, from, c);
+              while (next <= kk) dir[next++] = i;
+            }
+            while (next < nd) dir[next++] = n;
+          }
+        }
+        while (out.size() & 3u) out.push_back(0);
+      }
+    }
+  });
+  if (!ok) { why = "a mini-trie is too large for the pigeonhole layout"; return false; }
+  size_t total = 0;
+  std::vector<size_t> tbase(threads, 0);
+  for (uint32_t t = 0; t < threads; t++) { tbase[t] = total; total += local[t].size(); }
+  if (total / 4 > 0xFFFFFFF0ull) { why = "pigeonhole arena exceeds 2^34 words"; return false; }
+  ix.pg.resize(total + 4);                                       // + one block of slack: a 16-byte read at the last word stays inside
+  parallel_for(threads, threads, [&](size_t lo, size_t hi, uint32_t) {
+    for (size_t t = lo; t < hi; t++) {
+      if (!local[t].empty()) memcpy(ix.pg.data() + tbase[t], local[t].data(), local[t].size() * 4);
+      for (size_t k = t_lo[t]; k < t_hi[t]; k++)
+        for (int d = 0; d < 2; d++) if (root3[2 * (2 * k + d)] != NONE) root3[2 * (2 * k + d)] += (uint32_t)(tbase[t] / 4);
+    }
+  });
+  ix.root3.swap(root3);
   return true;
 }
 
@@ -824,7 +941,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
     smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
     const int rc = fn(user, in, *ix, why);
     if (rc != SMR_OK) { delete ix; set_err(err, errcap, why); return rc; }
-    if (!smr_build_bitsliced(*ix, threads, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }     // the second device layout, once, here: smr_index_upload only reads
+    if (!smr_build_bitsliced(*ix, threads, why) || !smr_build_pigeonhole(*ix, threads, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }     // the other device layouts, once, here: smr_index_upload only reads
     parts_out[pi] = ix;
   }
   *n_parts_out = (uint32_t)pr.size();

@@ -41,6 +41,8 @@ struct DIndex {
   const uint32_t* trie;
   const uint32_t* trie2;       // bit-sliced arena (smr_host.hpp) and its roots: forward / reverse mini-trie of key k at [2k], [2k+1]
   const uint32_t* root2;
+  const uint32_t* pg;          // pigeonhole arena (smr_host.hpp) and its block table {offset / 4, n | cA << 24 | cB << 28}
+  const uint2* root3;
   const uint32_t* pos_off;
   const uint2* pos_arr;        // {pos, seq}
   const uint8_t* ref_seq;
@@ -106,7 +108,7 @@ enum {
   C_NUM_ALIGNED = 0, C_NUM_SHORT = 1, C_PER_DB = 2,           // C_PER_DB .. C_PER_DB+63
   C_WINDOWS = 66, C_LOOKUP, C_NODE, C_ENTRY, C_HIT, C_READ_BYTES, C_SW_FWD, C_SW_REV, C_SW_CELLS,
   C_ERR_HITCAP, C_ERR_POOL, C_ERR_SLOTS, C_ERR_PAIRS, C_ERR_CIGAR, C_ERR_TRACE, C_POOL_CURSOR, C_WORK_NEXT,
-  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_FETCH_N, C_SW_SPEC, C_SW_SPEC_USED, C_COUNT = 96,
+  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_FETCH_N, C_SW_SPEC, C_SW_SPEC_USED, C_SEED_REDO, C_COUNT = 96,
   // Work counters and the pool cursor are sharded 64 ways (by block id): one address would serialise ~10 ns per
   // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k at C_SHARDS + 16*s + k; the host folds them.
   C_NSHARD = 64, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + 16 * C_NSHARD, C_TOTAL = C_PCUR + C_NSHARD
@@ -225,5 +227,6 @@ __global__ void k_commit_part(uint32_t n, DParams P, RState* __restrict__ saved,
 
 #include "smr_seed.hpp"
 #include "smr_seed_bfs.hpp"
+#include "smr_seed_pg.hpp"
 #include "smr_chain.hpp"
 #include "smr_trace.hpp"

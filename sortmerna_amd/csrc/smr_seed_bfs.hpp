@@ -58,10 +58,11 @@ __device__ __forceinline__ void lev1_unit(const uint32_t* __restrict__ unit, uin
     if ((uint32_t)q < nq) v = *reinterpret_cast<const uint4*>(unit + 4 * q);
     pl[4 * q] = v.x; pl[4 * q + 1] = v.y; pl[4 * q + 2] = v.z; pl[4 * q + 3] = v.w;
   }
-  // entries whose char at string position j equals pattern char pj: (lo ^ mlo) & (hi ^ mhi), mlo = P's low bit ? 0 : ~0
+  // entries whose char at string position j equals pattern char pj: xnor(lo, b_lo) & xnor(hi, b_hi), b = that bit of P broadcast to a
+  // whole word by a 1-bit signed field extract (v_bfe_i32)
   auto eq = [&](int j, int pj) -> uint32_t {
-    const uint32_t mlo = ((P >> (2 * pj)) & 1u) - 1u, mhi = ((P >> (2 * pj + 1)) & 1u) - 1u;
-    return (pl[2 * j] ^ mlo) & (pl[2 * j + 1] ^ mhi);
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_sbfe((int)P, 2 * pj, 1), bhi = (uint32_t)__builtin_amdgcn_sbfe((int)P, 2 * pj + 1, 1);
+    return ~(pl[2 * j] ^ blo) & ~(pl[2 * j + 1] ^ bhi);
   };
   // front to back: Pr[k] = Pr_{k-1}
   uint32_t Pr[NP + 1];
@@ -113,6 +114,14 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
   const bool full = P.is_full_search != 0;
   const uint32_t* __restrict__ arena = ix.trie2;           // the bit-sliced arena
   const unsigned long long lt = (1ull << lane) - 1ull;
+#ifdef SMR_SEED_PHASES                                    // per-phase cycle accounting (build with -DSMR_SEED_PHASES, run with SMR_DEBUG_PHASES=1)
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define SPH(i) { const unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; }
+#define SCN(v) { tph[6] += (v); }
+#else
+#define SPH(i)
+#define SCN(v)
+#endif
 
   // ---- the wave's 64 searches ----
   const uint32_t pos = first + blockIdx.x * 64u + lane;
@@ -150,6 +159,7 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
     top = (uint32_t)__popcll(mm);
   }
   __syncthreads();
+  SPH(0)
 
   while ((top > 0 || bqn > 0) && !overflow) {
     if (top > 0 && bqn + 64 <= BFS_BQ_CAP) {
@@ -176,6 +186,7 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
         top = base + ncn; bqn += nbn;
       }
       __syncthreads();
+      SPH(1) SCN(1ull)
     } else {
       // ---------- bucket batch: up to 64 buckets, one lane per bucket (its <= 32-entry units bit-sliced) ----------
       const uint32_t nb = min(64u, bqn);
@@ -208,6 +219,7 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
         }
       }
       __syncthreads();
+      SPH(2) SCN(1ull << 32)
       if (s_ncand > BFS_CAND_CAP) overflow = true;
       // drop the processed buckets: move the rest (< 64) to the front
       const uint32_t rest = bqn - nb;
@@ -217,10 +229,12 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
       if ((uint32_t)lane < rest) { bq0[lane] = m0; bq1[lane] = m1; bq2[lane] = m2; }
       bqn = rest;
       __syncthreads();
+      SPH(3)
     }
   }
   if (overflow) {                                          // hand the wave to k_seed_search
     if (lane == 0) {
+      atomicAdd(&ctr[C_SEED_REDO], 1ull);
       const uint32_t p = atomicAdd(&sb.sn[SN_REDO], 1u);
       if (p < sb.cap_redo) sb.redo[p] = blockIdx.x; else atomicAdd(&ctr[C_ERR_REDO], 1ull);
     }
@@ -247,6 +261,7 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
       last = best + 1;
     }
   }
+  SPH(4)
   // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
   const bool wr = mine && (DIR == 0 ? nh > 0 : (zero || nh > n_prev));
   const uint32_t need = wr ? 2 + 2 * nh : 0;
@@ -270,6 +285,10 @@ __global__ void __launch_bounds__(64, 5) k_seed_bfs(DIndex ix, DParams P, int pa
   }
   if (__any(hl_over) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
   if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); }
+#ifdef SMR_SEED_PHASES
+  SPH(5)
+  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
+#endif
 }
 
 }  // namespace smr

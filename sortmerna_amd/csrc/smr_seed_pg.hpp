@@ -1,0 +1,208 @@
+// smr_seed_pg.hpp -- the pigeonhole seed search (included by smr_kernels.hpp after smr_seed_bfs.hpp).
+#pragma once
+
+namespace smr {
+
+// ------------------------------------------------------------------------------------------------
+// k_seed_pg<DIR>: the same searches as k_seed_search (one lane = one window's half-seed search), without walking the trie.
+//
+// lev1_entry (smr_seed.hpp) says which complete candidate strings T (pw+1 chars) a pattern P (pw chars) accepts: with a = the
+// common prefix of P and T,  a + s0 >= pw-1  or  a + s1 >= pw  or  a + s2 >= pw-1,  s0/s1/s2 = the lengths of the runs of
+// T[i]==P[i] / T[i+1]==P[i] ending at i = pw-1 / T[i]==P[i+1] ending at i = pw-2.  With h = pw/2 either
+//   A   a >= h:  T[0..h-1] == P[0..h-1]
+// or a <= h-1, and then the run of the accepting term covers every position >= h:
+//   S0  T[h..pw-1] == P[h..pw-1]        S1  T[h..pw-1] == P[h-1..pw-2]        S2  T[h..pw-2] == P[h+1..pw-1]
+// Each is an EXACT key, so the index is stored a third time (smr_host.hpp: per mini-trie the entries sorted by string with a
+// directory over the first cA <= h chars, and sorted by chars h.. with a directory over cB <= pw-h of them): a search reads four
+// directory ranges, applies lev1_entry to the few entries inside (about n/4^cA + 3 n/4^cB instead of all n of the mini-trie) and
+// collects the accepted ones.  The reference's sequential semantics (traverse_bursttrie.cpp:100-298: DFS order A<C<G<T, 0-error
+// match clears the list and ends the search, duplicate `break`) are restored as in k_seed_bfs: each search applies ITS candidates in
+// DFS order, the order key being the entry's rank in the reference's traversal stored with it.  An entry reachable through several of
+// the four keys is taken from the first only.  Results are identical to k_seed_search (tests compare both); the work counters
+// count the entries looked at and the directory ranges read.  The candidates of the 64 searches share a pool of `ccap` records in
+// LDS, each search chaining its own; a wave whose pool overflows hands its 64 tuples to k_seed_search through the redo list (and
+// the host doubles ccap for the next launches when that happens to more than a few waves).
+// ------------------------------------------------------------------------------------------------
+#define PG_CAND_CAP0 256u                                 // initial pool size
+#define PG_CAND_CAP_MAX 2048u
+#define PG_NIL 0xFFFFu
+// dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16)
+#define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap))
+
+// the chars of a 2-bit packed string (char j at bits 2j) with char j moved to bits 30-2j: any run of chars is then a number with its
+// first char most significant
+__device__ __forceinline__ uint32_t pg_reversed(uint32_t s) {
+  const uint32_t rv = __brev(s);
+  return ((rv & 0xAAAAAAAAu) >> 1) | ((rv & 0x55555555u) << 1);
+}
+// chars from..from+cnt-1 (cnt >= 1) of a string given as pg_reversed
+__device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_t cnt) { return (rev >> (32u - 2u * (from + cnt))) & ((1u << (2u * cnt)) - 1u); }
+
+template <int DIR>
+__global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
+                                                uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
+  // this phase's tuples: forward bins first, reverse bins after them
+  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
+  const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
+  if (blockIdx.x * 64u >= n_tup) return;
+  SMR_DYN_LDS(uint32_t, lds_dyn);
+  uint32_t* hl = lds_dyn;
+  uint32_t* cdk = hl + 64 * hcap;                          // rank in the reference's traversal order
+  uint32_t* cdv = cdk + ccap;                              // id
+  uint32_t* cdn = cdv + ccap;                              // next record of the same search | kind << 16
+  __shared__ uint32_t s_ncand;
+  const int lane = lane_id();
+  const uint32_t pw = P.partialwin, h = pw / 2;
+  const bool full = P.is_full_search != 0;
+#ifdef SMR_SEED_PHASES                                    // per-phase cycle accounting (build with -DSMR_SEED_PHASES, run with SMR_DEBUG_PHASES=1)
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define GPH(i) { const unsigned long long tn_ = clock64(); tph[i] += tn_ - tlast; tlast = tn_; }
+#else
+#define GPH(i)
+#endif
+
+  // ---- the wave's 64 searches ----
+  const uint32_t pos = first + blockIdx.x * 64u + lane;
+  bool mine = blockIdx.x * 64u + lane < n_tup;
+  uint32_t win_pos = 0, nh = 0, n_prev = 0, P9 = 0;
+  uint2 rt = make_uint2(NONE, 0);
+  size_t slot = 0;
+  bool hl_over = false;
+  if (mine) {
+    const unsigned long long pl = sb.tup[pos];
+    rt = ix.root3[2 * (sb.tkey[pos] - (DIR ? sb.nkh : 0u)) + DIR];
+    const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
+    win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
+    P9 = (uint32_t)(pl >> 40);
+    slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
+    if (DIR == 1) {                                      // the window's list so far = the forward search's hits
+      const uint32_t seg = sb.wseg[slot];
+      if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+      else if (seg != NONE) {
+        n_prev = pool[seg + 1];
+        for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
+        if (n_prev > hcap) { hl_over = true; n_prev = hcap; }
+        nh = n_prev;
+      }
+    }
+  }
+  if (lane == 0) s_ncand = 0;
+  __syncthreads();
+  GPH(0)
+
+  // ---- the four directory ranges of the search: [0] in EA, [1..3] (S0, S1, S2) in EB ----
+  uint32_t rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0;
+  uint32_t kA = 0, kb0 = 0, kb1 = 0, cA = 0, cB = 0, n = 0;
+  const uint32_t* ents = nullptr;
+  if (mine && rt.x != NONE) {
+    n = rt.y & 0xFFFFFFu; cA = (rt.y >> 24) & 15u; cB = rt.y >> 28;
+    const uint32_t* blk = ix.pg + (size_t)rt.x * 4;
+    if (cA == 0) { rn0 = n; ents = blk; }
+    else {
+      const uint32_t nA = (1u << (2 * cA)) + 1u, nB = (1u << (2 * cB)) + 1u;
+      const uint32_t* dirA = blk; const uint32_t* dirB = blk + nA;
+      ents = dirB + nB;
+      const uint32_t rev = pg_reversed(P9);
+      kA = pg_rkey(rev, 0, cA); kb0 = pg_rkey(rev, h, cB); kb1 = pg_rkey(rev, h - 1, cB);
+      uint32_t lo2, hi2;
+      if (cB == pw - h) { const uint32_t k2 = pg_rkey(rev, h + 1, cB - 1); lo2 = 4 * k2; hi2 = lo2 + 4; }      // T[pw-1] is free under S2
+      else { lo2 = pg_rkey(rev, h + 1, cB); hi2 = lo2 + 1; }
+      const uint32_t a0 = dirA[kA], a1 = dirA[kA + 1], b0 = dirB[kb0], b1 = dirB[kb0 + 1], c0 = dirB[kb1], c1 = dirB[kb1 + 1], d0 = dirB[lo2], d1 = dirB[hi2];
+      rs0 = a0; rn0 = a1 - a0;
+      rs1 = b0; rn1 = b1 - b0;
+      if (kb1 != kb0) { rs2 = c0; rn2 = c1 - c0; }
+      rs3 = d0; rn3 = d1 - d0;
+    }
+  }
+  const uint32_t tot = rn0 + rn1 + rn2 + rn3;
+  unsigned long long w_node = 0, w_entry = 0;            // wave totals (uniform)
+  {
+    uint32_t wsum = tot, nsum = (mine && rt.x != NONE) ? (cA ? 4u : 1u) : 0u;
+    for (int d = 32; d > 0; d >>= 1) { wsum += __shfl_xor(wsum, d, 64); nsum += __shfl_xor(nsum, d, 64); }
+    w_entry = wsum; w_node = nsum;
+  }
+  GPH(1)
+  // ---- every lane walks its ranges; accepted entries go to the wave's candidate pool, chained per search ----
+  uint32_t head = PG_NIL;
+  for (uint32_t i = 0; __any(i < tot); i++) {
+    if (i < tot) {
+      uint32_t j = i, w = 0, st = rs0;
+      if (j >= rn0) { j -= rn0; w = 1; st = rs1;
+        if (j >= rn1) { j -= rn1; w = 2; st = rs2;
+          if (j >= rn2) { j -= rn2; w = 3; st = rs3; } } }
+      const uint32_t* e = ents + (w ? 3 * (size_t)n : 0) + 3 * (size_t)(st + j);
+      const uint32_t T = e[0], rk = e[1], id = e[2];
+      bool dup = false;                                    // reachable through an earlier key of this search?
+      if (w) {
+        const uint32_t rv = pg_reversed(T);
+        dup = pg_rkey(rv, 0, cA) == kA;
+        if (w == 3) { const uint32_t kt = pg_rkey(rv, h, cB); dup = dup || kt == kb0 || kt == kb1; }
+      }
+      const uint32_t r = dup ? 0u : lev1_entry(P9, T, pw);
+      if (r & 1u) {
+        const uint32_t p = atomicAdd(&s_ncand, 1u);
+        if (p < ccap) { cdk[p] = rk; cdv[p] = id; cdn[p] = head | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16); head = p; }
+      }
+    }
+  }
+  __syncthreads();
+  GPH(2)
+  if (s_ncand > ccap) {                             // hand the wave to k_seed_search
+    if (lane == 0) {
+      atomicAdd(&ctr[C_SEED_REDO], 1ull);
+      const uint32_t p = atomicAdd(&sb.sn[SN_REDO], 1u);
+      if (p < sb.cap_redo) sb.redo[p] = blockIdx.x; else atomicAdd(&ctr[C_ERR_REDO], 1ull);
+    }
+    return;
+  }
+  // ---------- every search applies its candidates in DFS order (selection by increasing rank) ----------
+  bool zero = false;
+  {
+    uint32_t last = 0;                                     // ranks already applied are < last
+    bool more = head != PG_NIL;
+    while (__any(more)) {
+      uint32_t best = 0xFFFFFFFFu, bi = 0;
+      if (more) for (uint32_t q = head; q != PG_NIL; q = cdn[q] & 0xFFFFu) {
+        const uint32_t k = cdk[q];
+        if (k >= last && k < best) { best = k; bi = q; }
+      }
+      if (!more || best == 0xFFFFFFFFu) { more = false; continue; }
+      const uint32_t idc = cdv[bi], kc = cdn[bi] >> 16;
+      bool present = false;
+      for (uint32_t f = 0; f < nh; f++) if (hl[f * 64 + lane] == idc) { present = true; break; }
+      if (kc == CK_COND && !present) { hl[lane] = idc; nh = 1; zero = true; more = false; }
+      else if (!present) { if (nh < hcap) { hl[nh * 64 + lane] = idc; nh++; } else hl_over = true; }
+      last = best + 1;
+    }
+  }
+  GPH(4)
+  // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
+  const bool wr = mine && (DIR == 0 ? nh > 0 : (zero || nh > n_prev));
+  const uint32_t need = wr ? 2 + 2 * nh : 0;
+  uint32_t incl = need;
+  for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+  const uint32_t total = __shfl(incl, 63, 64);
+  uint32_t base = 0;
+  if (total) {
+    if (lane == 0) {
+      const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
+      const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], (unsigned long long)total);
+      if (old + total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = shard * region + (uint32_t)old;
+    }
+    base = __shfl(base, 0, 64);
+  }
+  if (wr && base != NONE) {
+    const uint32_t o = base + incl - need;
+    pool[o] = NONE; pool[o + 1] = nh;
+    for (uint32_t q = 0; q < nh; q++) { pool[o + 2 + 2 * q] = hl[q * 64 + lane]; pool[o + 3 + 2 * q] = win_pos; }
+    sb.wseg[slot] = o | (zero ? SEED_ZERO_BIT : 0u);
+  }
+  if (__any(hl_over) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
+  if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); }
+#ifdef SMR_SEED_PHASES
+  GPH(5)
+  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
+#endif
+}
+
+}  // namespace smr

@@ -145,7 +145,7 @@ def test_mixed_read_lengths(engine, tmp_path):
     assert min(lens) < 200 and max(lens) > 300
 
 
-@pytest.mark.parametrize("lnwin", [12, 14, 16])
+@pytest.mark.parametrize("lnwin", [10, 12, 14, 16])
 def test_other_seed_lengths(engine, tmp_path, lnwin):
     """-L 12/14/16: other window lengths (partialwin 6/7/8), their trie depth limits and automaton tail tables"""
     w = Workload(str(tmp_path), db_nt=120_000, n_reads=1200, seed=50 + lnwin, frac_db=0.5, lnwin=lnwin)

@@ -18,7 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-SEED_SOURCES = ["smr_seed.hpp", "smr_seed_bfs.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
+SEED_SOURCES = ["smr_seed.hpp", "smr_seed_bfs.hpp", "smr_seed_pg.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
 
 
 def kernel_src_sha():
