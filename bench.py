@@ -16,7 +16,7 @@ collectives are the two tiny all-reduces the reference's semantics need: global 
 minimal_score, refstats.cpp:247-265) and the Readstats counters after (RCCL).
 
 The JSON line also carries
-  roofline      seed stage (k_seed_keys/scan/scatter/bfs/finish = "k_seed"): algorithmic bytes (SURVEY.md 8d formula, from exact
+  roofline      seed stage (k_seed_keys/scan/scatter/pg/finish = "k_seed"): algorithmic bytes (SURVEY.md 8d formula, from exact
                 device work counters of an untimed counting pass over the same batches) / HIP-event time of its launches in the
                 timed steps, against the 8 TB/s HBM3E peak
   kernels       HIP-event time and launch count of each kernel family in the timed region
@@ -251,7 +251,7 @@ def main():
     timed = [i % nb for i in range(args.warmup, n_total)]        # the resident batch of every timed step
     uses = [timed.count(b) for b in range(nb)]
     # Algorithmic bytes of the timed steps: a workload property, counted once per distinct batch by the per-lane DFS seed kernel whose
-    # work counters follow the reference's sequential scan exactly (untimed; the timed steps use the work-queue kernel, same results).
+    # work counters follow the reference's sequential scan exactly (untimed; the timed steps use the pigeonhole kernel, same results).
     eng.set_seed_mode(1)
     exact = [0] * 6
     exact_aligned = None if args.profile_run else 0

@@ -88,8 +88,9 @@ int smr_index_build(const char* ref_fasta, uint32_t seed_win_len, double max_fil
 /* Write one part in the REFERENCE's on-disk format (so the reference binary can consume our index). */
 int smr_index_write_files(const smr_index* const* parts, uint32_t n_parts, const char* ref_fasta, const char* prefix,
                           char* err, size_t errcap);
-/* Consistency check of the two device layouts of the mini-tries (reference-shaped arena for k_seed_search, bit-sliced arena for
- * k_seed_bfs): both must list the same (candidate string, id) entries in the same DFS order.  0 = ok. */
+/* Consistency check of the two device layouts of the mini-tries (reference-shaped arena for k_seed_search, pigeonhole arena for
+ * k_seed_pg): the second must hold the same (candidate string, id) entries with their ranks in the DFS order of the first, sorted by its
+ * two keys, under consistent directories.  0 = ok. */
 int smr_index_selfcheck(smr_index*, char* err, size_t errcap);
 void smr_index_free(smr_index*);
 
@@ -169,7 +170,7 @@ int smr_index_unload(smr_ctx*, int slot);
  * state, its Readstats counter block and its CIGAR pool; the caller sums the counters of its batches. */
 int smr_batch_select(smr_ctx*, int batch);
 
-/* Seed-search kernel selection.  0 (default): the work-queue kernel k_seed_bfs.  1: the per-lane DFS kernel k_seed_search for
+/* Seed-search kernel selection.  0 (default): the pigeonhole kernel k_seed_pg.  1: the per-lane DFS kernel k_seed_search for
  * every window; slower, but its work counters (smr_prof_get: n_node, n_entry) follow the reference's sequential scan exactly
  * (nothing after a 0-error match is counted) -- used to obtain the algorithmic byte counts of a workload.  Results are identical. */
 int smr_set_seed_mode(smr_ctx*, int exact_counters);

@@ -20,7 +20,7 @@ namespace {
 struct DevIndex {
   bool used = false;
   Lookup* lookup = nullptr; uint32_t* trie = nullptr; uint32_t* pos_off = nullptr; uint2* pos_arr = nullptr;
-  uint32_t* trie2 = nullptr; uint32_t* root2 = nullptr; uint32_t* pg = nullptr; uint32_t* root3 = nullptr;
+  uint32_t* pg = nullptr; uint32_t* root3 = nullptr;
   uint8_t* ref_seq = nullptr; uint64_t* ref_off = nullptr;
   uint32_t n_refs = 0, n_ids = 0, lnwin = 0;
   uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0;
@@ -64,9 +64,8 @@ struct smr_ctx {
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 4;                      // lane-local hit list capacity; doubles (and the part is redone) on overflow
-  int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_pg (+ redo)
+  int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_pg (+ redo of the waves whose pool overflowed)
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
-  int seed_bfs = 0;                       // SMR_SEED_BFS=1: k_seed_bfs instead of k_seed_pg (comparison runs)
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t* sb_scan_sums = nullptr; uint32_t* sb_scan_pre = nullptr;   // tile sums / prefixes of the bin-offset scan
@@ -146,7 +145,7 @@ int check_params(smr_ctx* c, const smr_params* p) {
 }
 
 DIndex dindex(const DevIndex& d) {
-  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.trie2 = d.trie2; x.root2 = d.root2; x.pg = d.pg; x.root3 = reinterpret_cast<const uint2*>(d.root3); x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
+  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.pg = d.pg; x.root3 = reinterpret_cast<const uint2*>(d.root3); x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
   x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2;
   return x;
 }
@@ -233,7 +232,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.cap_tuples = (uint32_t)(2 * slots);
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_bfs = (size_t)BFS_LDS_WORDS(c->hcap) * 4, lds_pg = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024), gs = (uint32_t)((2 * slots + 255) / 256);
   ev_begin(c, 0);
@@ -256,16 +255,14 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
       else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
     } else {
-      // work-queue search; the (rare) waves whose LDS queues overflowed are searched again by the DFS kernel
+      // pigeonhole search; the (rare) waves whose candidate pool overflowed are searched again by the DFS kernel
       const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
       HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       if (dir == 0) {
-        if (c->seed_bfs) hipLaunchKernelGGL(k_seed_bfs<0>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
-        else hipLaunchKernelGGL(k_seed_pg<0>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       } else {
-        if (c->seed_bfs) hipLaunchKernelGGL(k_seed_bfs<1>, dim3(gw), dim3(64), lds_bfs, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr);
-        else hipLaunchKernelGGL(k_seed_pg<1>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       }
     }
@@ -699,7 +696,6 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
     delete c; return SMR_ERR_DEVICE;
   }
   if (const char* e = getenv("SMR_SEED_EXACT")) c->seed_exact = atoi(e) != 0;
-  if (const char* e = getenv("SMR_SEED_BFS")) c->seed_bfs = atoi(e) != 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }
@@ -755,19 +751,16 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   d.lnwin = ix->lnwin; d.n_refs = ix->n_refs(); d.n_ids = ix->n_ids(); d.trie_words = ix->trie.size(); d.n_pos = ix->pos_arr.size() / 2; d.ref_bytes = ix->ref_seq.size();
   int rc;
   {
-    // the bit-sliced second layout of the tries: a host transform cached in the smr_index, built once under its mutex (the loaders and
+    // the pigeonhole layout of the tries: a host transform cached in the smr_index, built once under its mutex (the loaders and
     // builders already do it; this call only covers indexes made before that) -- concurrent uploads of one host index are safe
     std::string why;
-    if (!smr_build_bitsliced(*const_cast<smr_index*>(ix), 0, why) || !smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
+    if (!smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
   }
+  if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: index part: tries %.2f GB, pigeonhole arena %.2f GB, positions %.2f GB\n", ix->trie.size() * 4e-9, ix->pg.size() * 4e-9, ix->pos_arr.size() * 4e-9);
   if ((rc = dev_alloc(c, &d.pg, ix->pg.size()))) return rc;
   if ((rc = dev_alloc(c, &d.root3, ix->root3.size()))) return rc;
   HIPCHK(c, hipMemcpyAsync(d.pg, ix->pg.data(), ix->pg.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.root3, ix->root3.data(), ix->root3.size() * 4, hipMemcpyHostToDevice, c->stream));
-  if ((rc = dev_alloc(c, &d.trie2, ix->trie2.size()))) return rc;
-  if ((rc = dev_alloc(c, &d.root2, ix->root2.size()))) return rc;
-  HIPCHK(c, hipMemcpyAsync(d.trie2, ix->trie2.data(), ix->trie2.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d.root2, ix->root2.data(), ix->root2.size() * 4, hipMemcpyHostToDevice, c->stream));
   if ((rc = dev_alloc(c, &d.lookup, ix->lookup.size()))) return rc;
   if ((rc = dev_alloc(c, &d.trie, ix->trie.size()))) return rc;
   if ((rc = dev_alloc(c, &d.pos_off, ix->pos_off.size()))) return rc;
@@ -788,7 +781,7 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
 extern "C" int smr_index_unload(smr_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
   DevIndex& d = c->idx[slot];
-  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.trie2); dev_free(&d.root2); dev_free(&d.pg); dev_free(&d.root3); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
+  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.pg); dev_free(&d.root3); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
   d = DevIndex();
   return SMR_OK;
 }
@@ -953,7 +946,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       if (h[C_SEED_REDO] < c->b->redo_seen || h[C_WINDOWS] < c->b->win_seen) c->b->redo_seen = c->b->win_seen = 0;       // counters were reset
       const unsigned long long redo = h[C_SEED_REDO] - c->b->redo_seen, waves = (h[C_WINDOWS] - c->b->win_seen) / 32;   // forward + reverse search per window
       c->b->redo_seen = h[C_SEED_REDO]; c->b->win_seen = h[C_WINDOWS];
-      if (!retry && !c->seed_bfs && redo * 64 > waves && c->ccap < PG_CAND_CAP_MAX) {
+      if (!retry && redo * 64 > waves && c->ccap < PG_CAND_CAP_MAX) {
         c->ccap *= 2;
         if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: %llu of ~%llu seed-search waves overflowed their candidate pool: %u records per wave from now on\n", redo, waves, c->ccap);
       }
@@ -1400,7 +1393,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
       unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
       for (int s2 = 0; s2 < C_NSHARD; s2++) for (int q = 0; q < 7; q++) ph[q] += t[C_SHARDS + 16 * s2 + 9 + q];
       fprintf(stderr, "[smr] phase cycles (batch %d): %llu %llu %llu %llu %llu %llu %llu  (-DSMR_CHAIN_PHASES: claim, gather+prefix, walk1, walk2+cands, pairs+sort, "
-              "window/lis/book, sw; -DSMR_SEED_PHASES (k_seed_bfs): setup, node steps, bucket batches, queue compaction, candidate selection, output, steps + batches<<32)\n", k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
+              "window/lis/book, sw; -DSMR_SEED_PHASES (k_seed_pg): setup, directory ranges, entries, -, candidate selection, output, -)\n", k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
     }
     fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];

@@ -33,17 +33,8 @@ static constexpr uint32_t ELEM_NENT_SHIFT = 22;
 static constexpr uint32_t ELEM_OFF_MASK = (1u << 22) - 1;
 static constexpr uint32_t ELEM_NENT_MAX = 255;
 
-// Second device layout of the mini-tries, used by the work-queue seed search (k_seed_bfs): subtrees with at most
-// BS_UNIT entries are collapsed into ONE bucket (entries in DFS order, tails extended by the collapsed path), and a
-// bucket is stored BIT-SLICED in units of 32 entries: for every position j = 0..pw of the complete candidate string (trie
-// path + tail; the path positions hold the same char for all entries) a pair of words {lo_j, hi_j} whose bit e is the low /
-// high bit of character j of entry e, padded to a multiple of 4 words, then the 32 ids.  All units have the same size, and
-// one lane evaluates the LEV(1) closed form for 32 entries at once with plain bitwise logic.  Nodes keep the 4-word format.
-static constexpr uint32_t BS_UNIT = 32;
-__host__ __device__ inline uint32_t bs_plane_words(uint32_t pw) { return (2 * (pw + 1) + 3) & ~3u; }
-__host__ __device__ inline uint32_t bs_unit_words(uint32_t pw) { return bs_plane_words(pw) + BS_UNIT; }
-
-// Third device layout, used by the pigeonhole seed search (k_seed_pg): per mini-trie a flat block of its complete candidate strings.
+// Second device layout of the mini-tries, used by the pigeonhole seed search (k_seed_pg): per mini-trie a flat block of its complete
+// candidate strings (trie path + bucket tail, pw+1 chars, char j at bits 2j).
 // A string within LEV(1) of a pattern P either agrees with P on its first h = pw/2 chars, or -- the one edit being among those -- on
 // chars h..pw-1 with P[h..], P[h-1..] or P[h+1..] (smr_seed_pg.hpp), so only the entries under a handful of exact keys can match:
 //   dirA  4^cA + 1 offsets into EA: entries whose first cA chars (first char most significant) are < key
@@ -86,12 +77,9 @@ struct smr_index {
   std::vector<uint8_t> ref_seq;         // 0..4 per nt (References::convert_fix, references.cpp:162-169)
   std::vector<uint64_t> ref_off;        // n_refs + 1
   uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
-  std::vector<uint32_t> trie2;          // bit-sliced arena (built on demand by smr_build_bitsliced)
-  std::vector<uint32_t> root2;          // 2 * 4^(L/2): root word offset in trie2 of the forward / reverse mini-trie of key k at [2k], [2k+1]
   std::vector<uint32_t> pg;             // pigeonhole arena (smr_build_pigeonhole)
   std::vector<uint32_t> root3;          // 2 * 2 * 4^(L/2) words: {block offset / 4, n | cA << 24 | cB << 28} of the forward / reverse mini-trie of key k at [2k], [2k+1]
-  std::mutex pg_mutex;
-  std::mutex bs_mutex;                  // smr_build_bitsliced runs once, whichever thread / context asks first (several smr_ctx may upload the same host index)
+  std::mutex pg_mutex;                  // smr_build_pigeonhole runs once, whichever thread / context asks first (several smr_ctx may upload the same host index)
   // whole-DB statistics (.stats)
   double bg[4] = {0.25, 0.25, 0.25, 0.25};
   uint64_t full_len = 0, numseq = 0, filesize = 0;
@@ -110,9 +98,7 @@ typedef int (*smr_ibuild_part_fn)(void* user, const smr::IBuildInput& in, smr_in
 int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads, smr_ibuild_part_fn fn, void* user,
                          smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap);
 
-// builds trie2/root2 from trie/lookup (idempotent); false + message when a mini-trie does not fit the element encoding
-bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why);
-// builds pg/root3 from trie/lookup (idempotent)
+// builds pg/root3 from trie/lookup (idempotent); false + message when the part is too large for the block table
 bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why);
 
 // Packed read batch.  Record i = ceil(len/16) words of 2-bit codes (nt k in bits 2*(k%16) of word k/16)

@@ -282,67 +282,36 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   if (!load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix)) {
     delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO;
   }
-  if (!smr_build_bitsliced(*ix, 0, why) || !smr_build_pigeonhole(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the other device layouts, once, here: smr_index_upload only reads
+  if (!smr_build_pigeonhole(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the second device layout, once, here: smr_index_upload only reads
   *out = ix;
   return SMR_OK;
 }
 
-// ---- self check of the bit-sliced layout ---------------------------------------------------------
 namespace {
-struct FullEnt { uint32_t str, id; };                       // the complete pw+1-char candidate string, 2 bits per char
-void sc_walk_ref(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t path, std::vector<FullEnt>& out) {
+struct PgEnt { uint32_t str, id; };
+// entries below `node` in the reference's DFS order (A<C<G<T, bucket order) as complete strings; `pre` = the plen chars of the path to `node`
+void pg_collect(const uint32_t* t, uint32_t node, uint32_t pre, uint32_t plen, std::vector<PgEnt>& out) {
   for (uint32_t ne = 0; ne < 4; ne++) {
     const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
-    const uint32_t p2 = path | (ne << (2 * depth));
+    const uint32_t p2 = pre | (ne << (2 * plen));
     if (fl == 2) {
       const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
       const uint32_t* b = t + (e & ELEM_OFF_MASK);
-      for (uint32_t q = 0; q < n; q++) out.push_back({p2 | (b[2 * q] << (2 * (depth + 1))), b[2 * q + 1]});
-    } else if (fl == 1) sc_walk_ref(t, e & ELEM_OFF_MASK, depth + 1, p2, out);
+      for (uint32_t q = 0; q < n; q++) out.push_back({p2 | (b[2 * q] << (2 * (plen + 1))), b[2 * q + 1]});
+    } else if (fl == 1) pg_collect(t, e & ELEM_OFF_MASK, p2, plen + 1, out);
   }
-}
-bool sc_walk_bs(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t path, uint32_t pw, std::vector<FullEnt>& out) {
-  for (uint32_t ne = 0; ne < 4; ne++) {
-    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
-    const uint32_t p2 = path | (ne << (2 * depth));
-    if (fl == 2) {
-      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
-      for (uint32_t q = 0; q < n; q++) {
-        const uint32_t* unit = t + (e & ELEM_OFF_MASK) + (q / BS_UNIT) * bs_unit_words(pw);
-        uint32_t str = 0;
-        for (uint32_t j = 0; j <= pw; j++) str |= ((((unit[2 * j] >> (q % BS_UNIT)) & 1u)) | (((unit[2 * j + 1] >> (q % BS_UNIT)) & 1u) << 1)) << (2 * j);
-        if ((str & ((1u << (2 * (depth + 1))) - 1u)) != p2) return false;       // the path positions must hold the path's chars
-        out.push_back({str, unit[bs_plane_words(pw) + q % BS_UNIT]});
-      }
-    } else if (fl == 1) { if (!sc_walk_bs(t, e & ELEM_OFF_MASK, depth + 1, p2, pw, out)) return false; }
-  }
-  return true;
 }
 }  // namespace
 
-// The two device layouts of the mini-tries must list the same (candidate string, id) entries in the same DFS order.
+// ---- self check of the pigeonhole layout ----------------------------------------------------------
+// Both arrays of a block must hold exactly the reference-shaped mini-trie's entries (rank r = the r-th entry of its DFS), sorted by their
+// keys, and the directories must bound the keys.
 extern "C" int smr_index_selfcheck(smr_index* ix, char* err, size_t errcap) {
   if (!ix) return SMR_ERR_ARG;
   std::string why;
-  if (!smr_build_bitsliced(*ix, 0, why)) { set_err(err, errcap, why); return SMR_ERR_CAPACITY; }
-  const uint32_t pw = ix->lnwin / 2;
-  std::vector<FullEnt> a, b;
-  for (size_t k = 0; k < ix->lookup.size(); k++)
-    for (int d = 0; d < 2; d++) {
-      const uint32_t r1 = d == 0 ? ix->lookup[k].rootF : ix->lookup[k].rootR, r2 = ix->root2[2 * k + d];
-      if ((r1 == NONE) != (r2 == NONE)) { set_err(err, errcap, "bit-sliced layout: root presence differs at key " + std::to_string(k)); return SMR_ERR_STATE; }
-      if (r1 == NONE) continue;
-      a.clear(); b.clear();
-      sc_walk_ref(ix->trie.data() + r1, 0, 0, 0, a);
-      if (!sc_walk_bs(ix->trie2.data() + r2, 0, 0, 0, pw, b)) { set_err(err, errcap, "bit-sliced layout: path planes wrong at key " + std::to_string(k)); return SMR_ERR_STATE; }
-      bool same = a.size() == b.size();
-      for (size_t i = 0; same && i < a.size(); i++) same = a[i].str == b[i].str && a[i].id == b[i].id;
-      if (!same) { set_err(err, errcap, "bit-sliced layout: entries differ at key " + std::to_string(k)); return SMR_ERR_STATE; }
-    }
-  // pigeonhole layout: both arrays of a block hold exactly the reference's entries (rank r = the r-th entry of the DFS), sorted by
-  // their keys, and the directories bound the keys
   if (!smr_build_pigeonhole(*ix, 0, why)) { set_err(err, errcap, why); return SMR_ERR_CAPACITY; }
-  const uint32_t h = pw / 2;
+  const uint32_t pw = ix->lnwin / 2, h = pw / 2;
+  std::vector<PgEnt> a;
   std::vector<uint8_t> seen;
   for (size_t k = 0; k < ix->lookup.size(); k++)
     for (int d = 0; d < 2; d++) {
@@ -351,7 +320,7 @@ extern "C" int smr_index_selfcheck(smr_index* ix, char* err, size_t errcap) {
       if ((r1 == NONE) != (r3 == NONE)) { set_err(err, errcap, "pigeonhole layout: root presence differs" + at); return SMR_ERR_STATE; }
       if (r1 == NONE) continue;
       a.clear();
-      sc_walk_ref(ix->trie.data() + r1, 0, 0, 0, a);
+      pg_collect(ix->trie.data() + r1, 0, 0, 0, a);
       const uint32_t n = meta & 0xFFFFFFu, cA = (meta >> 24) & 15u, cB = meta >> 28;
       uint32_t wA, wB;
       pg_chars(n, pw, wA, wB);
@@ -493,135 +462,8 @@ void bucket_sort_u64(std::vector<uint64_t>& a, int keybits, uint32_t threads) {
 
 }  // namespace
 
-// ---- bit-sliced arena (smr_host.hpp) -----------------------------------------------------------
-namespace {
-struct BsEnt { uint32_t tail, id; };
-
-uint32_t bs_count(const uint32_t* t, uint32_t node) {
-  uint32_t n = 0;
-  for (int ne = 0; ne < 4; ne++) {
-    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
-    if (fl == 2) n += (e >> ELEM_NENT_SHIFT) & 0xFFu;
-    else if (fl == 1) n += bs_count(t, e & ELEM_OFF_MASK);
-  }
-  return n;
-}
-// entries below `node` (whose elements sit at level `lvl`) in DFS order; `pre` = chars of the levels between the
-// collapse root and `node`, `plen` their number
-void bs_collect(const uint32_t* t, uint32_t node, uint32_t pre, uint32_t plen, std::vector<BsEnt>& out) {
-  for (uint32_t ne = 0; ne < 4; ne++) {
-    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
-    const uint32_t p2 = pre | (ne << (2 * plen));
-    if (fl == 2) {
-      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
-      const uint32_t* b = t + (e & ELEM_OFF_MASK);
-      for (uint32_t q = 0; q < n; q++) out.push_back({p2 | (b[2 * q] << (2 * (plen + 1))), b[2 * q + 1]});
-    } else if (fl == 1) bs_collect(t, e & ELEM_OFF_MASK, p2, plen + 1, out);
-  }
-}
-// path = the nc chars of the trie path of the bucket's element (levels 0..nc-1), v[].tail = the remaining pw+1-nc chars
-uint32_t bs_emit_bucket(const BsEnt* v, uint32_t n, uint32_t path, uint32_t nc, uint32_t pw, std::vector<uint32_t>& out) {
-  const uint32_t off = (uint32_t)out.size();
-  for (uint32_t u = 0; u < n; u += BS_UNIT) {
-    const uint32_t c = std::min(BS_UNIT, n - u);
-    const size_t base = out.size();
-    out.resize(base + bs_unit_words(pw), 0);
-    for (uint32_t j = 0; j <= pw; j++) {
-      uint32_t lo = 0, hi = 0;
-      if (j < nc) { const uint32_t ch = (path >> (2 * j)) & 3u; lo = 0u - (ch & 1u); hi = 0u - (ch >> 1); }
-      else for (uint32_t e = 0; e < c; e++) { const uint32_t ch = (v[u + e].tail >> (2 * (j - nc))) & 3u; lo |= (ch & 1u) << e; hi |= (ch >> 1) << e; }
-      out[base + 2 * j] = lo; out[base + 2 * j + 1] = hi;
-    }
-    for (uint32_t e = 0; e < c; e++) out[base + bs_plane_words(pw) + e] = v[u + e].id;
-  }
-  return off;
-}
-uint32_t g_bs_collapse = 255;           // subtrees with at most this many entries become one bucket (max of the 8-bit count; knob SMR_BS_COLLAPSE):
-                                        // 16 -> 27.6 %, 32 -> 40.9 %, 64 -> 43.4 %, 128 -> 54.2 %, 255 -> 55.4 % of the HBM roofline on the bench workload
-
-bool bs_emit_node(const uint32_t* t, uint32_t node, uint32_t depth, uint32_t path, uint32_t pw, uint32_t out_off, std::vector<uint32_t>& out,
-                  std::vector<BsEnt>& tmp) {
-  for (uint32_t ne = 0; ne < 4; ne++) {
-    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
-    const uint32_t epath = path | (ne << (2 * depth));        // chars of levels 0..depth
-    uint32_t w = 0;
-    if (fl == 2) {
-      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
-      tmp.clear();
-      const uint32_t* b = t + (e & ELEM_OFF_MASK);
-      for (uint32_t q = 0; q < n; q++) tmp.push_back({b[2 * q], b[2 * q + 1]});
-      const uint32_t off = bs_emit_bucket(tmp.data(), n, epath, depth + 1, pw, out);
-      w = (2u << ELEM_FLAG_SHIFT) | (n << ELEM_NENT_SHIFT) | off;
-      if (off > ELEM_OFF_MASK) return false;
-    } else if (fl == 1) {
-      const uint32_t child = e & ELEM_OFF_MASK;
-      const uint32_t cnt = bs_count(t, child);
-      if (cnt <= g_bs_collapse) {                            // collapse the subtree into one bucket of this element
-        tmp.clear();
-        bs_collect(t, child, 0, 0, tmp);
-        const uint32_t off = bs_emit_bucket(tmp.data(), cnt, epath, depth + 1, pw, out);
-        w = (2u << ELEM_FLAG_SHIFT) | (cnt << ELEM_NENT_SHIFT) | off;
-        if (off > ELEM_OFF_MASK) return false;
-      } else {
-        const uint32_t off = (uint32_t)out.size();
-        if (off > ELEM_OFF_MASK) return false;
-        out.resize(out.size() + 4, 0);
-        w = (1u << ELEM_FLAG_SHIFT) | off;
-        if (!bs_emit_node(t, child, depth + 1, epath, pw, off, out, tmp)) return false;
-      }
-    }
-    out[out_off + ne] = w;
-  }
-  return true;
-}
-}  // namespace
-
-bool smr_build_bitsliced(smr_index& ix, uint32_t threads, std::string& why) {
-  std::lock_guard<std::mutex> once(ix.bs_mutex);
-  if (!ix.root2.empty()) return true;
-  if (const char* e = getenv("SMR_BS_COLLAPSE")) g_bs_collapse = std::min(255u, std::max(1u, (uint32_t)atoi(e)));
-  const size_t nk = ix.lookup.size();
-  const uint32_t pw = ix.lnwin / 2;
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
-  threads = std::min<uint32_t>(threads, 64);
-  std::vector<std::vector<uint32_t>> local(threads);
-  std::vector<uint32_t> root2(2 * nk, NONE);
-  std::vector<size_t> t_lo(threads, 0), t_hi(threads, 0);
-  bool ok = true;
-  parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
-    t_lo[tid] = lo; t_hi[tid] = hi;
-    std::vector<uint32_t>& out = local[tid];
-    std::vector<BsEnt> tmp;
-    for (size_t k = lo; k < hi; k++) {
-      for (int d = 0; d < 2; d++) {
-        const uint32_t root = d == 0 ? ix.lookup[k].rootF : ix.lookup[k].rootR;
-        if (root == NONE) continue;
-        const size_t base = out.size();
-        std::vector<uint32_t> one(4, 0);
-        if (!bs_emit_node(ix.trie.data() + root, 0, 0, 0, pw, 0, one, tmp)) { ok = false; return; }
-        out.insert(out.end(), one.begin(), one.end());
-        root2[2 * k + d] = (uint32_t)base;                   // thread-local for now
-      }
-    }
-  });
-  if (!ok) { why = "a bit-sliced mini-trie exceeds 2^22 words"; return false; }
-  size_t total = 0;
-  std::vector<size_t> tbase(threads, 0);
-  for (uint32_t t = 0; t < threads; t++) { tbase[t] = total; total += local[t].size(); }
-  if (total > 0xFFFFFFF0ull) { why = "bit-sliced trie arena exceeds 2^32 words"; return false; }
-  ix.trie2.resize(total);
-  parallel_for(threads, threads, [&](size_t lo, size_t hi, uint32_t) {
-    for (size_t t = lo; t < hi; t++) {
-      if (!local[t].empty()) memcpy(ix.trie2.data() + tbase[t], local[t].data(), local[t].size() * 4);
-      for (size_t k = t_lo[t]; k < t_hi[t]; k++)
-        for (int d = 0; d < 2; d++) if (root2[2 * k + d] != NONE) root2[2 * k + d] += (uint32_t)tbase[t];
-    }
-  });
-  ix.root2.swap(root2);
-  return true;
-}
-
 // ---- pigeonhole arena (smr_host.hpp) -------------------------------------------------------------
+
 bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
   std::lock_guard<std::mutex> once(ix.pg_mutex);
   if (!ix.root3.empty()) return true;
@@ -637,14 +479,14 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
   parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
     t_lo[tid] = lo; t_hi[tid] = hi;
     std::vector<uint32_t>& out = local[tid];
-    std::vector<BsEnt> v;
+    std::vector<PgEnt> v;
     std::vector<uint64_t> ord;
     for (size_t k = lo; k < hi; k++) {
       for (int d = 0; d < 2; d++) {
         const uint32_t root = d == 0 ? ix.lookup[k].rootF : ix.lookup[k].rootR;
         if (root == NONE) continue;
         v.clear();
-        bs_collect(ix.trie.data() + root, 0, 0, 0, v);          // complete strings (char j at bits 2j) in DFS order
+        pg_collect(ix.trie.data() + root, 0, 0, 0, v);          // complete strings (char j at bits 2j) in DFS order
         const uint32_t n = (uint32_t)v.size();
         if (n > 0xFFFFFFu) { ok = false; return; }
         uint32_t cA, cB;
@@ -654,7 +496,7 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
         root3[2 * (2 * k + d)] = (uint32_t)(base / 4);         // thread-local for now
         root3[2 * (2 * k + d) + 1] = n | (cA << 24) | (cB << 28);
         if (cA == 0) {
-          for (uint32_t r = 0; r < n; r++) { out.push_back(v[r].tail); out.push_back(r); out.push_back(v[r].id); }
+          for (uint32_t r = 0; r < n; r++) { out.push_back(v[r].str); out.push_back(r); out.push_back(v[r].id); }
         } else {
           const uint32_t nA = (1u << (2 * cA)) + 1, nB = (1u << (2 * cB)) + 1;
           out.resize(base + nA + nB + 6 * (size_t)n);
@@ -662,7 +504,7 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
           for (int o = 0; o < 2; o++) {
             ord.resize(n);
             for (uint32_t r = 0; r < n; r++) {
-              const uint64_t key = o == 0 ? pg_key(v[r].tail, 0, pw + 1) : (((uint64_t)pg_key(v[r].tail, h, pw - h) << 32) | r);
+              const uint64_t key = o == 0 ? pg_key(v[r].str, 0, pw + 1) : (((uint64_t)pg_key(v[r].str, h, pw - h) << 32) | r);
               ord[r] = o == 0 ? ((key << 32) | r) : key;
             }
             std::sort(ord.begin(), ord.end());
@@ -671,8 +513,8 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
             uint32_t next = 0;                                  // next directory slot to fill
             for (uint32_t i = 0; i < n; i++) {
               const uint32_t r = (uint32_t)(ord[i] & 0xFFFFFFFFull);
-              E[3 * i] = v[r].tail; E[3 * i + 1] = r; E[3 * i + 2] = v[r].id;
-              const uint32_t kk = pg_key(v[r].tail, from, c);
+              E[3 * i] = v[r].str; E[3 * i + 1] = r; E[3 * i + 2] = v[r].id;
+              const uint32_t kk = pg_key(v[r].str, from, c);
               while (next <= kk) dir[next++] = i;
             }
             while (next < nd) dir[next++] = n;
@@ -941,7 +783,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
     smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
     const int rc = fn(user, in, *ix, why);
     if (rc != SMR_OK) { delete ix; set_err(err, errcap, why); return rc; }
-    if (!smr_build_bitsliced(*ix, threads, why) || !smr_build_pigeonhole(*ix, threads, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }     // the other device layouts, once, here: smr_index_upload only reads
+    if (!smr_build_pigeonhole(*ix, threads, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }     // the second device layout, once, here: smr_index_upload only reads
     parts_out[pi] = ix;
   }
   *n_parts_out = (uint32_t)pr.size();

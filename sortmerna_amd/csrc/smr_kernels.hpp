@@ -12,8 +12,8 @@
 //
 // Design notes (DESIGN.md has the long form):
 //  * integer work, VALU-issue / latency bound: no MFMA anywhere.
-//  * seed stage: the windows of the whole batch are binned by 9-mer key (counting sort) and searched in key order, 64 searches per
-//    wave taken apart into node / bucket work items (k_seed_bfs); lane-local hit lists in LDS.
+//  * seed stage: the windows of the whole batch are binned by 9-mer key (counting sort) and searched in key order, one lane per
+//    search over the exact-key directories of the pigeonhole layout (k_seed_pg); lane-local hit lists in LDS.
 //  * k_cand: 16 lanes per read, four reads per wave.  k_chain: one wave per marked read, persistent blocks pulling chunks of 16 reads
 //    from an atomic counter (per-read work varies by orders of magnitude); the data-parallel pieces (position-list walks, bitonic
 //    sorts, LIS as patience piles across lanes, the SW systolic arrays) use all 64 lanes, control flow is wave-uniform.
@@ -39,9 +39,7 @@ namespace smr {
 struct DIndex {
   const Lookup* lookup;
   const uint32_t* trie;
-  const uint32_t* trie2;       // bit-sliced arena (smr_host.hpp) and its roots: forward / reverse mini-trie of key k at [2k], [2k+1]
-  const uint32_t* root2;
-  const uint32_t* pg;          // pigeonhole arena (smr_host.hpp) and its block table {offset / 4, n | cA << 24 | cB << 28}
+  const uint32_t* pg;          // pigeonhole arena (smr_host.hpp) and its block table: forward / reverse mini-trie of key k at [2k], [2k+1] = {offset / 4, n | cA << 24 | cB << 28}
   const uint2* root3;
   const uint32_t* pos_off;
   const uint2* pos_arr;        // {pos, seq}
@@ -226,7 +224,6 @@ __global__ void k_commit_part(uint32_t n, DParams P, RState* __restrict__ saved,
 }  // namespace smr
 
 #include "smr_seed.hpp"
-#include "smr_seed_bfs.hpp"
 #include "smr_seed_pg.hpp"
 #include "smr_chain.hpp"
 #include "smr_trace.hpp"

@@ -109,7 +109,7 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 //   k_seed_keys         window -> forward and reverse (key, rank in bin, payload)  [9-mer hash, lookup probes, flip34 view]
 //   k_scan_tile/add     exclusive scan of the bin counts (tiled; smr_ibuild.hpp)
 //   k_seed_scatter      tuples to bin order
-//   k_seed_bfs<DIR>     the searches, work-queue formulation (smr_seed_bfs.hpp) -- the default
+//   k_seed_pg<DIR>      the searches over the pigeonhole layout (smr_seed_pg.hpp) -- the default
 //   k_seed_search<DIR>  the searches, per-lane DFS formulation (below): overflow redo + exact work counters
 //   k_seed_finish       per read: gather the windows' hits into one block, hit_seeds / hit_total (paralleltraversal.cpp:242-249)
 //
@@ -148,7 +148,7 @@ struct SeedBufs {
   uint32_t* tkey;            // keys in key order
   uint32_t* wseg;            // [maxwin][n] (window-major: k_seed_finish's threads = reads read it coalesced) pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
   uint32_t* sn;              // SN_* counters
-  uint32_t* redo;            // waves of k_seed_bfs to be searched again by k_seed_search
+  uint32_t* redo;            // waves of k_seed_pg to be searched again by k_seed_search
   uint32_t nk, nkh, maxwin, cap_tuples, cap_redo;     // nk = 2 * nkh bins: forward keys [0, nkh), reverse keys [nkh, 2 nkh)
   uint32_t n;                // reads in the batch
 };
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
   const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
   uint32_t wave = blockIdx.x;
-  if (redo) {                                            // only the waves listed by k_seed_bfs (its LDS queues overflowed)
+  if (redo) {                                            // only the waves listed by k_seed_pg (its candidate pool overflowed)
     if (blockIdx.x >= min(sb.sn[SN_REDO], sb.cap_redo)) return;
     wave = redo[blockIdx.x];
   }

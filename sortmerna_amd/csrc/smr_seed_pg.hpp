@@ -1,4 +1,4 @@
-// smr_seed_pg.hpp -- the pigeonhole seed search (included by smr_kernels.hpp after smr_seed_bfs.hpp).
+// smr_seed_pg.hpp -- the pigeonhole seed search (included by smr_kernels.hpp after smr_seed.hpp).
 #pragma once
 
 namespace smr {
@@ -16,7 +16,7 @@ namespace smr {
 // directory over the first cA <= h chars, and sorted by chars h.. with a directory over cB <= pw-h of them): a search reads four
 // directory ranges, applies lev1_entry to the few entries inside (about n/4^cA + 3 n/4^cB instead of all n of the mini-trie) and
 // collects the accepted ones.  The reference's sequential semantics (traverse_bursttrie.cpp:100-298: DFS order A<C<G<T, 0-error
-// match clears the list and ends the search, duplicate `break`) are restored as in k_seed_bfs: each search applies ITS candidates in
+// match clears the list and ends the search, duplicate `break`) are restored afterwards: each search applies ITS candidates in
 // DFS order, the order key being the entry's rank in the reference's traversal stored with it.  An entry reachable through several of
 // the four keys is taken from the first only.  Results are identical to k_seed_search (tests compare both); the work counters
 // count the entries looked at and the directory ranges read.  The candidates of the 64 searches share a pool of `ccap` records in

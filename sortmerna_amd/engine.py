@@ -83,7 +83,7 @@ class Index:
             raise SmrError("smr_index_write_files: %s (rc=%d)" % (err.value.decode(), rc))
 
     def selfcheck(self):
-        """the bit-sliced device layout lists the same entries in the same DFS order as the reference-shaped one"""
+        """the pigeonhole device layout holds the same entries, with their DFS ranks, as the reference-shaped one"""
         err = C.create_string_buffer(512)
         rc = capi.load().smr_index_selfcheck(self.h, err, 512)
         if rc != 0:
@@ -233,7 +233,7 @@ class Engine:
         self._cur = batch
 
     def set_seed_mode(self, exact_counters):
-        """0: work-queue seed search (default); 1: per-lane DFS kernel with reference-exact work counters (same results)"""
+        """0: pigeonhole seed search (default); 1: per-lane DFS kernel with reference-exact work counters (same results)"""
         self._chk(self.L.smr_set_seed_mode(self.h, int(bool(exact_counters))), "smr_set_seed_mode")
 
     def sw_mode(self, set_to=-1):

@@ -4,7 +4,7 @@ tests/emu, must produce the oracle's / the reference's records too.  Same test b
 it catches logic errors and wave-divergent shuffles before GPU time is spent -- and not a substitute for the GPU tests:
 timing, occupancy, LDS limits and memory-ordering effects of the real machine are not modelled.
 
-By default a subset runs (work-queue seed kernel everywhere, the DFS kernel on the golden cases; ~2 min);
+By default a subset runs (pigeonhole seed kernel everywhere, the DFS kernel on the golden cases; ~2 min);
 SMR_EMU_FULL=1 runs every GPU test body with both seed kernels (~13 min on 8 cores)."""
 import os
 
@@ -36,7 +36,7 @@ def emulator():
         yield lib
 
 
-@pytest.fixture(scope="module", params=[0, 1] if FULL else [0], ids=["bfs", "dfs"] if FULL else ["bfs"])
+@pytest.fixture(scope="module", params=[0, 1] if FULL else [0], ids=["pg", "dfs"] if FULL else ["pg"])
 def engine(request, emulator):
     e = smr.Engine(0)
     e.set_seed_mode(request.param)
@@ -44,7 +44,7 @@ def engine(request, emulator):
     e.close()
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["bfs", "dfs"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["pg", "dfs"])
 def engine_both(request, emulator):
     e = smr.Engine(0)
     e.set_seed_mode(request.param)

@@ -45,7 +45,7 @@ def digests(records, chunk):
     return tot.hexdigest(), chunks
 
 
-@pytest.mark.parametrize("seed_mode", [0, 1], ids=["bfs", "dfs"])
+@pytest.mark.parametrize("seed_mode", [0, 1], ids=["pg", "dfs"])
 @pytest.mark.parametrize("run", ["default", "num_alignments_0"])
 def test_config2_fullsize_records_equal_the_reference(setup, run, seed_mode):
     g, e, parts, reads = setup

@@ -11,7 +11,7 @@ from helpers.cases import CASES, gpu_run
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["bfs", "dfs"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["pg", "dfs"])
 def engine(request):
     e = smr.Engine(0)      # raises without a GPU / without the HIP library: no CPU fallback
     e.set_seed_mode(request.param)

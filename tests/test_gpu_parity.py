@@ -12,9 +12,9 @@ from helpers.workload import Workload, iseq_for_strand
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["bfs", "dfs"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["pg", "dfs"])
 def engine(request):
-    """every test runs with both seed-search kernels: the work-queue kernel (default) and the per-lane DFS kernel"""
+    """every test runs with both seed-search kernels: the pigeonhole kernel (default) and the per-lane DFS kernel"""
     e = smr.Engine(0)      # raises without a GPU / without the HIP library: no CPU fallback
     e.set_seed_mode(request.param)
     yield e

@@ -158,9 +158,10 @@ def test_builder_part_split_matches_reference():
     assert i0.n_parts == 4 and i0.lnwin == 18 and i0.n_kmers == 4 ** 9
 
 
-@pytest.mark.parametrize("L", [12, 18])
-def test_bitsliced_layout_lists_the_same_entries_in_dfs_order(L):
-    """the second device layout (collapsed subtrees, 32-entry bit-plane units) vs the reference-shaped arena, every mini-trie"""
+@pytest.mark.parametrize("L", [10, 12, 18])
+def test_pigeonhole_layout_holds_the_same_entries_with_their_dfs_ranks(L):
+    """the second device layout (per mini-trie: entries sorted by string and by their second half, exact-key directories, DFS ranks)
+    vs the reference-shaped arena, every mini-trie; L = 10 and 12 give blocks with full directories, L = 18 mostly scan blocks"""
     db, _, _ = golden.inputs("syn_default")
     for ix in smr.Index.build(db, L, 3072.0, 10000, 0):
         ix.selfcheck()
@@ -193,7 +194,7 @@ def test_reference_index_files_round_trip_byte_exact(tmp_path):
     assert res.rc == 0, res.stdout[-800:]
     pfx = refrun.index_prefix_for(idx, db)
     ix = smr.Index.load_files(pfx, 0, db)
-    ix.selfcheck()                                  # the bit-sliced device layout built from the reference's own tries
+    ix.selfcheck()                                  # the pigeonhole device layout built from the reference's own tries
     out = str(tmp_path / "mine")
     smr.Index.write_files([ix], db, out)
     for ext in (".kmer_0.dat", ".bursttrie_0.dat", ".pos_0.dat", ".stats"):

@@ -132,72 +132,68 @@ def test_closed_form_equals_table_automaton(pw):
     assert n_acc > 20000
 
 
-def bitsliced_accept(P, Ts, pw):
-    """smr_seed_bfs.hpp::lev1_unit on Python ints: the closed form for up to 32 candidate strings at once, one bit per string.
-    Position j of string e is given by bit e of tlo[j] / thi[j].  -> (accept mask, 0-error mask)"""
-    n = len(Ts)
-    full = (1 << n) - 1
-    tlo = [sum((((T >> (2 * j)) & 1) << e) for e, T in enumerate(Ts)) for j in range(pw + 1)]
-    thi = [sum((((T >> (2 * j + 1)) & 1) << e) for e, T in enumerate(Ts)) for j in range(pw + 1)]
-
-    def eq(j, pj):                                   # strings whose char j equals char pj of P
-        c = (P >> (2 * pj)) & 3
-        lo = tlo[j] if c & 1 else ~tlo[j]
-        hi = thi[j] if c & 2 else ~thi[j]
-        return lo & hi & full
-
-    E0 = [eq(j, j) for j in range(pw)]
-    E1 = [None] + [eq(j, j - 1) for j in range(1, pw + 1)]
-    E2 = [eq(j, j + 1) for j in range(pw - 1)]
-    S0 = [full] * (pw + 2)
-    for j in range(pw - 1, -1, -1):
-        S0[j] = S0[j + 1] & E0[j]
-    S1 = [full] * (pw + 3)
-    for j in range(pw, 0, -1):
-        S1[j] = S1[j + 1] & E1[j]
-    S2 = [full] * (pw + 1)
-    for j in range(pw - 2, -1, -1):
-        S2[j] = S2[j + 1] & E2[j]
-    acc, pr = 0, full                                # pr = Pr_{k-1}
-    for k in range(pw + 1):
-        if k <= pw - 1:
-            acc |= pr & S0[k + 1]
-            acc |= pr & S2[k]
-        acc |= pr & S1[k + 1]
-        if k < pw:
-            pr &= E0[k]
-    return acc, pr                                   # pr is now Pr_{pw-1}: all pw chars equal
+def pg_key(T, frm, cnt):
+    """smr_host.hpp::pg_key: chars frm..frm+cnt-1 of a packed string as a number, first char most significant"""
+    k = 0
+    for q in range(cnt):
+        k = (k << 2) | ((T >> (2 * (frm + q))) & 3)
+    return k
 
 
-@pytest.mark.parametrize("pw", [4, 6, 7, 8, 9, 10])
-def test_bitsliced_unit_equals_closed_form(pw):
+def pigeonhole_reaches(P, T, pw, cA, cB):
+    """smr_seed_pg.hpp: is candidate string T inside one of the four directory ranges k_seed_pg reads for pattern P, with directories
+    over the first cA <= pw/2 chars (array EA) and over chars h..h+cB-1, cB <= pw-h (array EB)?"""
+    h = pw // 2
+    if pg_key(T, 0, cA) == pg_key(P, 0, cA):                       # A
+        return True
+    kt = pg_key(T, h, cB)
+    if kt == pg_key(P, h, cB) or kt == pg_key(P, h - 1, cB):       # S0, S1
+        return True
+    if cB == pw - h:                                               # S2: T[pw-1] is free
+        return (kt >> 2) == pg_key(P, h + 1, cB - 1)
+    return kt == pg_key(P, h + 1, cB)
+
+
+@pytest.mark.parametrize("pw", [4, 5, 6, 7, 8, 9, 10])
+def test_every_accepted_string_lies_under_one_of_the_four_exact_keys(pw):
+    """the completeness of the pigeonhole search: whatever lev1_entry accepts is found through key A, S0, S1 or S2, for every
+    directory width the index builder may choose (smr_host.hpp::pg_chars)"""
     rng = np.random.default_rng(300 + pw)
+    h = pw // 2
+    widths = [(cA, cB) for cA in range(1, h + 1) for cB in range(1, pw - h + 1)]
     n_acc = 0
-    for _ in range(1500):
+    for _ in range(6000 if pw < 9 else 3000):
         P = int(rng.integers(0, 4 ** pw))
         pl = [(P >> (2 * i)) & 3 for i in range(pw)]
-        Ts = []
-        for e in range(int(rng.integers(1, 33))):
-            t = pl[:]
-            kind = int(rng.integers(0, 7))
-            if kind == 1:
-                j = int(rng.integers(0, pw)); t[j] = (t[j] + int(rng.integers(1, 4))) & 3
-            elif kind == 2:
-                t.insert(int(rng.integers(0, pw + 1)), int(rng.integers(0, 4)))
-            elif kind == 3:
-                del t[int(rng.integers(0, pw))]
-            elif kind == 4:
-                j = int(rng.integers(0, pw)); t[j] = (t[j] + 1) & 3
-                j = int(rng.integers(0, pw)); t[j] = (t[j] + 2) & 3
-            elif kind >= 5:
-                t = [int(x) for x in rng.integers(0, 4, size=pw + 1)]
-            while len(t) < pw + 1:
-                t.append(int(rng.integers(0, 4)))
-            Ts.append(sum(c << (2 * i) for i, c in enumerate(t[:pw + 1])))
-        acc, zero = bitsliced_accept(P, Ts, pw)
-        for e, T in enumerate(Ts):
-            a, _, z = closed_form(P, T, pw)
-            assert bool((acc >> e) & 1) == a, (pw, P, T)
-            assert bool((zero >> e) & 1) == z, (pw, P, T)
-            n_acc += a
-    assert n_acc > 5000
+        t = pl[:]
+        kind = int(rng.integers(0, 6))
+        if kind == 1:
+            j = int(rng.integers(0, pw)); t[j] = (t[j] + int(rng.integers(1, 4))) & 3
+        elif kind == 2:
+            t.insert(int(rng.integers(0, pw + 1)), int(rng.integers(0, 4)))
+        elif kind == 3:
+            del t[int(rng.integers(0, pw))]
+        elif kind == 4:
+            j = int(rng.integers(0, pw)); t[j] = (t[j] + 1) & 3
+            j = int(rng.integers(0, pw)); t[j] = (t[j] + 2) & 3
+        elif kind == 5:
+            t = [int(x) for x in rng.integers(0, 4, size=pw + 1)]
+        while len(t) < pw + 1:
+            t.append(int(rng.integers(0, 4)))
+        T = sum(c << (2 * i) for i, c in enumerate(t[:pw + 1]))
+        acc, _, _ = closed_form(P, T, pw)
+        if acc:
+            n_acc += 1
+            for cA, cB in widths:
+                assert pigeonhole_reaches(P, T, pw, cA, cB), (pw, P, T, cA, cB)
+    assert n_acc > 1500
+
+
+def test_the_four_keys_are_exhaustive_on_a_small_alphabet_of_lengths():
+    """pw = 4 and 5 exhaustively: every (P, T) pair"""
+    for pw in (4, 5):
+        h = pw // 2
+        for P in range(4 ** pw):
+            for T in range(4 ** (pw + 1)):
+                if closed_form(P, T, pw)[0]:
+                    assert pigeonhole_reaches(P, T, pw, h, pw - h) and pigeonhole_reaches(P, T, pw, 1, 1), (pw, P, T)

@@ -47,7 +47,7 @@ say("index: ids %d, positions %d, trie words %d" % (info.n_ids, info.n_pos, info
 t = time.time()
 for s, ix in enumerate(parts):
     eng.upload_index(ix, s)
-say("index upload (incl. bit-sliced layout on the host): %.1f s" % (time.time() - t))
+say("index upload: %.1f s" % (time.time() - t))
 t = time.time(); codes, offs = synth.load_db_codes(db); say("load_db_codes %.1f s" % (time.time() - t))
 tot = 0
 t = time.time()

@@ -5,7 +5,7 @@
 
 Per kernel: sum of the counter over its dispatches and the dispatch count.  Unit of FETCH_SIZE / WRITE_SIZE: KiB.  gfx950 correction of the
 guide: FETCH_SIZE reports half of the bytes of wide coalesced reads -> the corrected figure doubles it (upper bound for the narrow accesses
-of the trie walk); both are stored.  The seed stage of one launch = keys + scan + scatter + bfs<0> + bfs<1> + finish (+ the redo launches of
+of the trie walk); both are stored.  The seed stage of one launch = keys + scan + scatter + pg<0> + pg<1> + finish (+ the redo launches of
 k_seed_search), summed per launch of k_seed_keys.  The file is stamped with a hash of the seed-stage kernel sources (SEED_SOURCES): bench.py only uses it when the
 hash, the batch size, the read length and the DB size are the ones of its own run."""
 import collections
@@ -18,7 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-SEED_SOURCES = ["smr_seed.hpp", "smr_seed_bfs.hpp", "smr_seed_pg.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
+SEED_SOURCES = ["smr_seed.hpp", "smr_seed_pg.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
 
 
 def kernel_src_sha():
