@@ -68,7 +68,6 @@ struct smr_ctx {
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
-  uint32_t* sb_scan_sums = nullptr; uint32_t* sb_scan_pre = nullptr;   // tile sums / prefixes of the bin-offset scan
   uint32_t chain_blocks = 0;
   unsigned long long* d_tuples = nullptr; uint32_t chain_scap = 512;   // (pos, slot, win) tuples; slots of the candidate set S in LDS
   uint32_t keys_need = 0;
@@ -203,22 +202,22 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   if (2 * slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^32): use smaller batches"; return SMR_ERR_CAPACITY; }
   int rc;
   if (c->sb_nk < nk) {
-    if ((rc = dev_alloc(c, &c->sb.hist, (size_t)nk + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->sb_scan_sums, (size_t)(nk + 1 + 2047) / 2048 + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->sb_scan_pre, (size_t)(nk + 1 + 2047) / 2048 + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.chist, (size_t)4096 + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.ccur, (size_t)4096))) return rc;
     if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.bin_off, (size_t)nk + 1))) return rc;
     if (!c->sb.sn && (rc = dev_alloc(c, &c->sb.sn, SN_COUNT))) return rc;
     c->sb_nk = nk;
   }
   if (c->sb_slots < slots) {
     if ((rc = dev_alloc(c, &c->sb.tmp, 2 * slots))) return rc;       // a forward and a reverse tuple per window
-    if ((rc = dev_alloc(c, &c->sb.tup, 2 * slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.tkey, 2 * slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.mid, 2 * slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.srt, 2 * slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.wseg, slots))) return rc;
     c->sb_slots = slots;
   }
   c->sb.nk = nk; c->sb.nkh = nk / 2;
+  c->sb.fb = std::min<uint32_t>(9, P.lnwin); c->sb.nc = nk >> c->sb.fb;       // L <= 20: at most 4096 coarse bins
   return SMR_OK;
 }
 
@@ -234,21 +233,16 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.cap_redo = SEED_REDO_CAP;
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024), gs = (uint32_t)((2 * slots + 255) / 256);
+  const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024);
   ev_begin(c, 0);
-  // one counting sort for the forward and the reverse tuples of the stage
-  HIPCHK(c, hipMemsetAsync(sb.hist, 0, ((size_t)sb.nk + 1) * 4, c->stream));
+  // one two-level counting sort for the forward and the reverse tuples of the stage (smr_seed.hpp)
+  HIPCHK(c, hipMemsetAsync(sb.chist, 0, ((size_t)sb.nc + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
   if (slots) HIPCHK(c, hipMemsetAsync(sb.wseg, 0xFF, (size_t)slots * 4, c->stream));       // NONE: no window has hits yet
-  hipLaunchKernelGGL(k_seed_keys, dim3(gk4), dim3(1024), 0, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr);
-  {  // bin offsets = exclusive scan of the histogram (bin_off[nk] = number of tuples): tiles of 2048 bins, at most 2048 tiles (L <= 20)
-    const uint64_t nscan = (uint64_t)sb.nk + 1;
-    const uint32_t tiles = (uint32_t)((nscan + 2047) / 2048);
-    hipLaunchKernelGGL(smr::k_scan_tile<uint32_t>, dim3(tiles), dim3(256), 0, c->stream, (const uint32_t*)sb.hist, sb.bin_off, c->sb_scan_sums, nscan);
-    hipLaunchKernelGGL(smr::k_scan_tile<uint32_t>, dim3(1), dim3(256), 0, c->stream, (const uint32_t*)c->sb_scan_sums, c->sb_scan_pre, c->sb_scan_sums + tiles, (uint64_t)tiles);
-    hipLaunchKernelGGL(smr::k_scan_add<uint32_t>, dim3(tiles), dim3(256), 0, c->stream, sb.bin_off, (const uint32_t*)c->sb_scan_pre, nscan);
-  }
-  hipLaunchKernelGGL(k_seed_scatter, dim3(gs), dim3(256), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_keys, dim3(std::min<uint32_t>(gk4, 2048u)), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, gk4);
+  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_split, dim3((uint32_t)((2 * slots + SEED_SPLIT_CHUNK - 1) / SEED_SPLIT_CHUNK)), dim3(1024), (size_t)sb.nc * 8, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), 0, c->stream, sb);
   for (int dir = 0; dir < 2; dir++) {
     const uint32_t* no_redo = nullptr;
     if (c->seed_exact) {
@@ -730,8 +724,8 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
-  dev_free(&c->sb.hist); dev_free(&c->sb.bin_off); dev_free(&c->sb.tmp); dev_free(&c->sb_scan_sums); dev_free(&c->sb_scan_pre);
-  dev_free(&c->sb.tup); dev_free(&c->sb.tkey); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
+  dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.ccur); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
+  dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -99,16 +99,15 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 //
 // The reference probes, per window, lookup_tbl[9-mer] and walks that mini burst trie (paralleltraversal.cpp:124-249,
 // traverse_bursttrie.cpp:100-298): a hash-scatter into a structure of GBs.  Here the windows of the WHOLE batch are
-// first binned by their 9-mer key (counting sort: histogram with rank -> scan -> scatter), and the searches run in
+// first sorted by their 9-mer key (two-level counting sort, below), and the searches run in
 // key order, 64 consecutive tuples per wave: neighbouring lanes walk the same or adjacent mini-tries, so their node
 // and bucket loads hit the same cache lines.  The forward half-seed searches of all windows run first (phase F), then
 // the reverse searches of the windows whose forward search did not end with a 0-error match (phase R,
 // paralleltraversal.cpp:188), seeded with the forward hit list so that the reference's in-order de-duplication rules
 // are applied exactly.
 //
-//   k_seed_keys         window -> forward and reverse (key, rank in bin, payload)  [9-mer hash, lookup probes, flip34 view]
-//   k_scan_tile/add     exclusive scan of the bin counts (tiled; smr_ibuild.hpp)
-//   k_seed_scatter      tuples to bin order
+//   k_seed_keys         window -> forward and reverse (key, payload)  [9-mer hash, lookup probes, flip34 view]
+//   k_seed_cscan/split/bins   tuples to key order
 //   k_seed_pg<DIR>      the searches over the pigeonhole layout (smr_seed_pg.hpp) -- the default
 //   k_seed_search<DIR>  the searches, per-lane DFS formulation (below): overflow redo + exact work counters
 //   k_seed_finish       per read: gather the windows' hits into one block, hit_seeds / hit_total (paralleltraversal.cpp:242-249)
@@ -136,20 +135,23 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 #define SEED_ZERO_BIT 0x80000000u
 
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
-enum { SN_TUPLES = 0, SN_REDO = 1, SN_COUNT = 4 };                  // device counters of the seed stage (u32)
+enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples
 
-struct SeedTmp { uint32_t key, rank; unsigned long long payload; };   // payload: read | win_pos << 24 | chars << 40
+struct alignas(16) SeedTmp { uint32_t key, pad; unsigned long long payload; };   // payload: read | win_pos << 24 | chars << 40
 
+#define SEED_SPLIT_CHUNK 16384u                           // tuples per block of k_seed_split
 struct SeedBufs {
-  uint32_t* hist;            // [NK] tuples per key (phase-local)
-  uint32_t* bin_off;         // [NK + 1]
+  uint32_t* chist;           // [nc + 1] tuples per COARSE bin (key >> fb)
+  uint32_t* cbase;           // [nc + 1] exclusive scan of chist
+  uint32_t* ccur;            // [nc] allocation cursors of the coarse bins (k_seed_split)
   SeedTmp* tmp;              // unsorted tuples
-  unsigned long long* tup;   // payloads in key order
-  uint32_t* tkey;            // keys in key order
+  SeedTmp* mid;              // tuples grouped by coarse bin
+  SeedTmp* srt;              // tuples in key order
   uint32_t* wseg;            // [maxwin][n] (window-major: k_seed_finish's threads = reads read it coalesced) pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
   uint32_t* sn;              // SN_* counters
   uint32_t* redo;            // waves of k_seed_pg to be searched again by k_seed_search
   uint32_t nk, nkh, maxwin, cap_tuples, cap_redo;     // nk = 2 * nkh bins: forward keys [0, nkh), reverse keys [nkh, 2 nkh)
+  uint32_t fb, nc;           // fine bits (min(9, L): a coarse bin never mixes forward and reverse keys), nc = nk >> fb coarse bins (<= 4096)
   uint32_t n;                // reads in the batch
 };
 __device__ __forceinline__ size_t wseg_slot(const SeedBufs& sb, uint32_t r, uint32_t k) { return (size_t)k * sb.n + r; }
@@ -189,76 +191,155 @@ __device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, 
 // The reverse tuple is speculative: the reverse search kernel drops it when the forward search ended with a 0-error match
 // (accept_zero_kmer, paralleltraversal.cpp:188).
 __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
-                                                   const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr) {
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
+                                                   const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, uint32_t n_tiles) {
+  SMR_DYN_LDS(uint32_t, lh);                              // [nc] this block's tuples per coarse bin
+  __shared__ uint32_t s_cnt[2][16], s_win[16], s_base;
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
+  __syncthreads();
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, L = P.lnwin;
-  bool emit[2] = {false, false};
-  uint32_t key[2] = {0, 0}, is_win = 0;
-  unsigned long long payload[2] = {0, 0};
-  if (r < rd.n) {
-    const RWork w = rw[r];
-    const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
-    const uint32_t len = rd.len[r];
-    const uint32_t stride = P.skip[pass];
-    const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
-    bool mine = k < numwin;
-    const uint32_t win_pos = k * stride;
-    if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
-    // (wseg starts as NONE everywhere: launch_seed fills it)
-    if (mine) {
-      // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
-      const uint32_t aval = w.is04 ? 0 : w.aval;
-      const unsigned long long wc = window_chars(rd.words + rd.rec_off[r], len, win_pos, L, w.reversed, aval);
-      const unsigned long long half = (1ull << (2 * pw)) - 1ull;
-      // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
-      const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
-      uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
-      ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
-      rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
-      is_win = 1;
-      const Lookup lf = ix.lookup[ra], lr = ix.lookup[rb];
-      emit[0] = lf.count > P.minoccur && lf.rootF != NONE;
-      emit[1] = lr.count > P.minoccur && lr.rootR != NONE;
-      key[0] = ra; key[1] = sb.nkh + rb;
-      const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
-      payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
-      payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
-    }
-  }
-  // block-aggregated slot allocation in the unsorted tuple array (one atomic per 1024 slots)
-  __shared__ uint32_t s_cnt[2][16], s_win[16], s_base;
   const uint32_t wv = threadIdx.x >> 6;
-  const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]), wm = __ballot(is_win);
-  if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tc = 0, tw = 0;
-    for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { tc += s_cnt[0][q] + s_cnt[1][q]; tw += s_win[q]; }
-    s_base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
-    if (tw) { ctr_add(ctr, C_WINDOWS, tw); ctr_add(ctr, C_LOOKUP, tw); }     // the forward lookups; the reverse ones are counted by k_seed_finish
-  }
-  __syncthreads();
-#pragma unroll
-  for (int d = 0; d < 2; d++) {
-    if (emit[d]) {
-      uint32_t base = s_base;
-      for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { if (d == 1) base += s_cnt[0][q]; if (q < wv) base += s_cnt[d][q]; }
-      const uint32_t idx = base + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
-      if (idx < sb.cap_tuples) {
-        SeedTmp t; t.key = key[d]; t.rank = atomicAdd(&sb.hist[key[d]], 1u); t.payload = payload[d];
-        sb.tmp[idx] = t;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t tid = tile * blockDim.x + threadIdx.x;
+    const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
+    bool emit[2] = {false, false};
+    uint32_t key[2] = {0, 0}, is_win = 0;
+    unsigned long long payload[2] = {0, 0};
+    if (r < rd.n) {
+      const RWork w = rw[r];
+      const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
+      const uint32_t len = rd.len[r];
+      const uint32_t stride = P.skip[pass];
+      const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
+      bool mine = k < numwin;
+      const uint32_t win_pos = k * stride;
+      if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
+      // (wseg starts as NONE everywhere: launch_seed fills it)
+      if (mine) {
+        // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
+        const uint32_t aval = w.is04 ? 0 : w.aval;
+        const unsigned long long wc = window_chars(rd.words + rd.rec_off[r], len, win_pos, L, w.reversed, aval);
+        const unsigned long long half = (1ull << (2 * pw)) - 1ull;
+        // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
+        const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
+        uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
+        ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
+        rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
+        is_win = 1;
+        const Lookup lf = ix.lookup[ra], lr = ix.lookup[rb];
+        emit[0] = lf.count > P.minoccur && lf.rootF != NONE;
+        emit[1] = lr.count > P.minoccur && lr.rootR != NONE;
+        key[0] = ra; key[1] = sb.nkh + rb;
+        const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
+        payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
+        payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
       }
     }
+    // block-aggregated slot allocation in the unsorted tuple array (one atomic per 1024 slots)
+    const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]), wm = __ballot(is_win);
+    if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tc = 0, tw = 0;
+      for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { tc += s_cnt[0][q] + s_cnt[1][q]; tw += s_win[q]; }
+      s_base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
+      if (tw) { ctr_add(ctr, C_WINDOWS, tw); ctr_add(ctr, C_LOOKUP, tw); }     // the forward lookups; the reverse ones are counted by k_seed_finish
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      if (emit[d]) {
+        uint32_t base = s_base;
+        for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { if (d == 1) base += s_cnt[0][q]; if (q < wv) base += s_cnt[d][q]; }
+        const uint32_t idx = base + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
+        if (idx < sb.cap_tuples) {
+          SeedTmp t; t.key = key[d]; t.pad = 0; t.payload = payload[d];
+          sb.tmp[idx] = t;
+          atomicAdd(&lh[key[d] >> sb.fb], 1u);
+        }
+      }
+    }
+    __syncthreads();                                       // s_cnt / s_base are rewritten by the next tile
+  }
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) if (lh[c]) atomicAdd(&sb.chist[c], lh[c]);
+}
+
+// The tuples are brought into key order by a two-level counting sort whose per-tuple atomics all stay in LDS:
+//   k_seed_keys    counts the tuples per COARSE bin (key >> fb, <= 4096 bins) in LDS while it writes them unsorted
+//   k_seed_cscan   exclusive scan of the coarse counts (one block)
+//   k_seed_split   a block takes SEED_SPLIT_CHUNK unsorted tuples: LDS histogram by coarse bin, one global atomic per non-empty bin reserves
+//                  the block's share of that bin, second pass copies the tuples there (runs of ~16 tuples per bin)
+//   k_seed_bins    one block per coarse bin: LDS histogram of the fine key bits (<= 512 bins), scan, second pass writes payload and key to
+//                  their final places
+// (One counting sort over all 2 * 4^pw keys with a global atomic per tuple took 4.3 ms per stage of 60 M tuples; this takes SORT_MS.)
+__global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb) {
+  __shared__ uint32_t s_part[16];
+  // <= 4096 bins: 4 consecutive bins per thread
+  const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+  uint32_t v[4], sum = 0;
+  for (int q = 0; q < 4; q++) { const uint32_t c = 4 * t + q; v[q] = c < sb.nc ? sb.chist[c] : 0u; sum += v[q]; }
+  uint32_t incl = sum;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += x; }
+  if (lane == 63) s_part[wv] = incl;
+  __syncthreads();
+  uint32_t pre = incl - sum;
+  for (uint32_t q = 0; q < wv; q++) pre += s_part[q];
+  for (int q = 0; q < 4; q++) {
+    const uint32_t c = 4 * t + q;
+    if (c < sb.nc) { sb.cbase[c] = pre; sb.ccur[c] = pre; if (c == (sb.nkh >> sb.fb)) sb.sn[SN_FWD] = pre; }
+    pre += v[q];
+    if (c + 1 == sb.nc) sb.cbase[sb.nc] = pre;
   }
 }
 
-// (the bin offsets = exclusive scan of hist are computed by k_scan_tile / k_scan_add of smr_ibuild.hpp, see launch_seed)
-__global__ void __launch_bounds__(256) k_seed_scatter(SeedBufs sb) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
+  SMR_DYN_LDS(uint32_t, lds);
+  uint32_t* lh = lds;                                     // [nc] count, then running offset inside the block's share
+  uint32_t* lb = lds + sb.nc;                             // [nc] start of the block's share of the coarse bin
   const uint32_t n = min(sb.sn[SN_TUPLES], sb.cap_tuples);
-  if (i < n) { const SeedTmp t = sb.tmp[i]; const uint32_t p = sb.bin_off[t.key] + t.rank; sb.tup[p] = t.payload; sb.tkey[p] = t.key; }
+  const uint32_t i0 = blockIdx.x * SEED_SPLIT_CHUNK, i1 = min(i0 + SEED_SPLIT_CHUNK, n);
+  if (i0 >= n) return;
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
+  __syncthreads();
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) atomicAdd(&lh[sb.tmp[i].key >> sb.fb], 1u);
+  __syncthreads();
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) { const uint32_t m = lh[c]; if (m) lb[c] = atomicAdd(&sb.ccur[c], m); lh[c] = 0; }
+  __syncthreads();
+  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const SeedTmp t = sb.tmp[i];
+    const uint32_t c = t.key >> sb.fb;
+    sb.mid[lb[c] + atomicAdd(&lh[c], 1u)] = t;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
+  __shared__ uint32_t fh[512], s_part[8];
+  const uint32_t c = blockIdx.x, lo = sb.cbase[c], hi = sb.cbase[c + 1];
+  if (lo == hi) return;
+  const uint32_t t = threadIdx.x, fm = (1u << sb.fb) - 1u;
+  if (t < 512) fh[t] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&fh[sb.mid[i].key & fm], 1u);
+  __syncthreads();
+  // exclusive scan of the 512 fine counts (waves 0..7)
+  uint32_t v = 0, incl = 0;
+  if (t < 512) {
+    v = fh[t]; incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)(t & 63u) >= d) incl += x; }
+    if ((t & 63u) == 63u) s_part[t >> 6] = incl;
+  }
+  __syncthreads();
+  if (t < 512) {
+    uint32_t pre = incl - v;
+    for (uint32_t q = 0; q < (t >> 6); q++) pre += s_part[q];
+    fh[t] = lo + pre;                                     // from now on: the next free place of the fine bin
+  }
+  __syncthreads();
+  for (uint32_t i = lo + t; i < hi; i += blockDim.x) {
+    const SeedTmp x = sb.mid[i];
+    const uint32_t p = atomicAdd(&fh[x.key & fm], 1u);
+    sb.srt[p] = x;
+  }
 }
 
 struct SeedLane {           // per-lane search result
@@ -448,7 +529,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
                                                     uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr,
                                                     const uint32_t* __restrict__ redo) {
   // this phase's tuples: forward bins first, reverse bins after them
-  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
+  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_all);
   const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
   uint32_t wave = blockIdx.x;
   if (redo) {                                            // only the waves listed by k_seed_pg (its candidate pool overflowed)
@@ -478,8 +559,9 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   SeedLane sl; sl.nh = 0; sl.zero = false; sl.overflow = false; sl.n_node = 0; sl.n_entry = 0;
   uint32_t n_prev = 0;
   if (mine) {
-    const unsigned long long pl = sb.tup[pos];
-    const Lookup lk = ix.lookup[sb.tkey[pos] - (DIR ? sb.nkh : 0u)];
+    const SeedTmp tp = sb.srt[pos];
+    const unsigned long long pl = tp.payload;
+    const Lookup lk = ix.lookup[tp.key - (DIR ? sb.nkh : 0u)];
     root = DIR == 0 ? lk.rootF : lk.rootR;
     r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
     slot = wseg_slot(sb, r, win_pos / P.skip[pass]);

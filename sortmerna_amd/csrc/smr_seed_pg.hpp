@@ -42,7 +42,7 @@ template <int DIR>
 __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
                                                 uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
   // this phase's tuples: forward bins first, reverse bins after them
-  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.bin_off[sb.nkh], n_all);
+  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_all);
   const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
   if (blockIdx.x * 64u >= n_tup) return;
   SMR_DYN_LDS(uint32_t, lds_dyn);
@@ -69,8 +69,9 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   size_t slot = 0;
   bool hl_over = false;
   if (mine) {
-    const unsigned long long pl = sb.tup[pos];
-    rt = ix.root3[2 * (sb.tkey[pos] - (DIR ? sb.nkh : 0u)) + DIR];
+    const SeedTmp tp = sb.srt[pos];
+    const unsigned long long pl = tp.payload;
+    rt = ix.root3[2 * (tp.key - (DIR ? sb.nkh : 0u)) + DIR];
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
     P9 = (uint32_t)(pl >> 40);
@@ -124,25 +125,37 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   GPH(1)
   // ---- every lane walks its ranges; accepted entries go to the wave's candidate pool, chained per search ----
   uint32_t head = PG_NIL;
-  for (uint32_t i = 0; __any(i < tot); i++) {
+  // (two entries per trip: both loads are in flight before either is looked at)
+  auto locate = [&](uint32_t i, uint32_t& w) -> const uint32_t* {
+    uint32_t j = i, st = rs0;
+    w = 0;
+    if (j >= rn0) { j -= rn0; w = 1; st = rs1;
+      if (j >= rn1) { j -= rn1; w = 2; st = rs2;
+        if (j >= rn2) { j -= rn2; w = 3; st = rs3; } } }
+    return ents + (w ? 3 * (size_t)n : 0) + 3 * (size_t)(st + j);
+  };
+  auto look = [&](uint32_t w, uint32_t T, uint32_t rk, uint32_t id) {
+    bool dup = false;                                      // reachable through an earlier key of this search?
+    if (w) {
+      const uint32_t rv = pg_reversed(T);
+      dup = pg_rkey(rv, 0, cA) == kA;
+      if (w == 3) { const uint32_t kt = pg_rkey(rv, h, cB); dup = dup || kt == kb0 || kt == kb1; }
+    }
+    const uint32_t r = dup ? 0u : lev1_entry(P9, T, pw);
+    if (r & 1u) {
+      const uint32_t p = atomicAdd(&s_ncand, 1u);
+      if (p < ccap) { cdk[p] = rk; cdv[p] = id; cdn[p] = head | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16); head = p; }
+    }
+  };
+  for (uint32_t i = 0; __any(i < tot); i += 2) {
     if (i < tot) {
-      uint32_t j = i, w = 0, st = rs0;
-      if (j >= rn0) { j -= rn0; w = 1; st = rs1;
-        if (j >= rn1) { j -= rn1; w = 2; st = rs2;
-          if (j >= rn2) { j -= rn2; w = 3; st = rs3; } } }
-      const uint32_t* e = ents + (w ? 3 * (size_t)n : 0) + 3 * (size_t)(st + j);
-      const uint32_t T = e[0], rk = e[1], id = e[2];
-      bool dup = false;                                    // reachable through an earlier key of this search?
-      if (w) {
-        const uint32_t rv = pg_reversed(T);
-        dup = pg_rkey(rv, 0, cA) == kA;
-        if (w == 3) { const uint32_t kt = pg_rkey(rv, h, cB); dup = dup || kt == kb0 || kt == kb1; }
-      }
-      const uint32_t r = dup ? 0u : lev1_entry(P9, T, pw);
-      if (r & 1u) {
-        const uint32_t p = atomicAdd(&s_ncand, 1u);
-        if (p < ccap) { cdk[p] = rk; cdv[p] = id; cdn[p] = head | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16); head = p; }
-      }
+      uint32_t w0, w1 = 0;
+      const uint32_t* e0 = locate(i, w0);
+      const bool two = i + 1 < tot;
+      const uint32_t* e1 = two ? locate(i + 1, w1) : e0;
+      const uint32_t T0 = e0[0], k0 = e0[1], d0 = e0[2], T1 = e1[0], k1 = e1[1], d1 = e1[2];
+      look(w0, T0, k0, d0);
+      if (two) look(w1, T1, k1, d1);
     }
   }
   __syncthreads();
