@@ -137,7 +137,8 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
 enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples
 
-struct alignas(16) SeedTmp { uint32_t key, pad; unsigned long long payload; };   // payload: read | win_pos << 24 | chars << 40
+struct SeedTmp { uint32_t key, lo, hi; };               // 12 bytes; payload = lo | hi << 32: read | win_pos << 24 | chars << 40
+__device__ __forceinline__ unsigned long long seed_payload(const SeedTmp& t) { return (unsigned long long)t.lo | ((unsigned long long)t.hi << 32); }
 
 #define SEED_SPLIT_CHUNK 16384u                           // tuples per block of k_seed_split
 struct SeedBufs {
@@ -193,7 +194,7 @@ __device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, 
 __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
                                                    const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, uint32_t n_tiles) {
   SMR_DYN_LDS(uint32_t, lh);                              // [nc] this block's tuples per coarse bin
-  __shared__ uint32_t s_cnt[2][16], s_win[16], s_base;
+  __shared__ uint32_t s_cnt[2][16], s_off[2][16], s_win[16];
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
   __syncthreads();
   const int lane = lane_id();
@@ -239,27 +240,27 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]), wm = __ballot(is_win);
     if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                                // the tile's forward tuples first, wave by wave, then its reverse tuples
       uint32_t tc = 0, tw = 0;
-      for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { tc += s_cnt[0][q] + s_cnt[1][q]; tw += s_win[q]; }
-      s_base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
+      for (int d = 0; d < 2; d++) for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { s_off[d][q] = tc; tc += s_cnt[d][q]; }
+      for (uint32_t q = 0; q < (blockDim.x >> 6); q++) tw += s_win[q];
+      const uint32_t base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
+      for (int d = 0; d < 2; d++) for (uint32_t q = 0; q < (blockDim.x >> 6); q++) s_off[d][q] += base;
       if (tw) { ctr_add(ctr, C_WINDOWS, tw); ctr_add(ctr, C_LOOKUP, tw); }     // the forward lookups; the reverse ones are counted by k_seed_finish
     }
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 2; d++) {
       if (emit[d]) {
-        uint32_t base = s_base;
-        for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { if (d == 1) base += s_cnt[0][q]; if (q < wv) base += s_cnt[d][q]; }
-        const uint32_t idx = base + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
+        const uint32_t idx = s_off[d][wv] + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
         if (idx < sb.cap_tuples) {
-          SeedTmp t; t.key = key[d]; t.pad = 0; t.payload = payload[d];
+          SeedTmp t; t.key = key[d]; t.lo = (uint32_t)payload[d]; t.hi = (uint32_t)(payload[d] >> 32);
           sb.tmp[idx] = t;
           atomicAdd(&lh[key[d] >> sb.fb], 1u);
         }
       }
     }
-    __syncthreads();                                       // s_cnt / s_base are rewritten by the next tile
+    __syncthreads();                                       // s_cnt / s_off are rewritten by the next tile
   }
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) if (lh[c]) atomicAdd(&sb.chist[c], lh[c]);
 }
@@ -560,7 +561,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   uint32_t n_prev = 0;
   if (mine) {
     const SeedTmp tp = sb.srt[pos];
-    const unsigned long long pl = tp.payload;
+    const unsigned long long pl = seed_payload(tp);
     const Lookup lk = ix.lookup[tp.key - (DIR ? sb.nkh : 0u)];
     root = DIR == 0 ? lk.rootF : lk.rootR;
     r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   bool hl_over = false;
   if (mine) {
     const SeedTmp tp = sb.srt[pos];
-    const unsigned long long pl = tp.payload;
+    const unsigned long long pl = seed_payload(tp);
     rt = ix.root3[2 * (tp.key - (DIR ? sb.nkh : 0u)) + DIR];
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
@@ -126,20 +126,21 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   // ---- every lane walks its ranges; accepted entries go to the wave's candidate pool, chained per search ----
   uint32_t head = PG_NIL;
   // (two entries per trip: both loads are in flight before either is looked at)
-  auto locate = [&](uint32_t i, uint32_t& w) -> const uint32_t* {
-    uint32_t j = i, st = rs0;
-    w = 0;
-    if (j >= rn0) { j -= rn0; w = 1; st = rs1;
-      if (j >= rn1) { j -= rn1; w = 2; st = rs2;
-        if (j >= rn2) { j -= rn2; w = 3; st = rs3; } } }
-    return ents + (w ? 3 * (size_t)n : 0) + 3 * (size_t)(st + j);
-  };
+  // the lane's walk over its ranges: next entry, entries left in the current range, its number; the ranges still to come wait in (q*s, q*n)
+  const uint32_t* cur = ents + 3 * (size_t)rs0;
+  const uint32_t* const eb = ents + 3 * (size_t)n;
+  uint32_t rng = 0, left = rn0;
+  uint32_t q1s = rs1, q1n = rn1, q2s = rs2, q2n = rn2, q3s = rs3, q3n = rn3;
+#define PG_NEXT_RANGE() { rng++; left = q1n; cur = eb + 3 * (size_t)q1s; q1s = q2s; q1n = q2n; q2s = q3s; q2n = q3n; q3n = 0; }
+#define PG_STEP(e, w) { if (left == 0) { PG_NEXT_RANGE() if (left == 0) { PG_NEXT_RANGE() if (left == 0) PG_NEXT_RANGE() } } e = cur; cur += 3; left--; w = rng; }
+  // "reachable through an earlier key of this search" needs no reversed strings: the keys are runs of chars, compared in place
+  const uint32_t mA = (1u << (2 * cA)) - 1u, mB = (1u << (2 * cB)) - 1u;
+  const uint32_t pb0 = (P9 >> (2 * h)) & mB, pb1 = (P9 >> (2 * h - 2)) & mB;
   auto look = [&](uint32_t w, uint32_t T, uint32_t rk, uint32_t id) {
-    bool dup = false;                                      // reachable through an earlier key of this search?
+    bool dup = false;
     if (w) {
-      const uint32_t rv = pg_reversed(T);
-      dup = pg_rkey(rv, 0, cA) == kA;
-      if (w == 3) { const uint32_t kt = pg_rkey(rv, h, cB); dup = dup || kt == kb0 || kt == kb1; }
+      dup = ((T ^ P9) & mA) == 0;                          // under key A
+      if (w == 3) { const uint32_t tb = (T >> (2 * h)) & mB; dup = dup || tb == pb0 || tb == pb1; }      // under S0 / S1
     }
     const uint32_t r = dup ? 0u : lev1_entry(P9, T, pw);
     if (r & 1u) {
@@ -150,9 +151,11 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   for (uint32_t i = 0; __any(i < tot); i += 2) {
     if (i < tot) {
       uint32_t w0, w1 = 0;
-      const uint32_t* e0 = locate(i, w0);
+      const uint32_t* e0; const uint32_t* e1;
+      PG_STEP(e0, w0)
       const bool two = i + 1 < tot;
-      const uint32_t* e1 = two ? locate(i + 1, w1) : e0;
+      e1 = e0;
+      if (two) PG_STEP(e1, w1)
       const uint32_t T0 = e0[0], k0 = e0[1], d0 = e0[2], T1 = e1[0], k1 = e1[1], d1 = e1[2];
       look(w0, T0, k0, d0);
       if (two) look(w1, T1, k1, d1);
