@@ -231,7 +231,9 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.cap_tuples = (uint32_t)(2 * slots);
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
+  const uint32_t pgw = (uint32_t)std::max<size_t>(1, std::min<size_t>(PG_WAVES, (60 * 1024) / lds_pg1));      // waves per block of k_seed_pg
+  const size_t lds_pg = lds_pg1 * pgw;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024);
   ev_begin(c, 0);
@@ -253,10 +255,10 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
       HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       if (dir == 0) {
-        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_pg<0>, dim3((gw + pgw - 1) / pgw), dim3(64 * pgw), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       } else {
-        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gw), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_pg<1>, dim3((gw + pgw - 1) / pgw), dim3(64 * pgw), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       }
     }

@@ -37,13 +37,14 @@ static constexpr uint32_t ELEM_NENT_MAX = 255;
 // candidate strings (trie path + bucket tail, pw+1 chars, char j at bits 2j).
 // A string within LEV(1) of a pattern P either agrees with P on its first h = pw/2 chars, or -- the one edit being among those -- on
 // chars h..pw-1 with P[h..], P[h-1..] or P[h+1..] (smr_seed_pg.hpp), so only the entries under a handful of exact keys can match:
-//   dirA  4^cA + 1 offsets into EA: entries whose first cA chars (first char most significant) are < key
-//   dirB  4^cB + 1 offsets into EB: the same over chars h..h+cB-1
-//   EA    n x {string, DFS rank, id} sorted by string (first char most significant)
-//   EB    the same entries sorted by chars h..pw-1
+//   dirA  4^cA + 1 offsets into TA: strings whose first cA chars (first char most significant) are < key
+//   dirB  4^cB + 1 offsets into TB: the same over chars h..h+cB-1
+//   TA    n strings sorted (first char most significant)          TB    the same strings sorted by chars h..pw-1
+//   RA    n x {DFS rank, id} in the order of TA                    RB    ... of TB
+// (strings apart from {rank, id}: a search reads the strings of its ranges -- nearly all fail -- and {rank, id} of the accepted ones only)
 // "DFS rank" = the entry's position in the reference's traversal order of the mini-trie (A<C<G<T, bucket order), which is the order the
 // reference meets -- and de-duplicates -- the hits in.  cA = min(h, log4 n), cB = min(pw-h, log4 2n); a block with n <= PG_SCAN entries
-// has no directories and one array in DFS order (the search looks at every entry).  Blocks are 16-byte aligned;
+// has no directories and only TA, RA in DFS order (the search looks at every entry).  Blocks are 16-byte aligned;
 // root3[2k + d] = {block offset / 4 words, n | cA << 24 | cB << 28} for the forward / reverse mini-trie of key k.
 static constexpr uint32_t PG_SCAN = 4;
 __host__ __device__ inline void pg_chars(uint32_t n, uint32_t pw, uint32_t& cA, uint32_t& cB) {

@@ -328,14 +328,15 @@ extern "C" int smr_index_selfcheck(smr_index* ix, char* err, size_t errcap) {
       const uint32_t* blk = ix->pg.data() + (size_t)r3 * 4;
       const uint32_t nA = cA ? (1u << (2 * cA)) + 1 : 0, nB = cA ? (1u << (2 * cB)) + 1 : 0;
       for (int o = 0; o < (cA ? 2 : 1); o++) {
-        const uint32_t* E = blk + nA + nB + (o ? 3 * (size_t)n : 0);
+        const uint32_t* Ts = blk + nA + nB + (o ? n : 0);
+        const uint32_t* Rs = blk + nA + nB + (cA ? 2 : 1) * (size_t)n + (o ? 2 * (size_t)n : 0);
         const uint32_t* dir = o ? blk + nA : blk;
         const uint32_t c = o ? cB : cA, from = o ? h : 0;
         seen.assign(n, 0);
         uint64_t prev = 0;
         for (uint32_t i = 0; i < n; i++) {
-          const uint32_t T = E[3 * i], r = E[3 * i + 1];
-          if (r >= n || seen[r] || a[r].str != T || a[r].id != E[3 * i + 2]) { set_err(err, errcap, "pigeonhole layout: entries differ" + at); return SMR_ERR_STATE; }
+          const uint32_t T = Ts[i], r = Rs[2 * i];
+          if (r >= n || seen[r] || a[r].str != T || a[r].id != Rs[2 * i + 1]) { set_err(err, errcap, "pigeonhole layout: entries differ" + at); return SMR_ERR_STATE; }
           seen[r] = 1;
           if (!cA) { if (r != i) { set_err(err, errcap, "pigeonhole layout: scan block not in DFS order" + at); return SMR_ERR_STATE; } continue; }
           const uint64_t key = o ? pg_key(T, h, pw - h) : pg_key(T, 0, pw + 1);
@@ -496,11 +497,12 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
         root3[2 * (2 * k + d)] = (uint32_t)(base / 4);         // thread-local for now
         root3[2 * (2 * k + d) + 1] = n | (cA << 24) | (cB << 28);
         if (cA == 0) {
-          for (uint32_t r = 0; r < n; r++) { out.push_back(v[r].str); out.push_back(r); out.push_back(v[r].id); }
+          for (uint32_t r = 0; r < n; r++) out.push_back(v[r].str);
+          for (uint32_t r = 0; r < n; r++) { out.push_back(r); out.push_back(v[r].id); }
         } else {
           const uint32_t nA = (1u << (2 * cA)) + 1, nB = (1u << (2 * cB)) + 1;
           out.resize(base + nA + nB + 6 * (size_t)n);
-          uint32_t* dirA = out.data() + base; uint32_t* dirB = dirA + nA; uint32_t* EA = dirB + nB; uint32_t* EB = EA + 3 * (size_t)n;
+          uint32_t* dirA = out.data() + base; uint32_t* dirB = dirA + nA; uint32_t* TT = dirB + nB; uint32_t* RR = TT + 2 * (size_t)n;     // TA TB | RA RB
           for (int o = 0; o < 2; o++) {
             ord.resize(n);
             for (uint32_t r = 0; r < n; r++) {
@@ -508,12 +510,12 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
               ord[r] = o == 0 ? ((key << 32) | r) : key;
             }
             std::sort(ord.begin(), ord.end());
-            uint32_t* E = o == 0 ? EA : EB; uint32_t* dir = o == 0 ? dirA : dirB;
+            uint32_t* Ts = TT + (o ? n : 0); uint32_t* Rs = RR + (o ? 2 * (size_t)n : 0); uint32_t* dir = o == 0 ? dirA : dirB;
             const uint32_t c = o == 0 ? cA : cB, from = o == 0 ? 0 : h, nd = o == 0 ? nA : nB;
             uint32_t next = 0;                                  // next directory slot to fill
             for (uint32_t i = 0; i < n; i++) {
               const uint32_t r = (uint32_t)(ord[i] & 0xFFFFFFFFull);
-              E[3 * i] = v[r].str; E[3 * i + 1] = r; E[3 * i + 2] = v[r].id;
+              Ts[i] = v[r].str; Rs[2 * i] = r; Rs[2 * i + 1] = v[r].id;
               const uint32_t kk = pg_key(v[r].str, from, c);
               while (next <= kk) dir[next++] = i;
             }

@@ -26,6 +26,12 @@ namespace smr {
 #define PG_CAND_CAP0 256u                                 // initial pool size
 #define PG_CAND_CAP_MAX 2048u
 #define PG_NIL 0xFFFFu
+#ifndef PG_WAVES
+#define PG_WAVES 1
+#endif
+#ifndef PG_TRIP
+#define PG_TRIP 4
+#endif
 // dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16)
 #define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap))
 
@@ -39,18 +45,21 @@ __device__ __forceinline__ uint32_t pg_reversed(uint32_t s) {
 __device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_t cnt) { return (rev >> (32u - 2u * (from + cnt))) & ((1u << (2u * cnt)) - 1u); }
 
 template <int DIR>
-__global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
+__global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
                                                 uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
   // this phase's tuples: forward bins first, reverse bins after them
   const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_all);
   const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
-  if (blockIdx.x * 64u >= n_tup) return;
+  // up to PG_WAVES independent waves per block, as many as the LDS of a block allows (measured: 4 waves per block 1.70 ms, one wave per block 1.57 ms)
+  const uint32_t vb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);          // this wave's 64 tuples
+  if (vb * 64u >= n_tup) return;
   SMR_DYN_LDS(uint32_t, lds_dyn);
-  uint32_t* hl = lds_dyn;
+  uint32_t* hl = lds_dyn + (threadIdx.x >> 6) * PG_LDS_WORDS(hcap, ccap);
   uint32_t* cdk = hl + 64 * hcap;                          // rank in the reference's traversal order
   uint32_t* cdv = cdk + ccap;                              // id
   uint32_t* cdn = cdv + ccap;                              // next record of the same search | kind << 16
-  __shared__ uint32_t s_ncand;
+  __shared__ uint32_t s_ncand_[PG_WAVES];
+  uint32_t& s_ncand = s_ncand_[threadIdx.x >> 6];
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, h = pw / 2;
   const bool full = P.is_full_search != 0;
@@ -62,8 +71,8 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
 #endif
 
   // ---- the wave's 64 searches ----
-  const uint32_t pos = first + blockIdx.x * 64u + lane;
-  bool mine = blockIdx.x * 64u + lane < n_tup;
+  const uint32_t pos = first + vb * 64u + lane;
+  bool mine = vb * 64u + lane < n_tup;
   uint32_t win_pos = 0, nh = 0, n_prev = 0, P9 = 0;
   uint2 rt = make_uint2(NONE, 0);
   size_t slot = 0;
@@ -91,18 +100,18 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   __syncthreads();
   GPH(0)
 
-  // ---- the four directory ranges of the search: [0] in EA, [1..3] (S0, S1, S2) in EB ----
+  // ---- the four directory ranges of the search: [0] in TA, [1..3] (S0, S1, S2) in TB ----
   uint32_t rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0;
   uint32_t kA = 0, kb0 = 0, kb1 = 0, cA = 0, cB = 0, n = 0;
-  const uint32_t* ents = nullptr;
+  const uint32_t* tt = nullptr;                            // the block's strings TA TB, followed by {rank, id} RA RB
   if (mine && rt.x != NONE) {
     n = rt.y & 0xFFFFFFu; cA = (rt.y >> 24) & 15u; cB = rt.y >> 28;
     const uint32_t* blk = ix.pg + (size_t)rt.x * 4;
-    if (cA == 0) { rn0 = n; ents = blk; }
+    if (cA == 0) { rn0 = n; tt = blk; }
     else {
       const uint32_t nA = (1u << (2 * cA)) + 1u, nB = (1u << (2 * cB)) + 1u;
       const uint32_t* dirA = blk; const uint32_t* dirB = blk + nA;
-      ents = dirB + nB;
+      tt = dirB + nB;
       const uint32_t rev = pg_reversed(P9);
       kA = pg_rkey(rev, 0, cA); kb0 = pg_rkey(rev, h, cB); kb1 = pg_rkey(rev, h - 1, cB);
       uint32_t lo2, hi2;
@@ -125,18 +134,18 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   GPH(1)
   // ---- every lane walks its ranges; accepted entries go to the wave's candidate pool, chained per search ----
   uint32_t head = PG_NIL;
-  // (two entries per trip: both loads are in flight before either is looked at)
-  // the lane's walk over its ranges: next entry, entries left in the current range, its number; the ranges still to come wait in (q*s, q*n)
-  const uint32_t* cur = ents + 3 * (size_t)rs0;
-  const uint32_t* const eb = ents + 3 * (size_t)n;
-  uint32_t rng = 0, left = rn0;
+  // (PG_TRIP strings per trip: their loads are all in flight before the first is looked at -- the kernel is bound by memory latency)
+  // the lane's walk over its ranges: next string (index into TA TB), strings left in the current range, its number; the ranges still to
+  // come wait in (q*s, q*n)
+  const uint32_t* const rr = tt + (cA ? 2 : 1) * (size_t)n;
+  uint32_t cur = rs0, rng = 0, left = rn0;
   uint32_t q1s = rs1, q1n = rn1, q2s = rs2, q2n = rn2, q3s = rs3, q3n = rn3;
-#define PG_NEXT_RANGE() { rng++; left = q1n; cur = eb + 3 * (size_t)q1s; q1s = q2s; q1n = q2n; q2s = q3s; q2n = q3n; q3n = 0; }
-#define PG_STEP(e, w) { if (left == 0) { PG_NEXT_RANGE() if (left == 0) { PG_NEXT_RANGE() if (left == 0) PG_NEXT_RANGE() } } e = cur; cur += 3; left--; w = rng; }
+#define PG_NEXT_RANGE() { rng++; left = q1n; cur = n + q1s; q1s = q2s; q1n = q2n; q2s = q3s; q2n = q3n; q3n = 0; }
+#define PG_STEP(u, w) { if (left == 0) { PG_NEXT_RANGE() if (left == 0) { PG_NEXT_RANGE() if (left == 0) PG_NEXT_RANGE() } } u = cur; cur++; left--; w = rng; }
   // "reachable through an earlier key of this search" needs no reversed strings: the keys are runs of chars, compared in place
   const uint32_t mA = (1u << (2 * cA)) - 1u, mB = (1u << (2 * cB)) - 1u;
   const uint32_t pb0 = (P9 >> (2 * h)) & mB, pb1 = (P9 >> (2 * h - 2)) & mB;
-  auto look = [&](uint32_t w, uint32_t T, uint32_t rk, uint32_t id) {
+  auto look = [&](uint32_t w, uint32_t T, uint32_t u) {
     bool dup = false;
     if (w) {
       dup = ((T ^ P9) & mA) == 0;                          // under key A
@@ -145,20 +154,21 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
     const uint32_t r = dup ? 0u : lev1_entry(P9, T, pw);
     if (r & 1u) {
       const uint32_t p = atomicAdd(&s_ncand, 1u);
-      if (p < ccap) { cdk[p] = rk; cdv[p] = id; cdn[p] = head | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16); head = p; }
+      if (p < ccap) { const uint32_t* ri = rr + 2 * (size_t)u; cdk[p] = ri[0]; cdv[p] = ri[1]; cdn[p] = head | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16); head = p; }
     }
   };
-  for (uint32_t i = 0; __any(i < tot); i += 2) {
+  for (uint32_t i = 0; __any(i < tot); i += PG_TRIP) {
     if (i < tot) {
-      uint32_t w0, w1 = 0;
-      const uint32_t* e0; const uint32_t* e1;
-      PG_STEP(e0, w0)
-      const bool two = i + 1 < tot;
-      e1 = e0;
-      if (two) PG_STEP(e1, w1)
-      const uint32_t T0 = e0[0], k0 = e0[1], d0 = e0[2], T1 = e1[0], k1 = e1[1], d1 = e1[2];
-      look(w0, T0, k0, d0);
-      if (two) look(w1, T1, k1, d1);
+      uint32_t u[PG_TRIP], w[PG_TRIP], T[PG_TRIP];
+#pragma unroll
+      for (int q = 0; q < PG_TRIP; q++) {
+        if (q == 0 || i + q < tot) PG_STEP(u[q], w[q])
+        else { u[q] = u[0]; w[q] = 0; }                    // (a string that exists; not looked at)
+      }
+#pragma unroll
+      for (int q = 0; q < PG_TRIP; q++) T[q] = tt[u[q]];
+#pragma unroll
+      for (int q = 0; q < PG_TRIP; q++) if (i + q < tot) look(w[q], T[q], u[q]);
     }
   }
   __syncthreads();
@@ -167,7 +177,7 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
     if (lane == 0) {
       atomicAdd(&ctr[C_SEED_REDO], 1ull);
       const uint32_t p = atomicAdd(&sb.sn[SN_REDO], 1u);
-      if (p < sb.cap_redo) sb.redo[p] = blockIdx.x; else atomicAdd(&ctr[C_ERR_REDO], 1ull);
+      if (p < sb.cap_redo) sb.redo[p] = vb; else atomicAdd(&ctr[C_ERR_REDO], 1ull);
     }
     return;
   }
@@ -201,7 +211,7 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   uint32_t base = 0;
   if (total) {
     if (lane == 0) {
-      const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
+      const uint32_t shard = vb & (C_NSHARD - 1), region = pool_words / C_NSHARD;
       const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], (unsigned long long)total);
       if (old + total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = shard * region + (uint32_t)old;
     }
@@ -217,7 +227,7 @@ __global__ void __launch_bounds__(64, 8) k_seed_pg(DIndex ix, DParams P, int pas
   if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); }
 #ifdef SMR_SEED_PHASES
   GPH(5)
-  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
+  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (vb & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
 #endif
 }
 
