@@ -20,7 +20,7 @@ namespace {
 struct DevIndex {
   bool used = false;
   Lookup* lookup = nullptr; uint32_t* trie = nullptr; uint32_t* pos_off = nullptr; uint2* pos_arr = nullptr;
-  uint32_t* pg = nullptr; uint32_t* root3 = nullptr;
+  uint32_t* pg = nullptr; uint32_t* root3 = nullptr; uint32_t* lkc = nullptr;
   uint8_t* ref_seq = nullptr; uint64_t* ref_off = nullptr;
   uint32_t n_refs = 0, n_ids = 0, lnwin = 0;
   uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0;
@@ -131,6 +131,7 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
 int check_params(smr_ctx* c, const smr_params* p) {
   if (!p) { c->err = "null params"; return SMR_ERR_ARG; }
   if (p->index_num >= 64) { c->err = "index_num must be < 64"; return SMR_ERR_ARG; }
+  if ((uint64_t)p->minoccur >= 0x3FFFFFFFull) { c->err = "minoccur must be < 2^30 - 1"; return SMR_ERR_ARG; }
   if (p->num_seeds < 1 || p->gap_open < 0 || p->gap_ext < 0 || p->match <= 0 || p->mismatch > 0) { c->err = "bad scoring/seed options"; return SMR_ERR_ARG; }
   // the reference's scoring matrix is int8_t (ssw_init, ssw.h:88); the SW kernel keeps a row's scores as 4 signed bytes
   if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { c->err = "scores must fit int8 / gaps uint8 like the reference's"; return SMR_ERR_ARG; }
@@ -144,7 +145,7 @@ int check_params(smr_ctx* c, const smr_params* p) {
 }
 
 DIndex dindex(const DevIndex& d) {
-  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.pg = d.pg; x.root3 = reinterpret_cast<const uint2*>(d.root3); x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
+  DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.pg = d.pg; x.lkc = d.lkc; x.root3 = reinterpret_cast<const uint2*>(d.root3); x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
   x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2;
   return x;
 }
@@ -757,6 +758,8 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   if ((rc = dev_alloc(c, &d.root3, ix->root3.size()))) return rc;
   HIPCHK(c, hipMemcpyAsync(d.pg, ix->pg.data(), ix->pg.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.root3, ix->root3.data(), ix->root3.size() * 4, hipMemcpyHostToDevice, c->stream));
+  if ((rc = dev_alloc(c, &d.lkc, ix->lkc.size()))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d.lkc, ix->lkc.data(), ix->lkc.size() * 4, hipMemcpyHostToDevice, c->stream));
   if ((rc = dev_alloc(c, &d.lookup, ix->lookup.size()))) return rc;
   if ((rc = dev_alloc(c, &d.trie, ix->trie.size()))) return rc;
   if ((rc = dev_alloc(c, &d.pos_off, ix->pos_off.size()))) return rc;
@@ -777,7 +780,7 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
 extern "C" int smr_index_unload(smr_ctx* c, int slot) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
   DevIndex& d = c->idx[slot];
-  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.pg); dev_free(&d.root3); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
+  dev_free(&d.lookup); dev_free(&d.trie); dev_free(&d.pg); dev_free(&d.root3); dev_free(&d.lkc); dev_free(&d.pos_off); dev_free(&d.pos_arr); dev_free(&d.ref_seq); dev_free(&d.ref_off);
   d = DevIndex();
   return SMR_OK;
 }

@@ -79,6 +79,7 @@ struct smr_index {
   std::vector<uint64_t> ref_off;        // n_refs + 1
   uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
   std::vector<uint32_t> pg;             // pigeonhole arena (smr_build_pigeonhole)
+  std::vector<uint32_t> lkc;            // per key: min(count, 2^30 - 1) | forward mini-trie present << 30 | reverse present << 31 (what the window scan needs of `lookup`, in one word)
   std::vector<uint32_t> root3;          // 2 * 2 * 4^(L/2) words: {block offset / 4, n | cA << 24 | cB << 28} of the forward / reverse mini-trie of key k at [2k], [2k+1]
   std::mutex pg_mutex;                  // smr_build_pigeonhole runs once, whichever thread / context asks first (several smr_ctx may upload the same host index)
   // whole-DB statistics (.stats)

@@ -539,6 +539,9 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
         for (int d = 0; d < 2; d++) if (root3[2 * (2 * k + d)] != NONE) root3[2 * (2 * k + d)] += (uint32_t)(tbase[t] / 4);
     }
   });
+  ix.lkc.resize(nk);
+  for (size_t k = 0; k < nk; k++)
+    ix.lkc[k] = std::min<uint32_t>(ix.lookup[k].count, 0x3FFFFFFFu) | (ix.lookup[k].rootF != NONE ? 1u << 30 : 0u) | (ix.lookup[k].rootR != NONE ? 1u << 31 : 0u);
   ix.root3.swap(root3);
   return true;
 }

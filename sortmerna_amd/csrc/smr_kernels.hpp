@@ -38,6 +38,7 @@ namespace smr {
 // ------------------------------------------------------------------------------------------------
 struct DIndex {
   const Lookup* lookup;
+  const uint32_t* lkc;         // min(count, 2^30 - 1) | forward mini-trie present << 30 | reverse present << 31
   const uint32_t* trie;
   const uint32_t* pg;          // pigeonhole arena (smr_host.hpp) and its block table: forward / reverse mini-trie of key k at [2k], [2k+1] = {offset / 4, n | cA << 24 | cB << 28}
   const uint2* root3;

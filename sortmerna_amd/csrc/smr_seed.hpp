@@ -140,7 +140,7 @@ enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device co
 struct SeedTmp { uint32_t key, lo, hi; };               // 12 bytes; payload = lo | hi << 32: read | win_pos << 24 | chars << 40
 __device__ __forceinline__ unsigned long long seed_payload(const SeedTmp& t) { return (unsigned long long)t.lo | ((unsigned long long)t.hi << 32); }
 
-#define SEED_SPLIT_CHUNK 16384u                           // tuples per block of k_seed_split
+#define SEED_SPLIT_CHUNK 32768u                           // tuples per block of k_seed_split
 struct SeedBufs {
   uint32_t* chist;           // [nc + 1] tuples per COARSE bin (key >> fb)
   uint32_t* cbase;           // [nc + 1] exclusive scan of chist
@@ -227,9 +227,9 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
         ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
         rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
         is_win = 1;
-        const Lookup lf = ix.lookup[ra], lr = ix.lookup[rb];
-        emit[0] = lf.count > P.minoccur && lf.rootF != NONE;
-        emit[1] = lr.count > P.minoccur && lr.rootR != NONE;
+        const uint32_t lf = ix.lkc[ra], lr = ix.lkc[rb];          // lookup_tbl[kmer].count and the presence of trie_F / trie_R (paralleltraversal.cpp:155-160, 186-192)
+        emit[0] = (lf & 0x3FFFFFFFu) > P.minoccur && ((lf >> 30) & 1u);
+        emit[1] = (lr & 0x3FFFFFFFu) > P.minoccur && (lr >> 31);
         key[0] = ra; key[1] = sb.nkh + rb;
         const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
         payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
