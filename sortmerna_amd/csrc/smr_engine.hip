@@ -693,6 +693,7 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
     delete c; return SMR_ERR_DEVICE;
   }
   if (const char* e = getenv("SMR_SEED_EXACT")) c->seed_exact = atoi(e) != 0;
+  if (const char* e = getenv("SMR_PG_CAND_CAP")) c->ccap = std::min<uint32_t>(PG_CAND_CAP_MAX, std::max<uint32_t>(4u, (uint32_t)atoi(e)));      // test aid: a small candidate pool
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   if (hipMalloc((void**)&c->b->d_ctr, C_TOTAL * 8) != hipSuccess) { if (err && errcap) snprintf(err, errcap, "hipMalloc failed"); delete c; return SMR_ERR_DEVICE; }

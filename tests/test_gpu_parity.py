@@ -277,6 +277,68 @@ def test_long_reads_with_large_gaps(engine, tmp_path, scoring):
     assert max(a["read_end1"] - a["read_begin1"] for a in spans) > 2500          # alignments really span the gap
 
 
+@pytest.mark.parametrize("lnwin,db_nt,family", [(18, 300_000, 40), (18, 3_000_000, 40), (14, 3_000_000, 8), (12, 300_000, 40)],
+                         ids=["L18-scan-blocks", "L18-partial-directories", "L14-full-directories", "L12-full-directories"])
+def test_pigeonhole_seed_kernel_equals_the_dfs_kernel(tmp_path, lnwin, db_nt, family):
+    """k_seed_pg (exact-key directories of the pigeonhole layout, candidates applied by stored DFS rank) against k_seed_search (the
+    reference's DFS with the table automaton) on index shapes that exercise every kind of block: the (read, id, window) hit triples of
+    every strand and pass must be the same set, and the fast kernel must really have produced them (no wave handed to the DFS kernel)."""
+    import numpy as np
+    w = Workload(str(tmp_path), db_nt=db_nt, n_reads=1500, seed=lnwin + db_nt % 97, frac_db=0.5, lnwin=lnwin, family_size=family)
+    p = smr.default_params(minimal_score=w.minimal_score)
+    p.lnwin = lnwin
+    p.skiplengths[0], p.skiplengths[1], p.skiplengths[2] = lnwin, lnwin // 2, 3
+    e = smr.Engine(0)
+    try:
+        e.upload_reads(w.reads, 1)
+        e.upload_index(w.parts[0], 0)
+        res = {}
+        for mode in (0, 1):
+            e.set_seed_mode(mode)
+            e.prof_reset()
+            out = []
+            for strand in (0, 1):
+                for pass_ in (0, 1, 2):
+                    e.reset_state()
+                    n = e.seed_scan(0, p, strand, pass_)
+                    got = e.seed_hits()
+                    assert len(got) == n
+                    out.append(got[np.lexsort((got[:, 2], got[:, 1], got[:, 0]))])
+            pr = e.prof()
+            res[mode] = (out, pr.n_seed_redo, pr.n_entry)
+        for a, b in zip(res[0][0], res[1][0]):
+            assert np.array_equal(a, b)
+        assert sum(len(x) for x in res[0][0]) > 10000
+        assert res[0][1] == 0 and res[1][1] == 0, "waves of the fast kernel were searched again by the DFS kernel"
+        if lnwin < 18 or db_nt > 1_000_000:
+            assert res[0][2] < res[1][2], "the directories did not narrow the search"
+    finally:
+        e.close()
+
+
+def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
+    """SMR_PG_CAND_CAP=8: most waves of k_seed_pg overflow their candidate pool and are searched again by the DFS kernel -- the records
+    stay the oracle's -- and smr_align_part doubles the pool for the next part, so a second run over the same reads is redone less."""
+    monkeypatch.setenv("SMR_PG_CAND_CAP", "8")
+    e = smr.Engine(0)
+    try:
+        recs_o, _ = wl.oracle_records()
+        e.prof_reset()
+        recs_g, _ = wl.gpu_records(e)
+        _compare(recs_g, recs_o, "small candidate pool")
+        first = e.prof().n_seed_redo
+        assert first > 0
+        e.prof_reset()
+        for _ in range(4):
+            wl.gpu_records(e)
+        e.prof_reset()
+        recs_g, _ = wl.gpu_records(e)
+        _compare(recs_g, recs_o, "grown candidate pool")
+        assert e.prof().n_seed_redo < first
+    finally:
+        e.close()
+
+
 def test_seed_work_counters_match_oracle(wl):
     """The numerator of bench.py's roofline: the device work counters of the per-lane DFS seed kernel (smr_prof_get in seed mode 1:
     windows searched, 9-mer lookups, trie nodes visited, bucket entries compared, seed hits) equal the oracle's counters of the
