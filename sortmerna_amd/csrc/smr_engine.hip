@@ -236,15 +236,15 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   const uint32_t pgw = (uint32_t)std::max<size_t>(1, std::min<size_t>(PG_WAVES, (60 * 1024) / lds_pg1));      // waves per block of k_seed_pg
   const size_t lds_pg = lds_pg1 * pgw;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gw = (uint32_t)((slots + 63) / 64), gk4 = (uint32_t)((slots + 1023) / 1024);
+  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((slots + 63) / 64)), gk4 = (uint32_t)((slots + 1023) / 1024);     // (every kernel checks its range: a batch without a single window launches one idle block each)
   ev_begin(c, 0);
   // one two-level counting sort for the forward and the reverse tuples of the stage (smr_seed.hpp)
   HIPCHK(c, hipMemsetAsync(sb.chist, 0, ((size_t)sb.nc + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
   if (slots) HIPCHK(c, hipMemsetAsync(sb.wseg, 0xFF, (size_t)slots * 4, c->stream));       // NONE: no window has hits yet
-  hipLaunchKernelGGL(k_seed_keys, dim3(std::min<uint32_t>(gk4, 2048u)), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, gk4);
+  hipLaunchKernelGGL(k_seed_keys, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(gk4, 2048u))), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, gk4);
   hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_split, dim3((uint32_t)((2 * slots + SEED_SPLIT_CHUNK - 1) / SEED_SPLIT_CHUNK)), dim3(1024), (size_t)sb.nc * 8, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_split, dim3(std::max<uint32_t>(1u, (uint32_t)((2 * slots + SEED_SPLIT_CHUNK - 1) / SEED_SPLIT_CHUNK))), dim3(1024), (size_t)sb.nc * 8, c->stream, sb);
   hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), 0, c->stream, sb);
   for (int dir = 0; dir < 2; dir++) {
     const uint32_t* no_redo = nullptr;

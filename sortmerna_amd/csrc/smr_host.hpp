@@ -1,6 +1,7 @@
 // smr_host.hpp -- host-side data model of libsmr_hip (index part, read batch).  Internal header.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <mutex>
@@ -61,6 +62,19 @@ __host__ __device__ inline uint32_t pg_key(uint32_t T, uint32_t from, uint32_t c
   return k;
 }
 
+// plain u32 buffer whose allocation does not zero-fill (the GBs of the pigeonhole arena are written exactly once, by many threads)
+struct WordBuf {
+  uint32_t* p = nullptr; size_t n = 0;
+  WordBuf() = default;
+  WordBuf(const WordBuf&) = delete;
+  WordBuf& operator=(const WordBuf&) = delete;
+  ~WordBuf() { free(p); }
+  uint32_t* data() { return p; }
+  const uint32_t* data() const { return p; }
+  size_t size() const { return n; }
+  bool resize_uninitialized(size_t m) { free(p); p = static_cast<uint32_t*>(malloc(m * 4 + 16)); n = p ? m : 0; return p != nullptr; }
+};
+
 struct PartStats {
   uint64_t start_part = 0, seq_part_size = 0;
   uint32_t numseq_part = 0;
@@ -78,7 +92,7 @@ struct smr_index {
   std::vector<uint8_t> ref_seq;         // 0..4 per nt (References::convert_fix, references.cpp:162-169)
   std::vector<uint64_t> ref_off;        // n_refs + 1
   uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0;
-  std::vector<uint32_t> pg;             // pigeonhole arena (smr_build_pigeonhole)
+  smr::WordBuf pg;                      // pigeonhole arena (smr_build_pigeonhole)
   std::vector<uint32_t> lkc;            // per key: min(count, 2^30 - 1) | forward mini-trie present << 30 | reverse present << 31 (what the window scan needs of `lookup`, in one word)
   std::vector<uint32_t> root3;          // 2 * 2 * 4^(L/2) words: {block offset / 4, n | cA << 24 | cB << 28} of the forward / reverse mini-trie of key k at [2k], [2k+1]
   std::mutex pg_mutex;                  // smr_build_pigeonhole runs once, whichever thread / context asks first (several smr_ctx may upload the same host index)

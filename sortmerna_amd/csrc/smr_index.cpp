@@ -465,80 +465,128 @@ void bucket_sort_u64(std::vector<uint64_t>& a, int keybits, uint32_t threads) {
 
 // ---- pigeonhole arena (smr_host.hpp) -------------------------------------------------------------
 
+namespace {
+uint32_t pg_count(const uint32_t* t, uint32_t node) {
+  uint32_t n = 0;
+  for (int ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    if (fl == 2) n += (e >> ELEM_NENT_SHIFT) & 0xFFu;
+    else if (fl == 1) n += pg_count(t, e & ELEM_OFF_MASK);
+  }
+  return n;
+}
+// pg_collect that also notes where each bucket starts in `out`
+void pg_collect_b(const uint32_t* t, uint32_t node, uint32_t pre, uint32_t plen, std::vector<PgEnt>& out, std::vector<uint32_t>& bstart) {
+  for (uint32_t ne = 0; ne < 4; ne++) {
+    const uint32_t e = t[node + ne], fl = e >> ELEM_FLAG_SHIFT;
+    const uint32_t p2 = pre | (ne << (2 * plen));
+    if (fl == 2) {
+      const uint32_t n = (e >> ELEM_NENT_SHIFT) & 0xFFu;
+      const uint32_t* b = t + (e & ELEM_OFF_MASK);
+      bstart.push_back((uint32_t)out.size());
+      for (uint32_t q = 0; q < n; q++) out.push_back({p2 | (b[2 * q] << (2 * (plen + 1))), b[2 * q + 1]});
+    } else if (fl == 1) pg_collect_b(t, e & ELEM_OFF_MASK, p2, plen + 1, out, bstart);
+  }
+}
+inline size_t pg_block_words(uint32_t n, uint32_t pw) {
+  uint32_t cA, cB;
+  pg_chars(n, pw, cA, cB);
+  const size_t w = cA ? (size_t)(1u << (2 * cA)) + 1 + (1u << (2 * cB)) + 1 + 6 * (size_t)n : 3 * (size_t)n;
+  return (w + 3) & ~(size_t)3;
+}
+}  // namespace
+
 bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
   std::lock_guard<std::mutex> once(ix.pg_mutex);
   if (!ix.root3.empty()) return true;
+  StageTimer tm;
   const size_t nk = ix.lookup.size();
   const uint32_t pw = ix.lnwin / 2, h = pw / 2;
   if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
   threads = std::min<uint32_t>(threads, 64);
-  std::vector<std::vector<uint32_t>> local(threads);
+  // pass 1: entries per mini-trie -> block sizes -> block offsets
+  std::vector<uint32_t> cnt(2 * nk, 0);
+  parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t) {
+    for (size_t k = lo; k < hi; k++)
+      for (int d = 0; d < 2; d++) {
+        const uint32_t root = d == 0 ? ix.lookup[k].rootF : ix.lookup[k].rootR;
+        if (root != NONE) cnt[2 * k + d] = pg_count(ix.trie.data() + root, 0);
+      }
+  });
   std::vector<uint32_t> root3(4 * nk, 0);
-  for (size_t i = 0; i < 2 * nk; i++) root3[2 * i] = NONE;
-  std::vector<size_t> t_lo(threads, 0), t_hi(threads, 0);
-  bool ok = true;
-  parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
-    t_lo[tid] = lo; t_hi[tid] = hi;
-    std::vector<uint32_t>& out = local[tid];
+  size_t total = 0;
+  for (size_t i = 0; i < 2 * nk; i++) {
+    const bool present = (i & 1 ? ix.lookup[i >> 1].rootR : ix.lookup[i >> 1].rootF) != NONE;
+    if (!present) { root3[2 * i] = NONE; continue; }
+    if (cnt[i] > 0xFFFFFFu) { why = "a mini-trie is too large for the pigeonhole layout"; return false; }
+    if (total / 4 > 0xFFFFFFF0ull) { why = "pigeonhole arena exceeds 2^34 words"; return false; }
+    uint32_t cA, cB;
+    pg_chars(cnt[i], pw, cA, cB);
+    root3[2 * i] = (uint32_t)(total / 4);
+    root3[2 * i + 1] = cnt[i] | (cA << 24) | (cB << 28);
+    total += pg_block_words(cnt[i], pw);
+  }
+  if (!ix.pg.resize_uninitialized(total + 4)) { why = "out of host memory for the pigeonhole arena"; return false; }      // + one block of slack: a 16-byte read at the last word stays inside
+  for (size_t i = 0; i < 4; i++) ix.pg.data()[total + i] = 0;
+  tm.lap("pigeonhole layout: sizes");
+  // pass 2: every block in place
+  parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t) {
     std::vector<PgEnt> v;
+    std::vector<uint32_t> bstart, ordB, cntB;
     std::vector<uint64_t> ord;
     for (size_t k = lo; k < hi; k++) {
       for (int d = 0; d < 2; d++) {
         const uint32_t root = d == 0 ? ix.lookup[k].rootF : ix.lookup[k].rootR;
         if (root == NONE) continue;
-        v.clear();
-        pg_collect(ix.trie.data() + root, 0, 0, 0, v);          // complete strings (char j at bits 2j) in DFS order
+        v.clear(); bstart.clear();
+        pg_collect_b(ix.trie.data() + root, 0, 0, 0, v, bstart);   // complete strings (char j at bits 2j) in DFS order
         const uint32_t n = (uint32_t)v.size();
-        if (n > 0xFFFFFFu) { ok = false; return; }
         uint32_t cA, cB;
         pg_chars(n, pw, cA, cB);
-        const size_t base = out.size();
-        if (base / 4 > 0xFFFFFFF0ull) { ok = false; return; }
-        root3[2 * (2 * k + d)] = (uint32_t)(base / 4);         // thread-local for now
-        root3[2 * (2 * k + d) + 1] = n | (cA << 24) | (cB << 28);
+        uint32_t* blk = ix.pg.data() + (size_t)root3[2 * (2 * k + d)] * 4;
+        const size_t words = pg_block_words(n, pw);
         if (cA == 0) {
-          for (uint32_t r = 0; r < n; r++) out.push_back(v[r].str);
-          for (uint32_t r = 0; r < n; r++) { out.push_back(r); out.push_back(v[r].id); }
-        } else {
-          const uint32_t nA = (1u << (2 * cA)) + 1, nB = (1u << (2 * cB)) + 1;
-          out.resize(base + nA + nB + 6 * (size_t)n);
-          uint32_t* dirA = out.data() + base; uint32_t* dirB = dirA + nA; uint32_t* TT = dirB + nB; uint32_t* RR = TT + 2 * (size_t)n;     // TA TB | RA RB
-          for (int o = 0; o < 2; o++) {
-            ord.resize(n);
-            for (uint32_t r = 0; r < n; r++) {
-              const uint64_t key = o == 0 ? pg_key(v[r].str, 0, pw + 1) : (((uint64_t)pg_key(v[r].str, h, pw - h) << 32) | r);
-              ord[r] = o == 0 ? ((key << 32) | r) : key;
-            }
-            std::sort(ord.begin(), ord.end());
-            uint32_t* Ts = TT + (o ? n : 0); uint32_t* Rs = RR + (o ? 2 * (size_t)n : 0); uint32_t* dir = o == 0 ? dirA : dirB;
-            const uint32_t c = o == 0 ? cA : cB, from = o == 0 ? 0 : h, nd = o == 0 ? nA : nB;
-            uint32_t next = 0;                                  // next directory slot to fill
-            for (uint32_t i = 0; i < n; i++) {
-              const uint32_t r = (uint32_t)(ord[i] & 0xFFFFFFFFull);
-              Ts[i] = v[r].str; Rs[2 * i] = r; Rs[2 * i + 1] = v[r].id;
-              const uint32_t kk = pg_key(v[r].str, from, c);
-              while (next <= kk) dir[next++] = i;
-            }
-            while (next < nd) dir[next++] = n;
-          }
+          for (uint32_t r = 0; r < n; r++) { blk[r] = v[r].str; blk[n + 2 * r] = r; blk[n + 2 * r + 1] = v[r].id; }
+          for (size_t q = 3 * (size_t)n; q < words; q++) blk[q] = 0;
+          continue;
         }
-        while (out.size() & 3u) out.push_back(0);
+        const uint32_t nA = (1u << (2 * cA)) + 1, nB = (1u << (2 * cB)) + 1;
+        uint32_t* dirA = blk; uint32_t* dirB = dirA + nA; uint32_t* TT = dirB + nB; uint32_t* RR = TT + 2 * (size_t)n;     // TA TB | RA RB
+        for (size_t q = nA + nB + 6 * (size_t)n; q < words; q++) blk[q] = 0;
+        // TA / RA: buckets come in string order (their paths are prefix-free and met in A<C<G<T order), so only each bucket is sorted
+        {
+          uint32_t next = 0, i = 0;
+          bstart.push_back(n);
+          for (size_t bq = 0; bq + 1 < bstart.size(); bq++) {
+            const uint32_t b0 = bstart[bq], b1 = bstart[bq + 1];
+            ord.resize(b1 - b0);
+            for (uint32_t r = b0; r < b1; r++) ord[r - b0] = ((uint64_t)pg_key(v[r].str, 0, pw + 1) << 32) | r;
+            std::sort(ord.begin(), ord.end());
+            for (uint32_t q = 0; q < b1 - b0; q++, i++) {
+              const uint32_t r = (uint32_t)(ord[q] & 0xFFFFFFFFull);
+              TT[i] = v[r].str; RR[2 * i] = r; RR[2 * i + 1] = v[r].id;
+              const uint32_t kk = (uint32_t)(ord[q] >> (32 + 2 * (pw + 1 - cA)));
+              while (next <= kk) dirA[next++] = i;
+            }
+          }
+          while (next < nA) dirA[next++] = n;
+        }
+        // TB / RB: counting sort by chars h..pw-1 (ranks ascending within a key)
+        {
+          const uint32_t kb = pw - h, nkeys = 1u << (2 * kb);
+          cntB.assign(nkeys + 1, 0);
+          ordB.resize(n);
+          for (uint32_t r = 0; r < n; r++) { const uint32_t kk = pg_key(v[r].str, h, kb); ordB[r] = kk; cntB[kk + 1]++; }
+          for (uint32_t q = 0; q < nkeys; q++) cntB[q + 1] += cntB[q];
+          const uint32_t sh = 2 * (kb - cB);
+          for (uint32_t q = 0; q < nB; q++) dirB[q] = q < nB - 1 ? cntB[(size_t)q << sh] : n;
+          uint32_t* TB = TT + n; uint32_t* RB = RR + 2 * (size_t)n;
+          for (uint32_t r = 0; r < n; r++) { const uint32_t i = cntB[ordB[r]]++; TB[i] = v[r].str; RB[2 * i] = r; RB[2 * i + 1] = v[r].id; }
+        }
       }
     }
   });
-  if (!ok) { why = "a mini-trie is too large for the pigeonhole layout"; return false; }
-  size_t total = 0;
-  std::vector<size_t> tbase(threads, 0);
-  for (uint32_t t = 0; t < threads; t++) { tbase[t] = total; total += local[t].size(); }
-  if (total / 4 > 0xFFFFFFF0ull) { why = "pigeonhole arena exceeds 2^34 words"; return false; }
-  ix.pg.resize(total + 4);                                       // + one block of slack: a 16-byte read at the last word stays inside
-  parallel_for(threads, threads, [&](size_t lo, size_t hi, uint32_t) {
-    for (size_t t = lo; t < hi; t++) {
-      if (!local[t].empty()) memcpy(ix.pg.data() + tbase[t], local[t].data(), local[t].size() * 4);
-      for (size_t k = t_lo[t]; k < t_hi[t]; k++)
-        for (int d = 0; d < 2; d++) if (root3[2 * (2 * k + d)] != NONE) root3[2 * (2 * k + d)] += (uint32_t)(tbase[t] / 4);
-    }
-  });
+  tm.lap("pigeonhole layout: blocks");
   ix.lkc.resize(nk);
   for (size_t k = 0; k < nk; k++)
     ix.lkc[k] = std::min<uint32_t>(ix.lookup[k].count, 0x3FFFFFFFu) | (ix.lookup[k].rootF != NONE ? 1u << 30 : 0u) | (ix.lookup[k].rootR != NONE ? 1u << 31 : 0u);
