@@ -7,7 +7,7 @@ import pytest
 
 import sortmerna_amd as smr
 from helpers import orc, refrun
-from helpers.workload import Workload, iseq_for_strand
+from helpers.workload import Workload, iseq_for_strand, GUMBEL_UNIFORM
 
 pytestmark = pytest.mark.gpu
 
@@ -337,6 +337,24 @@ def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
         assert e.prof().n_seed_redo < first
     finally:
         e.close()
+
+
+def test_batch_dominated_by_one_sequence(engine, tmp_path):
+    """3 000 copies of two reads among 500 others (a sample dominated by one organism's rRNA): all their windows share a few keys, so
+    the tuple sort sees bins of thousands (one block of k_seed_bins handles a whole coarse bin) and whole waves of k_seed_pg search the
+    same mini-trie with the same pattern"""
+    w = Workload(str(tmp_path), db_nt=200_000, n_reads=3500, seed=77, frac_db=0.6)
+    hot = [w.seqs[20], w.seqs[41]]
+    for i in range(500, 3500):
+        w.seqs[i] = hot[i & 1]
+    w.reads = smr.Reads.from_seqs(w.seqs)
+    lam, K = GUMBEL_UNIFORM
+    w.minimal_score = smr.minimal_score(lam, K, w.parts[0].info(), len(w.seqs), sum(map(len, w.seqs)))
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "hot reads")
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"]
+    assert recs_g[500] == recs_g[502] and recs_g[501] == recs_g[503]
 
 
 def test_seed_work_counters_match_oracle(wl):
