@@ -147,7 +147,7 @@ def test_mixed_read_lengths(engine, tmp_path):
 
 @pytest.mark.parametrize("lnwin", [10, 12, 14, 16])
 def test_other_seed_lengths(engine, tmp_path, lnwin):
-    """-L 12/14/16: other window lengths (partialwin 6/7/8), their trie depth limits and automaton tail tables"""
+    """-L 10/12/14/16: other window lengths (partialwin 5..8), their trie depth limits, automaton tail tables and directory widths"""
     w = Workload(str(tmp_path), db_nt=120_000, n_reads=1200, seed=50 + lnwin, frac_db=0.5, lnwin=lnwin)
     recs_o, ctr_o = w.oracle_records()
     recs_g, ctr_g = w.gpu_records(engine)
