@@ -443,7 +443,7 @@ __device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* s
 }
 
 // k_chain<EXT>: compute_lis_alignment (alignment.cpp:100-509) for the reads k_cand marked.  One block = one wave, persistent: chunks of
-// 16 reads are claimed with one atomic, their flags fetched by 16 lanes at once, the marked ones walked one by one.
+// 64 reads are claimed with one atomic, their flags fetched by the 64 lanes at once, the marked ones walked one by one.
 // Dynamic LDS (bytes), ML = max_len rounded to 16, MQ = min(ML, SW_X4_MAX_ROWS), RF = ML + 2 * edges + 16 rounded:
 //   read slots    ML + 4 MQ     the read being walked | four parked reads
 //   window slots  9 RF          0..3: batch of the read being walked, 4..7: parked tasks; slots 1..8 share their memory with the strip
@@ -522,7 +522,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   __shared__ int q_score[4], q_eref[4], q_eread[4];
   uint32_t q_n = 0, n_redo = 0, redo_slots = 0;          // parked tasks; parked reads to walk again (bit mask of their slots)
   bool q_hasn = false, need_flush = false, out_of_reads = false;
-  uint32_t chunk_base = 0, chunk_todo = 0;                // reads are claimed 16 at a time (one atomic per chunk); bit i: read chunk_base + i is still to be walked
+  uint32_t chunk_base = 0;                               // reads are claimed 64 at a time (one atomic per chunk: 31 k instead of 2 M same-address atomics per launch);
+  unsigned long long chunk_todo = 0;                     // bit i: read chunk_base + i is still to be walked
   for (;;) {
     uint32_t r;
     int mode = 0, seed_slot = -1;                         // mode 1: immediate (sequential walk), possibly seeded with the parked task's result
@@ -564,16 +565,16 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     } else {
       if (out_of_reads) break;
       if (chunk_todo == 0) {
-        // claim the next 16 reads.  Lane i looks at read i of the chunk: not in this (strand, pass) -> nothing to do; in it but without the
+        // claim the next 64 reads.  Lane i looks at read i of the chunk: not in this (strand, pass) -> nothing to do; in it but without the
         // seeds for compute_lis_alignment (:103-108) -> only the pass control, done by that lane on its own; the others are walked one by one
         __syncthreads();
-        if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 16ull);
+        if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 64ull);
         __syncthreads();
         chunk_base = s_next;
         if (chunk_base >= rd.n) { out_of_reads = true; continue; }
         bool todo = false;
         const uint32_t ri = chunk_base + (uint32_t)lane;
-        if (lane < 16 && ri < rd.n) {
+        if (ri < rd.n) {
           RWork wi = rw[ri];
           if (wi.strand_active && wi.search && wi.pass_n == (uint32_t)pass) {
             RState si = work[ri];
@@ -581,11 +582,11 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
             else finish_read(ri, si, wi, 1, true);
           }
         }
-        chunk_todo = (uint32_t)__ballot(todo);
+        chunk_todo = __ballot(todo);
         if (chunk_todo == 0) continue;
       }
       __syncthreads();
-      r = chunk_base + (uint32_t)(__ffs((int)chunk_todo) - 1);
+      r = chunk_base + (uint32_t)(__ffsll((long long)chunk_todo) - 1);
       chunk_todo &= chunk_todo - 1;
     }
     RWork w = rw[r];
@@ -596,7 +597,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     int search = 1;
     const uint32_t max_SW_score = len * (uint32_t)P.match;
     const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
-    if (!x4_ok && q_n > 0) { need_flush = true; chunk_todo |= 1u << (r - chunk_base); continue; }        // its strip boundaries would overwrite the parked windows: score those first
+    if (!x4_ok && q_n > 0) { need_flush = true; chunk_todo |= 1ull << (r - chunk_base); continue; }        // its strip boundaries would overwrite the parked windows: score those first
     bool parked = false;
 
     if (st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0) {
