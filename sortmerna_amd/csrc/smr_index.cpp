@@ -21,6 +21,11 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "smr_host.hpp"
 #include "smr_trie_layout.hpp"
 
@@ -43,6 +48,32 @@ bool slurp(const std::string& path, std::vector<uint8_t>& out) {
   fclose(f);
   return ok;
 }
+
+// read-only view of a whole file through the page cache: the GB-sized index files are parsed where they are, not copied first
+struct Mapped {
+  const uint8_t* p = nullptr; size_t n = 0;
+  Mapped() = default;
+  Mapped(const Mapped&) = delete;
+  Mapped& operator=(const Mapped&) = delete;
+  ~Mapped() { if (p && n) munmap(const_cast<uint8_t*>(p), n); }
+  bool open(const std::string& path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { ::close(fd); return false; }
+    n = (size_t)sb.st_size;
+    if (n) {
+      void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m == MAP_FAILED) { ::close(fd); n = 0; return false; }
+      madvise(m, n, MADV_SEQUENTIAL);
+      p = static_cast<const uint8_t*>(m);
+    }
+    ::close(fd);
+    return true;
+  }
+  const uint8_t* data() const { return p; }
+  size_t size() const { return n; }
+};
 
 // include/common.hpp:68-77 nt_table
 inline uint8_t nt_sw(int c) {
@@ -101,12 +132,37 @@ bool load_stats(const std::string& prefix, Stats& st) {
   return o <= b.size();
 }
 
+struct StageTimer {
+  bool on = getenv("SMR_IB_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[smr index build] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
+
+template <class F> void parallel_for(uint32_t threads, size_t n, F f) {
+  if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
+  std::vector<std::thread> th;
+  size_t chunk = (n + threads - 1) / threads;
+  for (uint32_t t = 0; t < threads; t++) {
+    size_t lo = (size_t)t * chunk, hi = std::min(n, lo + chunk);
+    if (lo >= hi) break;
+    th.emplace_back([=]() { f(lo, hi, t); });
+  }
+  for (auto& x : th) x.join();
+}
+
 // References::load (references.cpp:55-159), FASTA: numseq records starting at byte `start`.
 bool load_refs(const std::string& fasta, uint64_t start, uint32_t numseq, smr_index& ix) {
-  std::vector<uint8_t> b;
-  if (!slurp(fasta, b)) return false;
+  Mapped mf;
+  if (!mf.open(fasta)) return false;
+  const uint8_t* b = mf.data();
   ix.ref_seq.clear(); ix.ref_off.assign(1, 0);
-  size_t o = (size_t)start, n = b.size();
+  size_t o = (size_t)start, n = mf.size();
+  ix.ref_seq.reserve(n > o ? n - o : 0);
   bool have = false; uint32_t done = 0;
   while (o < n && done < numseq) {
     size_t e = o;
@@ -132,14 +188,15 @@ struct TmpElem { uint8_t flag = 0; uint32_t child = 0; uint32_t ent_begin = 0, e
 struct TmpNode { TmpElem e[4]; };
 
 // lays out one mini-trie (nodes[0] = root) in DFS order; entries = {tail,id} pairs in `ents`
+struct TrieCounts { uint64_t n_nodes = 0, n_buckets = 0, n_entries = 0; };
 bool emit_minitrie(const std::vector<TmpNode>& nodes, const std::vector<uint32_t>& ents, std::vector<uint32_t>& arena,
-                   uint32_t& root_off, smr_index& ix, std::string& why) {
+                   size_t& root_off, TrieCounts& ix, std::string& why) {
   // every node (4 words) and bucket starts on a 16-byte boundary so that the kernels can fetch a node with one
   // 128-bit load and a bucket entry with one 64-bit load: buckets with an odd entry count are padded by 2 zero words
   arena.resize((arena.size() + 3) & ~(size_t)3, 0);
   size_t base = arena.size();
   if (base > 0xFFFFFFF0ull) { why = "trie arena exceeds 2^32 words"; return false; }
-  root_off = (uint32_t)base;
+  root_off = base;
   // DFS with explicit stack; a node's 4 words are reserved when it is first visited
   std::vector<uint32_t> node_at(nodes.size(), 0);
   struct Fr { uint32_t node; int next; };
@@ -176,11 +233,10 @@ bool emit_minitrie(const std::vector<TmpNode>& nodes, const std::vector<uint32_t
 }
 
 // BFS stream of one mini-trie (index.cpp:176-316) -> TmpNode list
-bool parse_bfs(const std::vector<uint8_t>& b, size_t& o, std::vector<TmpNode>& nodes, std::vector<uint32_t>& ents) {
-  nodes.clear(); ents.clear();
-  std::vector<uint8_t> flags;
+bool parse_bfs(const uint8_t* b, size_t bn, size_t& o, std::vector<TmpNode>& nodes, std::vector<uint32_t>& ents, std::vector<uint8_t>& flags) {
+  nodes.clear(); ents.clear(); flags.clear();
   size_t hf = 0;
-  auto rd8 = [&]() -> uint8_t { return o < b.size() ? b[o++] : (o++, (uint8_t)0); };
+  auto rd8 = [&]() -> uint8_t { return o < bn ? b[o++] : (o++, (uint8_t)0); };
   nodes.emplace_back();
   for (int i = 0; i < 4; i++) flags.push_back(rd8());
   for (size_t head = 0; head < nodes.size(); head++) {
@@ -194,12 +250,12 @@ bool parse_bfs(const std::vector<uint8_t>& b, size_t& o, std::vector<TmpNode>& n
         nodes.emplace_back();
       } else if (fl == 2) {
         uint32_t sz = 0;
-        if (o + 4 <= b.size()) memcpy(&sz, b.data() + o, 4);
+        if (o + 4 <= bn) memcpy(&sz, b + o, 4);
         o += 4;
-        if (o + sz > b.size()) return false;
+        if (o + sz > bn) return false;
         el.ent_begin = (uint32_t)(ents.size() / 2); el.ent_count = sz / 8;
         size_t old = ents.size(); ents.resize(old + sz / 4);
-        memcpy(ents.data() + old, b.data() + o, sz);
+        memcpy(ents.data() + old, b + o, sz);
         o += sz;
       } else if (fl != 0) {
         return false;
@@ -207,7 +263,28 @@ bool parse_bfs(const std::vector<uint8_t>& b, size_t& o, std::vector<TmpNode>& n
       nodes[head].e[i] = el;
     }
   }
-  return o <= b.size();
+  return o <= bn;
+}
+
+// the same walk without building anything: where does the stream of this mini-trie end?
+bool skip_bfs(const uint8_t* b, size_t bn, size_t& o, std::vector<uint8_t>& flags) {
+  flags.clear();
+  size_t hf = 0, n_nodes = 1;
+  auto rd8 = [&]() -> uint8_t { return o < bn ? b[o++] : (o++, (uint8_t)0); };
+  for (int i = 0; i < 4; i++) flags.push_back(rd8());
+  for (size_t head = 0; head < n_nodes; head++) {
+    for (int i = 0; i < 4; i++) {
+      const uint8_t fl = flags[hf++];
+      if (fl == 1) { for (int k = 0; k < 4; k++) flags.push_back(rd8()); n_nodes++; }
+      else if (fl == 2) {
+        uint32_t sz = 0;
+        if (o + 4 <= bn) memcpy(&sz, b + o, 4);
+        o += 4 + (size_t)sz;
+        if (o > bn) return false;
+      } else if (fl != 0) return false;
+    }
+  }
+  return o <= bn;
 }
 
 }  // namespace
@@ -225,63 +302,129 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   ix->parts = st.parts; ix->sq_header = st.sq;
   std::string p = std::to_string(part);
   uint32_t nk = 1u << st.lnwin;
-  std::vector<uint8_t> kb, tb, pb;
-  if (!slurp(std::string(prefix) + ".kmer_" + p + ".dat", kb) || !slurp(std::string(prefix) + ".bursttrie_" + p + ".dat", tb) ||
-      !slurp(std::string(prefix) + ".pos_" + p + ".dat", pb)) {
+  StageTimer tm;
+  Mapped kb, tb, pb;                                          // parsed in place (page cache), by all host threads
+  if (!kb.open(std::string(prefix) + ".kmer_" + p + ".dat") || !tb.open(std::string(prefix) + ".bursttrie_" + p + ".dat") ||
+      !pb.open(std::string(prefix) + ".pos_" + p + ".dat")) {
     delete ix; set_err(err, errcap, "cannot read index part files"); return SMR_ERR_IO;
   }
+  const uint32_t threads = std::min<uint32_t>(64, std::max(1u, std::thread::hardware_concurrency()));
+  // the reference sequences and the position lists load in threads of their own while the tries are parsed
+  bool refs_ok = false;
+  std::thread t_refs([&]() { refs_ok = load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix); });
+  std::string pos_err;
+  std::thread t_pos([&]() {
+    // positions (index.cpp:322-352) -> CSR; keep file order (sorted by seq, then pos, by construction)
+    const uint8_t* b = pb.data(); const size_t bn = pb.size();
+    uint32_t nid = 0;
+    if (bn >= 4) memcpy(&nid, b, 4);
+    ix->pos_off.assign((size_t)nid + 1, 0);
+    std::vector<size_t> src((size_t)nid + 1, 0);             // byte offset of list i in the file
+    size_t o = 4; uint64_t total = 0;
+    for (uint32_t i = 0; i < nid; i++) {
+      uint32_t sz = 0;
+      if (o + 4 <= bn) memcpy(&sz, b + o, 4);
+      o += 4;
+      if (o + (size_t)sz * 8 > bn) { pos_err = "malformed pos file"; return; }
+      src[i] = o; o += (size_t)sz * 8; total += sz;
+      if (total > 0xFFFFFFFFull) { pos_err = "more than 2^32 positions"; return; }
+      ix->pos_off[i + 1] = (uint32_t)total;
+    }
+    ix->pos_arr.resize((size_t)total * 2);
+    parallel_for(std::max(1u, threads / 4), nid, [&](size_t lo, size_t hi, uint32_t) {
+      std::vector<std::pair<uint32_t, uint32_t>> v;
+      for (size_t i = lo; i < hi; i++) {
+        const uint32_t sz = ix->pos_off[i + 1] - ix->pos_off[i];
+        uint32_t* dst = ix->pos_arr.data() + (size_t)ix->pos_off[i] * 2;
+        memcpy(dst, b + src[i], (size_t)sz * 8);
+        // the device code binary-searches each list by seq: enforce (seq,pos) order
+        bool sorted = true;
+        for (uint32_t k = 1; k < sz && sorted; k++) {
+          const uint32_t* a = dst + (size_t)(k - 1) * 2;
+          if (a[1] > a[3] || (a[1] == a[3] && a[0] > a[2])) sorted = false;
+        }
+        if (!sorted) {
+          v.resize(sz);
+          for (uint32_t k = 0; k < sz; k++) v[k] = {dst[2 * k + 1], dst[2 * k]};
+          std::sort(v.begin(), v.end());
+          for (uint32_t k = 0; k < sz; k++) { dst[2 * k] = v[k].second; dst[2 * k + 1] = v[k].first; }
+        }
+      }
+    });
+  });
   ix->lookup.assign(nk, Lookup{0, NONE, NONE, 0, 0});
   for (uint32_t i = 0; i < nk && (size_t)(i + 1) * 4 <= kb.size(); i++) memcpy(&ix->lookup[i].count, kb.data() + (size_t)i * 4, 4);
-  size_t o = 0;
-  std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::string why;
-  for (uint32_t i = 0; i < nk && o < tb.size(); i++) {
-    uint32_t sz[2] = {0, 0};
-    if (o + 8 <= tb.size()) memcpy(sz, tb.data() + o, 8);
-    o += 8;
-    if (ix->lookup[i].count == 0) continue;       // index.cpp:190: tries are only read when count != 0
-    for (int j = 0; j < 2; j++) {
-      if (sz[j] == 0) continue;
-      uint32_t root = NONE;
-      if (!parse_bfs(tb, o, nodes, ents) || !emit_minitrie(nodes, ents, ix->trie, root, *ix, why)) {
-        delete ix; set_err(err, errcap, "malformed burst trie file: " + why); return SMR_ERR_IO;
+  // mini-tries: one sequential walk over the BFS streams finds where each begins (the sizes in the file are the reference's in-memory
+  // sizes, index.cpp:178-190, not stream lengths), then key ranges are parsed and laid out by all threads into arenas of their own
+  std::string why;
+  bool tries_ok = true;
+  {
+    const uint8_t* b = tb.data(); const size_t bn = tb.size();
+    std::vector<size_t> start(2 * (size_t)nk, (size_t)-1);
+    {
+      std::vector<uint8_t> flags;
+      size_t o = 0;
+      for (uint32_t i = 0; i < nk && o < bn && tries_ok; i++) {
+        uint32_t sz[2] = {0, 0};
+        if (o + 8 <= bn) memcpy(sz, b + o, 8);
+        o += 8;
+        if (ix->lookup[i].count == 0) continue;       // index.cpp:190: tries are only read when count != 0
+        for (int j = 0; j < 2 && tries_ok; j++) {
+          if (sz[j] == 0) continue;
+          start[2 * (size_t)i + j] = o;
+          if (!skip_bfs(b, bn, o, flags)) { tries_ok = false; why = "truncated stream"; }
+        }
       }
-      if (j == 0) { ix->lookup[i].rootF = root; ix->lookup[i].wordsF = (uint32_t)(ix->trie.size() - root); }
-      else { ix->lookup[i].rootR = root; ix->lookup[i].wordsR = (uint32_t)(ix->trie.size() - root); }
+    }
+    tm.lap("load: mini-trie boundaries");
+    std::vector<std::vector<uint32_t>> local(threads);
+    std::vector<TrieCounts> cnt(threads);
+    std::vector<size_t> t_lo(threads, 0), t_hi(threads, 0);
+    std::vector<size_t> rootw(2 * (size_t)nk, (size_t)-1), endw(2 * (size_t)nk, 0);     // thread-local word offsets
+    std::vector<std::string> twhy(threads);
+    if (tries_ok) parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
+      t_lo[tid] = lo; t_hi[tid] = hi;
+      std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::vector<uint8_t> flags;
+      for (size_t i = lo; i < hi; i++)
+        for (int j = 0; j < 2; j++) {
+          size_t o = start[2 * i + j];
+          if (o == (size_t)-1) continue;
+          if (!parse_bfs(b, bn, o, nodes, ents, flags) || !emit_minitrie(nodes, ents, local[tid], rootw[2 * i + j], cnt[tid], twhy[tid])) {
+            if (twhy[tid].empty()) twhy[tid] = "malformed stream";
+            return;
+          }
+          endw[2 * i + j] = local[tid].size();
+        }
+      local[tid].resize((local[tid].size() + 3) & ~(size_t)3, 0);
+    });
+    for (uint32_t t = 0; t < threads && tries_ok; t++) if (!twhy[t].empty()) { tries_ok = false; why = twhy[t]; }
+    size_t total = 0;
+    std::vector<size_t> tbase(threads, 0);
+    for (uint32_t t = 0; t < threads; t++) { tbase[t] = total; total += local[t].size(); }
+    if (tries_ok && total > 0xFFFFFFF0ull) { tries_ok = false; why = "trie arena exceeds 2^32 words"; }
+    if (tries_ok) {
+      ix->trie.resize(total);
+      parallel_for(threads, threads, [&](size_t lo, size_t hi, uint32_t) {
+        for (size_t t = lo; t < hi; t++) {
+          if (!local[t].empty()) memcpy(ix->trie.data() + tbase[t], local[t].data(), local[t].size() * 4);
+          for (size_t i = t_lo[t]; i < t_hi[t]; i++)
+            for (int j = 0; j < 2; j++) {
+              if (rootw[2 * i + j] == (size_t)-1) continue;
+              const uint32_t root = (uint32_t)(tbase[t] + rootw[2 * i + j]), words = (uint32_t)(endw[2 * i + j] - rootw[2 * i + j]);
+              if (j == 0) { ix->lookup[i].rootF = root; ix->lookup[i].wordsF = words; }
+              else { ix->lookup[i].rootR = root; ix->lookup[i].wordsR = words; }
+            }
+        }
+      });
+      for (uint32_t t = 0; t < threads; t++) { ix->n_nodes += cnt[t].n_nodes; ix->n_buckets += cnt[t].n_buckets; ix->n_entries += cnt[t].n_entries; }
     }
   }
-  // positions (index.cpp:322-352) -> CSR; keep file order (sorted by seq, then pos, by construction)
-  o = 0;
-  uint32_t nid = 0;
-  if (pb.size() >= 4) memcpy(&nid, pb.data(), 4);
-  o = 4;
-  ix->pos_off.assign((size_t)nid + 1, 0);
-  for (uint32_t i = 0; i < nid; i++) {
-    uint32_t sz = 0;
-    if (o + 4 <= pb.size()) memcpy(&sz, pb.data() + o, 4);
-    o += 4;
-    if (o + (size_t)sz * 8 > pb.size()) { delete ix; set_err(err, errcap, "malformed pos file"); return SMR_ERR_IO; }
-    size_t old = ix->pos_arr.size();
-    if (old / 2 + sz > 0xFFFFFFFFull) { delete ix; set_err(err, errcap, "more than 2^32 positions"); return SMR_ERR_IO; }
-    ix->pos_arr.resize(old + (size_t)sz * 2);
-    memcpy(ix->pos_arr.data() + old, pb.data() + o, (size_t)sz * 8);
-    o += (size_t)sz * 8;
-    ix->pos_off[i + 1] = (uint32_t)(ix->pos_arr.size() / 2);
-    // the device code binary-searches each list by seq: enforce (seq,pos) order
-    bool sorted = true;
-    for (uint32_t k = 1; k < sz && sorted; k++) {
-      const uint32_t* a = ix->pos_arr.data() + old + (size_t)(k - 1) * 2;
-      if (a[1] > a[3] || (a[1] == a[3] && a[0] > a[2])) sorted = false;
-    }
-    if (!sorted) {
-      std::vector<std::pair<uint32_t, uint32_t>> v(sz);
-      for (uint32_t k = 0; k < sz; k++) v[k] = {ix->pos_arr[old + 2 * k + 1], ix->pos_arr[old + 2 * k]};
-      std::sort(v.begin(), v.end());
-      for (uint32_t k = 0; k < sz; k++) { ix->pos_arr[old + 2 * k] = v[k].second; ix->pos_arr[old + 2 * k + 1] = v[k].first; }
-    }
-  }
-  if (!load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix)) {
-    delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO;
-  }
+  tm.lap("load: mini-tries");
+  t_pos.join(); t_refs.join();
+  if (!tries_ok) { delete ix; set_err(err, errcap, "malformed burst trie file: " + why); return SMR_ERR_IO; }
+  if (!pos_err.empty()) { delete ix; set_err(err, errcap, pos_err); return SMR_ERR_IO; }
+  if (!refs_ok) { delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO; }
+  tm.lap("load: positions and reference sequences (waited for)");
   if (!smr_build_pigeonhole(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the second device layout, once, here: smr_index_upload only reads
   *out = ix;
   return SMR_OK;
@@ -415,28 +558,6 @@ bool parse_fasta(const std::vector<uint8_t>& b, std::vector<SeqRec>& recs, std::
 }
 
 // SMR_IB_TIMING=1: stage times of the index build on stderr
-struct StageTimer {
-  bool on = getenv("SMR_IB_TIMING") != nullptr;
-  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-  void lap(const char* what) {
-    if (!on) return;
-    const auto n = std::chrono::steady_clock::now();
-    fprintf(stderr, "[smr index build] %-28s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
-    t = n;
-  }
-};
-
-template <class F> void parallel_for(uint32_t threads, size_t n, F f) {
-  if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
-  std::vector<std::thread> th;
-  size_t chunk = (n + threads - 1) / threads;
-  for (uint32_t t = 0; t < threads; t++) {
-    size_t lo = (size_t)t * chunk, hi = std::min(n, lo + chunk);
-    if (lo >= hi) break;
-    th.emplace_back([=]() { f(lo, hi, t); });
-  }
-  for (auto& x : th) x.join();
-}
 
 // sort u64 keys: partition by the top `topbits` bits (counting), then std::sort every bucket in parallel
 void bucket_sort_u64(std::vector<uint64_t>& a, int keybits, uint32_t threads) {
