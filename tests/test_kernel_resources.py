@@ -1,0 +1,58 @@
+"""CPU: what the compiler made of the hot kernels, read from the gfx950 code object inside libsmr_hip.so (no GPU needed).
+
+A kernel that silently starts to use scratch memory is several times slower on the MI355X and nothing else tells: during round 2 a
+by-reference lambda in k_seed_pg's string loop put the search's ranges into 152 bytes of private memory per lane and tripled the kernel's
+time; results, tests and the emulator were all unaffected.  The limits below are the register / scratch budgets DESIGN.md argues with."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+from sortmerna_amd import build
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _kernel_metadata():
+    bundler, readelf = os.path.join(LLVM, "clang-offload-bundler"), os.path.join(LLVM, "llvm-readelf")
+    if not (os.path.exists(bundler) and os.path.exists(readelf) and shutil.which("objcopy")):
+        pytest.skip("ROCm LLVM tools not installed")
+    lib = build.build_library()
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fatbin"), os.path.join(d, "gfx950.o")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([bundler, "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
+        notes = subprocess.check_output([readelf, "--notes", co]).decode()
+    out = {}
+    for blk in re.split(r"\n  - \.agpr_count", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        f = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, blk).group(1))   # noqa: E731
+        out[name] = dict(vgpr=f("vgpr_count"), spill=f("vgpr_spill_count"), scratch=f("private_segment_fixed_size"), lds=f("group_segment_fixed_size"))
+    return out
+
+
+def _find(md, *parts):
+    hits = [k for k in md if all(p in k for p in parts)]
+    assert hits, "kernel %s not in the code object" % (parts,)
+    return [md[k] for k in hits]
+
+
+def test_hot_kernels_use_no_scratch_and_stay_within_their_register_budget():
+    md = _kernel_metadata()
+    # seed stage: everything in registers; the search at (almost) full occupancy
+    for parts, max_vgpr in [(("k_seed_keys",), 64), (("k_seed_cscan",), 64), (("k_seed_split",), 64), (("k_seed_bins",), 64),
+                            (("k_seed_pgILi0",), 72), (("k_seed_pgILi1",), 72), (("k_seed_finish",), 64), (("k_seed_searchILi",), 64),
+                            (("k_candE",), 64), (("k_trace_bandILi8",), 128), (("k_trace_bandILi16",), 128), (("k_trace_wide",), 64)]:
+        for k in _find(md, *parts):
+            assert k["scratch"] == 0 and k["spill"] == 0, (parts, k)
+            assert k["vgpr"] <= max_vgpr, (parts, k)
+    # k_chain is built for 3 waves per SIMD (168 VGPRs) and is allowed the spills DESIGN.md 3.2 accounts for
+    for k in _find(md, "k_chainILb"):
+        assert k["vgpr"] <= 168 and k["spill"] <= 160, k
+    # the stand-alone Smith-Waterman / begin-cell kernels: 4 waves per SIMD
+    for parts in [("k_ssw_batch",), ("k_beginsE",)]:
+        for k in _find(md, *parts):
+            assert k["vgpr"] <= 128 and k["spill"] == 0, (parts, k)
