@@ -364,9 +364,10 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
     {
       std::vector<uint8_t> flags;
       size_t o = 0;
-      for (uint32_t i = 0; i < nk && o < bn && tries_ok; i++) {
+      for (uint32_t i = 0; i < nk && tries_ok; i++) {
         uint32_t sz[2] = {0, 0};
-        if (o + 8 <= bn) memcpy(sz, b + o, 8);
+        if (o + 8 > bn) { tries_ok = false; why = "file ends before the last k-mer"; break; }      // the reference writes the two sizes for every k-mer (indexdb.cpp:719-742)
+        memcpy(sz, b + o, 8);
         o += 8;
         if (ix->lookup[i].count == 0) continue;       // index.cpp:190: tries are only read when count != 0
         for (int j = 0; j < 2 && tries_ok; j++) {

@@ -184,6 +184,28 @@ def test_index_write_then_load_round_trip(tmp_path):
         assert filecmp.cmp(pfx + ext, pfx2 + ext, shallow=False), ext
 
 
+def test_damaged_index_files_are_refused(tmp_path):
+    """the loader parses the part's files in place with many threads: a trie or position file cut anywhere must end in an error
+    (SMR_ERR_IO), never in a crash or in an index with missing tries"""
+    import shutil
+    db, _, _ = golden.inputs("syn_default")
+    parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+    pfx = str(tmp_path / "a")
+    smr.Index.write_files(parts, db, pfx)
+    for ext in (".bursttrie_0.dat", ".pos_0.dat"):
+        whole = open(pfx + ext, "rb").read()
+        for frac in (0.999, 0.5, 0.01):
+            bad = str(tmp_path / ("bad%s_%g" % (ext.split("_")[0], frac)))
+            for e in (".kmer_0.dat", ".bursttrie_0.dat", ".pos_0.dat", ".stats"):
+                shutil.copy(pfx + e, bad + e)
+            with open(bad + ext, "wb") as f:
+                f.write(whole[: int(len(whole) * frac)])
+            with pytest.raises(smr.SmrError):
+                smr.Index.load_files(bad, 0, db)
+    with pytest.raises(smr.SmrError):
+        smr.Index.load_files(str(tmp_path / "nothing_here"), 0, db)
+
+
 @pytest.mark.skipif(not (paths.have_reference() and paths.have_ref_bin()), reason="needs /root/reference + oracle/_ref/sortmerna_ref")
 def test_reference_index_files_round_trip_byte_exact(tmp_path):
     """Load the files the REFERENCE's indexer wrote (CMPH ids, its BFS trie stream) and write them back: identical bytes.
