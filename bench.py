@@ -118,6 +118,22 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
         shutil.rmtree(wd, ignore_errors=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N ...` without a launcher: start the N ranks (one per GPU) through torch.distributed.run on this node,
+    exactly as the driver's wrapped command would, and hand their output and exit code through.  Rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    log("--gpus %d without a launcher: starting %d ranks through torch.distributed.run (port %d)" % (n, n, port))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,9 +155,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))          # `python bench.py --gpus N` as typed: this process becomes the launcher of N ranks
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
         args.gpus = world
     args.steps = max(args.steps, 1)
     args.warmup = max(args.warmup, 0)
@@ -346,7 +362,7 @@ def main():
             "config": {"workload": "synthetic 150-nt Illumina-like reads (10%% from DB, 90%% background) vs seeded synthetic rRNA-like DB "
                                    "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); default options (--fastx, best 1)" % args.db_nt,
                        "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
-                       "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus,
+                       "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus, "nranks": (dist.get_world_size() if dist is not None else 1),
                        "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": "packed 16-bit (v_pk): candidate windows scored ahead four per wave, single problems on 128 virtual lanes" if eng.sw_mode() >= 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,

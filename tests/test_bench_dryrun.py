@@ -55,3 +55,26 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
         assert cb["parity"]["aligned_read_ids_equal"] is True and cb["parity"]["reference_aligned"] == cb["parity"]["gpu_aligned"] > 0, cb
     else:
         assert out["cpu_baseline"] is None
+
+
+def test_unwrapped_multi_rank_command(tmp_path):
+    """`python bench.py --gpus 2 --steps 2 --warmup 1` exactly as the driver types it -- no torchrun around it: bench.py must start its own
+    two ranks (round 2 exited with a usage message here).  Ranks on the emulator, collectives on gloo; one JSON line, from rank 0."""
+    import subprocess
+    emu.build()
+    env = dict(os.environ, TMPDIR=str(tmp_path), SMR_BENCH_BACKEND="gloo", SMR_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(paths.REPO, "tests", "helpers", "bench_on_emu.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch-reads", "1200", "--db-nt", "150000", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    for k in KEYS:
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["counters"]["reads"] == 2 * 2 * 1200 and out["cpu_baseline"] is None
+    assert out["config"]["nranks"] == 2
+    r = out["roofline"]
+    assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
