@@ -302,11 +302,15 @@ def main():
     ctr_t = shard.reduce_counters(ctr.tolist(), device=cdev)
     pr = eng.prof()
     assert exact_aligned is None or int(ctr[0]) == exact_aligned, "the two seed kernels disagree on num_aligned: %d vs %d" % (int(ctr[0]), exact_aligned)
+    kp = eng.prof_kernels()                                  # per kernel family: HIP-event ms, launches, algorithmic bytes (device counters)
+    kp_names = list(kp)
     prof = torch.tensor([pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.seed_launches, pr.chain_launches, pr.trace_launches] +
-                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells, pr.n_sw_spec, pr.n_sw_spec_used], dtype=torch.float64, device=cdev)
+                        exact + [pr.n_sw_fwd, pr.n_sw_rev, pr.n_sw_cells, pr.n_sw_spec, pr.n_sw_spec_used] +
+                        [x for k in kp_names for x in (kp[k]["ms"], kp[k]["launches"], kp[k]["bytes"])], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(prof)
     prof = [float(x) for x in prof.cpu()]
+    kp = {k: {"ms": prof[17 + 3 * i], "launches": prof[18 + 3 * i], "bytes": prof[19 + 3 * i]} for i, k in enumerate(kp_names)}      # sums over ranks
 
     # informational: the same step when the boundary hands over a HOST buffer (packed batch -> smr_reads_upload: allocations + H2D over
     # PCIe + state reset), serial, no overlap with the previous batch.  Never `value`.
@@ -323,23 +327,47 @@ def main():
         reads_timed = args.gpus * args.steps * args.batch_reads
         seed_ms, chain_ms, trace_ms, seed_l, chain_l, trace_l = prof[0:6]
         n_lookup, n_node, n_entry, n_hit, n_read_bytes = prof[7], prof[8], prof[9], prof[10], prof[11]
-        b_seed = n_read_bytes + 12 * n_lookup + 16 * n_node + 8 * n_entry + 8 * n_hit
-        # per-rank kernel time: ranks run concurrently, the sums above are over ranks
-        ach = (b_seed / args.gpus) / (seed_ms / args.gpus * 1e-3) / 1e9 if seed_ms > 0 else 0.0
-        # PMC HBM bytes per seed-stage launch: measured with rocprofv3 in separate counter passes (tools/pmc_traffic.py), used only when it
-        # was measured on THESE kernel sources at THIS batch size / read length / DB size (otherwise null: never rescaled)
-        traffic = None
-        traffic_note = "no PMC measurement for these kernel sources and this workload (profiles/hbm_traffic.json)"
+        # what the reference's traversal would have moved (SURVEY.md 8d formula on the exact counters of the DFS kernel): reported as an
+        # EQUIVALENT rate only -- k_seed_pg does not perform that traversal, so this is not a roofline numerator
+        b_ref = n_read_bytes + 12 * n_lookup + 16 * n_node + 8 * n_entry + 8 * n_hit
+        # Roofline numerators: the algorithmic HBM bytes of the SHIPPED kernels, each counted by the kernel itself on the device
+        # (include/smr_hip.h smr_prof_kernels), over that kernel's own HIP-event time in the timed steps.  Ranks run
+        # concurrently: sums over ranks of bytes / sums of ms = the per-GPU rate.
+        traffic_all, traffic_note = None, "no PMC measurement for these kernel sources and this workload (profiles/hbm_traffic.json)"
         try:
             sys.path.insert(0, os.path.join(HERE, "tools"))
             import pmc_traffic
             tj = json.load(open(os.path.join(HERE, "profiles", "hbm_traffic.json")))
             w = tj["workload"]
             if (w["read_len"], w["db_nt"], w["batch_reads"]) == (args.read_len, args.db_nt, args.batch_reads) and tj.get("kernel_src_sha") == pmc_traffic.kernel_src_sha():
-                traffic = tj["seed_stage_bytes_per_launch"]
-                traffic_note = "rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE per seed-stage launch, kernel sources %s" % tj["kernel_src_sha"]
+                traffic_all = tj["per_launch_bytes"]
+                traffic_note = tj["note"]
         except Exception:
             pass
+        seed_k = [k for k in kp if k.startswith("k_seed")]
+        rk = {}
+        for k in seed_k:
+            v = kp[k]
+            if v["launches"] <= 0 or v["ms"] <= 0:
+                continue
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            rk[k] = {"avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"] / args.gpus, "algorithmic_bytes_per_launch": v["bytes"] / v["launches"],
+                     "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": (traffic_all or {}).get(k)}
+        dom = max(rk, key=lambda k: rk[k]["avg_launch_ms"] * rk[k]["launches"]) if rk else None
+        st_bytes = sum(kp[k]["bytes"] for k in seed_k)
+        st_ms = sum(kp[k]["ms"] for k in seed_k)
+        roof = {"kernel": dom, "bound": "hbm", "achieved": rk[dom]["achieved"] if dom else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (rk[dom]["achieved"] / HBM_PEAK_GBS) if dom else 0.0, "traffic": rk[dom]["traffic"] if dom else None, "traffic_note": traffic_note,
+                "algorithmic_bytes_per_launch": rk[dom]["algorithmic_bytes_per_launch"] if dom else 0.0, "avg_launch_ms": rk[dom]["avg_launch_ms"] if dom else 0.0,
+                "kernels": rk,
+                "seed_stage": {"achieved": st_bytes / max(st_ms * 1e-3, 1e-12) / 1e9, "frac": st_bytes / max(st_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_launch": st_bytes / max(seed_l, 1), "avg_launch_ms": st_ms / max(seed_l, 1), "bytes_per_read": st_bytes / reads_timed},
+                "equivalent_rate": {"GB/s": (b_ref / max(st_ms * 1e-3, 1e-12) / 1e9) if b_ref else None, "bytes_per_read": b_ref / reads_timed,
+                                    "note": "bytes the REFERENCE's trie traversal would move for these reads (SURVEY.md 8d formula on exact counters) / the seed stage's time; "
+                                            "not a roofline figure: the shipped search reaches the same hits without that traversal"},
+                "note": "kernel = the seed-stage kernel with the most time in the timed steps; achieved = the algorithmic HBM bytes THAT kernel counts for itself on the device "
+                        "(tuples, directory words, strings looked at, accepted {rank,id}, hit segments; smr_prof_kernels) / its own HIP-event time; kernels{} has every seed-stage "
+                        "kernel, seed_stage their sum"}
         # VALU model of the Smith-Waterman kernel: a wave64 VALU instruction occupies a SIMD for 4 cycles ->
         # 256 CU x 4 SIMD x 2.4 GHz / 4 = 6.14e11 wave-instructions/s; one systolic step costs 13 R + 14 (packed, R = ceil(m/128) cell pairs)
         # or 20 R + 15 (32-bit, R = ceil(m/64) cells) instructions and there are n + ceil(m/R) - 1 steps for an m x n problem
@@ -369,13 +397,7 @@ def main():
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,
                               "entries": n_entry / reads_timed, "hits": n_hit / reads_timed},
-            "roofline": {"kernel": "k_seed", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": b_seed / max(seed_l, 1), "avg_launch_ms": seed_ms / max(seed_l, 1),
-                         "bytes_per_read": b_seed / reads_timed,
-                         "hbm_achieved": (traffic / (seed_ms / max(seed_l, 1) * 1e-3) / 1e9) if traffic else None,
-                         "note": "achieved = algorithmic bytes of the reference's traversal (SURVEY.md 8d: every node and bucket entry its DFS visits) / launch time. "
-                                 "k_seed_pg finds the same hits through four exact-key directory ranges per search and never reads most of those entries, so achieved "
-                                 "is an equivalent rate and may exceed the HBM peak; hbm_achieved = measured PMC traffic / launch time is what the memory system really moved"},
+            "roofline": roof,
             "kernels": {"k_seed": {"ms": seed_ms / args.gpus, "launches": seed_l / args.gpus},
                         "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
                                     "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6,

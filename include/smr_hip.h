@@ -249,6 +249,15 @@ int smr_cigar_batch(smr_ctx*, uint32_t n_pairs, const uint8_t* reads, const uint
                     uint32_t* cigar_out, uint64_t cigar_cap, uint64_t* cigar_off_out);
 int smr_prof_reset(smr_ctx*);
 int smr_prof_get(smr_ctx*, smr_prof* out);
+/* The same period per kernel family (k_seed_keys, the tuple sort, k_seed_pg<0>, k_seed_pg<1>, k_seed_finish, k_cand, k_chain, k_begins,
+ * k_trace): HIP-event time on the engine's stream, number of launches, and for the seed-stage kernels the ALGORITHMIC HBM bytes of what
+ * the shipped kernels themselves do, from exact device counters: every tuple (12 B) written once by k_seed_keys next to its inputs
+ * (read records, per-read state, two lookup words per window), read and written once by each of the two sort passes, read once by
+ * k_seed_pg, which adds per search 8 B of block table, its directory words, 4 B per string looked at, 8 B per accepted {rank, id} and
+ * the hit-segment words it reads and writes; k_seed_finish the segment words it gathers.  bytes = 0 where nothing is counted.
+ * This -- not the traversal of the reference, which k_seed_pg does not perform -- is the numerator of bench.py's roofline. */
+typedef struct { char name[32]; double ms; uint64_t launches; uint64_t bytes; } smr_kprof;
+int smr_prof_kernels(smr_ctx*, smr_kprof* out, uint32_t cap, uint32_t* n_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Reports (host side): the reference's second pass over reads + KVDB (writeReports, output.cpp:169-272), fed by

@@ -993,7 +993,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     if (n_spec) atomicAdd(&ctr[C_SW_SPEC], n_spec);
     if (n_spec_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_spec_used);
 #if defined(SMR_CHAIN_PHASES) || defined(SMR_CHAIN_STATS)
-    for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
+    for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], tph[q]);
 #endif
   }
 }

@@ -26,11 +26,14 @@ struct DevIndex {
   uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0;
 };
 
-struct EvPair { hipEvent_t a, b; int kind; };
+struct EvMark { hipEvent_t e; int kind; };        // kind < 0: end of a run of intervals
 
 }  // namespace
 
 #define SMR_MAX_BATCHES 16
+// kernel families timed apart (one HIP event between them on the engine's stream)
+enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_COUNT };
+static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_chain", "k_begins", "k_trace"};
 
 // One resident read batch: packed reads + everything the reference keeps per read in the KVDB (read.cpp:429-539)
 // + its Readstats counter block + its CIGAR pool.  Several batches can be resident at once (the host uploads
@@ -83,11 +86,12 @@ struct smr_ctx {
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
   int* d_trrows = nullptr; uint64_t trrows_ints = 0;                   // its DP rows when the band does not fit LDS
   // profiling
-  std::vector<EvPair> events, ev_pool;
+  std::vector<EvMark> events; std::vector<hipEvent_t> ev_pool;
+  double kp_ms[KP_COUNT] = {}; uint64_t kp_l[KP_COUNT] = {};       // HIP-event time and launches per kernel family (smr_prof_kernels)
   hipStream_t upload_stream = nullptr;     // smr_reads_upload_batch: H2D of batch k+1 while batch k is aligned on `stream`
   unsigned long long* d_ctr_snap = nullptr; // counters of the selected batch at the start of smr_align_part (restored when an attempt is redone)
-  double seed_ms = 0, chain_ms = 0, trace_ms = 0; uint64_t seed_l = 0, chain_l = 0, trace_l = 0;
 };
+struct KpSave { double ms[KP_COUNT]; uint64_t l[KP_COUNT]; };
 
 #define SEED_REDO_CAP 16384u
 
@@ -171,25 +175,27 @@ int ensure_chain_scratch(smr_ctx* c, const DevIndex& di) {
   return SMR_OK;
 }
 
-void ev_begin(smr_ctx* c, int kind) {            // event pairs are pooled: created once, reused for every launch
-  EvPair e;
-  if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
-  else { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
-  e.kind = kind;
-  (void)hipEventRecord(e.a, c->stream);
-  c->events.push_back(e);
+// A mark = one pooled HIP event on the engine's stream.  The time between a mark of kind k >= 0 and the next mark belongs to kernel
+// family k; ev_stop ends a run.  (Kernels of one stream run back to back anyway: a mark costs a barrier packet, no bubble.)
+void ev_mark(smr_ctx* c, int kind) {
+  EvMark m; m.kind = kind;
+  if (!c->ev_pool.empty()) { m.e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+  else (void)hipEventCreate(&m.e);
+  (void)hipEventRecord(m.e, c->stream);
+  c->events.push_back(m);
 }
-void ev_end(smr_ctx* c) { (void)hipEventRecord(c->events.back().b, c->stream); }
+void ev_stop(smr_ctx* c) { ev_mark(c, -1); }
 void ev_collect(smr_ctx* c) {
-  for (auto& e : c->events) {
+  for (size_t i = 0; i + 1 < c->events.size(); i++) {
+    const int k = c->events[i].kind;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-      if (e.kind == 0) { c->seed_ms += ms; c->seed_l++; } else if (e.kind == 1) { c->chain_ms += ms; c->chain_l++; } else { c->trace_ms += ms; c->trace_l++; }
-    }
-    c->ev_pool.push_back(e);
+    if (k >= 0 && hipEventElapsedTime(&ms, c->events[i].e, c->events[i + 1].e) == hipSuccess) { c->kp_ms[k] += ms; c->kp_l[k]++; }
   }
+  for (auto& m : c->events) c->ev_pool.push_back(m.e);
   c->events.clear();
 }
+KpSave kp_save(const smr_ctx* c) { KpSave k; memcpy(k.ms, c->kp_ms, sizeof k.ms); memcpy(k.l, c->kp_l, sizeof k.l); return k; }
+void kp_restore(smr_ctx* c, const KpSave& k) { memcpy(c->kp_ms, k.ms, sizeof k.ms); memcpy(c->kp_l, k.l, sizeof k.l); }
 
 uint32_t num_windows(uint32_t max_len, uint32_t L, uint32_t stride) {
   return max_len >= L ? (max_len - L + stride) / stride : 1;
@@ -237,17 +243,20 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   const size_t lds_pg = lds_pg1 * pgw;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((slots + 63) / 64)), gk4 = (uint32_t)((slots + 1023) / 1024);     // (every kernel checks its range: a batch without a single window launches one idle block each)
-  ev_begin(c, 0);
+  ev_mark(c, KP_KEYS);
   // one two-level counting sort for the forward and the reverse tuples of the stage (smr_seed.hpp)
   HIPCHK(c, hipMemsetAsync(sb.chist, 0, ((size_t)sb.nc + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
   if (slots) HIPCHK(c, hipMemsetAsync(sb.wseg, 0xFF, (size_t)slots * 4, c->stream));       // NONE: no window has hits yet
   hipLaunchKernelGGL(k_seed_keys, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(gk4, 2048u))), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, gk4);
-  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb);
+  ev_mark(c, KP_SPLIT);                                    // (with the one-block scan of the coarse counts in front of it)
+  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
   hipLaunchKernelGGL(k_seed_split, dim3(std::max<uint32_t>(1u, (uint32_t)((2 * slots + SEED_SPLIT_CHUNK - 1) / SEED_SPLIT_CHUNK))), dim3(1024), (size_t)sb.nc * 8, c->stream, sb);
+  ev_mark(c, KP_BINS);
   hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), 0, c->stream, sb);
   for (int dir = 0; dir < 2; dir++) {
     const uint32_t* no_redo = nullptr;
+    ev_mark(c, dir ? KP_PG1 : KP_PG0);
     if (c->seed_exact) {
       if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
       else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
@@ -264,8 +273,9 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       }
     }
   }
+  ev_mark(c, KP_FINISH);
   hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, pool_words, c->b->d_ctr);
-  ev_end(c);
+  ev_stop(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
 }
@@ -288,9 +298,10 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
     c->chain_lds_attr = lds;
   }
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
-  ev_begin(c, 1);
+  ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool);
+  ev_mark(c, KP_CHAIN);
   hipLaunchKernelGGL(k_chain<false>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
                      c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap,
                      c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr);
@@ -301,7 +312,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
                        c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap,
                        c->d_stab, c->d_tuples2);
   }
-  ev_end(c);
+  ev_stop(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
 }
@@ -310,9 +321,10 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
 // C_POOL_CURSOR becomes the largest shard cursor
 void fold_shards(std::vector<unsigned long long>& h) {
   for (int s = 0; s < C_NSHARD; s++)
-    for (int k = 0; k < 16; k++) {
-      if (k < 9) h[C_WINDOWS + k] += h[C_SHARDS + 16 * s + k];
-      h[C_SHARDS + 16 * s + k] = 0;
+    for (int k = 0; k < C_SHARD_W; k++) {
+      if (k < C_SHARD_X) h[C_WINDOWS + k] += h[C_SHARDS + C_SHARD_W * s + k];
+      else if (k < C_SHARD_X + C_SHARD_NX) h[C_TUP_F + k - C_SHARD_X] += h[C_SHARDS + C_SHARD_W * s + k];
+      h[C_SHARDS + C_SHARD_W * s + k] = 0;
     }
   unsigned long long mx = 0;
   for (int s = 0; s < C_NSHARD; s++) mx = std::max(mx, h[C_PCUR + s]);
@@ -732,7 +744,8 @@ extern "C" void smr_destroy(smr_ctx* c) {
   dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
-  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& m : c->events) (void)hipEventDestroy(m.e);
+  for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   dev_free(&c->d_ctr_snap); dev_free(&c->d_fidx); dev_free(&c->d_fstate); dev_free(&c->d_faln);
   (void)hipStreamDestroy(c->upload_stream);
   (void)hipStreamDestroy(c->stream);
@@ -914,7 +927,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   const int num_strands = single ? 1 : 2;
   for (int attempt = 0; attempt < 8; attempt++) {
     if ((rc = ensure_chain_scratch(c, di))) return rc;
-    const double t_seed0 = c->seed_ms, t_chain0 = c->chain_ms; const uint64_t l_seed0 = c->seed_l, l_chain0 = c->chain_l;
+    const KpSave kp0 = kp_save(c);
     // restore counters (retry) and clear the per-part ones (processor.cpp:230 resets num_short per part)
     hipLaunchKernelGGL(k_ctr_begin, dim3(1), dim3(256), 0, c->stream, c->b->d_ctr, (const unsigned long long*)c->d_ctr_snap);
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
@@ -961,7 +974,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       if (c->keys_cap < CH_EXT_CAP) { dev_free(&c->d_keys); c->keys_cap = 0; c->keys_need = CH_EXT_CAP; }
     }
     if (h[C_ERR_SLOTS]) { c->err = "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"; return SMR_ERR_CAPACITY; }
-    if (retry) { c->seed_ms = t_seed0; c->chain_ms = t_chain0; c->seed_l = l_seed0; c->chain_l = l_chain0; }   // timings of a discarded attempt
+    if (retry) kp_restore(c, kp0);   // timings of a discarded attempt
     if (!retry) {
       // the begin cells of the alignments that are still stored (k_chain records the accepted ones "begin pending"): four reverse passes per wave
       {
@@ -978,11 +991,11 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
           c->begins_lds_attr = lds_b;
         }
         HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_BEGIN_N], 0, 16, c->stream));       // C_BEGIN_N, C_BEGIN_NEXT
-        ev_begin(c, 1);
+        ev_mark(c, KP_BEGINS);
         hipLaunchKernelGGL(k_begins_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->b->n, c->b->slots, (const RState*)c->b->d_work, (const RWork*)c->b->d_rw,
                            (const AlignRec*)c->b->d_work_aln, c->d_tasks, c->b->d_ctr);
         hipLaunchKernelGGL(k_begins, dim3((uint32_t)c->n_cu * 8u), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4);
-        ev_end(c);
+        ev_stop(c);
       }
       // only a clean attempt is committed to the persistent per-read state (kvdb.put, processor.cpp:150-155)
       hipLaunchKernelGGL(k_commit_part, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw);
@@ -1029,12 +1042,12 @@ static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
   auto before = [&]() -> int {
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_CIGAR], 0, 16, c->stream));     // C_ERR_CIGAR, C_ERR_TRACE
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_TRACE_DEFER], 0, 8, c->stream));
-    ev_begin(c, 2);
+    ev_mark(c, KP_TRACE);
     return SMR_OK;
   };
   // after a kernel: 0 = all done, 1 = tasks were handed on (n_tasks updated), 2 = the CIGAR pool was too small (grown; start over), < 0 = error
   auto after = [&](uint32_t& n_tasks) -> int {
-    ev_end(c);
+    ev_stop(c);
     HIPCHK(c, hipGetLastError());
     int r2 = read_ctr(c, h); if (r2) return r2;
     ev_collect(c);
@@ -1326,7 +1339,7 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_HITCAP], 0, 16, c->stream));          // HITCAP, POOL
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_HIT], 0, 8, c->stream));
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_SHARDS], 0, 16 * C_NSHARD * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_SHARDS], 0, C_SHARD_W * C_NSHARD * 8, c->stream));
     // fresh per-part/strand state: forward, or reverse-complement with ambiguous letters complemented (aval 0 -> 3)
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     DParams Q = P; Q.is_forward = 1; Q.is_reverse = 1;
@@ -1371,12 +1384,13 @@ extern "C" int smr_seed_hits_fetch(smr_ctx* c, uint32_t* triples, uint64_t cap_t
 extern "C" int smr_prof_reset(smr_ctx* c) {
   if (!c) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
-  c->seed_ms = c->chain_ms = c->trace_ms = 0; c->seed_l = c->chain_l = c->trace_l = 0;
+  for (int k = 0; k < KP_COUNT; k++) { c->kp_ms[k] = 0; c->kp_l[k] = 0; }
   for (int k = 0; k < SMR_MAX_BATCHES; k++)
     if (c->bt[k].d_ctr) {
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SW_SPEC], 0, 3 * 8, c->stream));
-      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SHARDS], 0, 16 * C_NSHARD * 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_TUP_F], 0, C_SHARD_NX * 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_SHARDS], 0, C_SHARD_W * C_NSHARD * 8, c->stream));
     }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SMR_OK;
@@ -1391,16 +1405,45 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (getenv("SMR_DEBUG_PHASES")) {
       unsigned long long ph[7] = {0, 0, 0, 0, 0, 0, 0};
-      for (int s2 = 0; s2 < C_NSHARD; s2++) for (int q = 0; q < 7; q++) ph[q] += t[C_SHARDS + 16 * s2 + 9 + q];
+      for (int s2 = 0; s2 < C_NSHARD; s2++) for (int q = 0; q < 7; q++) ph[q] += t[C_SHARDS + C_SHARD_W * s2 + C_SHARD_PH + q];
       fprintf(stderr, "[smr] phase cycles (batch %d): %llu %llu %llu %llu %llu %llu %llu  (-DSMR_CHAIN_PHASES: claim, gather+prefix, walk1, walk2+cands, pairs+sort, "
               "window/lis/book, sw; -DSMR_SEED_PHASES (k_seed_pg): setup, directory ranges, entries, -, candidate selection, output, -)\n", k, ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6]);
     }
     fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
-  o->seed_ms = c->seed_ms; o->seed_launches = c->seed_l; o->chain_ms = c->chain_ms; o->chain_launches = c->chain_l; o->trace_ms = c->trace_ms; o->trace_launches = c->trace_l;
+  o->seed_ms = c->kp_ms[KP_KEYS] + c->kp_ms[KP_SPLIT] + c->kp_ms[KP_BINS] + c->kp_ms[KP_PG0] + c->kp_ms[KP_PG1] + c->kp_ms[KP_FINISH]; o->seed_launches = c->kp_l[KP_KEYS];
+  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
+  o->trace_ms = c->kp_ms[KP_TRACE]; o->trace_launches = c->kp_l[KP_TRACE];
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];
   o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED]; o->n_seed_redo = h[C_SEED_REDO];
+  return SMR_OK;
+}
+
+// Per kernel family: HIP-event time, launches and the algorithmic HBM bytes the kernels counted for themselves (0: not counted)
+extern "C" int smr_prof_kernels(smr_ctx* c, smr_kprof* out, uint32_t cap, uint32_t* n_out) {
+  if (!c || !out || !n_out) return SMR_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<unsigned long long> h(C_TOTAL, 0), t(C_TOTAL);
+  for (int k = 0; k < SMR_MAX_BATCHES; k++) {
+    if (!c->bt[k].d_ctr) continue;
+    HIPCHK(c, hipMemcpyAsync(t.data(), c->bt[k].d_ctr, C_TOTAL * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fold_shards(t);
+    for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
+  }
+  const unsigned long long T = h[C_TUP_F] + h[C_TUP_R];
+  unsigned long long bytes[KP_COUNT] = {};
+  bytes[KP_KEYS] = h[C_B_KEYS] + sizeof(SeedTmp) * T;                 // its inputs (counted by the kernel) + every tuple written once
+  bytes[KP_SPLIT] = bytes[KP_BINS] = 2 * sizeof(SeedTmp) * T;         // each of the two sort passes reads and writes every tuple once
+  bytes[KP_PG0] = h[C_B_PG0]; bytes[KP_PG1] = h[C_B_PG1]; bytes[KP_FINISH] = h[C_B_FIN];
+  uint32_t n = 0;
+  for (int k = 0; k < KP_COUNT && n < cap; k++, n++) {
+    memset(&out[n], 0, sizeof out[n]);
+    snprintf(out[n].name, sizeof out[n].name, "%s", KP_NAME[k]);
+    out[n].ms = c->kp_ms[k]; out[n].launches = c->kp_l[k]; out[n].bytes = bytes[k];
+  }
+  *n_out = n;
   return SMR_OK;
 }

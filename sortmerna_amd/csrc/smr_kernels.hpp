@@ -107,13 +107,18 @@ enum {
   C_NUM_ALIGNED = 0, C_NUM_SHORT = 1, C_PER_DB = 2,           // C_PER_DB .. C_PER_DB+63
   C_WINDOWS = 66, C_LOOKUP, C_NODE, C_ENTRY, C_HIT, C_READ_BYTES, C_SW_FWD, C_SW_REV, C_SW_CELLS,
   C_ERR_HITCAP, C_ERR_POOL, C_ERR_SLOTS, C_ERR_PAIRS, C_ERR_CIGAR, C_ERR_TRACE, C_POOL_CURSOR, C_WORK_NEXT,
-  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_FETCH_N, C_SW_SPEC, C_SW_SPEC_USED, C_SEED_REDO, C_COUNT = 96,
+  C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_FETCH_N, C_SW_SPEC, C_SW_SPEC_USED, C_SEED_REDO,
+  // what the seed-stage kernels THEMSELVES move, for the roofline of each (smr_prof_kernels): tuples of the forward / reverse searches
+  // (every tuple is written once by k_seed_keys, read and written once by each of the two sort passes, read once by k_seed_pg), and the
+  // algorithmic HBM bytes of k_seed_keys' inputs, of the two search launches and of k_seed_finish -- every kernel documents its own sum
+  C_TUP_F, C_TUP_R, C_B_KEYS, C_B_PG0, C_B_PG1, C_B_FIN, C_COUNT = 112,
   // Work counters and the pool cursor are sharded 64 ways (by block id): one address would serialise ~10 ns per
-  // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k at C_SHARDS + 16*s + k; the host folds them.
-  C_NSHARD = 64, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + 16 * C_NSHARD, C_TOTAL = C_PCUR + C_NSHARD
+  // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k (k < 9) at C_SHARDS + 32*s + k and C_TUP_F+k at C_SHARDS + 32*s + 9 + k
+  // (slots 16.. of a shard: the cycle counters of the -DSMR_*_PHASES debug builds); the host folds them.
+  C_NSHARD = 64, C_SHARD_W = 32, C_SHARD_X = 9, C_SHARD_NX = 6, C_SHARD_PH = 16, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + C_SHARD_W * C_NSHARD, C_TOTAL = C_PCUR + C_NSHARD
 };
 __device__ __forceinline__ void ctr_add(unsigned long long* ctr, int idx, unsigned long long v) {
-  atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + (idx - C_WINDOWS)], v);
+  atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * C_SHARD_W + (idx >= C_TUP_F ? C_SHARD_X + idx - C_TUP_F : idx - C_WINDOWS)], v);
 }
 
 // LEV(1) universal automaton (traverse_bursttrie.cpp:68-98), flattened: t0[16][14], t1[8][14], t2[4][14], t3[2][14]

@@ -195,7 +195,9 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
                                                    const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, uint32_t n_tiles) {
   SMR_DYN_LDS(uint32_t, lh);                              // [nc] this block's tuples per coarse bin
   __shared__ uint32_t s_cnt[2][16], s_off[2][16], s_win[16];
+  __shared__ unsigned long long s_bytes;                  // algorithmic input bytes of this block (C_B_KEYS)
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
+  if (threadIdx.x == 0) s_bytes = 0;
   __syncthreads();
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, L = P.lnwin;
@@ -204,12 +206,14 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     const uint32_t tid = tile * blockDim.x + threadIdx.x;
     const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
     bool emit[2] = {false, false};
-    uint32_t key[2] = {0, 0}, is_win = 0;
+    uint32_t key[2] = {0, 0}, is_win = 0, in_bytes = 0;
     unsigned long long payload[2] = {0, 0};
     if (r < rd.n) {
       const RWork w = rw[r];
       const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
       const uint32_t len = rd.len[r];
+      // inputs, once per read (its first window's thread): per-read state + length; of an active read also the record offset and the packed record
+      if (k == 0) in_bytes = (uint32_t)sizeof(RWork) + 4u + (active ? 8u + 4u * (((len + 15) >> 4) + ((len + 31) >> 5)) : 0u);
       const uint32_t stride = P.skip[pass];
       const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
       bool mine = k < numwin;
@@ -226,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
         uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
         ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
         rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
-        is_win = 1;
+        is_win = 1; in_bytes += 8;                                  // two lookup words
         const uint32_t lf = ix.lkc[ra], lr = ix.lkc[rb];          // lookup_tbl[kmer].count and the presence of trie_F / trie_R (paralleltraversal.cpp:155-160, 186-192)
         emit[0] = (lf & 0x3FFFFFFFu) > P.minoccur && ((lf >> 30) & 1u);
         emit[1] = (lr & 0x3FFFFFFFu) > P.minoccur && (lr >> 31);
@@ -238,7 +242,8 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     }
     // block-aggregated slot allocation in the unsorted tuple array (one atomic per 1024 slots)
     const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]), wm = __ballot(is_win);
-    if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); }
+    for (int d = 32; d > 0; d >>= 1) in_bytes += __shfl_xor(in_bytes, d, 64);
+    if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); if (in_bytes) atomicAdd(&s_bytes, (unsigned long long)in_bytes); }
     __syncthreads();
     if (threadIdx.x == 0) {                                // the tile's forward tuples first, wave by wave, then its reverse tuples
       uint32_t tc = 0, tw = 0;
@@ -263,6 +268,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     __syncthreads();                                       // s_cnt / s_off are rewritten by the next tile
   }
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) if (lh[c]) atomicAdd(&sb.chist[c], lh[c]);
+  if (threadIdx.x == 0 && s_bytes) ctr_add(ctr, C_B_KEYS, s_bytes);
 }
 
 // The tuples are brought into key order by a two-level counting sort whose per-tuple atomics all stay in LDS:
@@ -274,7 +280,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
 //                  their final places
 // (One counting sort over all 2 * 4^pw keys with a returning global atomic per tuple took 2.4 + 1.9 ms per stage of 60 M tuples on the
 // MI355X; this takes 1.3 + 0.9 + 1.0 ms.)
-__global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb) {
+__global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long long* __restrict__ ctr) {
   __shared__ uint32_t s_part[16];
   // <= 4096 bins: 4 consecutive bins per thread
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
@@ -291,6 +297,11 @@ __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb) {
     if (c < sb.nc) { sb.cbase[c] = pre; sb.ccur[c] = pre; if (c == (sb.nkh >> sb.fb)) sb.sn[SN_FWD] = pre; }
     pre += v[q];
     if (c + 1 == sb.nc) sb.cbase[sb.nc] = pre;
+  }
+  __syncthreads();
+  if (t == 0) {                                             // the stage's tuples: the forward ones lie in front of coarse bin nkh >> fb
+    const uint32_t all = min(sb.sn[SN_TUPLES], sb.cap_tuples), fw = min(sb.cbase[sb.nkh >> sb.fb], all);
+    ctr_add(ctr, C_TUP_F, fw); ctr_add(ctr, C_TUP_R, all - fw);
   }
 }
 
@@ -607,15 +618,18 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     sb.wseg[slot] = o | (sl.zero ? SEED_ZERO_BIT : 0u);
   }
   if (__any(sl.overflow) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
-  unsigned long long v[2] = {sl.n_node, sl.n_entry};
-  for (int c = 0; c < 2; c++) {
+  // algorithmic bytes of this wave (C_B_PG0/1): tuple + lookup entry per search, 16 B per node, 8 B per entry, the forward list read (DIR 1),
+  // the segment written + its window slot
+  unsigned long long v[3] = {sl.n_node, sl.n_entry, 0};
+  v[2] = (wave * 64u + lane < n_tup ? sizeof(SeedTmp) + sizeof(Lookup) + (DIR ? 4u + (n_prev ? 4u + 8u * n_prev : 0u) : 0u) : 0u) + 16ull * sl.n_node + 8ull * sl.n_entry + 4ull * need + (wr ? 4u : 0u);
+  for (int c = 0; c < 3; c++) {
     unsigned long long x = v[c];
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    if (lane == 0 && x) ctr_add(ctr, C_NODE + c, x);
+    if (lane == 0 && x) ctr_add(ctr, c < 2 ? C_NODE + c : (DIR ? C_B_PG1 : C_B_PG0), x);
   }
 #ifdef SMR_SEED_PHASES
   SPH(5)
-  if (lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * 16 + 9 + q], sph[q]);
+  if (lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], sph[q]);
 #endif
 }
 
@@ -626,9 +640,10 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long hits = 0, bytes = 0, looks = 0;
+  unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0;      // moved: algorithmic bytes of this read (C_B_FIN)
   if (r < rd.n) {
     RWork w = rw[r];
+    moved = sizeof(RWork);
     if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
       const uint32_t len = rd.len[r], stride = P.skip[pass];
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
@@ -642,6 +657,8 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
         seeds++; total += pool[(s & ~SEED_ZERO_BIT) + 1];
       }
       looks = rlook;
+      // length, one window slot per window, per segment its count word, every (id, win_pos) pair read and written, per-read state written, hit_seeds
+      moved += 4u + 4ull * numwin + 4ull * seeds + 16ull * total + sizeof(RWork) + 8u;
       uint32_t base = 0;
       if (total) {
         const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
@@ -664,8 +681,8 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       hits = total; bytes = (len + 3) / 4;
     }
   }
-  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); }
-  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); if (looks) ctr_add(ctr, C_LOOKUP, looks); }
+  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); moved += __shfl_down(moved, d, 64); }
+  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); if (looks) ctr_add(ctr, C_LOOKUP, looks); if (moved) ctr_add(ctr, C_B_FIN, moved); }
 }
 
 }  // namespace smr

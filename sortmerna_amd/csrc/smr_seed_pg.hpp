@@ -224,10 +224,17 @@ __global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P,
     sb.wseg[slot] = o | (zero ? SEED_ZERO_BIT : 0u);
   }
   if (__any(hl_over) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
-  if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); }
+  // algorithmic bytes of this wave (C_B_PG0/1): per tuple 12 B + its block-table entry (8 B); a search with directories reads 8 directory
+  // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; DIR 1 reads the window slot and the forward search's list
+  // (count word + its ids with their win_pos); the segment written (4 B per word) and the window slot pointing to it
+  unsigned long long w_bytes = (vb * 64u + lane < n_tup ? sizeof(SeedTmp) + 8u + (DIR ? 4u + (n_prev ? 4u + 8u * n_prev : 0u) : 0u) : 0u) +
+                               ((mine && rt.x != NONE && cA) ? 32u : 0u) + 4ull * tot + 4ull * need + (wr ? 4u : 0u);
+  for (int d = 32; d > 0; d >>= 1) w_bytes += __shfl_xor(w_bytes, d, 64);
+  w_bytes += 8ull * min(s_ncand, ccap);
+  if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, w_bytes); }
 #ifdef SMR_SEED_PHASES
   GPH(5)
-  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (vb & (C_NSHARD - 1)) * 16 + 9 + q], tph[q]);
+  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (vb & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], tph[q]);
 #endif
 }
 

@@ -342,6 +342,13 @@ class Engine:
         self._chk(self.L.smr_prof_get(self.h, C.byref(p)), "smr_prof_get")
         return p
 
+    def prof_kernels(self):
+        """{kernel family: {"ms", "launches", "bytes"}} since the last prof_reset (smr_prof_kernels)"""
+        a = (capi.Kprof * 16)()
+        n = C.c_uint32()
+        self._chk(self.L.smr_prof_kernels(self.h, a, 16, C.byref(n)), "smr_prof_kernels")
+        return {a[i].name.decode(): {"ms": a[i].ms, "launches": int(a[i].launches), "bytes": int(a[i].bytes)} for i in range(n.value)}
+
     def close(self):
         if self.h:
             self.L.smr_destroy(self.h)
