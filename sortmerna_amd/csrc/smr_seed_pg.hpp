@@ -32,8 +32,8 @@ namespace smr {
 #ifndef PG_TRIP
 #define PG_TRIP 4
 #endif
-// dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16)
-#define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap))
+// dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16), chain heads of the 64 searches
+#define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap) + 64u)
 
 // the chars of a 2-bit packed string (char j at bits 2j) with char j moved to bits 30-2j: any run of chars is then a number with its
 // first char most significant
@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t pg_reversed(uint32_t s) {
 __device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_t cnt) { return (rev >> (32u - 2u * (from + cnt))) & ((1u << (2u * cnt)) - 1u); }
 
 template <int DIR>
-__global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
+__global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
                                                 uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
   // this phase's tuples: forward bins first, reverse bins after them
   const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_all);
@@ -58,6 +58,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P,
   uint32_t* cdk = hl + 64 * hcap;                          // rank in the reference's traversal order
   uint32_t* cdv = cdk + ccap;                              // id
   uint32_t* cdn = cdv + ccap;                              // next record of the same search | kind << 16
+  uint32_t* hd = cdn + ccap;                               // [64] newest record of each search
   __shared__ uint32_t s_ncand_[PG_WAVES];
   uint32_t& s_ncand = s_ncand_[threadIdx.x >> 6];
   const int lane = lane_id();
@@ -103,15 +104,13 @@ __global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P,
   // ---- the four directory ranges of the search: [0] in TA, [1..3] (S0, S1, S2) in TB ----
   uint32_t rs0 = 0, rs1 = 0, rs2 = 0, rs3 = 0, rn0 = 0, rn1 = 0, rn2 = 0, rn3 = 0;
   uint32_t kA = 0, kb0 = 0, kb1 = 0, cA = 0, cB = 0, n = 0;
-  const uint32_t* tt = nullptr;                            // the block's strings TA TB, followed by {rank, id} RA RB
   if (mine && rt.x != NONE) {
     n = rt.y & 0xFFFFFFu; cA = (rt.y >> 24) & 15u; cB = rt.y >> 28;
     const uint32_t* blk = ix.pg + (size_t)rt.x * 4;
-    if (cA == 0) { rn0 = n; tt = blk; }
+    if (cA == 0) { rn0 = n; }
     else {
       const uint32_t nA = (1u << (2 * cA)) + 1u, nB = (1u << (2 * cB)) + 1u;
       const uint32_t* dirA = blk; const uint32_t* dirB = blk + nA;
-      tt = dirB + nB;
       const uint32_t rev = pg_reversed(P9);
       kA = pg_rkey(rev, 0, cA); kb0 = pg_rkey(rev, h, cB); kb1 = pg_rkey(rev, h - 1, cB);
       uint32_t lo2, hi2;
@@ -132,43 +131,52 @@ __global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P,
     w_entry = wsum; w_node = nsum;
   }
   GPH(1)
-  // ---- every lane walks its ranges; accepted entries go to the wave's candidate pool, chained per search ----
-  uint32_t head = PG_NIL;
-  // (PG_TRIP strings per trip: their loads are all in flight before the first is looked at -- the kernel is bound by memory latency)
-  // the lane's walk over its ranges: next string (index into TA TB), strings left in the current range, its number; the ranges still to
-  // come wait in (q*s, q*n)
-  const uint32_t* const rr = tt + (cA ? 2 : 1) * (size_t)n;
-  uint32_t cur = rs0, rng = 0, left = rn0;
-  uint32_t q1s = rs1, q1n = rn1, q2s = rs2, q2n = rn2, q3s = rs3, q3n = rn3;
-#define PG_NEXT_RANGE() { rng++; left = q1n; cur = n + q1s; q1s = q2s; q1n = q2n; q2s = q3s; q2n = q3n; q3n = 0; }
-#define PG_STEP(u, w) { if (left == 0) { PG_NEXT_RANGE() if (left == 0) { PG_NEXT_RANGE() if (left == 0) PG_NEXT_RANGE() } } u = cur; cur++; left--; w = rng; }
-  // "reachable through an earlier key of this search" needs no reversed strings: the keys are runs of chars, compared in place
-  const uint32_t mA = (1u << (2 * cA)) - 1u, mB = (1u << (2 * cB)) - 1u;
-  const uint32_t pb0 = (P9 >> (2 * h)) & mB, pb1 = (P9 >> (2 * h - 2)) & mB;
-  auto look = [&](uint32_t w, uint32_t T, uint32_t u) {
-    bool dup = false;
-    if (w) {
-      dup = ((T ^ P9) & mA) == 0;                          // under key A
-      if (w == 3) { const uint32_t tb = (T >> (2 * h)) & mB; dup = dup || tb == pb0 || tb == pb1; }      // under S0 / S1
-    }
-    const uint32_t r = dup ? 0u : lev1_entry(P9, T, pw);
-    if (r & 1u) {
-      const uint32_t p = atomicAdd(&s_ncand, 1u);
-      if (p < ccap) { const uint32_t* ri = rr + 2 * (size_t)u; cdk[p] = ri[0]; cdv[p] = ri[1]; cdn[p] = head | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16); head = p; }
-    }
-  };
-  for (uint32_t i = 0; __any(i < tot); i += PG_TRIP) {
-    if (i < tot) {
-      uint32_t u[PG_TRIP], w[PG_TRIP], T[PG_TRIP];
+  // ---- the strings of the wave's 64 searches, 64 at a time whichever search they belong to (a search has 5 strings on average, the
+  // busiest of 64 about 13: lane = search would run the wave as long as that one).  String g of the wave belongs to the search s with
+  // excl[s] <= g < excl[s] + tot[s]; its lane fetches what it needs of s's state with ds_bpermute ----
+  uint32_t sinc = tot;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(sinc, d, 64); if (lane >= d) sinc += x; }
+  const uint32_t excl = sinc - tot, wtot = __shfl(sinc, 63, 64);
+  const uint32_t c1 = rn0, c2 = c1 + rn1, c3 = c2 + rn2;                 // where the ranges S0, S1, S2 begin in the search's own numbering
+  const uint32_t u1 = n + rs1, u2 = n + rs2, u3 = n + rs3;               // ... and in the block's strings (TA TB)
+  hd[lane] = PG_NIL;
+  for (uint32_t g0 = 0; g0 < wtot; g0 += 64) {
+    const uint32_t g = g0 + (uint32_t)lane;
+    uint32_t lo = 0, hi = 63;                                            // the last search whose strings start at or before g
 #pragma unroll
-      for (int q = 0; q < PG_TRIP; q++) {
-        if (q == 0 || i + q < tot) PG_STEP(u[q], w[q])
-        else { u[q] = u[0]; w[q] = 0; }                    // (a string that exists; not looked at)
+    for (int it = 0; it < 6; it++) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      const uint32_t v = __shfl(excl, (int)mid, 64);
+      if (v <= g) lo = mid; else hi = mid - 1;
+    }
+    const int s = (int)lo;
+    const uint32_t oe = __shfl(excl, s, 64), oP = __shfl(P9, s, 64), om = __shfl(rt.y, s, 64), ob = __shfl(rt.x, s, 64);
+    const uint32_t o0 = __shfl(rs0, s, 64), o1 = __shfl(u1, s, 64), o2 = __shfl(u2, s, 64), o3 = __shfl(u3, s, 64);
+    const uint32_t oc1 = __shfl(c1, s, 64), oc2 = __shfl(c2, s, 64), oc3 = __shfl(c3, s, 64);
+    if (g < wtot) {
+      const uint32_t j = g - oe;
+      uint32_t w = 0, u = o0 + j;
+      if (j >= oc1) { w = 1; u = o1 + (j - oc1); }
+      if (j >= oc2) { w = 2; u = o2 + (j - oc2); }
+      if (j >= oc3) { w = 3; u = o3 + (j - oc3); }
+      const uint32_t on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u, ocB = om >> 28;
+      const uint32_t* ott = ix.pg + (size_t)ob * 4 + (ocA ? (1u << (2 * ocA)) + (1u << (2 * ocB)) + 2u : 0u);
+      const uint32_t T = ott[u];
+      bool dup = false;                                    // reachable through an earlier key of its search?
+      if (w) {
+        const uint32_t mA = (1u << (2 * ocA)) - 1u, mB = (1u << (2 * ocB)) - 1u;
+        dup = ((T ^ oP) & mA) == 0;                        // under key A
+        if (w == 3) { const uint32_t tb = (T >> (2 * h)) & mB; dup = dup || tb == ((oP >> (2 * h)) & mB) || tb == ((oP >> (2 * h - 2)) & mB); }      // under S0 / S1
       }
-#pragma unroll
-      for (int q = 0; q < PG_TRIP; q++) T[q] = tt[u[q]];
-#pragma unroll
-      for (int q = 0; q < PG_TRIP; q++) if (i + q < tot) look(w[q], T[q], u[q]);
+      const uint32_t r = dup ? 0u : lev1_entry(oP, T, pw);
+      if (r & 1u) {
+        const uint32_t p = atomicAdd(&s_ncand, 1u);
+        if (p < ccap) {
+          const uint32_t* ri = ott + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u;
+          cdk[p] = ri[0]; cdv[p] = ri[1];
+          cdn[p] = atomicExch(&hd[s], p) | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16);
+        }
+      }
     }
   }
   __syncthreads();
@@ -184,6 +192,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES) k_seed_pg(DIndex ix, DParams P,
   // ---------- every search applies its candidates in DFS order (selection by increasing rank) ----------
   bool zero = false;
   {
+    const uint32_t head = hd[lane];
     uint32_t last = 0;                                     // ranks already applied are < last
     bool more = head != PG_NIL;
     while (__any(more)) {

@@ -1,0 +1,67 @@
+#!/bin/bash
+# Round-3 GPU sessions (run through gpurun from the repo root):
+#     /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/gpu_session_r3.sh <tag> <stage> ...'
+# Everything lands in gpurun_out/<tag>/ ; what should be judged is copied into profiles/ afterwards.
+TAG=${1:-r03x}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROOT=$PWD
+MB=$ROOT/tools/microbench/build/mb
+pmcrun() {   # pmcrun <name> <counters...> -- <command...> : one counter pass, summary into $OUT/<name>.txt
+  local NAME=$1; shift; local CTRS=(); while [ "$1" != "--" ]; do CTRS+=("$1"); shift; done; shift
+  ( cd /tmp && timeout 600 rocprofv3 --pmc "${CTRS[@]}" --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$NAME -o pmc -- "$@" > $ROOT/$OUT/pmc_$NAME.stdout 2> $ROOT/$OUT/pmc_$NAME.err )
+  local F=$(find $OUT/pmc_$NAME -name "*counter_collection.csv" | head -1)
+  if [ -n "$F" ]; then python tools/pmc_calib.py $F > $OUT/$NAME.txt 2>&1; else echo "no counter file (see pmc_$NAME.err)" > $OUT/$NAME.txt; tail -5 $OUT/pmc_$NAME.err >> $OUT/$NAME.txt; fi
+  rm -rf $OUT/pmc_$NAME
+}
+for W in "$@"; do case $W in
+counters)
+  ( cd /tmp && timeout 120 rocprofv3 -L 2>&1 | grep -iE "TCC_EA|FETCH_SIZE|WRITE_SIZE|TCC_HIT|TCC_MISS|MALL|TCC_REQ|TCC_READ|TCC_WRITE" | cut -c1-200 | head -120 ) > $OUT/counters_list.txt 2>&1; wc -l $OUT/counters_list.txt ;;
+calib)
+  timeout 300 $MB calib 12 > $OUT/calib_timing.txt 2>&1; cat $OUT/calib_timing.txt
+  pmcrun calib_fetch FETCH_SIZE -- $MB calib 12
+  pmcrun calib_write WRITE_SIZE -- $MB calib 12
+  pmcrun calib_ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum -- $MB calib 12
+  head -40 $OUT/calib_fetch.txt ;;
+sort)
+  timeout 300 $MB sort 60 > $OUT/sort_timing.txt 2>&1; cat $OUT/sort_timing.txt
+  pmcrun sort_write WRITE_SIZE -- $MB sort 60
+  pmcrun sort_fetch FETCH_SIZE -- $MB sort 60 ;;
+tests)
+  timeout 1200 python -m pytest tests -m gpu -x -q -rs --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -15 $OUT/pytest_gpu.log ;;
+bench20)
+  ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_steps20_warmup5.json 2> $OUT/bench_steps20_warmup5.err; tail -c 3000 $OUT/bench_steps20_warmup5.json; tail -4 $OUT/bench_steps20_warmup5.err ;;
+bench2)
+  # the unwrapped multi-rank command on ONE GPU: both ranks on device 0, collectives on gloo (tests the self-launch on the GPU box)
+  ( time SMR_BENCH_BACKEND=gloo SMR_BENCH_DEVICE=0 timeout 900 python bench.py --gpus 2 --steps 3 --warmup 1 --resident-batches 2 ) > $OUT/bench_2ranks_one_gpu.json 2> $OUT/bench_2ranks_one_gpu.err; tail -c 1500 $OUT/bench_2ranks_one_gpu.json; tail -4 $OUT/bench_2ranks_one_gpu.err ;;
+prof)
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --profile-run > $ROOT/$OUT/bench_prof.json 2> $ROOT/$OUT/bench_prof.err )
+  find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+  head -16 $OUT/kernel_stats.csv | cut -c1-60,150-260
+  rm -rf $OUT/prof ;;
+pmc)
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 500 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$CTR -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_$CTR.json 2> $ROOT/$OUT/pmc_$CTR.err )
+  done
+  F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py $F $W 2000000 150 140000000 $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt 2>&1; cat $OUT/hbm_traffic.txt | head -40
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
+sq)
+  ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > /dev/null 2> $ROOT/$OUT/pmc_sq.err )
+  find $OUT/pmc_sq -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmc_sq.txt 2>&1; head -14 $OUT/pmc_sq.txt
+  rm -rf $OUT/pmc_sq ;;
+mini)
+  timeout 300 python tools/hw_minibench.py > $OUT/minibench.log 2>&1; tail -8 $OUT/minibench.log ;;
+alt)
+  # alternative builds of the library (sortmerna_amd/lib/libsmr_hip_alt*.so, made in the container) on the same mini bench
+  for A in sortmerna_amd/lib/libsmr_hip_alt*.so; do [ -f $A ] || continue
+    cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp $A sortmerna_amd/lib/libsmr_hip.so
+    timeout 300 python tools/hw_minibench.py > $OUT/minibench_$(basename $A .so).log 2>&1; echo "== $A"; grep -E "SW kernel|kernels:" $OUT/minibench_$(basename $A .so).log | tail -4
+    cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
+  done ;;
+e2e)
+  timeout 900 python tools/e2e_cpp.py > $OUT/e2e_cpp.log 2>&1; tail -12 $OUT/e2e_cpp.log ;;
+esac; done
+ls $OUT

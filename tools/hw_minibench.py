@@ -71,7 +71,7 @@ def step(b):
 
 
 START = eng.sw_mode()                                  # 1, or 2 with SMR_SW_PACKED=2 (the wave_ror variant)
-for mode in (START, 0, START):
+for mode in ((START, 0, START) if os.environ.get('MB_SW32') else (START, START)):
     eng.sw_mode(mode)
     step(0)
     eng.prof_reset()
@@ -85,6 +85,7 @@ for mode in (START, 0, START):
     say("spec SW issued %d used %d; " % (p.n_sw_spec, p.n_sw_spec_used) + "SW kernel %s: %.2f M reads/s (%.1f ms per 2 M-read step); seed stage %.2f ms/launch x %d, k_chain %.2f ms/launch x %d, k_trace %.2f ms x %d; aligned(batch 1) %d" % (
         {0: "32-bit", 1: "packed", 2: "packed (wave_ror)"}[mode], 2 * BATCH / dt / 1e6, dt / 2 * 1e3, p.seed_ms / max(p.seed_launches, 1), p.seed_launches,
         p.chain_ms / max(p.chain_launches, 1), p.chain_launches, p.trace_ms / max(p.trace_launches, 1), p.trace_launches, al))
+    say("kernels: " + "  ".join("%s %.3f ms x %d (%.0f GB/s)" % (k, v["ms"] / max(v["launches"], 1), v["launches"], v["bytes"] / max(v["ms"], 1e-9) / 1e6) for k, v in eng.prof_kernels().items()))
 if os.environ.get("MB_HOST_BUILD"):
     t = time.time(); h2 = smr.Index.build(db, 18, 3072.0, 10000, 0); say("host index build: %.1f s" % (time.time() - t))
 eng.close()
