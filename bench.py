@@ -57,6 +57,22 @@ def make_batch(synth, codes, offs, n, read_len, seed):
     return synth.make_reads(codes, offs, n, read_len=read_len, frac_db=0.10, seed=seed, sub=0.005, indel=0.0001, n_rate=0.001)
 
 
+def read_kvdb_dump(path):
+    """key -> value of the dump the reference binary's KVDB stand-in writes (oracle/shim/rocksdb/db.h: u64 n, n x (u64 klen, key, u64 vlen, value))"""
+    import struct
+    d = open(path, "rb").read()
+    (n,) = struct.unpack_from("<Q", d, 0)
+    o, out = 8, {}
+    for _ in range(n):
+        (kl,) = struct.unpack_from("<Q", d, o)
+        k = d[o + 8:o + 8 + kl]
+        o += 8 + kl
+        (vl,) = struct.unpack_from("<Q", d, o)
+        out[k] = d[o + 8:o + 8 + vl]
+        o += 8 + vl
+    return out
+
+
 def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_slots):
     """Time the unmodified reference on a bounded sample; also compare the set of read ids it aligns (aligned.fq) with the GPU path's."""
     ref_bin = os.path.join(HERE, "oracle", "_ref", "sortmerna_ref")
@@ -79,7 +95,8 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
         threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 64)
         cmd = [ref_bin, "-ref", db, "-reads", reads, "-workdir", os.path.join(wd, "run"), "-idx-dir", idx, "-threads", str(threads), "-fastx", "-v"]
         t0 = time.time()
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+        dump = os.path.join(wd, "kvdb_dump.bin")             # the reference's per-read records (Read::toBinString values), written by the KVDB stand-in it is built with
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, env=dict(os.environ, SMR_KVDB_DUMP=dump))
         out = p.stdout.decode("latin-1")
         wall = time.time() - t0
         m = re.findall(r"done index: \d+ part: \d+ in ([0-9.eE+-]+) sec", out)
@@ -99,7 +116,7 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
                 eng.select_batch(15)
                 eng.upload_reads(r, 1)
                 p2 = smr.default_params(minimal_score=int(ms.group(1)))
-                smr.align_resident(eng, idx_slots, [p2], with_cigar=False)
+                smr.align_resident(eng, idx_slots, [p2], with_cigar=True)
                 gpu_ids = set(i for i in range(n) if eng.is_hit(i))
                 ref_ids = None
                 for nm in ("aligned.fq", "aligned.fastq"):
@@ -112,6 +129,31 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
                                  "aligned_read_ids_equal": (ref_ids == gpu_ids) if ref_ids is not None else None,
                                  "ids_only_reference": len(ref_ids - gpu_ids) if ref_ids is not None else None,
                                  "ids_only_gpu": len(gpu_ids - ref_ids) if ref_ids is not None else None}
+                if os.path.isfile(dump):
+                    # records, not only ids: every read's Read::toBinString value (alignments with coordinates, scores, CIGARs, best-N bookkeeping)
+                    # as the reference stored it against smr_result_record of the same read, byte for byte
+                    # The reference names a read '<slot>_<number within the slot>' (readfeed.cpp:793): one slot per thread, contiguous record
+                    # ranges of the file in slot order (readfeed.cpp:1253-1277); its log gives every slot's read count.
+                    ref_rec = read_kvdb_dump(dump)
+                    per_slot = dict((int(a), int(b)) for a, b in re.findall(r"EOF reached\. Slot: (\d+) Total reads: (\d+)", out))
+                    if sorted(per_slot) == list(range(threads)) and sum(per_slot.values()) == n:
+                        eng.fetch()
+                        n_rec = n_bad = i = 0
+                        first_bad = None
+                        for sl in range(threads):
+                            for k in range(per_slot[sl]):
+                                a = ref_rec.get(b"%d_%d" % (sl, k), b"")
+                                b = eng.record(i)
+                                n_rec += 1 if a else 0
+                                if a != b:
+                                    n_bad += 1
+                                    first_bad = i if first_bad is None else first_bad
+                                i += 1
+                        res["parity"].update({"records_compared": n, "reference_records": n_rec, "records_differing": n_bad, "records_equal": n_bad == 0,
+                                              "first_differing_read": first_bad})
+                    else:
+                        res["parity"]["records_equal"] = None
+                        res["parity"]["records_note"] = "the reference's log did not give the read count of every slot: %r" % (per_slot,)
                 r.free()
         return res
     finally:

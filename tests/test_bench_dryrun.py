@@ -53,6 +53,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
         cb = out["cpu_baseline"]
         assert cb["kind"] == "reference" and cb["unit"] == "reads/s" and cb["cores"] == 2 and cb["value"] and cb["value"] > 0, cb
         assert cb["parity"]["aligned_read_ids_equal"] is True and cb["parity"]["reference_aligned"] == cb["parity"]["gpu_aligned"] > 0, cb
+        assert cb["parity"]["records_equal"] is True and cb["parity"]["reference_records"] == cb["parity"]["gpu_aligned"], cb
     else:
         assert out["cpu_baseline"] is None
 
