@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- reads/sec of the MI355X hot path (libsmr_hip) on BASELINE.json's headline workload.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload illumina150|refs8|pacbio5k]
+  (N > 1: one rank per GPU; started by torch.distributed.run, or by this script itself when no launcher is around it)
+
+--workload: illumina150 (default) = BASELINE.json configs[2], the configuration the metric is quoted on (below);
+            refs8    = configs[3]: the same reads against EIGHT resident reference DBs (bundled silva-arc-16s-id95 + 7 seeded synthetic ones
+                       sized like the rRNA_databases set, incl. 5S / 5.8S families shorter than a read), (index, part) loop of
+                       processor.cpp:219-277, reads_matched_per_db[8] through the counter reduce;
+            pacbio5k = configs[4]: PacBio-like reads ~N(5000, 500) nt with 12 % errors against a 28S-like DB, long-read Smith-Waterman in
+                       strips + wide traceback (the `--sam --blast 1` path needs every alignment's CIGAR).
 
 Workload (BASELINE.json configs[2]): synthetic 150-nt Illumina-like reads (10 % sampled from
 the DB with sequencing errors, 90 % random background) against an rRNA-like reference DB of the size of
@@ -53,10 +61,6 @@ def eng_counters_aligned(eng, b):
     return int(eng.counters(1)["num_aligned"])
 
 
-def make_batch(synth, codes, offs, n, read_len, seed):
-    return synth.make_reads(codes, offs, n, read_len=read_len, frac_db=0.10, seed=seed, sub=0.005, indel=0.0001, n_rate=0.001)
-
-
 def read_kvdb_dump(path):
     """key -> value of the dump the reference binary's KVDB stand-in writes (oracle/shim/rocksdb/db.h: u64 n, n x (u64 klen, key, u64 vlen, value))"""
     import struct
@@ -73,27 +77,33 @@ def read_kvdb_dump(path):
     return out
 
 
-def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_slots):
-    """Time the unmodified reference on a bounded sample; also compare the set of read ids it aligns (aligned.fq) with the GPU path's."""
+def cpu_baseline(args, dbs, parts_per_db, sample, smr, eng, idx_slots):
+    """Time the unmodified reference on a bounded sample (sample = (blob, offsets) of its reads); compare the ids it aligns (aligned.fq)
+    and its per-read records (KVDB values) with the GPU path's."""
     ref_bin = os.path.join(HERE, "oracle", "_ref", "sortmerna_ref")
     strhash = os.path.join(HERE, "oracle", "_ref", "strhash")
     cores = os.cpu_count() or 1
     if not (os.path.isfile(ref_bin) and os.path.isfile(strhash)):
         return {"value": None, "unit": "reads/s", "cores": cores, "kind": "reference", "sample": "oracle/_ref/sortmerna_ref not built"}
     from sortmerna_amd import synth
-    n = min(len(letters), args.cpu_sample_reads)
+    blob, offs = sample
+    n = len(offs) - 1
     wd = tempfile.mkdtemp(prefix="smr_cpu_")
     try:
         reads = os.path.join(wd, "sample.fastq")
-        synth.write_fastq(reads, letters[:n])
+        synth.write_fastq_ragged(reads, blob, offs)
         idx = os.path.join(wd, "idx")
         os.makedirs(idx)
-        h = subprocess.check_output([strhash, os.path.basename(db)]).decode().strip()
         t0 = time.time()
-        smr.Index.write_files(parts, db, os.path.join(idx, h))
+        for db, parts in zip(dbs, parts_per_db):
+            h = subprocess.check_output([strhash, os.path.basename(db)]).decode().strip()
+            smr.Index.write_files(parts, db, os.path.join(idx, h))
         log("index files for the reference written in %.1fs" % (time.time() - t0))
         threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 64)
-        cmd = [ref_bin, "-ref", db, "-reads", reads, "-workdir", os.path.join(wd, "run"), "-idx-dir", idx, "-threads", str(threads), "-fastx", "-v"]
+        cmd = [ref_bin]
+        for db in dbs:
+            cmd += ["-ref", db]
+        cmd += ["-reads", reads, "-workdir", os.path.join(wd, "run"), "-idx-dir", idx, "-threads", str(threads), "-v"] + WORKLOADS[args.workload]["ref_opts"]
         t0 = time.time()
         dump = os.path.join(wd, "kvdb_dump.bin")             # the reference's per-read records (Read::toBinString values), written by the KVDB stand-in it is built with
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500, env=dict(os.environ, SMR_KVDB_DUMP=dump))
@@ -104,34 +114,37 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
             return {"value": None, "unit": "reads/s", "cores": threads, "kind": "reference", "sample": "reference run failed rc=%d: %s" % (p.returncode, out[-300:])}
         align_s = sum(float(x) for x in m)
         res = {"value": n / align_s, "unit": "reads/s", "cores": threads, "kind": "reference",
-               "sample": "first %d reads of batch 0, same index files, alignment stage only (%.2f s; whole process %.1f s incl. index load)" % (n, align_s, wall)}
+               "sample": "first %d reads of batch 0, same index files, alignment stage only (%.2f s over %d (index, part) passes; whole process %.1f s incl. index load and reports)" % (n, align_s, len(m), wall)}
         logp = os.path.join(wd, "run", "out", "aligned.log")
         if os.path.isfile(logp):
             t = open(logp).read()
-            ms = re.search(r"Minimal SW score based on E-value = (\d+)", t)
+            ms = [int(x) for x in re.findall(r"Minimal SW score based on E-value = (\d+)", t)]
             na = re.search(r"Total reads passing E-value threshold = (\d+)", t)
-            if ms and na:
-                # same sample through the GPU path with the reference's own minimal_score: the SETS of aligned read ids must be equal
-                r = smr.Reads.from_seqs([bytes(x).decode() for x in letters[:n]])
+            if len(ms) == len(dbs) and na:
+                # same sample through the GPU path with the reference's own minimal_score per DB: ids and records must be equal
+                import ctypes as C
+                h = C.c_void_p()
+                assert eng.L.smr_reads_pack(blob, offs.ctypes.data, n, C.byref(h)) == 0
+                r = smr.Reads(h)
                 eng.select_batch(15)
                 eng.upload_reads(r, 1)
-                p2 = smr.default_params(minimal_score=int(ms.group(1)))
-                smr.align_resident(eng, idx_slots, [p2], with_cigar=True)
+                smr.align_resident(eng, idx_slots, [smr.default_params(minimal_score=x) for x in ms], with_cigar=True)
                 gpu_ids = set(i for i in range(n) if eng.is_hit(i))
+                gpu_ctr = eng.counters(len(dbs))
                 ref_ids = None
                 for nm in ("aligned.fq", "aligned.fastq"):
                     fq = os.path.join(wd, "run", "out", nm)
                     if os.path.isfile(fq):
                         with open(fq, "rb") as f:
                             ref_ids = set(int(l[2:].split()[0]) for k, l in enumerate(f) if k % 4 == 0)
-                res["parity"] = {"reference_aligned": int(na.group(1)), "gpu_aligned": int(eng.counters(1)["num_aligned"]),
-                                 "minimal_score": int(ms.group(1)),
+                res["parity"] = {"reference_aligned": int(na.group(1)), "gpu_aligned": int(gpu_ctr["num_aligned"]),
+                                 "minimal_score": ms,
                                  "aligned_read_ids_equal": (ref_ids == gpu_ids) if ref_ids is not None else None,
                                  "ids_only_reference": len(ref_ids - gpu_ids) if ref_ids is not None else None,
                                  "ids_only_gpu": len(gpu_ids - ref_ids) if ref_ids is not None else None}
                 if os.path.isfile(dump):
                     # records, not only ids: every read's Read::toBinString value (alignments with coordinates, scores, CIGARs, best-N bookkeeping)
-                    # as the reference stored it against smr_result_record of the same read, byte for byte
+                    # as the reference stored it against smr_result_record of the same read, byte for byte.
                     # The reference names a read '<slot>_<number within the slot>' (readfeed.cpp:793): one slot per thread, contiguous record
                     # ranges of the file in slot order (readfeed.cpp:1253-1277); its log gives every slot's read count.
                     ref_rec = read_kvdb_dump(dump)
@@ -154,10 +167,102 @@ def cpu_baseline(args, db, parts, letters, smr, minimal_score_gpu_fn, eng, idx_s
                     else:
                         res["parity"]["records_equal"] = None
                         res["parity"]["records_note"] = "the reference's log did not give the read count of every slot: %r" % (per_slot,)
+                if len(dbs) > 1:
+                    res["parity"]["gpu_reads_matched_per_db"] = [int(x) for x in gpu_ctr["reads_matched_per_db"][:len(dbs)]]
                 r.free()
         return res
     finally:
         shutil.rmtree(wd, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# workloads (BASELINE.json configs[2], [3], [4]; SURVEY.md 8d "Configs restated as concrete inputs")
+# ---------------------------------------------------------------------------------------------------------------------------------------
+WORKLOADS = {
+    "illumina150": {"batch_reads": 2_000_000, "cpu_sample_reads": 200_000, "ref_opts": ["-fastx"],
+                    "options": "default options (--fastx, best 1)"},
+    "refs8": {"batch_reads": 2_000_000, "cpu_sample_reads": 100_000, "ref_opts": ["-fastx"],
+              "options": "default options (--fastx, best 1), 8 --ref"},
+    "pacbio5k": {"batch_reads": 50_000, "cpu_sample_reads": 4_000, "ref_opts": ["-fastx", "-sam", "-blast", "1"],
+                 "options": "--sam --blast 1 (every alignment with its CIGAR), best 1"},
+}
+# the 8-ref set: sizes (nt) and typical sequence lengths of sortmerna's rRNA_databases files; only silva-arc-16s-id95 is bundled with
+# this repository (tests/golden/config2, the reference's own file), the others are seeded synthetic families of the same size
+REFS8 = [("silva-bac-16s-like", 19_000_000, 1500, 400, 101), ("silva-arc-16s-id95", None, None, None, None), ("silva-euk-18s-like", 13_000_000, 1800, 400, 103),
+         ("silva-bac-23s-like", 12_000_000, 2900, 400, 104), ("silva-arc-23s-like", 700_000, 2900, 400, 105), ("silva-euk-28s-like", 14_000_000, 3600, 400, 106),
+         ("rfam-5s-like", 7_000_000, 119, 90, 107), ("rfam-5.8s-like", 2_000_000, 154, 120, 108)]
+
+
+def workload_dbs(args, synth, cache, rank):
+    """-> [(name, fasta path)]; rank 0 writes the files"""
+    out = []
+    if args.workload == "illumina150":
+        specs = [("synth_rrna_db_%d" % args.db_nt, args.db_nt, 1500, 400, 42)]
+    elif args.workload == "pacbio5k":
+        specs = [("synth_28s_like_%d" % args.db_nt, args.db_nt, 5500, 400, 77)]
+    else:
+        sc = args.db_nt / 140_000_000.0                       # (--db-nt scales the synthetic members; the tests use tiny ones)
+        specs = [(n, (int(nt * sc) if nt else None), ml, mn, sd) for n, nt, ml, mn, sd in REFS8]
+    for name, nt, mean_len, min_len, seed in specs:
+        path = os.path.join(cache, name + ("_%d" % nt if nt and args.workload == "refs8" else "") + ".fasta")
+        if rank == 0 and not os.path.isfile(path):
+            if nt is None:                                   # the bundled real DB
+                import gzip
+                src = os.path.join(HERE, "tests", "golden", "config2", "silva-arc-16s-id95.fasta.gz")
+                with gzip.open(src, "rb") as f, open(path + ".tmp", "wb") as g:
+                    shutil.copyfileobj(f, g)
+            else:
+                synth.make_db(path + ".tmp", nt, seed=seed, mean_len=mean_len, min_len=min_len, tag=name.replace("-", "_") + "_f")
+            os.replace(path + ".tmp", path)
+        out.append((name, path))
+    return out
+
+
+def load_all_codes(synth, paths):
+    """codes / offsets of all DBs together (reads are sampled from their union, uniformly over sequences)"""
+    import numpy as np
+    cs, os_ = [], [np.zeros(1, dtype=np.int64)]
+    base = 0
+    for p in paths:
+        c, o = load_codes_iupac(p)
+        cs.append(c)
+        os_.append(o[1:] + base)
+        base += int(o[-1])
+    return np.concatenate(cs), np.concatenate(os_)
+
+
+def load_codes_iupac(path):
+    """like synth.load_db_codes, for FASTA with lower case / IUPAC letters / multi-line records (the bundled real DB): other letters -> A"""
+    import numpy as np
+    seqs, cur = [], []
+    with open(path, "rb") as f:
+        for line in f:
+            if line.startswith(b">"):
+                if cur:
+                    seqs.append(b"".join(cur))
+                cur = []
+            else:
+                cur.append(line.strip())
+    if cur:
+        seqs.append(b"".join(cur))
+    lut = np.zeros(256, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        lut[c] = i
+        lut[ord(chr(c).lower())] = i
+    lut[ord("U")] = lut[ord("u")] = 3
+    offs = np.zeros(len(seqs) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(x) for x in seqs])
+    return lut[np.frombuffer(b"".join(seqs), dtype=np.uint8)], offs
+
+
+def make_batch(args, synth, codes, offs, n, seed):
+    """-> (blob of ASCII letters, offsets uint64[n+1])"""
+    import numpy as np
+    if args.workload == "pacbio5k":
+        L = args.long_read_len
+        return synth.make_long_reads(codes, offs, n, mean_len=L, sd_len=L // 10, min_len=L // 5, max_len=6 * L, seed=seed)
+    letters = synth.make_reads(codes, offs, n, read_len=args.read_len, frac_db=0.10, seed=seed, sub=0.005, indel=0.0001, n_rate=0.001)
+    return letters.tobytes(), (np.arange(n + 1, dtype=np.uint64) * np.uint64(args.read_len))
 
 
 def self_launch(n):
@@ -173,7 +278,11 @@ def self_launch(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
     log("--gpus %d without a launcher: starting %d ranks through torch.distributed.run (port %d)" % (n, n, port))
-    return subprocess.call(cmd, env=env)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    for line in p.stdout:                                   # stdout carries rank 0's JSON line and nothing else (gloo's connection chatter goes to stderr)
+        (sys.stdout if line.lstrip().startswith(b"{") else sys.stderr).buffer.write(line)
+    sys.stdout.flush()
+    return p.wait()
 
 
 def main():
@@ -181,10 +290,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-reads", type=int, default=2_000_000)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="illumina150")
+    ap.add_argument("--batch-reads", type=int, default=0, help="reads per resident batch (0 = the workload's default: 2 M short reads, 50 k long reads)")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--db-nt", type=int, default=140_000_000)
-    ap.add_argument("--cpu-sample-reads", type=int, default=200_000)
+    ap.add_argument("--long-read-len", type=int, default=5000, help="pacbio5k: mean read length (sd = a tenth of it, clipped to [a fifth, six times])")
+    ap.add_argument("--db-nt", type=int, default=0, help="size of the synthetic DB (0 = the workload's: 140 Mnt; pacbio5k 14 Mnt; refs8 scales its 7 synthetic members by db_nt / 140 M)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="reads of the CPU-baseline sample (0 = the workload's default)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the reference CPU baseline (0 = min(host cores, 64))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cigar", action="store_true", help="skip the banded traceback (not the reference's behaviour)")
@@ -203,6 +314,10 @@ def main():
         args.gpus = world
     args.steps = max(args.steps, 1)
     args.warmup = max(args.warmup, 0)
+    W = WORKLOADS[args.workload]
+    args.batch_reads = args.batch_reads or W["batch_reads"]
+    args.cpu_sample_reads = args.cpu_sample_reads or W["cpu_sample_reads"]
+    args.db_nt = args.db_nt or (14_000_000 if args.workload == "pacbio5k" else 140_000_000)
 
     import numpy as np
     import torch
@@ -234,51 +349,56 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- workload: DB (rank 0 writes the FASTA) + index (every rank builds its replica on its own GPU) ----------------
-    cache = os.path.join(tempfile.gettempdir(), "smr_bench_%d" % args.db_nt)
+    # ---------------- workload: DBs (rank 0 writes the FASTA files) + indexes (every rank builds its replicas on its own GPU) ----------------
+    cache = os.path.join(tempfile.gettempdir(), "smr_bench_%s_%d" % (args.workload, args.db_nt))
     os.makedirs(cache, exist_ok=True)
-    db = os.path.join(cache, "synth_rrna_db_%d.fasta" % args.db_nt)
     t0 = time.time()
-    if rank == 0 and not os.path.isfile(db):
-        synth.make_db(db + ".tmp", args.db_nt, seed=42)
-        os.replace(db + ".tmp", db)
-    log("DB ready (%.1fs)" % (time.time() - t0))
+    dbl = workload_dbs(args, synth, cache, rank)
+    dbs = [p for _, p in dbl]
+    log("%d DB file(s) ready (%.1fs)" % (len(dbs), time.time() - t0))
     barrier()
     t0 = time.time()
     eng = smr.Engine(local)
     # sorting / ids / positions / mini-tries as device kernels (seconds for 140 Mnt).  With several ranks every rank builds
-    # the same index from the same FASTA on its own GPU, concurrently: no index files, no N-fold host parsing of them
-    try:
-        parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)
-        index_built = "device (smr_index_build_gpu), %.1f s" % (time.time() - t0)
-    except smr.SmrError as e:
-        log("device index build failed (%s): host builder" % e)
-        parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
-        index_built = "host (smr_index_build), %.1f s" % (time.time() - t0)
-    info = parts[0].info()
-    log("index ready: %d part(s), trie %.0f MB, positions %.0f MB, %d refs (%.1fs)" % (
-        len(parts), sum(p.info().trie_words for p in parts) * 4 / 1e6, sum(p.info().n_pos for p in parts) * 8 / 1e6,
-        info.numseq, time.time() - t0))
-
-    idx_slots = list(range(len(parts)))
-    for s, ix in zip(idx_slots, parts):
-        eng.upload_index(ix, s)
+    # the same indexes from the same FASTA files on its own GPU, concurrently: no index files, no N-fold host parsing of them
+    parts_per_db, idx_slots, infos = [], [], []
+    built = "device (smr_index_build_gpu)"
+    for db in dbs:
+        try:
+            parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)
+        except smr.SmrError as e:
+            log("device index build failed (%s): host builder" % e)
+            parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
+            built = "host (smr_index_build)"
+        sl = []
+        for ix in parts:                                     # every part of every --ref stays resident (the engine has 64 slots)
+            slot = sum(len(x) for x in idx_slots) + len(sl)
+            eng.upload_index(ix, slot)
+            sl.append(slot)
+        parts_per_db.append(parts)
+        idx_slots.append(sl)
+        infos.append(parts[0].info())
+    index_built = "%s, %.1f s for %d DB(s)" % (built, time.time() - t0, len(dbs))
+    parts = [ix for pp in parts_per_db for ix in pp]
+    info = infos[0]
+    log("indexes ready: %d DB(s), %d part(s), tries %.0f MB, positions %.0f MB, %d refs (%.1fs)" % (
+        len(dbs), len(parts), sum(p.info().trie_words for p in parts) * 4 / 1e6, sum(p.info().n_pos for p in parts) * 8 / 1e6,
+        sum(int(i.numseq) for i in infos), time.time() - t0))
 
     # ---------------- reads: W + K different batches per rank, resident in HBM ----------------
     t0 = time.time()
-    codes, offs = synth.load_db_codes(db)
+    codes, offs = load_all_codes(synth, dbs)
     n_total = args.warmup + args.steps              # step i (warmup first, then timed) runs on resident batch i % nb
     nb = max(1, min(n_total, args.resident_batches, MAX_RESIDENT))
-    batch0 = None
-    tot_reads = 0
-    tot_len = 0
+    sample0 = None
+    tot_reads = tot_len = 0
+    min_len, max_len = 1 << 30, 0
+    import ctypes as C
     for b in range(nb):
-        letters = make_batch(synth, codes, offs, args.batch_reads, args.read_len, 1234 + 1000 * rank + b)
+        blob, o = make_batch(args, synth, codes, offs, args.batch_reads, 1234 + 1000 * rank + b)
         if b == 0:
-            batch0 = letters
-        blob = letters.tobytes()
-        o = (np.arange(args.batch_reads + 1, dtype=np.uint64) * np.uint64(args.read_len))
-        import ctypes as C
+            ns = min(args.batch_reads, args.cpu_sample_reads)
+            sample0 = (blob[:int(o[ns])], o[:ns + 1].copy())
         h = C.c_void_p()
         rc = eng.L.smr_reads_pack(blob, o.ctypes.data, args.batch_reads, C.byref(h))
         assert rc == 0
@@ -287,22 +407,24 @@ def main():
         eng.upload_reads(r, 1)
         tot_reads += r.count
         tot_len += r.total_len
+        min_len, max_len = min(min_len, r.min_len), max(max_len, r.max_len)
         if b == nb - 1:
             last_packed = r                                  # kept on the host for the PCIe-inclusive measurement below
         else:
             r.free()
     del codes, offs
-    log("%d batches of %d reads resident (%.1fs)" % (nb, args.batch_reads, time.time() - t0))
+    log("%d batches of %d reads resident, %.0f nt per read (%.1fs)" % (nb, args.batch_reads, tot_len / max(tot_reads, 1), time.time() - t0))
 
-    # C1: global read totals -> the same minimal_score on every rank (refstats.cpp:247-265)
-    g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, args.read_len, args.read_len, device=cdev)
-    ms = smr.minimal_score(GUMBEL[0], GUMBEL[1], info, g_reads, g_len)
-    params = smr.default_params(minimal_score=ms)
+    # C1: global read totals -> the same minimal_score (per DB) on every rank (refstats.cpp:247-265)
+    g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, min_len, max_len, device=cdev)
+    mss = [smr.minimal_score(GUMBEL[0], GUMBEL[1], i, g_reads, g_len) for i in infos]
+    plist = [smr.default_params(minimal_score=m) for m in mss]
+    ms = mss[0]
 
     def step(b):
         eng.select_batch(b)
         eng.reset_state()
-        smr.align_resident(eng, idx_slots, [params], with_cigar=not args.no_cigar)
+        smr.align_resident(eng, idx_slots, plist, with_cigar=not args.no_cigar)
 
     for i in range(args.warmup):
         step(i % nb)
@@ -334,13 +456,14 @@ def main():
 
     # C2: Readstats counters of the timed steps, summed over ranks (RCCL).  Every step starts from a reset state, so a batch's
     # counter block holds the counts of its last step; a batch used u times contributes u times.
-    ctr = np.zeros(3, dtype=np.int64)
+    n_db = len(dbs)
+    ctr = np.zeros(2 + n_db, dtype=np.int64)
     for b in range(nb):
         if uses[b] == 0:
             continue
         eng.select_batch(b)
-        c = eng.counters(1)
-        ctr += uses[b] * np.array([c["num_aligned"], c["num_short"], c["reads_matched_per_db"][0]], dtype=np.int64)
+        c = eng.counters(n_db)
+        ctr += uses[b] * np.array([c["num_aligned"], c["num_short"]] + list(c["reads_matched_per_db"][:n_db]), dtype=np.int64)
     ctr_t = shard.reduce_counters(ctr.tolist(), device=cdev)
     pr = eng.prof()
     assert exact_aligned is None or int(ctr[0]) == exact_aligned, "the two seed kernels disagree on num_aligned: %d vs %d" % (int(ctr[0]), exact_aligned)
@@ -360,7 +483,7 @@ def main():
     for _ in range(0 if args.profile_run else 2):
         eng.select_batch(nb - 1)
         eng.upload_reads(last_packed, 1)
-        smr.align_resident(eng, idx_slots, [params], with_cigar=not args.no_cigar)
+        smr.align_resident(eng, idx_slots, plist, with_cigar=not args.no_cigar)
     torch.cuda.synchronize()
     pcie_rate = None if args.profile_run else 2 * args.batch_reads / (time.perf_counter() - t0)
     last_packed.free()
@@ -413,10 +536,13 @@ def main():
         # VALU model of the Smith-Waterman kernel: a wave64 VALU instruction occupies a SIMD for 4 cycles ->
         # 256 CU x 4 SIMD x 2.4 GHz / 4 = 6.14e11 wave-instructions/s; one systolic step costs 13 R + 14 (packed, R = ceil(m/128) cell pairs)
         # or 20 R + 15 (32-bit, R = ceil(m/64) cells) instructions and there are n + ceil(m/R) - 1 steps for an m x n problem
-        m_sw, n_sw = args.read_len, args.read_len + 8
+        mean_len = int(round(g_len / max(g_reads, 1)))
+        m_sw, n_sw = mean_len, mean_len + 8
         if eng.sw_mode() >= 1:
-            r_sw = (m_sw + 127) // 128
-            instr = (n_sw + (m_sw + r_sw - 1) // r_sw - 1) * (13 * r_sw + 14)
+            # (reads beyond 512 letters: strips of 128 virtual lanes x 4 rows, n + 127 steps each)
+            r_sw = min((m_sw + 127) // 128, 4)
+            n_strips = (m_sw + 128 * r_sw - 1) // (128 * r_sw)
+            instr = n_strips * (n_sw + (min(m_sw, 128 * r_sw) + r_sw - 1) // r_sw - 1) * (13 * r_sw + 14)
         else:
             r_sw = (m_sw + 63) // 64
             instr = (n_sw + 63) * (20 * r_sw + 15)
@@ -426,17 +552,23 @@ def main():
         instr4 = (n_sw + (m_sw + r4 - 1) // r4 - 1) * (13 * r4 + 13)
         sw4_peak_gcups = 4 * m_sw * n_sw / (instr4 / 6.144e11) / 1e9 if m_sw <= 256 else None
         out = {
-            "metric": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "value": reads_timed / dt, "unit": "reads/s",
+            "metric": {"illumina150": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "refs8": "reads/sec (150 bp vs the 8-ref rRNA set)",
+                       "pacbio5k": "reads/sec (5 kb PacBio-like reads vs a 28S-like DB, every alignment with its CIGAR)"}[args.workload], "value": reads_timed / dt, "unit": "reads/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32", "data": "synthetic",
-            "config": {"workload": "synthetic 150-nt Illumina-like reads (10%% from DB, 90%% background) vs seeded synthetic rRNA-like DB "
-                                   "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); default options (--fastx, best 1)" % args.db_nt,
-                       "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": args.read_len, "db_nt": args.db_nt, "index_parts": len(parts),
-                       "db_seqs": int(info.numseq), "minimal_score": int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus, "nranks": (dist.get_world_size() if dist is not None else 1),
+            "config": {"workload": {
+                "illumina150": "BASELINE configs[2]: synthetic 150-nt Illumina-like reads (10%% from DB, 90%% background) vs seeded synthetic rRNA-like DB "
+                               "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); " % args.db_nt,
+                "refs8": "BASELINE configs[3]: the same reads (10%% from the union of the DBs) vs EIGHT resident reference DBs: the bundled silva-arc-16s-id95 + 7 seeded synthetic "
+                         "families sized like the rRNA_databases set (%s; the real files are absent offline); " % ", ".join("%s %.1f Mnt" % (n, int(i.full_len) / 1e6) for (n, _), i in zip(dbl, infos)),
+                "pacbio5k": "BASELINE configs[4]: synthetic PacBio-like reads ~N(%d, %d) nt," % (args.long_read_len, args.long_read_len // 10) + " 12%% errors (6%% ins, 4%% del, 2%% sub), all sampled from a seeded synthetic 28S-like DB "
+                            "of %d nt (silva-euk-28s-id98 is absent offline); " % args.db_nt}[args.workload] + W["options"],
+                       "name": args.workload, "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": (args.read_len if args.workload != "pacbio5k" else mean_len), "db_nt": args.db_nt, "index_parts": len(parts),
+                       "n_dbs": n_db, "db_seqs": sum(int(i.numseq) for i in infos), "minimal_score": [int(x) for x in mss] if n_db > 1 else int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus, "nranks": (dist.get_world_size() if dist is not None else 1),
                        "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": "packed 16-bit (v_pk): candidate windows scored ahead four per wave, single problems on 128 virtual lanes" if eng.sw_mode() >= 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
-            "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1])},
+            "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1]), "reads_matched_per_db": [int(x) for x in ctr_t[2:2 + n_db]]},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,
                               "entries": n_entry / reads_timed, "hits": n_hit / reads_timed},
             "roofline": roof,
@@ -453,7 +585,7 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline and not args.profile_run:
             try:
-                out["cpu_baseline"] = cpu_baseline(args, db, parts, batch0, smr, None, eng, idx_slots)
+                out["cpu_baseline"] = cpu_baseline(args, dbs, parts_per_db, sample0, smr, eng, idx_slots)
             except Exception as e:  # the baseline must never lose the measured GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": os.cpu_count(), "kind": "reference", "sample": "failed: %r" % (e,)}
         else:

@@ -8,7 +8,7 @@ _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
 _COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
 
 
-def make_db(path, total_nt, seed=42, mean_len=1500, family_size=40, sub_lo=0.03, sub_hi=0.10, indel=0.005):
+def make_db(path, total_nt, seed=42, mean_len=1500, family_size=40, sub_lo=0.03, sub_hi=0.10, indel=0.005, min_len=400, tag="fam"):
     """Write a FASTA of ~total_nt nucleotides: families of mutated copies of random ancestors.
     Returns (n_seqs, total_nt_written)."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -17,7 +17,7 @@ def make_db(path, total_nt, seed=42, mean_len=1500, family_size=40, sub_lo=0.03,
     with open(path, "wb") as f:
         fam = 0
         while n_written < total_nt:
-            L = int(max(400, rng.normal(mean_len, mean_len * 0.07)))
+            L = int(max(min_len, rng.normal(mean_len, mean_len * 0.07)))
             anc = rng.integers(0, 4, size=L, dtype=np.uint8)
             for m in range(family_size):
                 if n_written >= total_nt:
@@ -34,7 +34,7 @@ def make_db(path, total_nt, seed=42, mean_len=1500, family_size=40, sub_lo=0.03,
                         s = np.delete(s, p)
                     else:
                         s = np.insert(s, p, rng.integers(0, 4, dtype=np.uint8))
-                f.write(b">fam%d_m%d synthetic rRNA-like\n" % (fam, m))
+                f.write(b">%s%d_m%d synthetic rRNA-like\n" % (tag.encode(), fam, m))
                 f.write(_ACGT[s].tobytes())
                 f.write(b"\n")
                 n_written += len(s)
@@ -90,6 +90,60 @@ def make_reads(db_codes, db_offs, n_reads, read_len=150, frac_db=0.10, seed=1234
     nm = rng.random(letters.shape) < n_rate
     letters[nm] = ord("N")
     return letters
+
+
+def make_long_reads(db_codes, db_offs, n_reads, mean_len=5000, sd_len=500, min_len=1000, max_len=30000, frac_db=1.0, seed=77,
+                    ins=0.06, dele=0.04, sub=0.02):
+    """PacBio-like reads: target length ~N(mean_len, sd_len) clipped to [min_len, max_len]; a read sampled from the
+    DB is a stretch of one DB sequence (either strand; as long as the target when the sequence allows, random letters around it
+    otherwise), then 12 % errors (6 % insertions, 4 % deletions, 2 % substitutions).  Returns (blob bytes of ASCII letters, offsets uint64[n+1])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nseq = len(db_offs) - 1
+    out = []
+    offs = np.zeros(n_reads + 1, dtype=np.uint64)
+    for i in range(n_reads):
+        T = int(min(max(rng.normal(mean_len, sd_len), min_len), max_len))
+        g = rng.integers(0, 4, size=T, dtype=np.uint8)
+        if rng.random() < frac_db:
+            sq = int(rng.integers(0, nseq))
+            L = int(db_offs[sq + 1] - db_offs[sq])
+            take = min(L, T)
+            a = int(rng.integers(0, L - take + 1))
+            piece = db_codes[db_offs[sq] + a:db_offs[sq] + a + take]
+            if rng.random() < 0.5:
+                piece = _COMP[piece[::-1]]
+            b = int(rng.integers(0, T - take + 1))
+            g[b:b + take] = piece
+        # errors: one pass, per position: deletion / substitution / (letter kept), then possibly an inserted letter after it
+        u = rng.random(T)
+        keep = u >= dele
+        subm = (u >= dele) & (u < dele + sub)
+        g = g.copy()
+        g[subm] = (g[subm] + rng.integers(1, 4, size=int(subm.sum()), dtype=np.uint8)) & 3
+        insm = rng.random(T) < ins
+        rep = keep.astype(np.int64) + insm.astype(np.int64)
+        res = np.repeat(g, rep)
+        # the inserted letters (the second copy of a kept letter, or the only copy of a deleted one) become random letters
+        idx_end = np.cumsum(rep)
+        ins_pos = idx_end[insm] - 1
+        res[ins_pos] = rng.integers(0, 4, size=len(ins_pos), dtype=np.uint8)
+        if len(res) < min_len:
+            res = np.concatenate([res, rng.integers(0, 4, size=min_len - len(res), dtype=np.uint8)])
+        out.append(_ACGT[res])
+        offs[i + 1] = offs[i] + np.uint64(len(res))
+    return np.concatenate(out).tobytes(), offs
+
+
+def write_fastq_ragged(path, blob, offs, n=None, first_id=0):
+    n = (len(offs) - 1) if n is None else n
+    with open(path, "wb") as f:
+        for i in range(n):
+            a, b = int(offs[i]), int(offs[i + 1])
+            f.write(b"@r%d\n" % (first_id + i))
+            f.write(blob[a:b])
+            f.write(b"\n+\n")
+            f.write(b"I" * (b - a))
+            f.write(b"\n")
 
 
 def write_fastq(path, letters, first_id=0):

@@ -15,8 +15,8 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "config", "roofline", "cpu_baseline"]
 
 
-@pytest.mark.parametrize("steps,warmup", [(2, 1), (20, 5)])          # (20, 5) = the driver's own command line of round 1, which aborted
-def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup):
+@pytest.mark.parametrize("steps,warmup,workload", [(2, 1, "illumina150"), (20, 5, "illumina150"), (2, 1, "refs8"), (2, 1, "pacbio5k")])          # (20, 5) = the driver's own command line of round 1, which aborted
+def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup, workload):
     baseline = paths.have_ref_bin() and steps == 2               # with the reference binary at hand the CPU-baseline leg runs too
     import torch
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
@@ -26,7 +26,9 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
     monkeypatch.setenv("SMR_BENCH_BACKEND", "gloo")          # the (world-size-1) reductions on CPU tensors
     import tempfile
     monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
-    argv = ["bench.py", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch-reads", "1500", "--db-nt", "150000", "--cpu-sample-reads", "1500", "--cpu-threads", "2"]
+    nreads = 60 if workload == "pacbio5k" else 1500
+    argv = ["bench.py", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch-reads", str(nreads), "--db-nt", "1000000" if workload == "refs8" else "150000",
+            "--cpu-sample-reads", str(nreads), "--cpu-threads", "2", "--workload", workload, "--long-read-len", "600"]
     if not baseline:
         argv.append("--no-cpu-baseline")
     monkeypatch.setattr(sys, "argv", argv)
@@ -45,9 +47,11 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
     assert "workload" in out["config"] and "sw_kernel" in out["config"] and out["config"]["index_build"].startswith("device")
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert out["counters"]["reads"] == steps * 1500
+    assert out["counters"]["reads"] == steps * nreads and out["config"]["name"] == workload
+    if workload == "refs8":
+        assert out["config"]["n_dbs"] == 8 and len(out["counters"]["reads_matched_per_db"]) == 8 and sum(out["counters"]["reads_matched_per_db"]) == out["counters"]["num_aligned"] > 0
     assert out["config"]["resident_batches"] == min(steps + warmup, 8)
-    assert abs(out["ms_per_step"] * steps / 1e3 * out["value"] - steps * 1500) < 1e-3
+    assert abs(out["ms_per_step"] * steps / 1e3 * out["value"] - steps * nreads) < 1e-3
     assert out["kernels"]["k_chain"]["valu_model_peak_gcups"] > 0
     if baseline:
         cb = out["cpu_baseline"]

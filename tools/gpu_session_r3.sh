@@ -52,6 +52,22 @@ sq)
   ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > /dev/null 2> $ROOT/$OUT/pmc_sq.err )
   find $OUT/pmc_sq -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmc_sq.txt 2>&1; head -14 $OUT/pmc_sq.txt
   rm -rf $OUT/pmc_sq ;;
+batchsize)
+  # does a larger resident batch amortise the index streaming of the seed searches?
+  for B in 4000000 8000000; do
+    timeout 600 python bench.py --steps 4 --warmup 1 --resident-batches 2 --batch-reads $B --no-cpu-baseline > $OUT/bench_batch_$B.json 2> $OUT/bench_batch_$B.err
+    python - $OUT/bench_batch_$B.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); r = d["roofline"]
+print("batch", d["config"]["batch_reads"], "reads/s %.2f M" % (d["value"] / 1e6), "ms/step %.1f" % d["ms_per_step"], "pcie-incl %.2f M" % ((d["pcie_inclusive_reads_per_s_per_gpu"] or 0) / 1e6))
+for k, v in r["kernels"].items(): print("   %-16s %.3f ms x %d" % (k, v["avg_launch_ms"], v["launches"]))
+print("   k_chain %.1f ms/step  k_trace %.2f" % (d["kernels"]["k_chain"]["ms"] / d["steps"], d["kernels"]["k_trace"]["ms"] / d["steps"]))
+PY
+  done ;;
+refs8)
+  ( time timeout 900 python bench.py --workload refs8 --steps 5 --warmup 1 --resident-batches 2 ) > $OUT/bench_refs8.json 2> $OUT/bench_refs8.err; tail -c 2500 $OUT/bench_refs8.json; tail -4 $OUT/bench_refs8.err ;;
+pacbio)
+  ( time timeout 1200 python bench.py --workload pacbio5k --steps 3 --warmup 1 --resident-batches 2 ) > $OUT/bench_pacbio5k.json 2> $OUT/bench_pacbio5k.err; tail -c 2500 $OUT/bench_pacbio5k.json; tail -6 $OUT/bench_pacbio5k.err ;;
 mini)
   timeout 300 python tools/hw_minibench.py > $OUT/minibench.log 2>&1; tail -8 $OUT/minibench.log ;;
 alt)
