@@ -76,7 +76,7 @@ struct smr_ctx {
   uint32_t keys_need = 0;
   bool chain_ext = false;                                              // a read's candidate set has outgrown the LDS table once: global tables are on
   uint32_t* d_stab = nullptr; unsigned long long* d_tuples2 = nullptr; // per block: CH_EXT_CAP-slot table (4 arrays), tuples grouped by member
-  size_t chain_lds_attr = 0, begins_lds_attr = 0;
+  size_t chain_lds_attr = 0, begins_lds_attr = 0, split_lds_attr = 0;
   uint32_t* d_fidx = nullptr; RState* d_fstate = nullptr; AlignRec* d_faln = nullptr; size_t fetch_cap_r = 0, fetch_cap_a = 0;   // staging of smr_results_fetch
   int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 2;   // 1 / 2: packed 16-bit Smith-Waterman kernels (smr_sw_pk.hpp; 2 = lane hand-over by wave_ror, measured faster) where they apply
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
@@ -206,21 +206,25 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   for (int p = 0; p < 3; p++) mw = std::max(mw, num_windows(c->b->max_len, P.lnwin, P.skip[p]));
   const uint64_t slots = (uint64_t)std::max(c->b->n, 1u) * mw;
   const uint32_t nk = 2u << P.lnwin;                      // 2 x 4^(L/2) bins: forward and reverse keys
-  if (2 * slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^32): use smaller batches"; return SMR_ERR_CAPACITY; }
+  if (2 * slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^31): use smaller batches"; return SMR_ERR_CAPACITY; }
   int rc;
   if (c->sb_nk < nk) {
     if ((rc = dev_alloc(c, &c->sb.chist, (size_t)4096 + 1))) return rc;
     if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.ccur, (size_t)4096))) return rc;
+    if (!c->sb.rows && (rc = dev_alloc(c, &c->sb.rows, (size_t)SEED_KEY_BLOCKS * 4096))) return rc;
+    if (!c->sb.bcnt && (rc = dev_alloc(c, &c->sb.bcnt, (size_t)SEED_KEY_BLOCKS))) return rc;
     if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
     if (!c->sb.sn && (rc = dev_alloc(c, &c->sb.sn, SN_COUNT))) return rc;
     c->sb_nk = nk;
   }
   if (c->sb_slots < slots) {
-    if ((rc = dev_alloc(c, &c->sb.tmp, 2 * slots))) return rc;       // a forward and a reverse tuple per window
+    // a forward and a reverse tuple per window; tmp is cut into one region per block of k_seed_keys (whole tiles: up to one tile per block more)
+    const size_t tmp_slots = 2 * (size_t)SEED_TILE * ((slots + SEED_TILE - 1) / SEED_TILE + SEED_KEY_BLOCKS);
+    if ((rc = dev_alloc(c, &c->sb.tmp, tmp_slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.mid, 2 * slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.srt, 2 * slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.wseg, slots))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.fbits, slots / 32 + 2))) return rc;
     c->sb_slots = slots;
   }
   c->sb.nk = nk; c->sb.nkh = nk / 2;
@@ -238,22 +242,31 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   sb.cap_tuples = (uint32_t)(2 * slots);
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
+  const uint32_t n_tiles = (uint32_t)((slots + SEED_TILE - 1) / SEED_TILE);
+  sb.kb = std::max<uint32_t>(1u, std::min<uint32_t>(n_tiles, SEED_KEY_BLOCKS));
+  sb.tpb = std::max<uint32_t>(1u, (n_tiles + sb.kb - 1) / sb.kb);
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
   const uint32_t pgw = (uint32_t)std::max<size_t>(1, std::min<size_t>(PG_WAVES, (60 * 1024) / lds_pg1));      // waves per block of k_seed_pg
   const size_t lds_pg = lds_pg1 * pgw;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((slots + 63) / 64)), gk4 = (uint32_t)((slots + 1023) / 1024);     // (every kernel checks its range: a batch without a single window launches one idle block each)
+  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((slots + 63) / 64));     // (every kernel checks its range: a batch without a single window launches one idle block each)
+  const size_t lds_split = (size_t)3 * sb.nc * 4 + (size_t)SEED_PIECE * sizeof(SeedTmp), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTmp);
+  if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
+    c->split_lds_attr = lds_split;
+  }
   ev_mark(c, KP_KEYS);
-  // one two-level counting sort for the forward and the reverse tuples of the stage (smr_seed.hpp)
   HIPCHK(c, hipMemsetAsync(sb.chist, 0, ((size_t)sb.nc + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
-  if (slots) HIPCHK(c, hipMemsetAsync(sb.wseg, 0xFF, (size_t)slots * 4, c->stream));       // NONE: no window has hits yet
-  hipLaunchKernelGGL(k_seed_keys, dim3(std::max<uint32_t>(1u, std::min<uint32_t>(gk4, 2048u))), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, gk4);
-  ev_mark(c, KP_SPLIT);                                    // (with the one-block scan of the coarse counts in front of it)
+  HIPCHK(c, hipMemsetAsync(sb.fbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
+  hipLaunchKernelGGL(k_seed_keys, dim3(sb.kb), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, n_tiles);
+  // the two-level sort of the stage's forward and reverse tuples (smr_seed.hpp)
+  ev_mark(c, KP_SPLIT);                                    // (with the scans of the block histograms in front of it)
   hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
-  hipLaunchKernelGGL(k_seed_split, dim3(std::max<uint32_t>(1u, (uint32_t)((2 * slots + SEED_SPLIT_CHUNK - 1) / SEED_SPLIT_CHUNK))), dim3(1024), (size_t)sb.nc * 8, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
   ev_mark(c, KP_BINS);
-  hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
   for (int dir = 0; dir < 2; dir++) {
     const uint32_t* no_redo = nullptr;
     ev_mark(c, dir ? KP_PG1 : KP_PG0);
@@ -740,8 +753,8 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
-  dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.ccur); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
-  dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.sn);
+  dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
+  dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.fbits); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
   for (auto& m : c->events) (void)hipEventDestroy(m.e);
@@ -1433,7 +1446,7 @@ extern "C" int smr_prof_kernels(smr_ctx* c, smr_kprof* out, uint32_t cap, uint32
     fold_shards(t);
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
-  const unsigned long long T = h[C_TUP_F] + h[C_TUP_R];
+  const unsigned long long T = h[C_TUP_ALL];
   unsigned long long bytes[KP_COUNT] = {};
   bytes[KP_KEYS] = h[C_B_KEYS] + sizeof(SeedTmp) * T;                 // its inputs (counted by the kernel) + every tuple written once
   bytes[KP_SPLIT] = bytes[KP_BINS] = 2 * sizeof(SeedTmp) * T;         // each of the two sort passes reads and writes every tuple once

@@ -108,10 +108,10 @@ enum {
   C_WINDOWS = 66, C_LOOKUP, C_NODE, C_ENTRY, C_HIT, C_READ_BYTES, C_SW_FWD, C_SW_REV, C_SW_CELLS,
   C_ERR_HITCAP, C_ERR_POOL, C_ERR_SLOTS, C_ERR_PAIRS, C_ERR_CIGAR, C_ERR_TRACE, C_POOL_CURSOR, C_WORK_NEXT,
   C_CIGAR_CURSOR, C_TRACE_NEXT, C_ERR_SCAP, C_ERR_REDO, C_TRACE_DEFER, C_BEGIN_N, C_BEGIN_NEXT, C_FETCH_N, C_SW_SPEC, C_SW_SPEC_USED, C_SEED_REDO,
-  // what the seed-stage kernels THEMSELVES move, for the roofline of each (smr_prof_kernels): tuples of the forward / reverse searches
+  // what the seed-stage kernels THEMSELVES move, for the roofline of each (smr_prof_kernels): tuples of the forward searches / of both
   // (every tuple is written once by k_seed_keys, read and written once by each of the two sort passes, read once by k_seed_pg), and the
   // algorithmic HBM bytes of k_seed_keys' inputs, of the two search launches and of k_seed_finish -- every kernel documents its own sum
-  C_TUP_F, C_TUP_R, C_B_KEYS, C_B_PG0, C_B_PG1, C_B_FIN, C_COUNT = 112,
+  C_TUP_F, C_TUP_ALL, C_B_KEYS, C_B_PG0, C_B_PG1, C_B_FIN, C_COUNT = 112,
   // Work counters and the pool cursor are sharded 64 ways (by block id): one address would serialise ~10 ns per
   // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k (k < 9) at C_SHARDS + 32*s + k and C_TUP_F+k at C_SHARDS + 32*s + 9 + k
   // (slots 16.. of a shard: the cycle counters of the -DSMR_*_PHASES debug builds); the host folds them.

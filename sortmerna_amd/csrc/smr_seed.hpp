@@ -140,22 +140,31 @@ enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device co
 struct SeedTmp { uint32_t key, lo, hi; };               // 12 bytes; payload = lo | hi << 32: read | win_pos << 24 | chars << 40
 __device__ __forceinline__ unsigned long long seed_payload(const SeedTmp& t) { return (unsigned long long)t.lo | ((unsigned long long)t.hi << 32); }
 
-#define SEED_SPLIT_CHUNK 32768u                           // tuples per block of k_seed_split
+#define SEED_KEY_BLOCKS 2048u                              // most blocks of k_seed_keys / k_seed_split (rows of the histogram matrix)
+#define SEED_TILE 1024u                                   // windows per tile of k_seed_keys
+#ifndef SEED_PIECE
+#define SEED_PIECE 4096u                                  // tuples a sort pass stages in LDS at a time
+#endif
 struct SeedBufs {
   uint32_t* chist;           // [nc + 1] tuples per COARSE bin (key >> fb)
   uint32_t* cbase;           // [nc + 1] exclusive scan of chist
-  uint32_t* ccur;            // [nc] allocation cursors of the coarse bins (k_seed_split)
-  SeedTmp* tmp;              // unsorted tuples
+  uint32_t* rows;            // [kb][nc] tuples of block b of k_seed_keys per coarse bin; after k_seed_colscan: where its first tuple of that bin goes in mid
+  uint32_t* bcnt;            // [kb] tuples block b wrote (at tmp[2 * SEED_TILE * tpb * b ...), compact)
+  SeedTmp* tmp;              // unsorted tuples, one compact region per block of k_seed_keys
   SeedTmp* mid;              // tuples grouped by coarse bin
   SeedTmp* srt;              // tuples in key order
-  uint32_t* wseg;            // [maxwin][n] (window-major: k_seed_finish's threads = reads read it coalesced) pool offset of the window's hit segment | SEED_ZERO_BIT ; NONE = no hits
+  uint32_t* wseg;            // [maxwin][n] (window-major: k_seed_finish's threads = reads read it coalesced) pool offset of the window's hit segment | SEED_ZERO_BIT; valid where the window's bit in fbits is set
+  uint32_t* fbits;           // [ceil(maxwin * n / 32)] bit per window slot: the window has a hit segment
   uint32_t* sn;              // SN_* counters
   uint32_t* redo;            // waves of k_seed_pg to be searched again by k_seed_search
   uint32_t nk, nkh, maxwin, cap_tuples, cap_redo;     // nk = 2 * nkh bins: forward keys [0, nkh), reverse keys [nkh, 2 nkh)
   uint32_t fb, nc;           // fine bits (min(9, L): a coarse bin never mixes forward and reverse keys), nc = nk >> fb coarse bins (<= 4096)
   uint32_t n;                // reads in the batch
+  uint32_t kb, tpb;          // blocks of k_seed_keys / k_seed_split, tiles per block
 };
 __device__ __forceinline__ size_t wseg_slot(const SeedBufs& sb, uint32_t r, uint32_t k) { return (size_t)k * sb.n + r; }
+__device__ __forceinline__ bool wseg_has(const SeedBufs& sb, size_t slot) { return (sb.fbits[slot >> 5] >> (slot & 31u)) & 1u; }
+__device__ __forceinline__ void wseg_put(const SeedBufs& sb, size_t slot, uint32_t v) { sb.wseg[slot] = v; atomicOr(&sb.fbits[slot >> 5], 1u << (slot & 31u)); }
 
 // nbits <= 40 bits starting at bit `bit0` of a little-endian word stream (reads up to 2 words past the first)
 __device__ __forceinline__ unsigned long long extract_bits(const uint32_t* w, uint32_t bit0, uint32_t nbits) {
@@ -186,40 +195,42 @@ __device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, 
   return wchars;
 }
 
-// Both half-seed searches of a window become tuples in ONE pass (so the counting sort runs once per stage):
+// Both half-seed searches of a window become tuples in ONE pass (so the sort runs once per stage):
 //   forward: key = first 9-mer, automaton fed by chars [pw, 2pw)          (init_win_f bitvector.cpp:57-91)  -> bins [0, nkh)
 //   reverse: key = second 9-mer, automaton fed by chars pw-1 .. 0         (init_win_r :99-132)              -> bins [nkh, 2 nkh)
 // The reverse tuple is speculative: the reverse search kernel drops it when the forward search ended with a 0-error match
 // (accept_zero_kmer, paralleltraversal.cpp:188).
+// A block owns `tpb` consecutive tiles of SEED_TILE windows and writes its tuples compactly into ITS region of tmp (the slots of its
+// first window onwards: no allocation between blocks, no barrier inside the tile loop -- a wave reserves its slots with one LDS atomic).
+// It counts them per COARSE bin (key >> fb) in LDS and leaves that histogram as its row of sb.rows: the first sort pass needs no
+// counting pass of its own.
 __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
                                                    const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, uint32_t n_tiles) {
   SMR_DYN_LDS(uint32_t, lh);                              // [nc] this block's tuples per coarse bin
-  __shared__ uint32_t s_cnt[2][16], s_off[2][16], s_win[16];
-  __shared__ unsigned long long s_bytes;                  // algorithmic input bytes of this block (C_B_KEYS)
+  __shared__ uint32_t s_cur, s_win;
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
-  if (threadIdx.x == 0) s_bytes = 0;
+  if (threadIdx.x == 0) { s_cur = 0; s_win = 0; }
   __syncthreads();
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, L = P.lnwin;
-  const uint32_t wv = threadIdx.x >> 6;
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint32_t tid = tile * blockDim.x + threadIdx.x;
+  const uint32_t t0 = blockIdx.x * sb.tpb, t1 = min(t0 + sb.tpb, n_tiles);
+  SeedTmp* const region = sb.tmp + (size_t)2 * SEED_TILE * t0;
+  uint32_t nwin = 0;                                      // windows of this wave (uniform)
+  for (uint32_t tile = t0; tile < t1; tile++) {
+    const uint32_t tid = tile * SEED_TILE + threadIdx.x;
     const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
     bool emit[2] = {false, false};
-    uint32_t key[2] = {0, 0}, is_win = 0, in_bytes = 0;
+    uint32_t key[2] = {0, 0}, is_win = 0;
     unsigned long long payload[2] = {0, 0};
     if (r < rd.n) {
       const RWork w = rw[r];
       const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
       const uint32_t len = rd.len[r];
-      // inputs, once per read (its first window's thread): per-read state + length; of an active read also the record offset and the packed record
-      if (k == 0) in_bytes = (uint32_t)sizeof(RWork) + 4u + (active ? 8u + 4u * (((len + 15) >> 4) + ((len + 31) >> 5)) : 0u);
       const uint32_t stride = P.skip[pass];
       const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
       bool mine = k < numwin;
       const uint32_t win_pos = k * stride;
       if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
-      // (wseg starts as NONE everywhere: launch_seed fills it)
       if (mine) {
         // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
         const uint32_t aval = w.is04 ? 0 : w.aval;
@@ -230,7 +241,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
         uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
         ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
         rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
-        is_win = 1; in_bytes += 8;                                  // two lookup words
+        is_win = 1;
         const uint32_t lf = ix.lkc[ra], lr = ix.lkc[rb];          // lookup_tbl[kmer].count and the presence of trie_F / trie_R (paralleltraversal.cpp:155-160, 186-192)
         emit[0] = (lf & 0x3FFFFFFFu) > P.minoccur && ((lf >> 30) & 1u);
         emit[1] = (lr & 0x3FFFFFFFu) > P.minoccur && (lr >> 31);
@@ -240,46 +251,42 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
         payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
       }
     }
-    // block-aggregated slot allocation in the unsorted tuple array (one atomic per 1024 slots)
-    const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]), wm = __ballot(is_win);
-    for (int d = 32; d > 0; d >>= 1) in_bytes += __shfl_xor(in_bytes, d, 64);
-    if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(em0); s_cnt[1][wv] = (uint32_t)__popcll(em1); s_win[wv] = (uint32_t)__popcll(wm); if (in_bytes) atomicAdd(&s_bytes, (unsigned long long)in_bytes); }
-    __syncthreads();
-    if (threadIdx.x == 0) {                                // the tile's forward tuples first, wave by wave, then its reverse tuples
-      uint32_t tc = 0, tw = 0;
-      for (int d = 0; d < 2; d++) for (uint32_t q = 0; q < (blockDim.x >> 6); q++) { s_off[d][q] = tc; tc += s_cnt[d][q]; }
-      for (uint32_t q = 0; q < (blockDim.x >> 6); q++) tw += s_win[q];
-      const uint32_t base = tc ? atomicAdd(&sb.sn[SN_TUPLES], tc) : 0u;
-      for (int d = 0; d < 2; d++) for (uint32_t q = 0; q < (blockDim.x >> 6); q++) s_off[d][q] += base;
-      if (tw) { ctr_add(ctr, C_WINDOWS, tw); ctr_add(ctr, C_LOOKUP, tw); }     // the forward lookups; the reverse ones are counted by k_seed_finish
-    }
-    __syncthreads();
+    const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]);
+    nwin += (uint32_t)__popcll(__ballot(is_win));
+    const uint32_t c0 = (uint32_t)__popcll(em0), c1 = (uint32_t)__popcll(em1);
+    uint32_t base = 0;
+    if (lane == 0 && c0 + c1) base = atomicAdd(&s_cur, c0 + c1);       // the wave's slots in the block's region: its forward tuples, then its reverse tuples
+    base = (uint32_t)__shfl((int)base, 0, 64);
 #pragma unroll
     for (int d = 0; d < 2; d++) {
       if (emit[d]) {
-        const uint32_t idx = s_off[d][wv] + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
-        if (idx < sb.cap_tuples) {
-          SeedTmp t; t.key = key[d]; t.lo = (uint32_t)payload[d]; t.hi = (uint32_t)(payload[d] >> 32);
-          sb.tmp[idx] = t;
-          atomicAdd(&lh[key[d] >> sb.fb], 1u);
-        }
+        const uint32_t idx = base + (d ? c0 : 0u) + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
+        SeedTmp t; t.key = key[d]; t.lo = (uint32_t)payload[d]; t.hi = (uint32_t)(payload[d] >> 32);
+        region[idx] = t;
+        atomicAdd(&lh[key[d] >> sb.fb], 1u);
       }
     }
-    __syncthreads();                                       // s_cnt / s_off are rewritten by the next tile
   }
-  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) if (lh[c]) atomicAdd(&sb.chist[c], lh[c]);
-  if (threadIdx.x == 0 && s_bytes) ctr_add(ctr, C_B_KEYS, s_bytes);
+  if (lane == 0 && nwin) atomicAdd(&s_win, nwin);
+  __syncthreads();
+  uint32_t* const row = sb.rows + (size_t)blockIdx.x * sb.nc;
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) { const uint32_t v = lh[c]; row[c] = v; if (v) atomicAdd(&sb.chist[c], v); }
+  if (threadIdx.x == 0) {
+    sb.bcnt[blockIdx.x] = s_cur;
+    if (s_win) { ctr_add(ctr, C_WINDOWS, s_win); ctr_add(ctr, C_LOOKUP, s_win); }     // the forward lookups; the reverse ones are counted by k_seed_finish
+  }
 }
 
-// The tuples are brought into key order by a two-level counting sort whose per-tuple atomics all stay in LDS:
-//   k_seed_keys    counts the tuples per COARSE bin (key >> fb, <= 4096 bins) in LDS while it writes them unsorted
-//   k_seed_cscan   exclusive scan of the coarse counts (one block)
-//   k_seed_split   a block takes SEED_SPLIT_CHUNK unsorted tuples: LDS histogram by coarse bin, one global atomic per non-empty bin reserves
-//                  the block's share of that bin, second pass copies the tuples there (runs of ~32 tuples per bin)
-//   k_seed_bins    one block per coarse bin: LDS histogram of the fine key bits (<= 512 bins), scan, second pass writes payload and key to
-//                  their final places
-// (One counting sort over all 2 * 4^pw keys with a returning global atomic per tuple took 2.4 + 1.9 ms per stage of 60 M tuples on the
-// MI355X; this takes 1.3 + 0.9 + 1.0 ms.)
+// The tuples are brought into key order by a two-level counting sort.  No pass writes a tuple with a store of its own lane's choosing
+// (scattered 12-byte stores run at 0.9 TB/s on the MI355X whatever the run length, coalesced ones at 5.6 TB/s; profiles/r03a_pmc_calibration_*):
+// a pass stages SEED_PIECE tuples in LDS in bin order and copies them out with consecutive lanes on consecutive tuples.
+//   k_seed_keys     leaves per block the number of its tuples per COARSE bin (key >> fb, <= 4096 bins)       -> rows, chist
+//   k_seed_cscan    exclusive scan of the coarse counts (one block)                                            -> cbase, SN_TUPLES, SN_FWD
+//   k_seed_colscan  rows[b][c] = cbase[c] + the tuples of bin c in the rows above: where block b's tuples of bin c go
+//   k_seed_split    block b reads ITS tuples once, piece by piece, and moves them to their coarse bins
+//   k_seed_bins     one block per coarse bin: histogram of the fine key bits (<= 512 bins), then the same staged move to the final places
+// History per 60 M tuples on the MI355X: one counting sort with a returning global atomic per tuple 2.4 + 1.9 ms; two-level with LDS
+// atomics and per-lane stores 1.3 + 0.9 + 1.0 ms (HBM writes 3.0 x and 2.7 x the tuple bytes, profiles/r03a_sort_variants_*).
 __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long long* __restrict__ ctr) {
   __shared__ uint32_t s_part[16];
   // <= 4096 bins: 4 consecutive bins per thread
@@ -294,65 +301,111 @@ __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long 
   for (uint32_t q = 0; q < wv; q++) pre += s_part[q];
   for (int q = 0; q < 4; q++) {
     const uint32_t c = 4 * t + q;
-    if (c < sb.nc) { sb.cbase[c] = pre; sb.ccur[c] = pre; if (c == (sb.nkh >> sb.fb)) sb.sn[SN_FWD] = pre; }
+    if (c < sb.nc) { sb.cbase[c] = pre; if (c == (sb.nkh >> sb.fb)) { sb.sn[SN_FWD] = pre; if (pre) ctr_add(ctr, C_TUP_F, pre); } }   // the forward tuples lie in front of coarse bin nkh >> fb
     pre += v[q];
-    if (c + 1 == sb.nc) sb.cbase[sb.nc] = pre;
+    if (c + 1 == sb.nc) { sb.cbase[sb.nc] = pre; sb.sn[SN_TUPLES] = pre; if (pre) ctr_add(ctr, C_TUP_ALL, pre); }
   }
+}
+
+// one block per 64 coarse bins (lane = bin); wave w takes the rows [w * kb / 16, (w + 1) * kb / 16): their sum, then -- offset by the waves
+// above and the bin's base -- the running place of every row
+__global__ void __launch_bounds__(1024) k_seed_colscan(SeedBufs sb) {
+  __shared__ uint32_t s_sum[16][64];
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t c = blockIdx.x * 64u + lane;
+  const uint32_t per = (sb.kb + 15u) / 16u, r0 = min(wv * per, sb.kb), r1 = min(r0 + per, sb.kb);
+  uint32_t sum = 0;
+  if (c < sb.nc) for (uint32_t r = r0; r < r1; r++) sum += sb.rows[(size_t)r * sb.nc + c];
+  s_sum[wv][lane] = sum;
   __syncthreads();
-  if (t == 0) {                                             // the stage's tuples: the forward ones lie in front of coarse bin nkh >> fb
-    const uint32_t all = min(sb.sn[SN_TUPLES], sb.cap_tuples), fw = min(sb.cbase[sb.nkh >> sb.fb], all);
-    ctr_add(ctr, C_TUP_F, fw); ctr_add(ctr, C_TUP_R, all - fw);
+  if (c >= sb.nc) return;
+  uint32_t run = sb.cbase[c];
+  for (uint32_t q = 0; q < wv; q++) run += s_sum[q][lane];
+  for (uint32_t r = r0; r < r1; r++) { const size_t o = (size_t)r * sb.nc + c; const uint32_t v = sb.rows[o]; sb.rows[o] = run; run += v; }
+}
+
+// exclusive prefix of cnt[0..nb) (nb <= 4096, block of 1024 threads) into out[], plus `add`; all threads must call it
+__device__ __forceinline__ void block_excl_scan(const uint32_t* cnt, uint32_t* out, uint32_t nb, uint32_t* s_part /* [16] */) {
+  const uint32_t t = threadIdx.x;
+  uint32_t v[4], sum = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const uint32_t k = 4 * t + q; v[q] = k < nb ? cnt[k] : 0u; sum += v[q]; }
+  uint32_t incl = sum;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)(t & 63u) >= d) incl += x; }
+  if ((t & 63u) == 63u) s_part[t >> 6] = incl;
+  __syncthreads();
+  uint32_t pre = incl - sum;
+  for (uint32_t q = 0; q < (t >> 6); q++) pre += s_part[q];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { const uint32_t k = 4 * t + q; if (k < nb) out[k] = pre; pre += v[q]; }
+  __syncthreads();
+}
+
+// One staged move of the tuples src[i0, i1) into `nb` bins whose next free places are cur[] (LDS, global indices into dst): piece by piece --
+// load (each tuple once), take a place in its bin (LDS atomic), put the piece into LDS in bin order, copy it out with consecutive lanes on
+// consecutive staged tuples (lanes of one bin's run write neighbouring addresses).  LDS: cur / pc0 / pst [nb], stage [SEED_PIECE].
+template <class BINOF>
+__device__ __forceinline__ void staged_move(const SeedTmp* __restrict__ src, uint32_t i0, uint32_t i1, SeedTmp* __restrict__ dst, uint32_t nb,
+                                            uint32_t* cur, uint32_t* pc0, uint32_t* pst, SeedTmp* stage, uint32_t* s_part, BINOF binof) {
+  constexpr int PER = SEED_PIECE / 1024;
+  for (uint32_t p0 = i0; p0 < i1; p0 += SEED_PIECE) {
+    const uint32_t np = min(SEED_PIECE, i1 - p0);
+    for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pc0[q] = cur[q];
+    __syncthreads();
+    SeedTmp mine[PER]; uint32_t place[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
+      if (i < np) { mine[j] = src[p0 + i]; place[j] = atomicAdd(&cur[binof(mine[j].key)], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pst[q] = cur[q] - pc0[q];      // the piece's tuples per bin ...
+    __syncthreads();
+    block_excl_scan(pst, pst, nb, s_part);                                                 // ... become where the bin's run starts in the staged piece
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
+      if (i < np) { const uint32_t f = binof(mine[j].key); stage[pst[f] + (place[j] - pc0[f])] = mine[j]; }
+    }
+    __syncthreads();
+    for (uint32_t sidx = threadIdx.x; sidx < np; sidx += blockDim.x) {
+      const SeedTmp t = stage[sidx];
+      const uint32_t f = binof(t.key);
+      dst[pc0[f] + (sidx - pst[f])] = t;
+    }
+    __syncthreads();
   }
 }
 
 __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
-  SMR_DYN_LDS(uint32_t, lds);
-  uint32_t* lh = lds;                                     // [nc] count, then running offset inside the block's share
-  uint32_t* lb = lds + sb.nc;                             // [nc] start of the block's share of the coarse bin
-  const uint32_t n = min(sb.sn[SN_TUPLES], sb.cap_tuples);
-  const uint32_t i0 = blockIdx.x * SEED_SPLIT_CHUNK, i1 = min(i0 + SEED_SPLIT_CHUNK, n);
-  if (i0 >= n) return;
-  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
+  SMR_DYN_LDS(uint32_t, lds);                             // cur | pc0 | pst [nc each] | stage
+  __shared__ uint32_t s_part[16];
+  uint32_t* cur = lds; uint32_t* pc0 = lds + sb.nc; uint32_t* pst = lds + 2 * sb.nc;
+  SeedTmp* stage = reinterpret_cast<SeedTmp*>(lds + 3 * sb.nc);
+  const uint32_t nmine = sb.bcnt[blockIdx.x];
+  if (nmine == 0) return;
+  const uint32_t* row = sb.rows + (size_t)blockIdx.x * sb.nc;
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) cur[c] = row[c];
   __syncthreads();
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) atomicAdd(&lh[sb.tmp[i].key >> sb.fb], 1u);
-  __syncthreads();
-  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) { const uint32_t m = lh[c]; if (m) lb[c] = atomicAdd(&sb.ccur[c], m); lh[c] = 0; }
-  __syncthreads();
-  for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-    const SeedTmp t = sb.tmp[i];
-    const uint32_t c = t.key >> sb.fb;
-    sb.mid[lb[c] + atomicAdd(&lh[c], 1u)] = t;
-  }
+  const uint32_t fb = sb.fb;
+  staged_move(sb.tmp + (size_t)2 * SEED_TILE * sb.tpb * blockIdx.x, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part, [fb](uint32_t key) { return key >> fb; });
 }
 
 __global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
-  __shared__ uint32_t fh[512], s_part[8];
+  __shared__ uint32_t cur[512], pc0[512], pst[512], s_part[16];
+  SMR_DYN_LDS(uint32_t, lds);
+  SeedTmp* stage = reinterpret_cast<SeedTmp*>(lds);
   const uint32_t c = blockIdx.x, lo = sb.cbase[c], hi = sb.cbase[c + 1];
   if (lo == hi) return;
-  const uint32_t t = threadIdx.x, fm = (1u << sb.fb) - 1u;
-  if (t < 512) fh[t] = 0;
+  const uint32_t t = threadIdx.x, nf = 1u << sb.fb, fm = nf - 1u;
+  if (t < 512) pst[t] = 0;
   __syncthreads();
-  for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&fh[sb.mid[i].key & fm], 1u);
+  for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&pst[sb.mid[i].key & fm], 1u);
   __syncthreads();
-  // exclusive scan of the 512 fine counts (waves 0..7)
-  uint32_t v = 0, incl = 0;
-  if (t < 512) {
-    v = fh[t]; incl = v;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)(t & 63u) >= d) incl += x; }
-    if ((t & 63u) == 63u) s_part[t >> 6] = incl;
-  }
+  block_excl_scan(pst, cur, nf, s_part);
+  if (t < nf) cur[t] += lo;                               // the next free place of every fine bin
   __syncthreads();
-  if (t < 512) {
-    uint32_t pre = incl - v;
-    for (uint32_t q = 0; q < (t >> 6); q++) pre += s_part[q];
-    fh[t] = lo + pre;                                     // from now on: the next free place of the fine bin
-  }
-  __syncthreads();
-  for (uint32_t i = lo + t; i < hi; i += blockDim.x) {
-    const SeedTmp x = sb.mid[i];
-    const uint32_t p = atomicAdd(&fh[x.key & fm], 1u);
-    sb.srt[p] = x;
-  }
+  staged_move(sb.mid, lo, hi, sb.srt, nf, cur, pc0, pst, stage, s_part, [fm](uint32_t key) { return key & fm; });
 }
 
 struct SeedLane {           // per-lane search result
@@ -578,10 +631,10 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     root = DIR == 0 ? lk.rootF : lk.rootR;
     r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
     slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
-    if (DIR == 1) {                                      // the window's list so far = the forward search's hits
+    if (DIR == 1 && wseg_has(sb, slot)) {                // the window's list so far = the forward search's hits
       const uint32_t seg = sb.wseg[slot];
-      if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
-      else if (seg != NONE) {
+      if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+      else {
         n_prev = pool[seg + 1];
         for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
         if (n_prev > hcap) { sl.overflow = true; n_prev = hcap; }
@@ -615,13 +668,13 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     const uint32_t o = base + incl - need;
     pool[o] = NONE; pool[o + 1] = sl.nh;
     for (uint32_t q = 0; q < sl.nh; q++) { pool[o + 2 + 2 * q] = hl[q * 64 + lane]; pool[o + 3 + 2 * q] = win_pos; }
-    sb.wseg[slot] = o | (sl.zero ? SEED_ZERO_BIT : 0u);
+    wseg_put(sb, slot, o | (sl.zero ? SEED_ZERO_BIT : 0u));
   }
   if (__any(sl.overflow) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
   // algorithmic bytes of this wave (C_B_PG0/1): tuple + lookup entry per search, 16 B per node, 8 B per entry, the forward list read (DIR 1),
   // the segment written + its window slot
   unsigned long long v[3] = {sl.n_node, sl.n_entry, 0};
-  v[2] = (wave * 64u + lane < n_tup ? sizeof(SeedTmp) + sizeof(Lookup) + (DIR ? 4u + (n_prev ? 4u + 8u * n_prev : 0u) : 0u) : 0u) + 16ull * sl.n_node + 8ull * sl.n_entry + 4ull * need + (wr ? 4u : 0u);
+  v[2] = (wave * 64u + lane < n_tup ? sizeof(SeedTmp) + sizeof(Lookup) + (DIR ? 1u + (n_prev ? 8u + 8u * n_prev : 0u) : 0u) : 0u) + 16ull * sl.n_node + 8ull * sl.n_entry + 4ull * need + (wr ? 4u : 0u);
   for (int c = 0; c < 3; c++) {
     unsigned long long x = v[c];
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
@@ -640,25 +693,29 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0;      // moved: algorithmic bytes of this read (C_B_FIN)
+  unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
   if (r < rd.n) {
     RWork w = rw[r];
     moved = sizeof(RWork);
+    kin = sizeof(RWork) + 4u;                              // k_seed_keys looks at every read's state and length ...
     if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
       const uint32_t len = rd.len[r], stride = P.skip[pass];
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
-      uint32_t seeds = 0, total = 0, rlook = 0;
+      uint32_t seeds = 0, total = 0, rlook = 0, nsearched = 0;
       for (uint32_t k = 0; k < numwin; k++) {
-        const uint32_t s = sb.wseg[wseg_slot(sb, r, k)];
+        const size_t sl = wseg_slot(sb, r, k);
+        const uint32_t s = wseg_has(sb, sl) ? sb.wseg[sl] : NONE;
         bool searched = true;                                // windows of this pass: not searched by an earlier pass (:128-131)
         for (int q = 0; q < pass; q++) if ((k * stride) % P.skip[q] == 0) searched = false;
+        nsearched += searched ? 1u : 0u;
         if (searched && !(s != NONE && (s & SEED_ZERO_BIT))) rlook++;     // the reverse lookup happens unless the forward search hit exactly (:188-198)
         if (s == NONE) continue;
         seeds++; total += pool[(s & ~SEED_ZERO_BIT) + 1];
       }
       looks = rlook;
-      // length, one window slot per window, per segment its count word, every (id, win_pos) pair read and written, per-read state written, hit_seeds
-      moved += 4u + 4ull * numwin + 4ull * seeds + 16ull * total + sizeof(RWork) + 8u;
+      kin += 8u + 4u * (((len + 15) >> 4) + ((len + 31) >> 5)) + 8ull * nsearched;      // ... of an active read also its record offset, its packed record, two lookup words per window
+      // length, one window bit per window, per segment its count word, every (id, win_pos) pair read and written, per-read state written, hit_seeds
+      moved += 4u + (numwin + 7u) / 8u + 8ull * seeds + 16ull * total + sizeof(RWork) + 8u;
       uint32_t base = 0;
       if (total) {
         const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
@@ -668,8 +725,9 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       }
       uint32_t o = base;
       if (total) for (uint32_t k = 0; k < numwin; k++) {
-        const uint32_t s = sb.wseg[wseg_slot(sb, r, k)];
-        if (s == NONE) continue;
+        const size_t sl = wseg_slot(sb, r, k);
+        if (!wseg_has(sb, sl)) continue;
+        const uint32_t s = sb.wseg[sl];
         const uint32_t sg = s & ~SEED_ZERO_BIT, c = pool[sg + 1];
         for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
         o += 2 * c;
@@ -681,8 +739,8 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       hits = total; bytes = (len + 3) / 4;
     }
   }
-  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); moved += __shfl_down(moved, d, 64); }
-  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); if (looks) ctr_add(ctr, C_LOOKUP, looks); if (moved) ctr_add(ctr, C_B_FIN, moved); }
+  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); moved += __shfl_down(moved, d, 64); kin += __shfl_down(kin, d, 64); }
+  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); if (looks) ctr_add(ctr, C_LOOKUP, looks); if (moved) ctr_add(ctr, C_B_FIN, moved); if (kin) ctr_add(ctr, C_B_KEYS, kin); }
 }
 
 }  // namespace smr

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   uint32_t win_pos = 0, nh = 0, n_prev = 0, P9 = 0;
   uint2 rt = make_uint2(NONE, 0);
   size_t slot = 0;
-  bool hl_over = false;
+  bool hl_over = false, had_seg = false;
   if (mine) {
     const SeedTmp tp = sb.srt[pos];
     const unsigned long long pl = seed_payload(tp);
@@ -86,10 +86,11 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
     P9 = (uint32_t)(pl >> 40);
     slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
-    if (DIR == 1) {                                      // the window's list so far = the forward search's hits
-      const uint32_t seg = sb.wseg[slot];
-      if (seg != NONE && (seg & SEED_ZERO_BIT)) mine = false;     // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
-      else if (seg != NONE) {
+    if (DIR == 1 && wseg_has(sb, slot)) {                // the window's list so far = the forward search's hits (one bit per window says whether
+      had_seg = true;
+      const uint32_t seg = sb.wseg[slot];                //  there is one: the bitmap stays in the caches, the segment table would not)
+      if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+      else {
         n_prev = pool[seg + 1];
         for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
         if (n_prev > hcap) { hl_over = true; n_prev = hcap; }
@@ -230,16 +231,16 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     const uint32_t o = base + incl - need;
     pool[o] = NONE; pool[o + 1] = nh;
     for (uint32_t q = 0; q < nh; q++) { pool[o + 2 + 2 * q] = hl[q * 64 + lane]; pool[o + 3 + 2 * q] = win_pos; }
-    sb.wseg[slot] = o | (zero ? SEED_ZERO_BIT : 0u);
+    wseg_put(sb, slot, o | (zero ? SEED_ZERO_BIT : 0u));
   }
   if (__any(hl_over) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
   // algorithmic bytes of this wave (C_B_PG0/1): per tuple 12 B + its block-table entry (8 B); a search with directories reads 8 directory
-  // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; DIR 1 reads the window slot and the forward search's list
-  // (count word + its ids with their win_pos); the segment written (4 B per word) and the window slot pointing to it
-  unsigned long long w_bytes = (vb * 64u + lane < n_tup ? sizeof(SeedTmp) + 8u + (DIR ? 4u + (n_prev ? 4u + 8u * n_prev : 0u) : 0u) : 0u) +
+  // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; DIR 1 reads the window's bit and, where it is set, its slot and
+  // the forward search's list (count word + its ids with their win_pos); the segment written (4 B per word) and the window slot pointing to it
+  unsigned long long w_bytes = (vb * 64u + lane < n_tup ? sizeof(SeedTmp) + 8u + (had_seg ? 8u + 8u * n_prev : 0u) : 0u) +
                                ((mine && rt.x != NONE && cA) ? 32u : 0u) + 4ull * tot + 4ull * need + (wr ? 4u : 0u);
   for (int d = 32; d > 0; d >>= 1) w_bytes += __shfl_xor(w_bytes, d, 64);
-  w_bytes += 8ull * min(s_ncand, ccap);
+  w_bytes += 8ull * min(s_ncand, ccap) + (DIR ? 8u : 0u);          // (DIR 1: one window bit per tuple)
   if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, w_bytes); }
 #ifdef SMR_SEED_PHASES
   GPH(5)
