@@ -87,39 +87,46 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
     uint32_t bkey = 0;
     int lastH = 0, lastF = 0, Hdiag0 = 0, fnt = 4;
     const bool has_prev = s > 0, has_next = s + 1 < nstrips;
-    int inH = has_prev ? bound[0] : 0, inF = has_prev ? bound[1] : 0, cin = n > 0 ? rfq[rf0] : 4;
     const int steps = n + 63;
-    for (int t = 0; t < steps; t++) {
-      const int cH = inH, cF = inF, cc = cin;
-      const int tn = t + 1;                                // prefetch lane 0's inputs of the next step
-      cin = tn < n ? rfq[rf0 + rfstep * tn] : 4;
-      inH = (has_prev && tn < n) ? bound[2 * tn] : 0;
-      inF = (has_prev && tn < n) ? bound[2 * tn + 1] : 0;
-      const int upH = dpp_shr1(cH, lastH), upF = dpp_shr1(cF, lastF);
-      fnt = dpp_shr1(cc, fnt);
-      const int col = t - lane;
-      const bool colok = col >= 0 && col < n;
-      const bool refN = fnt == 4;
-      const int sh = (fnt & 3) * 8;
-      const uint32_t colkey = (uint32_t)(0xFFFF - col) << 2;
-      int diag = Hdiag0, uh = upH, uf = upF;
-#pragma unroll
-      for (int r = 0; r < R; r++) {
-        const int sc = refN ? scoreN : (int)__builtin_amdgcn_sbfe(sct[r], sh, 8);
-        const int e = max(E[r] - ge, H[r] - go);
-        const int f = max(uf - ge, uh - go);
-        const int h = max(max(diag + sc, e), max(f, 0));
-        diag = H[r];                                         // H(row, col-1) is the diagonal of the next row
-        if (colok && vr[r]) {
-          H[r] = h; E[r] = e;
-          if (PACKED) bkey = max(bkey, ((uint32_t)h << 18) | colkey | (uint32_t)(3 - r));
-          else if (h > bestH || (h == bestH && h > 0 && col < bestcol)) { bestH = h; bestcol = col; bestrow = row0 + r; }
-        }
-        uh = h; uf = f;
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+      // lane 0's inputs of the next 64 steps (reference letter; boundary H / F of the previous strip), one column per lane, read back with
+      // v_readlane: the step loop has no memory access (the boundary rows live in global memory)
+      const int cq = t0 + lane;
+      int chC = 4, chH = 0, chF = 0;
+      if (cq < n) {
+        chC = rfq[rf0 + rfstep * cq];
+        if (has_prev) { chH = bound[2 * cq]; chF = bound[2 * cq + 1]; }
       }
-      Hdiag0 = col >= 0 ? upH : 0;                           // H(row0-1, col): diagonal of row0 at the next column
-      if (colok) { lastH = H[R - 1]; lastF = uf; }
-      if (has_next && lane == 63 && colok) { bound[2 * col] = lastH; bound[2 * col + 1] = lastF; }
+      const int tend = min(64, steps - t0);
+      for (int tt = 0; tt < tend; tt++) {
+        const int t = t0 + tt;
+        const int cH = __builtin_amdgcn_readlane(chH, tt), cF = __builtin_amdgcn_readlane(chF, tt), cc = __builtin_amdgcn_readlane(chC, tt);
+        const int upH = dpp_shr1(cH, lastH), upF = dpp_shr1(cF, lastF);
+        fnt = dpp_shr1(cc, fnt);
+        const int col = t - lane;
+        const bool colok = col >= 0 && col < n;
+        const bool refN = fnt == 4;
+        const int sh = (fnt & 3) * 8;
+        const uint32_t colkey = (uint32_t)(0xFFFF - col) << 2;
+        int diag = Hdiag0, uh = upH, uf = upF;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+          const int sc = refN ? scoreN : (int)__builtin_amdgcn_sbfe(sct[r], sh, 8);
+          const int e = max(E[r] - ge, H[r] - go);
+          const int f = max(uf - ge, uh - go);
+          const int h = max(max(diag + sc, e), max(f, 0));
+          diag = H[r];                                         // H(row, col-1) is the diagonal of the next row
+          if (colok && vr[r]) {
+            H[r] = h; E[r] = e;
+            if (PACKED) bkey = max(bkey, ((uint32_t)h << 18) | colkey | (uint32_t)(3 - r));
+            else if (h > bestH || (h == bestH && h > 0 && col < bestcol)) { bestH = h; bestcol = col; bestrow = row0 + r; }
+          }
+          uh = h; uf = f;
+        }
+        Hdiag0 = col >= 0 ? upH : 0;                           // H(row0-1, col): diagonal of row0 at the next column
+        if (colok) { lastH = H[R - 1]; lastF = uf; }
+        if (has_next && lane == 63 && colok) { bound[2 * col] = lastH; bound[2 * col + 1] = lastF; }
+      }
     }
     if (PACKED) {
       const int h = (int)(bkey >> 18), col = 0xFFFF - (int)((bkey >> 2) & 0xFFFF), row = row0 + 3 - (int)(bkey & 3);
@@ -444,10 +451,9 @@ __device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* s
 
 // k_chain<EXT>: compute_lis_alignment (alignment.cpp:100-509) for the reads k_cand marked.  One block = one wave, persistent: chunks of
 // 64 reads are claimed with one atomic, their flags fetched by the 64 lanes at once, the marked ones walked one by one.
-// Dynamic LDS (bytes), ML = max_len rounded to 16, MQ = min(ML, SW_X4_MAX_ROWS), RF = ML + 2 * edges + 16 rounded:
+// Dynamic LDS (bytes), ML = max_len rounded to 16, MQ = min(ML, SW_X4_MAX_ROWS), RF = ML + 2 * edges + 16 rounded, RQ = the same for a read of MQ letters:
 //   read slots    ML + 4 MQ     the read being walked | four parked reads
-//   window slots  9 RF          0..3: batch of the read being walked, 4..7: parked tasks; slots 1..8 share their memory with the strip
-//                               boundaries (2 RF ints) that only reads longer than SW_X4_MAX_ROWS need
+//   window slots  RF + 8 RQ     0: any window of the read being walked, 1..3: the rest of its batch, 4..7: parked tasks (strip boundaries: global)
 //   keys[CH_KEYS_LDS] u64 | region R = max(4 CH_PAIRS_LDS, 2 s_cap) u32: pairs (two halves) + serial-LIS arrays during the candidate loop,
 //   Bloom words + counts while the candidate set is built | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS + 8] u32 | skey[s_cap] u32
 // Candidate references (alignment.cpp:117-148) without a per-reference counter array: see chain_build_set.  EXT = true is the second
@@ -461,20 +467,24 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
-                                              uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2) {
+                                              uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2,
+                                              uint32_t lds_rq, int* g_bound) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
   const int lane = lane_id();
   // rdq: read slot 0 (lds_ml bytes: the read being walked) + 4 slots of lds_mq = min(lds_ml, SW_X4_MAX_ROWS) bytes (the parked reads);
-  // rfq: 9 reference-window slots of lds_rf bytes
-  // (0..3: the batch of the read being walked, 4..7: the parked tasks) of which slots 1..8 share their memory with `bound`, the
-  // strip-boundary array that only reads of more than SW_X4_MAX_ROWS letters need (nothing is ever parked while such a read is walked)
+  // rfq: reference-window slot 0 of lds_rf bytes (any window) + slots 1..8 of lds_rq bytes (windows of reads <= SW_X4_MAX_ROWS letters:
+  // 1..3 = the rest of the batch of the read being walked, 4..7 = the parked tasks).  The strip-boundary rows that only reads of more than
+  // one strip need (2 ints per reference column) live in global memory (g_bound, per block): a wave that walks 5 kb reads keeps ~20 KB of
+  // LDS instead of ~60 KB, i.e. 7 instead of 2 waves per CU
   uint8_t* rdq = lds_raw;
   const uint32_t lds_mq = min(lds_ml, (uint32_t)SW_X4_MAX_ROWS);
   uint8_t* rfq = rdq + (size_t)lds_ml + 4 * (size_t)lds_mq;
-  int* bound = (int*)(rfq + lds_rf);
-  unsigned long long* l_keys = (unsigned long long*)(bound + 2 * lds_rf);
+  uint8_t* const rfq1 = rfq + lds_rf;
+  auto wslot = [&](int e) -> uint8_t* { return e == 0 ? rfq : rfq1 + (size_t)(e - 1) * lds_rq; };
+  int* bound = g_bound ? g_bound + (size_t)blockIdx.x * 2 * lds_rf : nullptr;
+  unsigned long long* l_keys = (unsigned long long*)(rfq1 + 8 * (size_t)lds_rq);
   // region R: [pairs | lis] during the candidate loop, [bloom | scnt] while the candidate set is built (dead afterwards)
   unsigned long long* l_pairs = l_keys + CH_KEYS_LDS;
   uint32_t* l_lis = (uint32_t*)(l_pairs + CH_PAIRS_LDS);
@@ -540,10 +550,10 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         const int gm = mine ? (int)q_m[g] : 0, gn = mine ? (int)q_nref[g] : 0, gq = mine ? (int)q_aq[g] : 0;
         int mm = gm;
         for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
-        const SwRes r4 = sw_wave_x4(rdq + (size_t)lds_ml + (size_t)g * lds_mq, gm, gq, 1, rfq + (size_t)(4 + g) * lds_rf, gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, q_hasn);
+        const SwRes r4 = sw_wave_x4(rdq + (size_t)lds_ml + (size_t)g * lds_mq, gm, gq, 1, wslot(4 + g), gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, q_hasn);
         if ((lane & 15) == 0 && mine) { q_score[g] = r4.score; q_eref[g] = r4.end_ref; q_eread[g] = r4.end_read; }
       } else {
-        const SwRes r1 = sw_wave(rdq + lds_ml, (int)q_m[0], (int)q_aq[0], 1, rfq + (size_t)4 * lds_rf, (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+        const SwRes r1 = sw_wave(rdq + lds_ml, (int)q_m[0], (int)q_aq[0], 1, wslot(4), (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
         if (lane == 0) { q_score[0] = r1.score; q_eref[0] = r1.end_ref; q_eread[0] = r1.end_read; }
       }
       __syncthreads();
@@ -597,7 +607,6 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     int search = 1;
     const uint32_t max_SW_score = len * (uint32_t)P.match;
     const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
-    if (!x4_ok && q_n > 0) { need_flush = true; chunk_todo |= 1ull << (r - chunk_base); continue; }        // its strip boundaries would overwrite the parked windows: score those first
     bool parked = false;
 
     if (st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0) {
@@ -814,7 +823,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
             __syncthreads();
           }
         };
-        auto task_fits = [&](const SwTask& t) -> bool { return t.m > 0 && t.nref > 0 && (uint32_t)t.m <= lds_ml && (uint32_t)t.nref <= lds_rf; };
+        // (a task that is parked or scored next to others goes into one of the slots 1..8)
+        auto task_fits = [&](const SwTask& t) -> bool { return t.m > 0 && t.nref > 0 && (uint32_t)t.m <= lds_mq && (uint32_t)t.nref <= lds_rq; };
 
         Walk R;
         R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0;
@@ -841,7 +851,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               const uint32_t aval = (w.has_amb && !w.is04) ? 4u : (uint32_t)w.aval;             // read.flip34() before SSW (:360-361)
               __syncthreads();
               uint8_t* rq = rdq + (size_t)lds_ml + (size_t)e * lds_mq;
-              uint8_t* fq = rfq + (size_t)(4 + e) * lds_rf;
+              uint8_t* fq = wslot(4 + (int)e);
               for (uint32_t q = lane; q < len; q += 64) rq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, aval);
               bool hn = false;
               for (int q = lane; q < t1.nref; q += 64) { const uint8_t ch = ix.ref_seq[t1.rf_start + q]; fq[q] = ch; hn |= ch == 4; }
@@ -892,7 +902,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               __syncthreads();
               bool hasn = false;
               for (int e = 0; e < n_cached; e++) {
-                uint8_t* dst = rfq + (size_t)e * lds_rf;                    // windows 1..3 overlay the strip-boundary array, which single-strip problems do not use
+                uint8_t* dst = wslot(e);
                 for (int q = lane; q < ctk[e].nref; q += 64) { const uint8_t ch = ix.ref_seq[ctk[e].rf_start + q]; dst[q] = ch; hasn |= ch == 4; }
               }
               __syncthreads();
@@ -905,7 +915,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                 const int gq = mine ? (int)(g == 0 ? ctk[0].align_que_start : g == 1 ? ctk[1].align_que_start : g == 2 ? ctk[2].align_que_start : ctk[3].align_que_start) : 0;
                 int mm = gm;
                 for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
-                const SwRes r4 = sw_wave_x4(rdq, gm, gq, 1, rfq + (size_t)g * lds_rf, gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
+                const SwRes r4 = sw_wave_x4(rdq, gm, gq, 1, wslot(g), gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
                 for (int e = 0; e < n_cached; e++) {
                   cfw[e].score = __builtin_amdgcn_readlane(r4.score, 16 * e); cfw[e].end_ref = __builtin_amdgcn_readlane(r4.end_ref, 16 * e);
                   cfw[e].end_read = __builtin_amdgcn_readlane(r4.end_read, 16 * e);
@@ -1006,7 +1016,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 // done, so only the survivors cost a reverse pass (43 % of the accepted ones on the bench workload), and they are independent problems:
 // four per wave through the four-problem kernel (reads <= SW_X4_MAX_ROWS), else one per wave through sw_wave.
 // k_begins_collect lists the pending slots of the reads with a new hit; k_begins claims them four at a time.
-// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4), or 1 + 1 + the strip-boundary array.
+// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4), or 1 + 1 (strip boundaries in global memory).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __restrict__ work, const RWork* __restrict__ rw, const AlignRec* __restrict__ work_aln,
                                  uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
@@ -1019,7 +1029,7 @@ __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __res
 }
 
 __global__ void __launch_bounds__(64) k_begins(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, AlignRec* __restrict__ work_aln,
-                                               unsigned long long* __restrict__ ctr, uint32_t lds_m, uint32_t lds_n, int x4) {
+                                               unsigned long long* __restrict__ ctr, uint32_t lds_m, uint32_t lds_n, int x4, int* g_bound) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_t0;
   const int lane = lane_id();
@@ -1028,7 +1038,7 @@ __global__ void __launch_bounds__(64) k_begins(DReads rd, DIndex ix, DParams P, 
   const int g = x4 ? lane >> 4 : 0;
   uint8_t* rdq = lds_raw + (size_t)g * lds_m;
   uint8_t* rfq = lds_raw + (size_t)per * lds_m + (size_t)g * lds_n;
-  int* bound = (int*)(lds_raw + (size_t)lds_m + lds_n);          // single-problem mode only
+  int* bound = g_bound ? g_bound + (size_t)blockIdx.x * 2 * lds_n : nullptr;          // strip boundaries (single-problem mode, reads of more than one strip)
   unsigned long long n_rev = 0, n_cells = 0;
   for (;;) {
     __syncthreads();
