@@ -9,18 +9,29 @@
 // It replaces the reference's thread fan-out over one read file (processor.cpp:248-256, split of the file into one range
 // per thread readfeed.cpp:1253-1277) by a fan-out over GPUs.
 //
+// A rank STREAMS its shard (readfeed.cpp:776-873 streams any file size): chunks of --chunk-reads reads go through three recycled batch
+// slots of the engine -- while chunk c is aligned on the GPU, a second host thread uploads chunk c+1 and a third one serialises the
+// records (and report rows) of chunk c-1 from the host copy smr_results_fetch made of it.  Any number of chunks; the Readstats counters
+// of the chunks are summed on the device (smr_counters_accumulate) into the block that RCCL then all-reduces.
+//
 // Output:  <out>/records.bin (same format as examples/smr_align.cpp: KVDB key "0_<global read number>" / Read::toBinString value,
-//          shards concatenated in rank order), <out>/summary.txt (the reduced counters), and one "[timing]" line per stage.
+//          shards concatenated in rank order), <out>/summary.txt (the reduced counters), one "[timing]" line per stage, and with
+//          --fastx / --other / --blast / --sam the reference's report files (aligned.fq, other.fq, aligned.blast, aligned.sam): every rank
+//          writes its shard's files into <out>/rank<r>/, rank order concatenation = Report::merge (report.cpp:56-97).
 // Build:   hipcc -std=c++17 -O2 examples/smr_align_mgpu.cpp -Iinclude -Lsortmerna_amd/lib -lsmr_hip -lrccl -Wl,-rpath,$PWD/sortmerna_amd/lib -o smr_align_mgpu
 // Options: --ref DB.fasta [--idx PREFIX] --gumbel LAMBDA K  [--ref ...]  --reads READS[.gz]  --out DIR
 //          --gpus N            ranks (default: all visible devices)
 //          --devices a,b,..    device of every rank (default 0,1,..,N-1)
 //          --reduce rccl|host  how C1 / C2 are reduced; `host` (a mutex-protected sum between the rank threads) exists for dry
 //                              runs of the N-rank path on fewer GPUs than ranks -- RCCL needs one device per rank
-//          --chunk-reads M     per rank: upload / align in chunks of M reads, chunk k+1 uploaded while chunk k is aligned (0 = one batch)
+//          --chunk-reads M     per rank: chunks of M reads (0 = 2 M), any number of them
+//          --fastx --other --blast '1 [cigar] [qcov] [qstrand]' --sam   report files (BLAST tabular, SAM without @SQ)
 //          -num_alignments N, -no-best, -e EVALUE as in smr_align
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
+
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -91,7 +102,7 @@ struct RankOut {
   std::vector<uint8_t> records;        // concatenated (u64 klen, key, u64 vlen, value) entries of the shard
   uint64_t n_records = 0;
   std::vector<uint64_t> counters;      // reduced: identical on every rank
-  double t_upload = 0, t_align = 0, t_fetch = 0;
+  double t_upload = 0, t_align = 0, t_fetch = 0, t_write = 0;
   uint32_t minimal_score0 = 0;
 };
 }  // namespace
@@ -103,6 +114,7 @@ int main(int argc, char** argv) {
   double evalue = 1.0;
   int world = 0;
   uint64_t chunk_reads = 0;
+  smr_report_opts ro; memset(&ro, 0, sizeof ro);
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value after " + a); return argv[++i]; };
@@ -118,6 +130,17 @@ int main(int argc, char** argv) {
     else if (a == "--devices" || a == "-devices") devlist = val();
     else if (a == "--reduce" || a == "-reduce") reduce = val();
     else if (a == "--chunk-reads" || a == "-chunk-reads") chunk_reads = strtoull(val().c_str(), nullptr, 10);
+    else if (a == "-fastx" || a == "--fastx") ro.fastx = 1;
+    else if (a == "-other" || a == "--other") ro.other = 1;
+    else if (a == "-blast" || a == "--blast") {            // "1 [cigar] [qcov] [qstrand]" = tabular (options.cpp opt_blast)
+      const std::string v = val();
+      if (v.empty() || v[0] != '1') die("-blast: '1 [cigar] [qcov] [qstrand]' (tabular)");
+      ro.blast_tabular = 1;
+      const std::string cols = v.size() > 2 ? v.substr(2) : "";
+      if (cols.size() >= sizeof ro.blast_cols) die("-blast: too many columns");
+      strcpy(ro.blast_cols, cols.c_str());
+    }
+    else if (a == "-sam" || a == "--sam") ro.sam = 1;
     else die("unknown option " + a);
   }
   if (dbs.empty() || reads_path.empty()) die("--ref and --reads are required");
@@ -142,8 +165,11 @@ int main(int argc, char** argv) {
   // ---- host side, once: the reads (all cores parse and pack), the index parts (one host copy shared by all ranks) ----
   const double t0 = now_s();
   smr_reads* all = nullptr;
-  if (smr_reads_load_fastx_mt(reads_path.c_str(), 0, &all, err, sizeof err) != SMR_OK) die(err);
+  const bool want_reports = ro.fastx || ro.other || ro.blast_tabular || ro.sam;
+  // (with report files the text of the reads file stays mapped: the writers copy headers / letters / qualities from it)
+  if ((want_reports ? smr_reads_load_fastx_text(reads_path.c_str(), 0, &all, err, sizeof err) : smr_reads_load_fastx_mt(reads_path.c_str(), 0, &all, err, sizeof err)) != SMR_OK) die(err);
   const uint64_t n = smr_reads_count(all);
+  const int is_fastq = want_reports ? smr_reads_is_fastq(all) : 0;
   const double t_reads = now_s() - t0;
   for (auto& d : dbs) {
     if (!d.idx_prefix.empty()) {
@@ -186,9 +212,8 @@ int main(int argc, char** argv) {
     // the read shard of this rank, in chunks (each chunk is one resident batch of the engine)
     uint64_t first = 0, count = 0;
     shard_range(n, rank, world, first, count);
-    const uint64_t chunk = chunk_reads ? chunk_reads : std::max<uint64_t>(count, 1);
+    const uint64_t chunk = chunk_reads ? chunk_reads : 2000000;
     const size_t n_chunks = (size_t)((count + chunk - 1) / chunk);
-    if (n_chunks > 14) die("--chunk-reads: more than 14 chunks per rank (the engine keeps 16 batches resident)");
     // C1: global read totals (this rank only knows its shard)
     uint64_t* d_tot = nullptr;
     if (hipMalloc((void**)&d_tot, 2 * 8) != hipSuccess) die("hipMalloc failed");
@@ -221,23 +246,82 @@ int main(int argc, char** argv) {
     }
     O.minimal_score0 = pk[0].minimal_score;
     O.t_upload += now_s() - t;
-    // upload chunk c+1 on a helper thread while chunk c is aligned (smr_reads_upload works on its own stream and only touches its batch)
+    // the shard's report files (this rank's directory; merged in rank order afterwards)
+    smr_report* rep = nullptr;
+    if (want_reports) {
+      const std::string rd = out_dir + "/rank" + std::to_string(rank);
+      mkdir(rd.c_str(), 0777);
+      if (smr_report_open(rd.c_str(), &ro, is_fastq, &rep, e2, sizeof e2) != SMR_OK) die(e2);
+      for (size_t k = 0; k < dbs.size(); k++) {
+        smr_index_info info; smr_index_get_info(dbs[k].parts[0], &info);
+        uint64_t fr = 0, fq = 0;
+        smr_refstats_corrected(dbs[k].K, info.bg, info.full_len, info.numseq, tot[0], tot[1], &fr, &fq);
+        smr_report_set_db(rep, (uint32_t)k, dbs[k].lambda, dbs[k].K, fr, fq);
+        for (size_t part = 0; part < dbs[k].parts.size(); part++) smr_report_set_part(rep, (uint32_t)k, (uint32_t)part, dbs[k].parts[part]);
+      }
+    }
+    // ---- three stages over recycled batch slots: upload (thread U) -> align + fetch (this thread) -> records / report rows (thread W) ----
+    constexpr int NS = 3;                                // chunk c lives in batch slot c % NS; batch 15 is what stays "selected" between chunks
+    std::mutex pm; std::condition_variable pcv;
+    size_t uploaded = 0, fetched = 0, written = 0;       // chunks that have completed each stage
     std::vector<smr_reads*> cr(n_chunks, nullptr);
-    auto upload = [&](size_t c) {
-      const uint64_t f = first + c * chunk, cnt = std::min<uint64_t>(chunk, first + count - f);
-      if (smr_reads_slice(all, f, cnt, &cr[c]) != SMR_OK) die("smr_reads_slice failed");
-      // chunk 0 goes into the selected batch (nothing is running yet); later chunks go into their own batch on the upload stream while the previous one is aligned
-      if (c == 0) { if (smr_batch_select(gpu, 0) != SMR_OK || smr_reads_upload(gpu, cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu)); }
-      else if (smr_reads_upload_batch(gpu, (int)c, cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu));
-    };
-    t = now_s();
-    if (n_chunks) upload(0);
-    O.t_upload += now_s() - t;
+    auto chunk_first = [&](size_t c) { return first + c * chunk; };
+    auto chunk_count = [&](size_t c) { return std::min<uint64_t>(chunk, first + count - chunk_first(c)); };
+    if (smr_batch_select(gpu, 15) != SMR_OK) die(smr_last_error(gpu));
+    double t_up = 0, t_wr = 0;
+    std::thread U([&] {
+      for (size_t c = 0; c < n_chunks; c++) {
+        { std::unique_lock<std::mutex> l(pm); pcv.wait(l, [&] { return c < (size_t)NS || written + NS > c; }); }        // its slot's previous chunk has been written out
+        const double tu = now_s();
+        if (smr_reads_slice(all, chunk_first(c), chunk_count(c), &cr[c]) != SMR_OK) die("smr_reads_slice failed");
+        if (smr_reads_upload_batch(gpu, (int)(c % NS), cr[c], slots_per_read) != SMR_OK) die(smr_last_error(gpu));
+        t_up += now_s() - tu;
+        { std::lock_guard<std::mutex> l(pm); uploaded = c + 1; }
+        pcv.notify_all();
+      }
+    });
+    std::thread Wt([&] {
+      std::vector<uint8_t> rec; std::vector<char> hh, ss, qq;
+      for (size_t c = 0; c < n_chunks; c++) {
+        { std::unique_lock<std::mutex> l(pm); pcv.wait(l, [&] { return fetched > c; }); }
+        const double tw = now_s();
+        const uint32_t cnt = smr_reads_count(cr[c]);
+        for (uint32_t i = 0; i < cnt; i++) {
+          // results of the shard (kvdb.put(read.id, read.toBinString()), processor.cpp:150-155), keys carry the GLOBAL read number
+          const size_t len = smr_result_record_batch(gpu, (int)(c % NS), i, nullptr, 0);
+          if (!len && !(rep && ro.other)) continue;
+          rec.resize(len);
+          if (len) smr_result_record_batch(gpu, (int)(c % NS), i, rec.data(), len);
+          const uint64_t gi = chunk_first(c) + i;
+          if (rep) {
+            size_t tl[3];
+            smr_reads_record_text(all, (uint32_t)gi, nullptr, 0, nullptr, 0, nullptr, 0, tl);
+            hh.resize(tl[0] + 1); ss.resize(tl[1] + 1); qq.resize(tl[2] + 1);
+            smr_reads_record_text(all, (uint32_t)gi, hh.data(), hh.size(), ss.data(), ss.size(), qq.data(), qq.size(), tl);
+            if (smr_report_add(rep, hh.data(), ss.data(), is_fastq ? qq.data() : nullptr, len ? rec.data() : nullptr, len) != SMR_OK) die(smr_report_last_error(rep));
+          }
+          if (!len) continue;
+          const std::string key = "0_" + std::to_string(gi);
+          const uint64_t kl = key.size(), vl = len;
+          const size_t o = O.records.size();
+          O.records.resize(o + 16 + kl + vl);
+          memcpy(&O.records[o], &kl, 8); memcpy(&O.records[o + 8], key.data(), kl); memcpy(&O.records[o + 8 + kl], &vl, 8); memcpy(&O.records[o + 16 + kl], rec.data(), vl);
+          O.n_records++;
+        }
+        smr_reads_free(cr[c]); cr[c] = nullptr;
+        t_wr += now_s() - tw;
+        { std::lock_guard<std::mutex> l(pm); written = c + 1; }
+        pcv.notify_all();
+      }
+    });
+    // C2 accumulator: the Readstats counters of all chunks of this rank, summed on the device
+    void* d_acc = nullptr; uint32_t nctr = 0;
+    { void* dummy = nullptr; if (smr_counters_device(gpu, &dummy, &nctr) != SMR_OK) die(smr_last_error(gpu)); }
+    if (hipMalloc(&d_acc, (size_t)nctr * 8) != hipSuccess || hipMemset(d_acc, 0, (size_t)nctr * 8) != hipSuccess) die("hipMalloc failed");
     for (size_t c = 0; c < n_chunks; c++) {
-      std::thread up;
-      if (c + 1 < n_chunks) up = std::thread(upload, c + 1);
+      { std::unique_lock<std::mutex> l(pm); pcv.wait(l, [&] { return uploaded > c; }); }
       t = now_s();
-      if (smr_batch_select(gpu, (int)c) != SMR_OK) die(smr_last_error(gpu));
+      if (smr_batch_select(gpu, (int)(c % NS)) != SMR_OK) die(smr_last_error(gpu));
       for (size_t k = 0; k < dbs.size(); k++)
         for (size_t part = 0; part < dbs[k].parts.size(); part++) {
           smr_params p = pk[k];
@@ -245,44 +329,27 @@ int main(int argc, char** argv) {
           p.is_last_index_part = (k + 1 == dbs.size() && part + 1 == dbs[k].parts.size());
           if (smr_align_part(gpu, slot[k][part], &p) != SMR_OK || smr_traceback(gpu, slot[k][part], &p) != SMR_OK) die(smr_last_error(gpu));
         }
+      if (smr_counters_accumulate(gpu, d_acc, nctr) != SMR_OK || smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
+      if (smr_batch_select(gpu, 15) != SMR_OK) die(smr_last_error(gpu));          // nothing of slot c % NS is "selected" while the uploader refills it later
       O.t_align += now_s() - t;
-      if (up.joinable()) up.join();
+      { std::lock_guard<std::mutex> l(pm); fetched = c + 1; }
+      pcv.notify_all();
     }
-    // C2: the Readstats counters of all chunks of this rank summed into chunk 0's block, then reduced over the ranks IN PLACE on the device
+    U.join(); Wt.join();
+    O.t_upload += t_up;
     t = now_s();
-    void* dctr0 = nullptr; uint32_t nctr = 0;
-    if (n_chunks == 0) { if (smr_batch_select(gpu, 0) != SMR_OK) die(smr_last_error(gpu)); }
-    if (smr_batch_select(gpu, 0) != SMR_OK || smr_counters_device(gpu, &dctr0, &nctr) != SMR_OK) die(smr_last_error(gpu));
-    for (size_t c = 1; c < n_chunks; c++) {
-      std::vector<uint64_t> a(nctr), b(nctr);
-      void* dc = nullptr; uint32_t nc = 0;
-      if (smr_batch_select(gpu, (int)c) != SMR_OK || smr_counters_device(gpu, &dc, &nc) != SMR_OK) die(smr_last_error(gpu));
-      if (hipMemcpy(a.data(), dctr0, nctr * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(b.data(), dc, nctr * 8, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy failed");
-      for (uint32_t q = 0; q < nctr; q++) a[q] += b[q];
-      if (hipMemcpy(dctr0, a.data(), nctr * 8, hipMemcpyHostToDevice) != hipSuccess) die("hipMemcpy failed");
+    // C2: reduced over the ranks IN PLACE on the device block of sums
+    all_reduce_sum_u64(S, rank, d_acc, nctr, cstream);
+    {
+      std::vector<uint64_t> hc(nctr);
+      if (hipMemcpy(hc.data(), d_acc, (size_t)nctr * 8, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy failed");
+      O.counters.assign(2 + dbs.size(), 0);
+      O.counters[0] = hc[0]; O.counters[1] = hc[1];
+      for (size_t k = 0; k < dbs.size(); k++) O.counters[2 + k] = hc[2 + k];
     }
-    all_reduce_sum_u64(S, rank, dctr0, nctr, cstream);
-    O.counters.assign(2 + dbs.size(), 0);
-    if (smr_batch_select(gpu, 0) != SMR_OK || smr_counters(gpu, O.counters.data(), (uint32_t)dbs.size()) != SMR_OK) die(smr_last_error(gpu));
-    // results of the shard (kvdb.put(read.id, read.toBinString()), processor.cpp:150-155), keys carry the GLOBAL read number
-    std::vector<uint8_t> rec;
-    for (size_t c = 0; c < n_chunks; c++) {
-      if (smr_batch_select(gpu, (int)c) != SMR_OK || smr_results_fetch(gpu) != SMR_OK) die(smr_last_error(gpu));
-      const uint32_t cnt = smr_reads_count(cr[c]);
-      for (uint32_t i = 0; i < cnt; i++) {
-        const size_t len = smr_result_record(gpu, i, nullptr, 0);
-        if (!len) continue;
-        rec.resize(len);
-        smr_result_record(gpu, i, rec.data(), len);
-        const std::string key = "0_" + std::to_string(first + c * chunk + i);
-        const uint64_t kl = key.size(), vl = len;
-        const size_t o = O.records.size();
-        O.records.resize(o + 16 + kl + vl);
-        memcpy(&O.records[o], &kl, 8); memcpy(&O.records[o + 8], key.data(), kl); memcpy(&O.records[o + 8 + kl], &vl, 8); memcpy(&O.records[o + 16 + kl], rec.data(), vl);
-        O.n_records++;
-      }
-      smr_reads_free(cr[c]);
-    }
+    (void)hipFree(d_acc);
+    if (rep && smr_report_close(rep) != SMR_OK) die("cannot write the report files");
+    O.t_write = t_wr;
     O.t_fetch = now_s() - t;
     smr_destroy(gpu);
     (void)hipStreamDestroy(cstream);
@@ -293,6 +360,34 @@ int main(int argc, char** argv) {
   const double t_ranks = now_s() - t_start;
   if (S.use_rccl) for (auto& c : S.comms) ncclCommDestroy(c);
 
+  // ---- report files: the shards' files concatenated in rank order (Report::merge, report.cpp:56-97) ----
+  if (want_reports) {
+    const char* names[] = {"aligned.fq", "aligned.fa", "other.fq", "other.fa", "aligned.blast", "aligned.sam"};
+    std::vector<char> buf(1 << 22);
+    for (const char* nm : names) {
+      FILE* o = nullptr;
+      for (int r = 0; r < world; r++) {
+        const std::string pth = out_dir + "/rank" + std::to_string(r) + "/" + nm;
+        FILE* in = fopen(pth.c_str(), "rb");
+        if (!in) continue;
+        if (!o && !(o = fopen((out_dir + "/" + nm).c_str(), "wb"))) die(std::string("cannot write ") + nm);
+        size_t g;
+        bool first_line = true;
+        while ((g = fread(buf.data(), 1, buf.size(), in)) > 0) {
+          size_t off = 0;
+          if (first_line && r > 0 && std::string(nm) == "aligned.sam") {          // one @HD / @PG header block: the later shards' header lines are dropped
+            while (off < g && buf[off] == '@') { while (off < g && buf[off] != '\n') off++; if (off < g) off++; }
+          }
+          first_line = false;
+          fwrite(buf.data() + off, 1, g - off, o);
+        }
+        fclose(in);
+        remove(pth.c_str());
+      }
+      if (o) fclose(o);
+    }
+    for (int r = 0; r < world; r++) rmdir((out_dir + "/rank" + std::to_string(r)).c_str());
+  }
   // ---- rank 0's view of the reduced counters is everybody's; shards concatenate in rank order ----
   for (int r = 1; r < world; r++) if (outs[r].counters != outs[0].counters) die("the ranks disagree on the reduced counters");
   const std::string rp = out_dir + "/records.bin", sp = out_dir + "/summary.txt";
@@ -310,12 +405,12 @@ int main(int argc, char** argv) {
           (unsigned long long)ctr[0], (unsigned long long)ctr[1]);
   for (size_t k = 0; k < dbs.size(); k++) fprintf(f, "%s\t%llu\n", dbs[k].fasta.c_str(), (unsigned long long)ctr[2 + k]);
   fclose(f);
-  double tu = 0, ta = 0, tf = 0;
-  for (auto& o : outs) { tu = std::max(tu, o.t_upload); ta = std::max(ta, o.t_align); tf = std::max(tf, o.t_fetch); }
+  double tu = 0, ta = 0, tf = 0, tw = 0;
+  for (auto& o : outs) { tu = std::max(tu, o.t_upload); ta = std::max(ta, o.t_align); tf = std::max(tf, o.t_fetch); tw = std::max(tw, o.t_write); }
   const double t_all = now_s() - t0;
-  printf("[timing] ranks %d (%s reduction), reads %llu: parse+pack %.3f s, index load/build %.3f s, per-rank max: index+first upload %.3f s, align+traceback %.3f s "
-         "(uploads of later chunks overlapped), counters+records %.3f s; rank stage %.3f s; end to end %.3f s = %.0f reads/s (rank stage alone: %.0f reads/s)\n",
-         world, S.use_rccl ? "RCCL" : "host", (unsigned long long)n, t_reads, t_index, tu, ta, tf, t_ranks, t_all, n / t_all, n / t_ranks);
+  printf("[timing] ranks %d (%s reduction), reads %llu: parse+pack %.3f s, index load/build %.3f s, per-rank max: index upload + chunk uploads %.3f s (overlapped), align+traceback+fetch %.3f s, "
+         "records%s %.3f s (overlapped), counter reduce + close %.3f s; rank stage %.3f s; end to end %.3f s = %.0f reads/s (rank stage alone: %.0f reads/s)\n",
+         world, S.use_rccl ? "RCCL" : "host", (unsigned long long)n, t_reads, t_index, tu, ta, want_reports ? " + report rows" : "", tw, tf, t_ranks, t_all, n / t_all, n / t_ranks);
   printf("%llu reads, %llu aligned, %llu records, minimal_score %u -> %s\n", (unsigned long long)n, (unsigned long long)ctr[0], (unsigned long long)nrec, outs[0].minimal_score0, rp.c_str());
   for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
   smr_reads_free(all);

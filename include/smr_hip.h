@@ -156,6 +156,7 @@ uint32_t smr_reads_max_len(const smr_reads*);
 /* ------------------------------------------------------------------------------------------------
  * Device context
  * ---------------------------------------------------------------------------------------------- */
+int  smr_device_count(void);   /* HIP devices this process sees (0: none -- there is no CPU fallback); a host that spreads its read chunks over the GPUs of a node creates one context per device (the reference: one aligner thread per core, processor.cpp:248-256) */
 int  smr_create(int device, smr_ctx** out, char* err, size_t errcap);
 void smr_destroy(smr_ctx*);
 const char* smr_last_error(const smr_ctx*);
@@ -199,11 +200,18 @@ int smr_traceback(smr_ctx*, int slot, const smr_params*);
 int smr_counters(smr_ctx*, uint64_t* out, uint32_t n_db);
 /* Device pointer + count of the u64 counters block (for an in-place RCCL all-reduce by the caller). */
 int smr_counters_device(smr_ctx*, void** dptr, uint32_t* n_u64);
+/* d_acc[k] += counter k of the selected batch for k < n_u64 (<= the count smr_counters_device gives), on the device: a host that aligns its
+ * shard chunk by chunk through a few recycled batches keeps one device block of sums (and all-reduces THAT over the ranks). */
+int smr_counters_accumulate(smr_ctx*, void* d_acc, uint32_t n_u64);
 
 /* Results.  smr_result_record writes Read::toBinString() bytes of read i (the KVDB value,
  * read.cpp:429-462; 0 bytes when the read has no alignment) and returns the size needed. */
 int    smr_results_fetch(smr_ctx*);                       /* device -> host copy of all per-read results */
 size_t smr_result_record(const smr_ctx*, uint32_t read_idx, uint8_t* buf, size_t cap);
+/* The same for read i of batch `batch`, whichever batch is selected.  It only reads the host copy that smr_results_fetch made of that
+ * batch, so a second host thread may serialise the records of batch k while the first one is aligning batch k+1 (the reference's writer
+ * thread works the same way behind its aligners, output.cpp:169-272). */
+size_t smr_result_record_batch(const smr_ctx*, int batch, uint32_t read_idx, uint8_t* buf, size_t cap);
 int    smr_result_is_hit(const smr_ctx*, uint32_t read_idx);
 
 /* Seed hits of the last smr_seed_scan call (kernel-level parity + roofline bench of the seed-scan kernel).

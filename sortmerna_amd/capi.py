@@ -62,7 +62,7 @@ EXPORTS = [
     "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free", "smr_reads_slice",
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
-    "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record",
+    "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record", "smr_result_record_batch", "smr_counters_accumulate",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_sw_selfcheck", "smr_sw_mode", "smr_ssw_batch", "smr_cigar_batch", "smr_prof_reset", "smr_prof_get", "smr_prof_kernels", "smr_refstats_corrected", "smr_report_open",
     "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_add_pair", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
     "smr_summary_write", "smr_readstats_record", "smr_readstats_key",
@@ -154,6 +154,10 @@ def bind(L):
     L.smr_results_fetch.argtypes = [vp]
     L.smr_result_record.restype = C.c_size_t
     L.smr_result_record.argtypes = [vp, u32, vp, C.c_size_t]
+    L.smr_result_record_batch.restype = C.c_size_t
+    L.smr_result_record_batch.argtypes = [vp, i32, u32, vp, C.c_size_t]
+    L.smr_counters_accumulate.restype = i32
+    L.smr_counters_accumulate.argtypes = [vp, vp, u32]
     L.smr_result_is_hit.restype = i32
     L.smr_result_is_hit.argtypes = [vp, u32]
     L.smr_seed_scan.restype = i32

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -59,7 +60,8 @@ struct Batch {
 struct smr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  std::string err;
+  std::string err;                        // last error; written under err_m (smr_reads_upload_batch runs on a second host thread)
+  std::mutex err_m, sel_m;                // sel_m: which batch is selected (read by smr_reads_upload_batch)
   int n_cu = 256;
   DevIndex idx[64];
   Batch bt[SMR_MAX_BATCHES];
@@ -102,6 +104,7 @@ namespace {
   do {                                                                                           \
     hipError_t e_ = (call);                                                                      \
     if (e_ != hipSuccess) {                                                                      \
+      std::lock_guard<std::mutex> l_((ctx)->err_m);                                              \
       (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
       return SMR_ERR_DEVICE;                                                                     \
     }                                                                                            \
@@ -715,6 +718,11 @@ extern "C" int smr_sw_mode(smr_ctx* c, int set_to) {      // set_to: 0 / 1 = sel
 }
 
 // =================================================================================================
+extern "C" int smr_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   if (!out) return SMR_ERR_ARG;
   int ndev = 0;
@@ -780,7 +788,12 @@ extern "C" void smr_destroy(smr_ctx* c) {
   delete c;
 }
 
-extern "C" const char* smr_last_error(const smr_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" const char* smr_last_error(const smr_ctx* c) {
+  if (!c) return "null context";
+  static thread_local std::string copy;                  // the caller's own copy: another host thread may be setting the next error
+  { std::lock_guard<std::mutex> l(const_cast<smr_ctx*>(c)->err_m); copy = c->err; }
+  return copy.c_str();
+}
 
 extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   if (!c || !ix || slot < 0 || slot >= 64) return SMR_ERR_ARG;
@@ -836,7 +849,7 @@ extern "C" int smr_batch_select(smr_ctx* c, int batch) {
     HIPCHK(c, hipMemset(B.d_ctr, 0, C_TOTAL * 8));
   }
   B.used = true;
-  c->b = &B;
+  { std::lock_guard<std::mutex> l(c->sel_m); c->b = &B; }
   return SMR_OK;
 }
 
@@ -913,7 +926,10 @@ extern "C" int smr_reads_upload(smr_ctx* c, const smr_reads* r, uint32_t max_aln
 // batch owns its reads, per-read state, counters and CIGAR pool; the scratch of the kernels is sized inside smr_align_part).
 extern "C" int smr_reads_upload_batch(smr_ctx* c, int batch, const smr_reads* r, uint32_t max_aln) {
   if (!c || !r || batch < 0 || batch >= SMR_MAX_BATCHES) return SMR_ERR_ARG;
-  if (&c->bt[batch] == c->b) { c->err = "smr_reads_upload_batch: the batch is the selected one (use smr_reads_upload)"; return SMR_ERR_STATE; }
+  {
+    std::lock_guard<std::mutex> l(c->sel_m);
+    if (&c->bt[batch] == c->b) { std::lock_guard<std::mutex> l2(c->err_m); c->err = "smr_reads_upload_batch: the batch is the selected one (use smr_reads_upload)"; return SMR_ERR_STATE; }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   return upload_into(c, c->bt[batch], r, max_aln, c->upload_stream);
 }
@@ -1259,6 +1275,21 @@ extern "C" int smr_counters_device(smr_ctx* c, void** dptr, uint32_t* n_u64) {
   return SMR_OK;
 }
 
+__global__ void k_ctr_accumulate(const unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ acc, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) acc[k] += ctr[k];
+}
+// acc[k] += the selected batch's counter k, k < n_u64 <= the block smr_counters_device hands out, on the device (a host that aligns its
+// shard in chunks keeps ONE device block of sums and all-reduces that over the ranks)
+extern "C" int smr_counters_accumulate(smr_ctx* c, void* d_acc, uint32_t n_u64) {
+  if (!c || !d_acc || n_u64 > C_PER_DB + 64 || !c->b->d_ctr) return SMR_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_ctr_accumulate, dim3((n_u64 + 127) / 128), dim3(128), 0, c->stream, (const unsigned long long*)c->b->d_ctr, (unsigned long long*)d_acc, n_u64);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SMR_OK;
+}
+
 // the reads that have alignments, packed: read number, state, alignment slots (order = whatever the atomics hand out)
 __global__ void k_results_compact(uint32_t n, uint32_t slots, const RState* __restrict__ saved, const AlignRec* __restrict__ saved_aln,
                                   uint32_t* __restrict__ out_idx, RState* __restrict__ out_state, AlignRec* __restrict__ out_aln, unsigned long long* __restrict__ ctr) {
@@ -1308,8 +1339,17 @@ extern "C" int smr_results_fetch(smr_ctx* c) {
 }
 
 // Read::toBinString read.cpp:429-462 (+ alignment_struct2::toString, s_align2::toString ssw.hpp:106-140)
-extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, size_t cap) {
-  if (!c || !c->b->fetched || i >= c->b->n) return 0;
+static size_t record_of(const Batch& B, uint32_t i, uint8_t* buf, size_t cap);
+extern "C" size_t smr_result_record(const smr_ctx* c, uint32_t i, uint8_t* buf, size_t cap) { return c ? record_of(*c->b, i, buf, cap) : 0; }
+// the same for batch `batch` whichever batch is selected: reads only the host copy smr_results_fetch made of THAT batch, so a second host
+// thread can serialise the records of batch k while the first one aligns batch k+1
+extern "C" size_t smr_result_record_batch(const smr_ctx* c, int batch, uint32_t i, uint8_t* buf, size_t cap) {
+  return (c && batch >= 0 && batch < SMR_MAX_BATCHES) ? record_of(c->bt[batch], i, buf, cap) : 0;
+}
+static size_t record_of(const Batch& B, uint32_t i, uint8_t* buf, size_t cap) {
+  const Batch* const b_ = &B;
+  struct { const Batch* b; } cc{b_}; const auto* c = &cc;          // (the body below reads c->b)
+  if (!c->b->fetched || i >= c->b->n) return 0;
   const uint32_t j = c->b->h_map[i];
   if (j == 0xFFFFFFFFu) return 0;
   const RState& s = c->b->h_state[j];

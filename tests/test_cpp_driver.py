@@ -164,8 +164,19 @@ def _check_mgpu(case, tmp_path, extra):
         cmd += ["--ref", db, "--gumbel", repr(g["log"]["lambda"][k]), repr(g["log"]["K"][k])]
     if "num_alignments" in g["params"]:
         cmd += ["-num_alignments", str(g["params"]["num_alignments"])]
+    if case == "syn_default":
+        cmd += ["--fastx", "--other", "--sam", "--blast", "1 qstrand cigar"]
     out = subprocess.check_output(cmd).decode()
     assert "[timing]" in out
+    if case == "syn_default":            # the shards' report files, merged in rank order, are the reference's own files for the same options
+        sam = [l.rstrip("\n") for l in open(tmp_path / "aligned.sam") if not l.startswith("@")]
+        assert sam == [l for l in g["sam"] if not l.startswith("@")]
+        assert len([l for l in open(tmp_path / "aligned.sam") if l.startswith("@HD")]) == 1
+        blast = [l.rstrip("\n").split("\t") for l in open(tmp_path / "aligned.blast")]
+        exp_b = [l.split("\t") for l in g["blast"]]
+        assert [a[:10] + a[11:] for a in blast] == [b[:10] + b[11:] for b in exp_b]
+        assert [l.split()[0][1:] for l in open(tmp_path / "aligned.fa") if l.startswith(">")] == g["aligned_ids"]
+        assert [l.split()[0][1:] for l in open(tmp_path / "other.fa") if l.startswith(">")] == g["other_ids"]
     kv = refrun.parse_kvdb_dump(str(tmp_path / "records.bin"))
     got = [kv.get(b"0_%d" % i, b"") for i in range(len(seqs))]
     exp = golden.records(case)
@@ -187,8 +198,9 @@ def test_mgpu_host_one_rank_rccl(case, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case,ranks,chunk", [("syn_default", 2, 0), ("syn_all", 3, 40), ("two_db_default", 2, 64)])
+@pytest.mark.parametrize("case,ranks,chunk", [("syn_default", 2, 0), ("syn_default", 2, 50), ("syn_all", 3, 40), ("syn_all", 1, 16), ("two_db_default", 2, 64)])
 def test_mgpu_host_shards_and_chunks_on_one_device(case, ranks, chunk, tmp_path):
     """the N-rank path on one GPU (every rank thread gets device 0; the two reductions go through the host because RCCL needs a device per rank):
-    record-range shards, chunked upload overlapped with alignment, counters summed over chunks and ranks, records concatenated in rank order"""
+    record-range shards, any number of chunks streamed through three recycled batch slots (upload | align | records + report rows overlapped),
+    counters summed over chunks on the device and over ranks, records and report files concatenated in rank order"""
     _check_mgpu(case, tmp_path, ["--gpus", str(ranks), "--devices", ",".join(["0"] * ranks), "--reduce", "host", "--chunk-reads", str(chunk)])

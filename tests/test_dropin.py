@@ -21,7 +21,7 @@ CASES = {
 }
 
 
-def run_binary(exe, case, wd):
+def run_binary(exe, case, wd, env_extra=None):
     c = CASES[case]
     cmd = [exe]
     for r in c["refs"]:
@@ -31,6 +31,7 @@ def run_binary(exe, case, wd):
     cmd += ["-workdir", str(wd), "-threads", "1"] + c["extra"]
     env = dict(os.environ)
     env["SMR_KVDB_DUMP"] = os.path.join(str(wd), "kvdb_dump.bin")
+    env.update(env_extra or {})
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1800)
     assert p.returncode == 0, p.stdout.decode("latin-1")[-3000:]
     out = {}
@@ -46,10 +47,13 @@ def run_binary(exe, case, wd):
     return out, refrun.parse_kvdb_dump(env["SMR_KVDB_DUMP"]), p.stdout.decode("latin-1")
 
 
-def compare(exe_gpu, case, tmp_path):
+def compare(exe_gpu, case, tmp_path, env_extra=None, min_chunks=1):
     ref_files, ref_kv, _ = run_binary(paths.REF_BIN, case, tmp_path / "ref")
-    gpu_files, gpu_kv, log = run_binary(exe_gpu, case, tmp_path / "gpu")
+    gpu_files, gpu_kv, log = run_binary(exe_gpu, case, tmp_path / "gpu", env_extra)
     assert "Starting alignment (libsmr_hip)" in log
+    import re
+    m = re.search(r"reads in (\d+) chunk\(s\)", log)
+    assert m and int(m.group(1)) >= min_chunks, log[-600:]
     assert sorted(ref_files) == sorted(gpu_files)
     assert any(fn.startswith("aligned") and fn.endswith(".blast") for fn in ref_files)
     for fn in ref_files:
@@ -67,10 +71,21 @@ def test_reference_cli_with_the_gpu_in_the_middle(case, tmp_path):
     compare(REF_GPU, case, tmp_path)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,chunk", [("real_two_db", 100), ("paired", 64)])
+def test_reads_stream_through_the_gpu_in_chunks(case, chunk, tmp_path):
+    """a reads file several times larger than a chunk: the binding pulls Readfeed::next() chunk by chunk (reader thread | one worker per GPU |
+    KVDB writer thread); every output file and every KVDB value is still the unmodified binary's"""
+    if not (os.path.isfile(REF_GPU) and os.path.isfile(paths.REF_BIN)):
+        pytest.skip("oracle/_ref/sortmerna_gpu / sortmerna_ref are not in this snapshot")
+    compare(REF_GPU, case, tmp_path, {"SMR_DROPIN_CHUNK": str(chunk)}, min_chunks=4)
+
+
 @pytest.mark.skipif(not (paths.have_reference() and paths.have_ref_bin()), reason="needs /root/reference and `make -C oracle ref`")
-@pytest.mark.parametrize("case", ["t0", "paired"])
-def test_reference_cli_with_the_kernel_emulator_in_the_middle(case, tmp_path):
+@pytest.mark.parametrize("case,chunk", [("t0", 0), ("paired", 0), ("paired", 64)])
+def test_reference_cli_with_the_kernel_emulator_in_the_middle(case, chunk, tmp_path):
+    """(chunk 64: the 200 mate pairs stream through the emulator in 7 chunks)"""
     from helpers import emu
     lib = emu.build()
     subprocess.check_call(["make", "-s", "-j8", "-C", paths.ORACLE_DIR, "dropin", "SMRLIB=" + os.path.dirname(lib), "SMRNAME=smr_emu", "DROPIN_BIN=sortmerna_gpu_emu"])
-    compare(os.path.join(paths.ORACLE_DIR, "_ref", "sortmerna_gpu_emu"), case, tmp_path)
+    compare(os.path.join(paths.ORACLE_DIR, "_ref", "sortmerna_gpu_emu"), case, tmp_path, {"SMR_DROPIN_CHUNK": str(chunk)} if chunk else None, min_chunks=4 if chunk else 1)

@@ -72,6 +72,15 @@ sqi)
   ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sqi -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_sqi.json 2> $ROOT/$OUT/pmc_sqi.err )
   find $OUT/pmc_sqi -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmc_sqi.txt 2>&1; head -16 $OUT/pmc_sqi.txt
   rm -rf $OUT/pmc_sqi ;;
+pacbio_phases)
+  # where a wave of k_chain spends its cycles on 5 kb reads (-DSMR_CHAIN_PHASES build of the library)
+  if [ -f sortmerna_amd/lib/libsmr_hip_phases.so ]; then
+    cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp sortmerna_amd/lib/libsmr_hip_phases.so sortmerna_amd/lib/libsmr_hip.so
+    SMR_DEBUG_PHASES=1 timeout 600 python bench.py --workload pacbio5k --steps 1 --warmup 1 --resident-batches 2 --no-cpu-baseline --profile-run > $OUT/pacbio_phases.json 2> $OUT/pacbio_phases.err; grep "phase cycles" $OUT/pacbio_phases.err | tail -3 | cut -c1-400
+    cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
+  fi ;;
+dropin)
+  timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 mini)
   timeout 300 python tools/hw_minibench.py > $OUT/minibench.log 2>&1; tail -8 $OUT/minibench.log ;;
 alt)
