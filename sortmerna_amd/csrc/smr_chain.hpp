@@ -150,6 +150,14 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
 #include "smr_sw_pk.hpp"
 namespace smr {
 
+// reads of more than 512 letters (mode 2): strips of 128 x 8 rows.  A function of its own so that its registers (8 rows of state per lane) are not
+// the footprint of every other call of sw_wave
+__device__ __attribute__((noinline)) SwRes sw_wave_long(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                              int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
+  if (hn) return sw_wave_pk_r<8, true, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  return sw_wave_pk_r<8, false, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+}
+
 // mode 1 / 2: the packed 16-bit kernel (smr_sw_pk.hpp; 2 = its wave_ror variant) where its preconditions hold; mode 0: always the 32-bit kernel
 __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                          int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
@@ -158,6 +166,8 @@ __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, in
     bool hasn = false;
     for (int q = lane_id(); q < n; q += 64) hasn |= rfq[rf0 + rfstep * q] == 4;
     const bool hn = __any(hasn);
+    // rows per virtual lane: 1 / 2 / 4 for reads up to 128 / 256 / 512 letters (one strip); longer reads take strips of 128 x 8 rows -- the
+    // per-step overhead (hand-over between lanes, inputs of lane 0, the boundary row for the next strip) is paid per 1024 cells instead of 512
     if (mode == 2) {
       if (hn) { if (m <= 128) return sw_wave_pk_r<1, true, true>(SW_ARGS); if (m <= 256) return sw_wave_pk_r<2, true, true>(SW_ARGS); return sw_wave_pk_r<4, true, true>(SW_ARGS); }
       if (m <= 128) return sw_wave_pk_r<1, false, true>(SW_ARGS);
@@ -178,6 +188,18 @@ __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, in
   }
   return sw_wave_r<4, false>(SW_ARGS);
 #undef SW_ARGS
+}
+
+// a read of more than 512 letters through the 8-row strips where the packed kernel applies (the caller knows that its batch has such reads:
+// the instantiations that never see one do not carry the call)
+__device__ __forceinline__ SwRes sw_wave_any(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                             int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
+  if (mode == 2 && m > 512 && (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255) {
+    bool hasn = false;
+    for (int q = lane_id(); q < n; q += 64) hasn |= rfq[rf0 + rfstep * q] == 4;
+    return sw_wave_long(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, __any(hasn));
+  }
+  return sw_wave(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, mode);
 }
 
 #define CH_EXT_CAP 65536u          // slots of the global candidate-set table of a block (tuples carry the slot in 16 bits)
@@ -449,11 +471,11 @@ __device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* s
   __syncthreads();
 }
 
-// k_chain<EXT>: compute_lis_alignment (alignment.cpp:100-509) for the reads k_cand marked.  One block = one wave, persistent: chunks of
+// k_chain<EXT, LONG>: compute_lis_alignment (alignment.cpp:100-509) for the reads k_cand marked.  One block = one wave, persistent: chunks of
 // 64 reads are claimed with one atomic, their flags fetched by the 64 lanes at once, the marked ones walked one by one.
 // Dynamic LDS (bytes), ML = max_len rounded to 16, MQ = min(ML, SW_X4_MAX_ROWS), RF = ML + 2 * edges + 16 rounded, RQ = the same for a read of MQ letters:
-//   read slots    ML + 4 MQ     the read being walked | four parked reads
-//   window slots  RF + 8 RQ     0: any window of the read being walked, 1..3: the rest of its batch, 4..7: parked tasks (strip boundaries: global)
+//   read slots    5 MQ          the read being walked | four parked reads      (reads of more than MQ letters: global, see below)
+//   window slots  9 RQ          0..3: the batch of the read being walked, 4..7: parked tasks
 //   keys[CH_KEYS_LDS] u64 | region R = max(4 CH_PAIRS_LDS, 2 s_cap) u32: pairs (two halves) + serial-LIS arrays during the candidate loop,
 //   Bloom words + counts while the candidate set is built | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS + 8] u32 | skey[s_cap] u32
 // Candidate references (alignment.cpp:117-148) without a per-reference counter array: see chain_build_set.  EXT = true is the second
@@ -461,27 +483,27 @@ __device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* s
 #ifndef SMR_CHAIN_WAVES_PER_SIMD
 #define SMR_CHAIN_WAVES_PER_SIMD 3
 #endif
-template <bool EXT>
+template <bool EXT, bool LONG>
 __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
                                               RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
                                               uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2,
-                                              uint32_t lds_rq, int* g_bound) {
+                                              uint32_t lds_rq, int* g_bound, uint8_t* g_rdq) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
   const int lane = lane_id();
-  // rdq: read slot 0 (lds_ml bytes: the read being walked) + 4 slots of lds_mq = min(lds_ml, SW_X4_MAX_ROWS) bytes (the parked reads);
-  // rfq: reference-window slot 0 of lds_rf bytes (any window) + slots 1..8 of lds_rq bytes (windows of reads <= SW_X4_MAX_ROWS letters:
-  // 1..3 = the rest of the batch of the read being walked, 4..7 = the parked tasks).  The strip-boundary rows that only reads of more than
-  // one strip need (2 ints per reference column) live in global memory (g_bound, per block): a wave that walks 5 kb reads keeps ~20 KB of
-  // LDS instead of ~60 KB, i.e. 7 instead of 2 waves per CU
+  // LDS holds the letters and reference windows of reads of ONE strip only (<= SW_X4_MAX_ROWS letters, lds_mq / lds_rq bytes per slot):
+  // rdq: read slot 0 (the read being walked) + 4 slots (the parked reads); rfq: 9 reference-window slots (0..3 = the batch of the read being
+  // walked, 4..7 = the parked tasks).  A LONGER read never shares a Smith-Waterman pass with others: its letters go to this block's row of
+  // g_rdq, its reference window is read where it lies (ix.ref_seq: same alphabet), and the strip-boundary rows (2 ints per reference column)
+  // live in g_bound -- so a wave that walks 5 kb reads keeps ~13 KB of LDS instead of ~60 KB: 12 waves per CU (the register budget) instead of 2
   uint8_t* rdq = lds_raw;
   const uint32_t lds_mq = min(lds_ml, (uint32_t)SW_X4_MAX_ROWS);
-  uint8_t* rfq = rdq + (size_t)lds_ml + 4 * (size_t)lds_mq;
-  uint8_t* const rfq1 = rfq + lds_rf;
+  uint8_t* rfq = rdq + 5 * (size_t)lds_mq;
+  uint8_t* const rfq1 = rfq + lds_rq;
   auto wslot = [&](int e) -> uint8_t* { return e == 0 ? rfq : rfq1 + (size_t)(e - 1) * lds_rq; };
   int* bound = g_bound ? g_bound + (size_t)blockIdx.x * 2 * lds_rf : nullptr;
   unsigned long long* l_keys = (unsigned long long*)(rfq1 + 8 * (size_t)lds_rq);
@@ -550,10 +572,10 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         const int gm = mine ? (int)q_m[g] : 0, gn = mine ? (int)q_nref[g] : 0, gq = mine ? (int)q_aq[g] : 0;
         int mm = gm;
         for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
-        const SwRes r4 = sw_wave_x4(rdq + (size_t)lds_ml + (size_t)g * lds_mq, gm, gq, 1, wslot(4 + g), gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, q_hasn);
+        const SwRes r4 = sw_wave_x4(rdq + (size_t)lds_mq + (size_t)g * lds_mq, gm, gq, 1, wslot(4 + g), gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, q_hasn);
         if ((lane & 15) == 0 && mine) { q_score[g] = r4.score; q_eref[g] = r4.end_ref; q_eread[g] = r4.end_read; }
       } else {
-        const SwRes r1 = sw_wave(rdq + lds_ml, (int)q_m[0], (int)q_aq[0], 1, wslot(4), (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+        const SwRes r1 = sw_wave(rdq + lds_mq, (int)q_m[0], (int)q_aq[0], 1, wslot(4), (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
         if (lane == 0) { q_score[0] = r1.score; q_eref[0] = r1.end_ref; q_eread[0] = r1.end_read; }
       }
       __syncthreads();
@@ -607,6 +629,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     int search = 1;
     const uint32_t max_SW_score = len * (uint32_t)P.match;
     const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
+    const bool long_rd = LONG && len > lds_mq;             // more than one strip: letters in g_rdq, reference windows read in place (LONG: the batch has such reads)
+    uint8_t* const RD = long_rd ? g_rdq + (size_t)blockIdx.x * lds_ml : rdq;
     bool parked = false;
 
     if (st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0) {
@@ -850,7 +874,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               const uint32_t e = q_n;
               const uint32_t aval = (w.has_amb && !w.is04) ? 4u : (uint32_t)w.aval;             // read.flip34() before SSW (:360-361)
               __syncthreads();
-              uint8_t* rq = rdq + (size_t)lds_ml + (size_t)e * lds_mq;
+              uint8_t* rq = rdq + (size_t)lds_mq + (size_t)e * lds_mq;
               uint8_t* fq = wslot(4 + (int)e);
               for (uint32_t q = lane; q < len; q += 64) rq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, aval);
               bool hn = false;
@@ -883,7 +907,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           SwRes fw; fw.score = 0; fw.end_ref = -1; fw.end_read = m - 1;
           int ce = -1;
           if (sw_ok) {
-            if (!rdq_staged) { __syncthreads(); for (uint32_t q = lane; q < len; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, w.aval); rdq_staged = true; __syncthreads(); }
+            if (!rdq_staged) { __syncthreads(); for (uint32_t q = lane; q < len; q += 64) RD[q] = (uint8_t)read_nt(rec, len, q, w.reversed, w.aval); rdq_staged = true; __syncthreads(); }
             for (int e = 0; e < n_cached; e++)
               if (ctk[e].max_ref == tk.max_ref && ctk[e].rf_start == tk.rf_start && ctk[e].align_que_start == tk.align_que_start && ctk[e].m == m && ctk[e].nref == nref) { ce = e; break; }
             if (ce < 0) {
@@ -901,7 +925,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               }
               __syncthreads();
               bool hasn = false;
-              for (int e = 0; e < n_cached; e++) {
+              if (!long_rd) for (int e = 0; e < n_cached; e++) {
                 uint8_t* dst = wslot(e);
                 for (int q = lane; q < ctk[e].nref; q += 64) { const uint8_t ch = ix.ref_seq[ctk[e].rf_start + q]; dst[q] = ch; hasn |= ch == 4; }
               }
@@ -922,7 +946,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                 }
                 if (n_cached > 1) n_spec += (unsigned long long)(n_cached - 1);
               } else {
-                cfw[0] = sw_wave(rdq, m, (int)tk.align_que_start, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+                if (LONG) cfw[0] = sw_wave_any(RD, m, (int)tk.align_que_start, 1, long_rd ? ix.ref_seq + tk.rf_start : rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+                else cfw[0] = sw_wave(rdq, m, (int)tk.align_que_start, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
               }
               __syncthreads();
               TPH(6)
@@ -1016,7 +1041,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 // done, so only the survivors cost a reverse pass (43 % of the accepted ones on the bench workload), and they are independent problems:
 // four per wave through the four-problem kernel (reads <= SW_X4_MAX_ROWS), else one per wave through sw_wave.
 // k_begins_collect lists the pending slots of the reads with a new hit; k_begins claims them four at a time.
-// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4), or 1 + 1 (strip boundaries in global memory).
+// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4); none in single-problem mode.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __restrict__ work, const RWork* __restrict__ rw, const AlignRec* __restrict__ work_aln,
                                  uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
@@ -1028,16 +1053,19 @@ __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __res
   tasks[atomicAdd(&ctr[C_BEGIN_N], 1ull)] = i;
 }
 
-__global__ void __launch_bounds__(64) k_begins(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, AlignRec* __restrict__ work_aln,
-                                               unsigned long long* __restrict__ ctr, uint32_t lds_m, uint32_t lds_n, int x4, int* g_bound) {
+template <bool LONG>
+__global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, AlignRec* __restrict__ work_aln,
+                                               unsigned long long* __restrict__ ctr, uint32_t lds_m, uint32_t lds_n, int x4, int* g_bound, uint8_t* g_rdq) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_t0;
   const int lane = lane_id();
   const uint32_t n_tasks = (uint32_t)ctr[C_BEGIN_N];
   const int per = x4 ? 4 : 1;
   const int g = x4 ? lane >> 4 : 0;
-  uint8_t* rdq = lds_raw + (size_t)g * lds_m;
-  uint8_t* rfq = lds_raw + (size_t)per * lds_m + (size_t)g * lds_n;
+  // four-problem mode: 4 read + 4 reference windows in LDS; single-problem mode (some read has more than one strip): the read's letters in this
+  // block's row of g_rdq, the reference window read in place
+  uint8_t* rdq = x4 ? lds_raw + (size_t)g * lds_m : g_rdq + (size_t)blockIdx.x * lds_m;
+  uint8_t* rfq_l = lds_raw + (size_t)per * lds_m + (size_t)g * lds_n;
   int* bound = g_bound ? g_bound + (size_t)blockIdx.x * 2 * lds_n : nullptr;          // strip boundaries (single-problem mode, reads of more than one strip)
   unsigned long long n_rev = 0, n_cells = 0;
   for (;;) {
@@ -1051,6 +1079,7 @@ __global__ void __launch_bounds__(64) k_begins(DReads rd, DIndex ix, DParams P, 
     uint32_t slot = 0;
     AlignRec al;
     int m = 0, n = 0;
+    const uint8_t* rfq = rfq_l;
     if (have) {
       slot = tasks[t]; al = work_aln[slot];
       m = al.read_end1 - al.read_begin1 + 1; n = al.ref_end1 - al.ref_begin1 + 1;       // the window prefixes that end in the forward end cell
@@ -1059,18 +1088,20 @@ __global__ void __launch_bounds__(64) k_begins(DReads rd, DIndex ix, DParams P, 
       const uint8_t* ref = ix.ref_seq + ix.ref_off[al.ref_num] + al.ref_begin1;
       const int l0 = x4 ? (lane & 15) : lane, ls = x4 ? 16 : 64;
       for (int q = l0; q < m; q += ls) rdq[q] = (uint8_t)read_nt(rec, len, (uint32_t)(al.read_begin1 + q), al.strand ? 0u : 1u, 4u);
-      for (int q = l0; q < n; q += ls) rfq[q] = ref[q];
+      if (x4) for (int q = l0; q < n; q += ls) rfq_l[q] = ref[q];
+      rfq = x4 ? rfq_l : ref;
     }
     bool hasn = false;
     __syncthreads();
-    if (have) { const int l0 = x4 ? (lane & 15) : lane, ls = x4 ? 16 : 64; for (int q = l0; q < n; q += ls) hasn |= rfq[q] == 4; }
+    if (have && x4) { const int l0 = lane & 15; for (int q = l0; q < n; q += 16) hasn |= rfq[q] == 4; }
     SwRes bw;
     if (x4) {
       int mm = m;
       for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
       bw = sw_wave_x4(rdq, m, m - 1, -1, rfq, n, n - 1, -1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
     } else {
-      bw = sw_wave(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+      if (LONG) bw = sw_wave_any(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+      else bw = sw_wave(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
     }
     if (have && (x4 ? (lane & 15) == 0 : lane == 0)) {
       al.ref_begin1 = al.ref_end1 - bw.end_ref;

@@ -84,6 +84,7 @@ struct smr_ctx {
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
+  uint8_t* d_rdq = nullptr; size_t rdq_cap = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
@@ -304,15 +305,17 @@ void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, u
   ml = (c->b->max_len + 15) & ~15u;
   rf = (c->b->max_len + 2 * chain_edges(P, c->b->max_len) + 16 + 15) & ~15u;
   rq = std::min(rf, (mq_len + 2 * chain_edges(P, mq_len) + 16 + 15) & ~15u);
-  bytes = (size_t)ml + 4 * (size_t)std::min<uint32_t>(ml, SW_X4_MAX_ROWS) + rf + (size_t)8 * rq + (size_t)CH_KEYS_LDS * 8 + (size_t)std::max<uint32_t>(4u * CH_PAIRS_LDS, 2u * c->chain_scap) * 4 +
+  bytes = 5 * (size_t)std::min<uint32_t>(ml, SW_X4_MAX_ROWS) + (size_t)9 * rq + (size_t)CH_KEYS_LDS * 8 + (size_t)std::max<uint32_t>(4u * CH_PAIRS_LDS, 2u * c->chain_scap) * 4 +
           (size_t)CH_HITS_LDS * 8 + (size_t)(CH_HITS_LDS + 8) * 4 + (size_t)c->chain_scap * 4;
 }
 void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, size_t& bytes) { uint32_t rq; chain_lds(c, P, ml, rf, rq, bytes); }
-// strip-boundary rows of the Smith-Waterman kernels (2 ints per reference column and block): only batches with reads of more than one strip
+// per block: strip-boundary rows of the Smith-Waterman kernels (2 ints per reference column) and the letters of the read being walked
+// (1 byte each) -- only batches with reads of more than one strip
 int ensure_bound(smr_ctx* c, uint32_t blocks, uint32_t rf) {
   if (c->b->max_len <= SW_X4_MAX_ROWS) return SMR_OK;
-  const size_t need = (size_t)blocks * 2 * rf;
+  const size_t need = (size_t)blocks * 2 * rf, need_rd = (size_t)blocks * ((c->b->max_len + 15) & ~15u);
   if (c->bound_cap < need) { int rc = dev_alloc(c, &c->d_bound, need); if (rc) return rc; c->bound_cap = need; }
+  if (c->rdq_cap < need_rd) { int rc = dev_alloc(c, &c->d_rdq, need_rd); if (rc) return rc; c->rdq_cap = need_rd; }
   return SMR_OK;
 }
 
@@ -321,27 +324,32 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   chain_lds(c, P, ml, rf, rq, lds);
   HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
   if (lds > 64 * 1024 && lds > c->chain_lds_attr) {     // reads beyond ~5.6 kb: more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     c->chain_lds_attr = lds;
   }
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
   { int rc = ensure_bound(c, c->chain_blocks, rf); if (rc) return rc; }
   int* const gb = c->b->max_len > SW_X4_MAX_ROWS ? c->d_bound : nullptr;
+  uint8_t* const grd = c->b->max_len > SW_X4_MAX_ROWS ? c->d_rdq : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool);
   ev_mark(c, KP_CHAIN);
-  hipLaunchKernelGGL(k_chain<false>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
-                     c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap,
-                     c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr, rq, gb);
+#define CHAIN_ARGS(stab, t2) dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, \
+                             c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd
+  // (LONG: the batch has reads of more than one Smith-Waterman strip; the short-read instantiation carries none of their state)
+  if (gb) hipLaunchKernelGGL((k_chain<false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
+  else hipLaunchKernelGGL((k_chain<false, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
   if (c->chain_ext) {
     // the reads whose candidate set outgrew the LDS table of the first launch: same walk, set in the block's global table
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
-    hipLaunchKernelGGL(k_chain<true>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln,
-                       c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap,
-                       c->d_stab, c->d_tuples2, rq, gb);
+    if (gb) hipLaunchKernelGGL((k_chain<true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
+    else hipLaunchKernelGGL((k_chain<true, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
   }
+#undef CHAIN_ARGS
   ev_stop(c);
   HIPCHK(c, hipGetLastError());
   return SMR_OK;
@@ -775,7 +783,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
-  dev_free(&c->d_bound);
+  dev_free(&c->d_bound); dev_free(&c->d_rdq);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
   dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.fbits); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
@@ -1029,19 +1037,22 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
         const int x4 = (P.sw_mode >= 1 && c->b->max_len <= SW_X4_MAX_ROWS &&
                         (long long)c->b->max_len * P.match + 255 < 32768 && rf + 128 <= 8191 && P.gap_open + P.mismatch >= 0 && P.gap_open + P.score_N >= 0 &&
                         P.match + P.gap_open <= 255 && P.score_N + P.gap_open <= 255) ? 1 : 0;
-        const size_t lds_b = x4 ? (size_t)4 * (ml + rf) : (size_t)ml + rf;
+        const size_t lds_b = x4 ? (size_t)4 * (ml + rf) : 0;
         const uint32_t bg_blocks = (uint32_t)c->n_cu * 8u;
         if ((rc = ensure_bound(c, std::max(bg_blocks, c->chain_blocks), rf))) return rc;
         if (lds_b > 64 * 1024 && lds_b > c->begins_lds_attr) {
-          HIPCHK(c, hipFuncSetAttribute((const void*)k_begins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          HIPCHK(c, hipFuncSetAttribute((const void*)k_begins<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          HIPCHK(c, hipFuncSetAttribute((const void*)k_begins<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
           c->begins_lds_attr = lds_b;
         }
         HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_BEGIN_N], 0, 16, c->stream));       // C_BEGIN_N, C_BEGIN_NEXT
         ev_mark(c, KP_BEGINS);
         hipLaunchKernelGGL(k_begins_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->b->n, c->b->slots, (const RState*)c->b->d_work, (const RWork*)c->b->d_rw,
                            (const AlignRec*)c->b->d_work_aln, c->d_tasks, c->b->d_ctr);
-        hipLaunchKernelGGL(k_begins, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4,
-                           c->b->max_len > SW_X4_MAX_ROWS ? c->d_bound : nullptr);
+        if (c->b->max_len > SW_X4_MAX_ROWS)
+          hipLaunchKernelGGL(k_begins<true>, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, c->d_bound, c->d_rdq);
+        else
+          hipLaunchKernelGGL(k_begins<false>, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, (int*)nullptr, (uint8_t*)nullptr);
         ev_stop(c);
       }
       // only a clean attempt is committed to the persistent per-read state (kvdb.put, processor.cpp:150-155)

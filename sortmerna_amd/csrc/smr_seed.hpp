@@ -216,56 +216,63 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
   const uint32_t t0 = blockIdx.x * sb.tpb, t1 = min(t0 + sb.tpb, n_tiles);
   SeedTmp* const region = sb.tmp + (size_t)2 * SEED_TILE * t0;
   uint32_t nwin = 0;                                      // windows of this wave (uniform)
-  for (uint32_t tile = t0; tile < t1; tile++) {
+  struct Win { bool emit[2]; uint32_t key[2], is_win; unsigned long long payload[2]; };
+  // the window of this thread in `tile`: nothing but loads and arithmetic, so the loads of two tiles can be in flight together
+  auto window_of = [&](uint32_t tile, Win& W) {
+    W.emit[0] = W.emit[1] = false; W.key[0] = W.key[1] = 0; W.is_win = 0; W.payload[0] = W.payload[1] = 0;
     const uint32_t tid = tile * SEED_TILE + threadIdx.x;
     const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
-    bool emit[2] = {false, false};
-    uint32_t key[2] = {0, 0}, is_win = 0;
-    unsigned long long payload[2] = {0, 0};
-    if (r < rd.n) {
-      const RWork w = rw[r];
-      const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
-      const uint32_t len = rd.len[r];
-      const uint32_t stride = P.skip[pass];
-      const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
-      bool mine = k < numwin;
-      const uint32_t win_pos = k * stride;
-      if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
-      if (mine) {
-        // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
-        const uint32_t aval = w.is04 ? 0 : w.aval;
-        const unsigned long long wc = window_chars(rd.words + rd.rec_off[r], len, win_pos, L, w.reversed, aval);
-        const unsigned long long half = (1ull << (2 * pw)) - 1ull;
-        // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
-        const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
-        uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
-        ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
-        rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
-        is_win = 1;
-        const uint32_t lf = ix.lkc[ra], lr = ix.lkc[rb];          // lookup_tbl[kmer].count and the presence of trie_F / trie_R (paralleltraversal.cpp:155-160, 186-192)
-        emit[0] = (lf & 0x3FFFFFFFu) > P.minoccur && ((lf >> 30) & 1u);
-        emit[1] = (lr & 0x3FFFFFFFu) > P.minoccur && (lr >> 31);
-        key[0] = ra; key[1] = sb.nkh + rb;
-        const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
-        payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
-        payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
-      }
-    }
-    const unsigned long long em0 = __ballot(emit[0]), em1 = __ballot(emit[1]);
-    nwin += (uint32_t)__popcll(__ballot(is_win));
+    if (tile >= t1 || r >= rd.n) return;
+    const RWork w = rw[r];
+    const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
+    const uint32_t len = rd.len[r];
+    const uint32_t stride = P.skip[pass];
+    const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
+    bool mine = k < numwin;
+    const uint32_t win_pos = k * stride;
+    if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
+    if (!mine) return;
+    // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
+    const uint32_t aval = w.is04 ? 0 : w.aval;
+    const unsigned long long wc = window_chars(rd.words + rd.rec_off[r], len, win_pos, L, w.reversed, aval);
+    const unsigned long long half = (1ull << (2 * pw)) - 1ull;
+    // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
+    const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
+    uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
+    ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
+    rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
+    W.is_win = 1;
+    const uint32_t lf = ix.lkc[ra], lr = ix.lkc[rb];          // lookup_tbl[kmer].count and the presence of trie_F / trie_R (paralleltraversal.cpp:155-160, 186-192)
+    W.emit[0] = (lf & 0x3FFFFFFFu) > P.minoccur && ((lf >> 30) & 1u);
+    W.emit[1] = (lr & 0x3FFFFFFFu) > P.minoccur && (lr >> 31);
+    W.key[0] = ra; W.key[1] = sb.nkh + rb;
+    const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
+    W.payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
+    W.payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
+  };
+  auto put = [&](const Win& W) {
+    const unsigned long long em0 = __ballot(W.emit[0]), em1 = __ballot(W.emit[1]);
+    nwin += (uint32_t)__popcll(__ballot(W.is_win));
     const uint32_t c0 = (uint32_t)__popcll(em0), c1 = (uint32_t)__popcll(em1);
     uint32_t base = 0;
     if (lane == 0 && c0 + c1) base = atomicAdd(&s_cur, c0 + c1);       // the wave's slots in the block's region: its forward tuples, then its reverse tuples
     base = (uint32_t)__shfl((int)base, 0, 64);
 #pragma unroll
     for (int d = 0; d < 2; d++) {
-      if (emit[d]) {
+      if (W.emit[d]) {
         const uint32_t idx = base + (d ? c0 : 0u) + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
-        SeedTmp t; t.key = key[d]; t.lo = (uint32_t)payload[d]; t.hi = (uint32_t)(payload[d] >> 32);
+        SeedTmp t; t.key = W.key[d]; t.lo = (uint32_t)W.payload[d]; t.hi = (uint32_t)(W.payload[d] >> 32);
         region[idx] = t;
-        atomicAdd(&lh[key[d] >> sb.fb], 1u);
+        atomicAdd(&lh[W.key[d] >> sb.fb], 1u);
       }
     }
+  };
+  for (uint32_t tile = t0; tile < t1; tile += 2) {
+    Win A, B;
+    window_of(tile, A);
+    window_of(tile + 1, B);
+    put(A);
+    if (tile + 1 < t1) put(B);
   }
   if (lane == 0 && nwin) atomicAdd(&s_win, nwin);
   __syncthreads();

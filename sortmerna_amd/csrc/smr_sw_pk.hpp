@@ -103,15 +103,24 @@ __device__ __forceinline__ SwRes sw_wave_pk_r(const uint8_t* rdq, int m, int rd0
     // running-maximum key: h << 16 | (0x3FFF - column) << 1 | (1 for the low half): larger = higher score, then earlier column, then
     // the low half (smaller row); 15 bits hold the column term for every column -127 .. 8191, so nothing spills into h
     uint32_t xlo = ((uint32_t)(0x3FFF + lane) << 1) | 1u;
-    for (int t0 = 0; t0 < steps; t0 += 64) {
-      // the inputs of virtual lane 0 for the next 64 steps (columns t0 .. t0+63), one per lane; read back with v_readlane
+    // the inputs of virtual lane 0 (reference letter; boundary row of the previous strip) for 64 steps = columns t0 .. t0+63, one per lane, read
+    // back with v_readlane; the next 64 are fetched before the current 64 are worked on (the letters of a long read's window and the boundary
+    // rows come from global memory)
+    auto fetch_in = [&](int t0, uint32_t& cS, int& cY, int& cF) {
       const int cq = t0 + lane;
-      uint32_t chS = PK_SEL_NONE;
-      int chY = -go, chF = 0;
+      cS = PK_SEL_NONE; cY = -go; cF = 0;
       if (cq < n) {
-        chS = pk_sel_of(rfq[rf0 + rfstep * cq]);
-        if (has_prev) { chY = bound[2 * cq] - go; chF = bound[2 * cq + 1]; }
+        cS = pk_sel_of(rfq[rf0 + rfstep * cq]);
+        if (has_prev) { cY = bound[2 * cq] - go; cF = bound[2 * cq + 1]; }
       }
+    };
+    uint32_t nxS; int nxY, nxF;
+    fetch_in(0, nxS, nxY, nxF);
+    for (int t0 = 0; t0 < steps; t0 += 64) {
+      const uint32_t chS = nxS;
+      const int chY = nxY, chF = nxF;
+      // (the strip that writes bound[] for the next one runs 127 columns behind its own reads: what it fetches ahead is never what it has yet to write)
+      if (t0 + 64 < steps) fetch_in(t0 + 64, nxS, nxY, nxF);
       const int tend = min(64, steps - t0);
       for (int tt = 0; tt < tend; tt++) {
         const uint32_t inS = (uint32_t)__builtin_amdgcn_readlane((int)chS, tt);

@@ -1,0 +1,97 @@
+"""BASELINE.json configs[3] and configs[4] as parity cases at size (the workloads of `bench.py --workload refs8 | pacbio5k`, scaled so that the
+CPU oracle finishes in about a minute): every per-read record of the GPU path equals the oracle's, byte for byte.
+  refs8     20 000 reads against EIGHT resident reference DBs (the bundled silva-arc-16s-id95 at full size + 7 seeded synthetic families,
+            among them 5S / 5.8S-like sequences SHORTER than a read), the (index, part) loop of processor.cpp:219-277,
+            reads_matched_per_db[8] (readstats.hpp:84)
+  pacbio5k  2 000 PacBio-like reads ~N(5000, 500) nt with 12 % errors against a 28S-like DB: Smith-Waterman in strips of 512 rows with the
+            boundary rows in global memory (ssw.c:399-575), wide banded traceback (ssw.c:577-773): every alignment with its CIGAR
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import sortmerna_amd as smr
+from sortmerna_amd import synth
+
+from helpers import orc, paths
+from helpers.workload import GUMBEL_UNIFORM
+
+sys.path.insert(0, paths.REPO)
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(tmp_path, workload, db_nt, n_reads):
+    import bench
+    args = argparse.Namespace(workload=workload, db_nt=db_nt, read_len=150, long_read_len=5000)
+    dbl = bench.workload_dbs(args, synth, str(tmp_path), 0)
+    dbs = [p for _, p in dbl]
+    codes, offs = bench.load_all_codes(synth, dbs)
+    blob, o = bench.make_batch(args, synth, codes, offs, n_reads, 4242)
+    seqs = [blob[int(o[i]):int(o[i + 1])].decode() for i in range(n_reads)]
+    return dbs, seqs
+
+
+def _compare(tmp_path, dbs, seqs, eng):
+    parts_per_db, prefixes, stats = [], [], []
+    slots = []
+    for k, db in enumerate(dbs):
+        parts = smr.Index.build_gpu(eng, db, 18, 3072.0, 10000)           # the index is built on the device
+        parts_per_db.append(parts)
+        pre = os.path.join(str(tmp_path), "idx_%d" % k)
+        smr.Index.write_files(parts, db, pre)                              # ... and written in the reference's format for the oracle
+        prefixes.append(pre)
+        stats.append(orc.load_stats(pre))
+        sl = []
+        for ix in parts:
+            s = sum(len(x) for x in slots) + len(sl)
+            eng.upload_index(ix, s)
+            sl.append(s)
+        slots.append(sl)
+    lam, K = GUMBEL_UNIFORM
+    n, tot = len(seqs), sum(map(len, seqs))
+    mss = [smr.minimal_score(lam, K, pp[0].info(), n, tot) for pp in parts_per_db]
+    # oracle
+    run = orc.Run(seqs)
+    for k, db in enumerate(dbs):
+        p = orc.default_params(minimal_score=mss[k])
+        p.index_num = k
+        for part in range(stats[k].nparts):
+            p.part = part
+            p.is_last_index_part = int(k == len(dbs) - 1 and part == stats[k].nparts - 1)
+            run.align_part(prefixes[k], db, stats[k], part, p)
+    exp = run.records()
+    octr = run.counters
+    exp_aligned, exp_per_db = octr.num_aligned, [octr.reads_matched_per_db[k] for k in range(len(dbs))]
+    run.close()
+    # GPU
+    reads = smr.Reads.from_seqs(seqs)
+    eng.select_batch(0)
+    eng.upload_reads(reads, 1)
+    smr.align_resident(eng, slots, [smr.default_params(minimal_score=m) for m in mss], with_cigar=True)
+    got = eng.records()
+    bad = [i for i in range(n) if got[i] != exp[i]]
+    assert not bad, "%d of %d records differ from the oracle's, first: read %d" % (len(bad), n, bad[0])
+    c = eng.counters(len(dbs))
+    assert c["num_aligned"] == exp_aligned and list(c["reads_matched_per_db"][:len(dbs)]) == exp_per_db
+    return c, sum(1 for r in exp if r)
+
+
+def test_config4_eight_reference_dbs(tmp_path):
+    eng = smr.Engine(0)
+    dbs, seqs = _setup(tmp_path, "refs8", 14_000_000, 20_000)                # the 7 synthetic DBs at a tenth of their size, the real one at full size
+    c, n_rec = _compare(tmp_path, dbs, seqs, eng)
+    assert len(dbs) == 8 and n_rec > 500 and sum(1 for x in c["reads_matched_per_db"][:8] if x > 0) >= 6
+    eng.close()
+
+
+def test_config5_two_thousand_5kb_reads(tmp_path):
+    eng = smr.Engine(0)
+    dbs, seqs = _setup(tmp_path, "pacbio5k", 3_000_000, 2_000)
+    assert 4500 < np.mean([len(s) for s in seqs]) < 5600 and max(map(len, seqs)) > 5800
+    c, n_rec = _compare(tmp_path, dbs, seqs, eng)
+    assert n_rec >= 1990                                                      # every read comes from the DB
+    eng.close()
