@@ -35,6 +35,23 @@ def _setup(tmp_path, workload, db_nt, n_reads):
     return dbs, seqs
 
 
+def _oracle_slice(job):
+    seqs, dbs, prefixes, mss = job
+    run = orc.Run(seqs)
+    for k, db in enumerate(dbs):
+        st = orc.load_stats(prefixes[k])
+        p = orc.default_params(minimal_score=mss[k])
+        p.index_num = k
+        for part in range(st.nparts):
+            p.part = part
+            p.is_last_index_part = int(k == len(dbs) - 1 and part == st.nparts - 1)
+            run.align_part(prefixes[k], db, st, part, p)
+    recs = run.records()
+    out = (recs, int(run.counters.num_aligned), [int(run.counters.reads_matched_per_db[k]) for k in range(len(dbs))])
+    run.close()
+    return out
+
+
 def _compare(tmp_path, dbs, seqs, eng):
     parts_per_db, prefixes, stats = [], [], []
     slots = []
@@ -54,19 +71,17 @@ def _compare(tmp_path, dbs, seqs, eng):
     lam, K = GUMBEL_UNIFORM
     n, tot = len(seqs), sum(map(len, seqs))
     mss = [smr.minimal_score(lam, K, pp[0].info(), n, tot) for pp in parts_per_db]
-    # oracle
-    run = orc.Run(seqs)
-    for k, db in enumerate(dbs):
-        p = orc.default_params(minimal_score=mss[k])
-        p.index_num = k
-        for part in range(stats[k].nparts):
-            p.part = part
-            p.is_last_index_part = int(k == len(dbs) - 1 and part == stats[k].nparts - 1)
-            run.align_part(prefixes[k], db, stats[k], part, p)
-    exp = run.records()
-    octr = run.counters
-    exp_aligned, exp_per_db = octr.num_aligned, [octr.reads_matched_per_db[k] for k in range(len(dbs))]
-    run.close()
+    # oracle: the reads are independent given (index, references, minimal_score), so slices of them go to a pool of processes (the plain-C
+    # oracle aligns ~3 long reads per second and core)
+    import multiprocessing as mp
+    nproc = max(1, min(os.cpu_count() or 1, 64, len(seqs) // 16))
+    bounds = [len(seqs) * i // nproc for i in range(nproc + 1)]
+    jobs = [(seqs[bounds[i]:bounds[i + 1]], dbs, prefixes, mss) for i in range(nproc)]
+    with mp.get_context("fork").Pool(nproc) as pool:
+        parts_out = pool.map(_oracle_slice, jobs)
+    exp = [r for recs, _, _ in parts_out for r in recs]
+    exp_aligned = sum(a for _, a, _ in parts_out)
+    exp_per_db = [sum(pd[k] for _, _, pd in parts_out) for k in range(len(dbs))]
     # GPU
     reads = smr.Reads.from_seqs(seqs)
     eng.select_batch(0)
