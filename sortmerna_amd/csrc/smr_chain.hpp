@@ -600,13 +600,16 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         // claim the next 64 reads.  Lane i looks at read i of the chunk: not in this (strand, pass) -> nothing to do; in it but without the
         // seeds for compute_lis_alignment (:103-108) -> only the pass control, done by that lane on its own; the others are walked one by one
         __syncthreads();
-        if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], 64ull);
+        // (a claim is 64 reads when the batch has many per wave -- one atomic per 64 reads instead of one per read --, fewer when it has few: a batch
+        // of 50 000 long reads claimed 64 at a time kept 781 of the 3 072 waves busy)
+        const uint32_t claim = max(1u, min(64u, rd.n / (gridDim.x * 4u)));
+        if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], (unsigned long long)claim);
         __syncthreads();
         chunk_base = s_next;
         if (chunk_base >= rd.n) { out_of_reads = true; continue; }
         bool todo = false;
         const uint32_t ri = chunk_base + (uint32_t)lane;
-        if (ri < rd.n) {
+        if ((uint32_t)lane < claim && ri < rd.n) {
           RWork wi = rw[ri];
           if (wi.strand_active && wi.search && wi.pass_n == (uint32_t)pass) {
             RState si = work[ri];
@@ -1041,7 +1044,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 // done, so only the survivors cost a reverse pass (43 % of the accepted ones on the bench workload), and they are independent problems:
 // four per wave through the four-problem kernel (reads <= SW_X4_MAX_ROWS), else one per wave through sw_wave.
 // k_begins_collect lists the pending slots of the reads with a new hit; k_begins claims them four at a time.
-// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4); none in single-problem mode.
+// Dynamic LDS: 4 read windows of lds_m bytes | 4 reference windows of lds_n bytes (x4); 1 + 1 in single-problem mode of one-strip reads; none for LONG.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __restrict__ work, const RWork* __restrict__ rw, const AlignRec* __restrict__ work_aln,
                                  uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
@@ -1062,9 +1065,10 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
   const uint32_t n_tasks = (uint32_t)ctr[C_BEGIN_N];
   const int per = x4 ? 4 : 1;
   const int g = x4 ? lane >> 4 : 0;
-  // four-problem mode: 4 read + 4 reference windows in LDS; single-problem mode (some read has more than one strip): the read's letters in this
-  // block's row of g_rdq, the reference window read in place
-  uint8_t* rdq = x4 ? lds_raw + (size_t)g * lds_m : g_rdq + (size_t)blockIdx.x * lds_m;
+  // four-problem mode: 4 read + 4 reference windows in LDS; single-problem mode: one of each in LDS, or -- LONG: the batch has reads of more
+  // than one strip -- the read's letters in this block's row of g_rdq and the reference window read in place
+  const bool in_lds = x4 || !LONG;
+  uint8_t* rdq = in_lds ? lds_raw + (size_t)g * lds_m : g_rdq + (size_t)blockIdx.x * lds_m;
   uint8_t* rfq_l = lds_raw + (size_t)per * lds_m + (size_t)g * lds_n;
   int* bound = g_bound ? g_bound + (size_t)blockIdx.x * 2 * lds_n : nullptr;          // strip boundaries (single-problem mode, reads of more than one strip)
   unsigned long long n_rev = 0, n_cells = 0;
@@ -1088,8 +1092,8 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
       const uint8_t* ref = ix.ref_seq + ix.ref_off[al.ref_num] + al.ref_begin1;
       const int l0 = x4 ? (lane & 15) : lane, ls = x4 ? 16 : 64;
       for (int q = l0; q < m; q += ls) rdq[q] = (uint8_t)read_nt(rec, len, (uint32_t)(al.read_begin1 + q), al.strand ? 0u : 1u, 4u);
-      if (x4) for (int q = l0; q < n; q += ls) rfq_l[q] = ref[q];
-      rfq = x4 ? rfq_l : ref;
+      if (in_lds) for (int q = l0; q < n; q += ls) rfq_l[q] = ref[q];
+      rfq = in_lds ? rfq_l : ref;
     }
     bool hasn = false;
     __syncthreads();

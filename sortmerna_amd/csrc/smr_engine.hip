@@ -1037,7 +1037,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
         const int x4 = (P.sw_mode >= 1 && c->b->max_len <= SW_X4_MAX_ROWS &&
                         (long long)c->b->max_len * P.match + 255 < 32768 && rf + 128 <= 8191 && P.gap_open + P.mismatch >= 0 && P.gap_open + P.score_N >= 0 &&
                         P.match + P.gap_open <= 255 && P.score_N + P.gap_open <= 255) ? 1 : 0;
-        const size_t lds_b = x4 ? (size_t)4 * (ml + rf) : 0;
+        const size_t lds_b = x4 ? (size_t)4 * (ml + rf) : (c->b->max_len > SW_X4_MAX_ROWS ? 0 : (size_t)ml + rf);
         const uint32_t bg_blocks = (uint32_t)c->n_cu * 8u;
         if ((rc = ensure_bound(c, std::max(bg_blocks, c->chain_blocks), rf))) return rc;
         if (lds_b > 64 * 1024 && lds_b > c->begins_lds_attr) {

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <exception>
 #include <thread>
 #include <vector>
 
@@ -143,16 +144,20 @@ struct StageTimer {
   }
 };
 
+// (an exception in a worker -- std::bad_alloc on a damaged file's sizes -- is carried to the caller's thread instead of ending the process)
 template <class F> void parallel_for(uint32_t threads, size_t n, F f) {
   if (threads <= 1 || n < 2) { f(0, n, 0u); return; }
   std::vector<std::thread> th;
+  std::exception_ptr failed;
+  std::mutex fm;
   size_t chunk = (n + threads - 1) / threads;
   for (uint32_t t = 0; t < threads; t++) {
     size_t lo = (size_t)t * chunk, hi = std::min(n, lo + chunk);
     if (lo >= hi) break;
-    th.emplace_back([=]() { f(lo, hi, t); });
+    th.emplace_back([=, &failed, &fm]() { try { f(lo, hi, t); } catch (...) { std::lock_guard<std::mutex> l(fm); if (!failed) failed = std::current_exception(); } });
   }
   for (auto& x : th) x.join();
+  if (failed) std::rethrow_exception(failed);
 }
 
 // References::load (references.cpp:55-159), FASTA: numseq records starting at byte `start`.
@@ -311,13 +316,15 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   const uint32_t threads = std::min<uint32_t>(64, std::max(1u, std::thread::hardware_concurrency()));
   // the reference sequences and the position lists load in threads of their own while the tries are parsed
   bool refs_ok = false;
-  std::thread t_refs([&]() { refs_ok = load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix); });
+  // (an exception inside a std::thread would end the process: the bodies catch and report -- a damaged file must come back as SMR_ERR_IO)
+  std::thread t_refs([&]() { try { refs_ok = load_refs(ref_fasta, st.parts[part].start_part, st.parts[part].numseq_part, *ix); } catch (const std::exception&) { refs_ok = false; } });
   std::string pos_err;
-  std::thread t_pos([&]() {
+  std::thread t_pos([&]() { try {
     // positions (index.cpp:322-352) -> CSR; keep file order (sorted by seq, then pos, by construction)
     const uint8_t* b = pb.data(); const size_t bn = pb.size();
     uint32_t nid = 0;
     if (bn >= 4) memcpy(&nid, b, 4);
+    if (bn < 4 || (size_t)nid > (bn - 4) / 4) { pos_err = "malformed pos file: it cannot hold the number of lists it announces"; return; }      // every list has at least its 4-byte size: checked BEFORE anything is sized by nid
     ix->pos_off.assign((size_t)nid + 1, 0);
     std::vector<size_t> src((size_t)nid + 1, 0);             // byte offset of list i in the file
     size_t o = 4; uint64_t total = 0;
@@ -351,8 +358,9 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
         }
       }
     });
-  });
+  } catch (const std::exception& e) { pos_err = std::string("pos file: ") + e.what(); } });
   ix->lookup.assign(nk, Lookup{0, NONE, NONE, 0, 0});
+  if (kb.size() < (size_t)nk * 4) { t_pos.join(); t_refs.join(); delete ix; set_err(err, errcap, "malformed kmer file: shorter than 4^(L/2) counts"); return SMR_ERR_IO; }
   for (uint32_t i = 0; i < nk && (size_t)(i + 1) * 4 <= kb.size(); i++) memcpy(&ix->lookup[i].count, kb.data() + (size_t)i * 4, 4);
   // mini-tries: one sequential walk over the BFS streams finds where each begins (the sizes in the file are the reference's in-memory
   // sizes, index.cpp:178-190, not stream lengths), then key ranges are parsed and laid out by all threads into arenas of their own

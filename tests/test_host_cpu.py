@@ -192,7 +192,7 @@ def test_damaged_index_files_are_refused(tmp_path):
     parts = smr.Index.build(db, 18, 3072.0, 10000, 0)
     pfx = str(tmp_path / "a")
     smr.Index.write_files(parts, db, pfx)
-    for ext in (".bursttrie_0.dat", ".pos_0.dat"):
+    for ext in (".bursttrie_0.dat", ".pos_0.dat", ".kmer_0.dat"):
         whole = open(pfx + ext, "rb").read()
         for frac in (0.999, 0.5, 0.01):
             bad = str(tmp_path / ("bad%s_%g" % (ext.split("_")[0], frac)))
@@ -202,6 +202,15 @@ def test_damaged_index_files_are_refused(tmp_path):
                 f.write(whole[: int(len(whole) * frac)])
             with pytest.raises(smr.SmrError):
                 smr.Index.load_files(bad, 0, db)
+    # a position file that announces 2^32 - 1 lists (12 * 4 G bytes of tables if the count were believed before the file size is checked)
+    bad = str(tmp_path / "bad_nid")
+    for e in (".kmer_0.dat", ".bursttrie_0.dat", ".pos_0.dat", ".stats"):
+        shutil.copy(pfx + e, bad + e)
+    whole = open(pfx + ".pos_0.dat", "rb").read()
+    with open(bad + ".pos_0.dat", "wb") as f:
+        f.write(b"\xff\xff\xff\xff" + whole[4:])
+    with pytest.raises(smr.SmrError):
+        smr.Index.load_files(bad, 0, db)
     with pytest.raises(smr.SmrError):
         smr.Index.load_files(str(tmp_path / "nothing_here"), 0, db)
 
