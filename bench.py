@@ -16,8 +16,9 @@ the DB with sequencing errors, 90 % random background) against an rRNA-like refe
 smr_v4.3_default_db.fasta (140 Mnt; the real file is a release download that is not available offline, so a seeded
 synthetic DB of families of mutated copies stands in -- `config.workload` says so).  A "step" is one pass of the
 whole hot path -- both strands, all three seed passes, LIS chaining, Smith-Waterman, banded traceback, result fetch --
-over ONE batch of `--batch-reads` reads that is already resident in HBM; every step uses a different batch.
-The 10 M read job of the config is `10 M / batch` such steps; reads/s does not depend on how many of them are timed.
+over ONE batch of `--batch-reads` reads (default 8 M: the larger the batch, the smaller the share of launch gaps and of the tail of the
+persistent kernels -- 2 M: 23.5, 4 M: 24.7, 8 M: 25.3 M reads/s, profiles/r3s6_*) that is already resident in HBM; consecutive steps use
+different batches and every step starts from a reset per-read state.  The 10 M read job of the config is 1.25 such steps.
 
 Reads shard across GPUs (one rank per GPU, each with a full index replica, no data-path collective); the only
 collectives are the two tiny all-reduces the reference's semantics need: global read totals before (they define
@@ -179,9 +180,9 @@ def cpu_baseline(args, dbs, parts_per_db, sample, smr, eng, idx_slots):
 # workloads (BASELINE.json configs[2], [3], [4]; SURVEY.md 8d "Configs restated as concrete inputs")
 # ---------------------------------------------------------------------------------------------------------------------------------------
 WORKLOADS = {
-    "illumina150": {"batch_reads": 2_000_000, "cpu_sample_reads": 200_000, "ref_opts": ["-fastx"],
+    "illumina150": {"batch_reads": 8_000_000, "cpu_sample_reads": 200_000, "ref_opts": ["-fastx"],
                     "options": "default options (--fastx, best 1)"},
-    "refs8": {"batch_reads": 2_000_000, "cpu_sample_reads": 100_000, "ref_opts": ["-fastx"],
+    "refs8": {"batch_reads": 8_000_000, "cpu_sample_reads": 100_000, "ref_opts": ["-fastx"],
               "options": "default options (--fastx, best 1), 8 --ref"},
     "pacbio5k": {"batch_reads": 50_000, "cpu_sample_reads": 4_000, "ref_opts": ["-fastx", "-sam", "-blast", "1"],
                  "options": "--sam --blast 1 (every alignment with its CIGAR), best 1"},
@@ -301,8 +302,8 @@ def main():
     ap.add_argument("--no-cigar", action="store_true", help="skip the banded traceback (not the reference's behaviour)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 counter passes: only warm-up + timed steps (no exact-count pass, no PCIe leg, no CPU baseline), so every dispatch is a timed-path dispatch")
-    ap.add_argument("--resident-batches", type=int, default=8,
-                    help="distinct read batches kept resident in HBM (1..%d); step i runs on batch i %% this" % MAX_RESIDENT)
+    ap.add_argument("--resident-batches", type=int, default=0,
+                    help="distinct read batches kept resident in HBM (1..%d); step i runs on batch i %% this; 0 = as many as hold 16 M reads, between 2 and 8" % MAX_RESIDENT)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -318,6 +319,8 @@ def main():
     args.batch_reads = args.batch_reads or W["batch_reads"]
     args.cpu_sample_reads = args.cpu_sample_reads or W["cpu_sample_reads"]
     args.db_nt = args.db_nt or (14_000_000 if args.workload == "pacbio5k" else 140_000_000)
+    if args.resident_batches <= 0:
+        args.resident_batches = max(2, min(8, 16_000_000 // max(args.batch_reads, 1)))
 
     import numpy as np
     import torch

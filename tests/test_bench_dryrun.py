@@ -50,7 +50,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
     assert out["counters"]["reads"] == steps * nreads and out["config"]["name"] == workload
     if workload == "refs8":
         assert out["config"]["n_dbs"] == 8 and len(out["counters"]["reads_matched_per_db"]) == 8 and sum(out["counters"]["reads_matched_per_db"]) == out["counters"]["num_aligned"] > 0
-    assert out["config"]["resident_batches"] == min(steps + warmup, 8)
+    assert out["config"]["resident_batches"] == min(steps + warmup, 8)       # (tiny batches: the automatic choice is 8)
     assert abs(out["ms_per_step"] * steps / 1e3 * out["value"] - steps * nreads) < 1e-3
     assert out["kernels"]["k_chain"]["valu_model_peak_gcups"] > 0
     if baseline:
