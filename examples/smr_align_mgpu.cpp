@@ -162,15 +162,19 @@ int main(int argc, char** argv) {
   Barrier bar(world); S.bar = &bar;
   char err[512] = "";
 
-  // ---- host side, once: the reads (all cores parse and pack), the index parts (one host copy shared by all ranks) ----
+  // ---- host side, once: the reads (parsed and packed by a thread of their own, which fans out over the cores) while the index parts are
+  // loaded or built (one host copy shared by all ranks) ----
   const double t0 = now_s();
   smr_reads* all = nullptr;
   const bool want_reports = ro.fastx || ro.other || ro.blast_tabular || ro.sam;
-  // (with report files the text of the reads file stays mapped: the writers copy headers / letters / qualities from it)
-  if ((want_reports ? smr_reads_load_fastx_text(reads_path.c_str(), 0, &all, err, sizeof err) : smr_reads_load_fastx_mt(reads_path.c_str(), 0, &all, err, sizeof err)) != SMR_OK) die(err);
-  const uint64_t n = smr_reads_count(all);
-  const int is_fastq = want_reports ? smr_reads_is_fastq(all) : 0;
-  const double t_reads = now_s() - t0;
+  double t_reads = 0;
+  char rerr[512] = "";
+  int reads_rc = SMR_OK;
+  std::thread reads_thread([&] {
+    // (with report files the text of the reads file stays mapped: the writers copy headers / letters / qualities from it)
+    reads_rc = want_reports ? smr_reads_load_fastx_text(reads_path.c_str(), 0, &all, rerr, sizeof rerr) : smr_reads_load_fastx_mt(reads_path.c_str(), 0, &all, rerr, sizeof rerr);
+    t_reads = now_s() - t0;
+  });
   for (auto& d : dbs) {
     if (!d.idx_prefix.empty()) {
       smr_index* p0 = nullptr;
@@ -193,7 +197,12 @@ int main(int argc, char** argv) {
       d.parts.assign(arr, arr + np);
     }
   }
-  const double t_index = now_s() - t0 - t_reads;
+  const double t_index = now_s() - t0;
+  reads_thread.join();
+  if (reads_rc != SMR_OK) die(rerr);
+  const uint64_t n = smr_reads_count(all);
+  const int is_fastq = want_reports ? smr_reads_is_fastq(all) : 0;
+  const double t_host = now_s() - t0;
   size_t total_parts = 0;
   for (auto& d : dbs) total_parts += d.parts.size();
   if (total_parts > 64) die("more than 64 index parts in total");
@@ -368,14 +377,18 @@ int main(int argc, char** argv) {
       FILE* o = nullptr;
       for (int r = 0; r < world; r++) {
         const std::string pth = out_dir + "/rank" + std::to_string(r) + "/" + nm;
+        if (!o) {                                            // the first shard's file becomes the merged file (no copy), the others are appended
+          if (rename(pth.c_str(), (out_dir + "/" + nm).c_str()) != 0) continue;
+          if (!(o = fopen((out_dir + "/" + nm).c_str(), "ab"))) die(std::string("cannot write ") + nm);
+          continue;
+        }
         FILE* in = fopen(pth.c_str(), "rb");
         if (!in) continue;
-        if (!o && !(o = fopen((out_dir + "/" + nm).c_str(), "wb"))) die(std::string("cannot write ") + nm);
         size_t g;
         bool first_line = true;
         while ((g = fread(buf.data(), 1, buf.size(), in)) > 0) {
           size_t off = 0;
-          if (first_line && r > 0 && std::string(nm) == "aligned.sam") {          // one @HD / @PG header block: the later shards' header lines are dropped
+          if (first_line && std::string(nm) == "aligned.sam") {          // one @HD / @PG header block: the later shards' header lines are dropped
             while (off < g && buf[off] == '@') { while (off < g && buf[off] != '\n') off++; if (off < g) off++; }
           }
           first_line = false;
@@ -408,9 +421,9 @@ int main(int argc, char** argv) {
   double tu = 0, ta = 0, tf = 0, tw = 0;
   for (auto& o : outs) { tu = std::max(tu, o.t_upload); ta = std::max(ta, o.t_align); tf = std::max(tf, o.t_fetch); tw = std::max(tw, o.t_write); }
   const double t_all = now_s() - t0;
-  printf("[timing] ranks %d (%s reduction), reads %llu: parse+pack %.3f s, index load/build %.3f s, per-rank max: index upload + chunk uploads %.3f s (overlapped), align+traceback+fetch %.3f s, "
+  printf("[timing] ranks %d (%s reduction), reads %llu: parse+pack %.3f s alongside index load/build %.3f s = %.3f s, per-rank max: index upload + chunk uploads %.3f s (overlapped), align+traceback+fetch %.3f s, "
          "records%s %.3f s (overlapped), counter reduce + close %.3f s; rank stage %.3f s; end to end %.3f s = %.0f reads/s (rank stage alone: %.0f reads/s)\n",
-         world, S.use_rccl ? "RCCL" : "host", (unsigned long long)n, t_reads, t_index, tu, ta, want_reports ? " + report rows" : "", tw, tf, t_ranks, t_all, n / t_all, n / t_ranks);
+         world, S.use_rccl ? "RCCL" : "host", (unsigned long long)n, t_reads, t_index, t_host, tu, ta, want_reports ? " + report rows" : "", tw, tf, t_ranks, t_all, n / t_all, n / t_ranks);
   printf("%llu reads, %llu aligned, %llu records, minimal_score %u -> %s\n", (unsigned long long)n, (unsigned long long)ctr[0], (unsigned long long)nrec, outs[0].minimal_score0, rp.c_str());
   for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
   smr_reads_free(all);

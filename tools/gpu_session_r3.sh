@@ -91,6 +91,6 @@ alt)
     cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
   done ;;
 e2e)
-  timeout 900 python tools/e2e_cpp.py > $OUT/e2e_cpp.log 2>&1; tail -12 $OUT/e2e_cpp.log ;;
+  SMR_IB_TIMING=1 timeout 900 python tools/e2e_cpp.py > $OUT/e2e_cpp.log 2>&1; grep -E "timing|smr index build|wall|aligned.fq" $OUT/e2e_cpp.log | tail -60 | cut -c1-420 ;;
 esac; done
 ls $OUT
