@@ -163,6 +163,10 @@ const char* smr_last_error(const smr_ctx*);
 
 /* Copy an index part to HBM; it stays resident under `slot` (0..63) until freed. */
 int smr_index_upload(smr_ctx*, const smr_index*, int slot);
+/* Test seam: the pigeonhole layout that smr_index_upload BUILT ON THE DEVICE for `slot` (from the uploaded lookup table and mini-trie arena;
+ * it replaces a host pass over every mini-trie, indexdb.cpp's in-memory tries being what both start from) against the host transform of the
+ * same index, word for word.  SMR_PG_HOST=1 makes smr_index_upload use the host transform instead. */
+int smr_index_check_device(smr_ctx*, int slot, smr_index*);
 int smr_index_unload(smr_ctx*, int slot);
 
 /* Several read batches (0..15) can be resident at once, so the host can upload batch k+1 while batch k is being

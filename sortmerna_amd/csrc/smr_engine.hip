@@ -13,6 +13,7 @@
 
 #include "smr_kernels.hpp"
 #include "smr_ibuild.hpp"
+#include "smr_pgbuild.hpp"
 
 using namespace smr;
 
@@ -24,7 +25,7 @@ struct DevIndex {
   uint32_t* pg = nullptr; uint32_t* root3 = nullptr; uint32_t* lkc = nullptr;
   uint8_t* ref_seq = nullptr; uint64_t* ref_off = nullptr;
   uint32_t n_refs = 0, n_ids = 0, lnwin = 0;
-  uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0;
+  uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0, pg_words = 0;
 };
 
 struct EvMark { hipEvent_t e; int kind; };        // kind < 0: end of a run of intervals
@@ -803,6 +804,49 @@ extern "C" const char* smr_last_error(const smr_ctx* c) {
   return copy.c_str();
 }
 
+namespace {
+// The pigeonhole layout of the part in slot d (its lookup table and reference-shaped arena are on the device already): smr_pgbuild.hpp
+int build_pigeonhole_device(smr_ctx* c, DevIndex& d, uint32_t nk, uint32_t pw) {
+  DevPool pool;
+  const uint32_t nb = 2 * nk;
+  IB_GET(cnt, uint32_t, nb); IB_GET(eoff, uint32_t, nb); IB_GET(words, smr::u64, nb); IB_GET(woff, smr::u64, nb); IB_GET(derr, uint32_t, 1);
+  HIPCHK(c, hipMemsetAsync(derr, 0, 4, c->stream));
+  hipLaunchKernelGGL(smr::k_pgb_sizes, dim3((nb + 255) / 256), dim3(256), 0, c->stream, (const Lookup*)d.lookup, (const uint32_t*)d.trie, nk, pw, cnt, words);
+  smr::u64 W = 0;
+  int rc = dev_scan<smr::u64>(c, pool, words, woff, nb, &W); if (rc) return rc;
+  if (W / 3 > 0xFFFFFFF0ull || W / 4 > 0xFFFFFFF0ull) { c->err = "pigeonhole arena exceeds 2^34 words"; return SMR_ERR_CAPACITY; }
+  uint32_t E = 0;
+  if ((rc = dev_scan<uint32_t>(c, pool, cnt, eoff, nb, &E))) return rc;
+  if ((rc = dev_alloc(c, &d.pg, (size_t)W + 4))) return rc;
+  if ((rc = dev_alloc(c, &d.root3, (size_t)2 * nb))) return rc;
+  HIPCHK(c, hipMemsetAsync(d.pg + W, 0, 16, c->stream));                 // one block of slack: a 16-byte read at the last word stays inside
+  IB_GET(estr, uint32_t, E); IB_GET(eid, uint32_t, E); IB_GET(eblk, uint32_t, E);
+  IB_GET(k0, smr::u64, E); IB_GET(k1, smr::u64, E); IB_GET(v0, uint32_t, E); IB_GET(v1, uint32_t, E);
+  hipLaunchKernelGGL(smr::k_pgb_collect, dim3((nb + 255) / 256), dim3(256), 0, c->stream, (const Lookup*)d.lookup, (const uint32_t*)d.trie, nk, pw,
+                     (const uint32_t*)cnt, (const uint32_t*)eoff, (const smr::u64*)woff, d.root3, d.pg, estr, eid, eblk, derr);
+  int blockbits = 1; while ((1u << blockbits) < nb) blockbits++;
+  const uint32_t gE = (uint32_t)(((smr::u64)E + 255) / 256);
+  for (int order = 0; order < 2 && E; order++) {
+    const uint32_t kbits = order == 0 ? 2 * (pw + 1) : 2 * (pw - pw / 2);
+    smr::u64 *ka = k0, *kb = k1; uint32_t *va = v0, *vb = v1;
+    if (order == 0) hipLaunchKernelGGL(smr::k_pgb_keys<0>, dim3(gE), dim3(256), 0, c->stream, (const uint32_t*)estr, (const uint32_t*)eblk, (smr::u64)E, pw, kbits, ka, va);
+    else hipLaunchKernelGGL(smr::k_pgb_keys<1>, dim3(gE), dim3(256), 0, c->stream, (const uint32_t*)estr, (const uint32_t*)eblk, (smr::u64)E, pw, kbits, ka, va);
+    if ((rc = dev_radix_sort(c, pool, ka, kb, va, vb, E, 0, (int)kbits + blockbits))) return rc;
+    if (order == 0) hipLaunchKernelGGL(smr::k_pgb_emit<0>, dim3(gE), dim3(256), 0, c->stream, (const smr::u64*)ka, (const uint32_t*)va, (smr::u64)E, pw, kbits,
+                                       (const uint32_t*)estr, (const uint32_t*)eid, (const uint32_t*)eoff, (const uint32_t*)d.root3, d.pg);
+    else hipLaunchKernelGGL(smr::k_pgb_emit<1>, dim3(gE), dim3(256), 0, c->stream, (const smr::u64*)ka, (const uint32_t*)va, (smr::u64)E, pw, kbits,
+                            (const uint32_t*)estr, (const uint32_t*)eid, (const uint32_t*)eoff, (const uint32_t*)d.root3, d.pg);
+  }
+  uint32_t herr = 0;
+  HIPCHK(c, hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  if (herr) { c->err = (herr & 1u) ? "a mini-trie is too large for the pigeonhole layout" : "pigeonhole arena exceeds 2^34 words"; return SMR_ERR_CAPACITY; }
+  d.pg_words = W;
+  return SMR_OK;
+}
+}  // namespace
+
 extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   if (!c || !ix || slot < 0 || slot >= 64) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
@@ -810,33 +854,53 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   DevIndex& d = c->idx[slot];
   d.lnwin = ix->lnwin; d.n_refs = ix->n_refs(); d.n_ids = ix->n_ids(); d.trie_words = ix->trie.size(); d.n_pos = ix->pos_arr.size() / 2; d.ref_bytes = ix->ref_seq.size();
   int rc;
-  {
-    // the pigeonhole layout of the tries: a host transform cached in the smr_index, built once under its mutex (the loaders and
-    // builders already do it; this call only covers indexes made before that) -- concurrent uploads of one host index are safe
-    std::string why;
-    if (!smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
-  }
-  if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: index part: tries %.2f GB, pigeonhole arena %.2f GB, positions %.2f GB\n", ix->trie.size() * 4e-9, ix->pg.size() * 4e-9, ix->pos_arr.size() * 4e-9);
-  if ((rc = dev_alloc(c, &d.pg, ix->pg.size()))) return rc;
-  if ((rc = dev_alloc(c, &d.root3, ix->root3.size()))) return rc;
-  HIPCHK(c, hipMemcpyAsync(d.pg, ix->pg.data(), ix->pg.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d.root3, ix->root3.data(), ix->root3.size() * 4, hipMemcpyHostToDevice, c->stream));
+  smr_build_lkc(*const_cast<smr_index*>(ix));              // (cached in the smr_index under its mutex: concurrent uploads of one host index are safe)
   if ((rc = dev_alloc(c, &d.lkc, ix->lkc.size()))) return rc;
   HIPCHK(c, hipMemcpyAsync(d.lkc, ix->lkc.data(), ix->lkc.size() * 4, hipMemcpyHostToDevice, c->stream));
   if ((rc = dev_alloc(c, &d.lookup, ix->lookup.size()))) return rc;
   if ((rc = dev_alloc(c, &d.trie, ix->trie.size()))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d.lookup, ix->lookup.data(), ix->lookup.size() * sizeof(Lookup), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d.trie, ix->trie.data(), ix->trie.size() * 4, hipMemcpyHostToDevice, c->stream));
+  // The pigeonhole layout of the tries (what k_seed_pg reads) is built on the device from the arena just uploaded (smr_pgbuild.hpp).  An index
+  // that already carries the host-built layout (smr_index_selfcheck, SMR_PG_HOST=1) is uploaded as it is.
+  const bool host_pg = !ix->root3.empty() || (getenv("SMR_PG_HOST") && atoi(getenv("SMR_PG_HOST")));
+  if (host_pg) {
+    std::string why;
+    if (!smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
+    if ((rc = dev_alloc(c, &d.pg, ix->pg.size()))) return rc;
+    if ((rc = dev_alloc(c, &d.root3, ix->root3.size()))) return rc;
+    HIPCHK(c, hipMemcpyAsync(d.pg, ix->pg.data(), ix->pg.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d.root3, ix->root3.data(), ix->root3.size() * 4, hipMemcpyHostToDevice, c->stream));
+    d.pg_words = ix->pg.size() >= 4 ? ix->pg.size() - 4 : 0;
+  } else if ((rc = build_pigeonhole_device(c, d, (uint32_t)ix->lookup.size(), ix->lnwin / 2))) return rc;
+  if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: index part: tries %.2f GB, pigeonhole arena %.2f GB (%s), positions %.2f GB\n", ix->trie.size() * 4e-9, d.pg_words * 4e-9,
+                                     host_pg ? "host-built" : "built on the device", ix->pos_arr.size() * 4e-9);
   if ((rc = dev_alloc(c, &d.pos_off, ix->pos_off.size()))) return rc;
   if ((rc = dev_alloc(c, &d.pos_arr, ix->pos_arr.size() / 2))) return rc;
   if ((rc = dev_alloc(c, &d.ref_seq, ix->ref_seq.size() + 64))) return rc;
   if ((rc = dev_alloc(c, &d.ref_off, ix->ref_off.size()))) return rc;
-  HIPCHK(c, hipMemcpyAsync(d.lookup, ix->lookup.data(), ix->lookup.size() * sizeof(Lookup), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d.trie, ix->trie.data(), ix->trie.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.pos_off, ix->pos_off.data(), ix->pos_off.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.pos_arr, ix->pos_arr.data(), ix->pos_arr.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.ref_seq, ix->ref_seq.data(), ix->ref_seq.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.ref_off, ix->ref_off.data(), ix->ref_off.size() * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   d.used = true;
+  return SMR_OK;
+}
+
+// the device-built pigeonhole layout of slot `slot` against the host transform of the same index (smr_build_pigeonhole): word for word
+extern "C" int smr_index_check_device(smr_ctx* c, int slot, smr_index* ix) {
+  if (!c || !ix || slot < 0 || slot >= 64 || !c->idx[slot].used) return SMR_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const DevIndex& d = c->idx[slot];
+  std::string why;
+  if (!smr_build_pigeonhole(*ix, 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
+  if (ix->pg.size() != d.pg_words + 4) { c->err = "pigeonhole layout: the device arena has " + std::to_string(d.pg_words) + " words, the host's " + std::to_string(ix->pg.size() - 4); return SMR_ERR_STATE; }
+  std::vector<uint32_t> r3(ix->root3.size()), pg(ix->pg.size());
+  HIPCHK(c, hipMemcpy(r3.data(), d.root3, r3.size() * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(pg.data(), d.pg, pg.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t q = 0; q < r3.size(); q++) if (r3[q] != ix->root3[q]) { c->err = "pigeonhole layout: block table differs at word " + std::to_string(q); return SMR_ERR_STATE; }
+  for (size_t q = 0; q < pg.size(); q++) if (pg[q] != ix->pg.data()[q]) { c->err = "pigeonhole layout: arena differs at word " + std::to_string(q); return SMR_ERR_STATE; }
   return SMR_OK;
 }
 

@@ -114,8 +114,11 @@ typedef int (*smr_ibuild_part_fn)(void* user, const smr::IBuildInput& in, smr_in
 int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos, uint32_t threads, smr_ibuild_part_fn fn, void* user,
                          smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap);
 
-// builds pg/root3 from trie/lookup (idempotent); false + message when the part is too large for the block table
+// builds pg/root3 from trie/lookup on the HOST (idempotent); false + message when the part is too large for the block table.  smr_index_upload
+// builds the same layout on the device (smr_pgbuild.hpp); this transform is its checker (smr_index_selfcheck, smr_index_check_device) and
+// what SMR_PG_HOST=1 uploads instead
 bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why);
+void smr_build_lkc(smr_index& ix);
 
 // Packed read batch.  Record i = ceil(len/16) words of 2-bit codes (nt k in bits 2*(k%16) of word k/16)
 // followed by ceil(len/32) words of ambiguity mask (bit k%32 of word k/32 set when the input letter

@@ -434,7 +434,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   if (!pos_err.empty()) { delete ix; set_err(err, errcap, pos_err); return SMR_ERR_IO; }
   if (!refs_ok) { delete ix; set_err(err, errcap, std::string("cannot load reference sequences from ") + ref_fasta); return SMR_ERR_IO; }
   tm.lap("load: positions and reference sequences (waited for)");
-  if (!smr_build_pigeonhole(*ix, 0, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }            // the second device layout, once, here: smr_index_upload only reads
+  smr_build_lkc(*ix);                                       // (the pigeonhole layout of the tries is built on the device by smr_index_upload)
   *out = ix;
   return SMR_OK;
 }
@@ -717,11 +717,18 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
     }
   });
   tm.lap("pigeonhole layout: blocks");
+  ix.root3.swap(root3);
+  return true;
+}
+
+// what the window scan needs of `lookup`, in one word per key (cached; several contexts may upload the same host index)
+void smr_build_lkc(smr_index& ix) {
+  std::lock_guard<std::mutex> once(ix.pg_mutex);
+  if (!ix.lkc.empty()) return;
+  const size_t nk = ix.lookup.size();
   ix.lkc.resize(nk);
   for (size_t k = 0; k < nk; k++)
     ix.lkc[k] = std::min<uint32_t>(ix.lookup[k].count, 0x3FFFFFFFu) | (ix.lookup[k].rootF != NONE ? 1u << 30 : 0u) | (ix.lookup[k].rootR != NONE ? 1u << 31 : 0u);
-  ix.root3.swap(root3);
-  return true;
 }
 
 // occurrences of one part -> lookup table, mini-tries, positions (host version)
@@ -966,7 +973,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
     smr::IBuildInput in; in.codes = codes.data(); in.seq_off = seq_off.data(); in.n_seqs = (uint32_t)members.size(); in.L = L; in.max_pos = max_pos; in.threads = threads;
     const int rc = fn(user, in, *ix, why);
     if (rc != SMR_OK) { delete ix; set_err(err, errcap, why); return rc; }
-    if (!smr_build_pigeonhole(*ix, threads, why)) { delete ix; set_err(err, errcap, why); return SMR_ERR_CAPACITY; }     // the second device layout, once, here: smr_index_upload only reads
+    smr_build_lkc(*ix);                                     // (the pigeonhole layout of the tries is built on the device by smr_index_upload)
     parts_out[pi] = ix;
   }
   *n_parts_out = (uint32_t)pr.size();

@@ -224,6 +224,10 @@ class Engine:
     def upload_index(self, index, slot=0):
         self._chk(self.L.smr_index_upload(self.h, index.h, slot), "smr_index_upload")
 
+    def check_device_index(self, index, slot=0):
+        """the pigeonhole layout built on the device for `slot` == the host transform of the same index (raises SmrError on a difference)"""
+        self._chk(self.L.smr_index_check_device(self.h, slot, index.h), "smr_index_check_device")
+
     def unload_index(self, slot=0):
         self._chk(self.L.smr_index_unload(self.h, slot), "smr_index_unload")
 

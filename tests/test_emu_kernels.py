@@ -187,3 +187,19 @@ def test_chunked_pipeline_equals_one_batch(emulator, wl):
     for c in chunks:
         c.free()
     e.close()
+
+
+@pytest.mark.parametrize("lnwin,db_nt", [(18, 300_000), (14, 120_000), (10, 60_000)])
+def test_pigeonhole_layout_built_on_the_device_equals_the_host_transform(emulator, tmp_path, lnwin, db_nt):
+    """smr_index_upload builds the layout k_seed_pg reads (smr_pgbuild.hpp: DFS collection per mini-trie, two stable radix sorts, directory
+    slots by the entries themselves) from the uploaded arena; the host transform smr_build_pigeonhole is its checker: every word equal --
+    big blocks with directories, blocks of <= 4 entries, absent mini-tries, seed lengths with other h / pw"""
+    from sortmerna_amd import synth
+    db = str(tmp_path / "db.fasta")
+    synth.make_db(db, db_nt, seed=11, family_size=25)
+    e = smr.Engine(0)
+    parts = smr.Index.build(db, lnwin, 3072.0, 10000, 0)
+    for s, ix in enumerate(parts):
+        e.upload_index(ix, s)
+        e.check_device_index(ix, s)
+    e.close()

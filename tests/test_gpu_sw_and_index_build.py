@@ -94,3 +94,16 @@ def test_cpp_driver_with_two_mate_files(tmp_path):
     """examples/smr_align.cpp with two mate files (two resident batches) and -paired_in -out2 / -sout: the reference's output files and records"""
     import test_cpp_driver as drv
     drv._check_paired(drv.build_driver(), tmp_path)
+
+
+@pytest.mark.parametrize("lnwin,db_nt", [(18, 2_000_000), (14, 300_000)])
+def test_pigeonhole_layout_built_on_the_device_equals_the_host_transform(engine, tmp_path, lnwin, db_nt):
+    """the layout k_seed_pg reads is built by smr_index_upload on the device (smr_pgbuild.hpp); the host transform is its checker: word for word"""
+    from sortmerna_amd import synth
+    db = str(tmp_path / "db.fasta")
+    synth.make_db(db, db_nt, seed=11, family_size=25)
+    parts = smr.Index.build_gpu(engine, db, lnwin, 3072.0, 10000)
+    for s, ix in enumerate(parts):
+        engine.upload_index(ix, 8 + s)
+        engine.check_device_index(ix, 8 + s)
+        engine.unload_index(8 + s)
