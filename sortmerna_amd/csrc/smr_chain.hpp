@@ -284,12 +284,12 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 // POSITION and every reference number sets one bit of a Bloom bitmap in LDS (2 KB per read).  No bit set twice -> no reference seen
 // twice -> no candidate (for num_seeds >= 2): the read's pass ends here, exactly as the candidate loop would end it without a single
 // ssw_align (pass control + write-back by one lane).  Anything else -- a collision, more hits than the group holds, num_seeds < 2 --
-// only marks the read (RWork::pad_[0]) for k_chain, which does the exact work.  k_chain then walks the marked reads only.
+// only marks the read (one byte per read, `marks`) for k_chain, which does the exact work.  k_chain then walks the marked reads only.
 // ------------------------------------------------------------------------------------------------
 #define CAND_HITS 64u                 // seed hits per read handled here
 #define CAND_BLOOM_WORDS 512u         // 16 384 bits per read
 __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
-                                              const uint32_t* __restrict__ pool) {
+                                              const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks) {
   __shared__ uint32_t s_bloom[16][CAND_BLOOM_WORDS];
   __shared__ uint32_t s_hp[16][CAND_HITS + 1], s_lo[16][CAND_HITS];
   const int lane = lane_id(), gl = lane & 15, g = (int)(threadIdx.x >> 4);
@@ -352,9 +352,10 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   const unsigned long long hm = __ballot(hit);
   if (scan && ((hm >> (lane & 48)) & 0xFFFFull)) mark = true;
   if (eligible) {
-    if (mark) { if (gl == 0) rw[r].pad_[0] = 1; }
-    else { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+    if (!mark) { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
   }
+  // one byte per read says whether k_chain has to walk it: its waves claim reads by looking at 64 of these bytes, not at 64 per-read states
+  if (r < rd.n && gl == 0) marks[r] = (eligible && mark) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -490,7 +491,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
                                               uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2,
-                                              uint32_t lds_rq, int* g_bound, uint8_t* g_rdq) {
+                                              uint32_t lds_rq, int* g_bound, uint8_t* g_rdq, uint8_t* __restrict__ marks) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
@@ -597,8 +598,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     } else {
       if (out_of_reads) break;
       if (chunk_todo == 0) {
-        // claim the next 64 reads.  Lane i looks at read i of the chunk: not in this (strand, pass) -> nothing to do; in it but without the
-        // seeds for compute_lis_alignment (:103-108) -> only the pass control, done by that lane on its own; the others are walked one by one
+        // claim the next reads.  Lane i looks at the mark of read i of the chunk (k_cand: reads outside this (strand, pass) and reads without
+        // the seeds for compute_lis_alignment, :103-108, are not marked); the marked ones are walked one by one
         __syncthreads();
         // (a claim is 64 reads when the batch has many per wave -- one atomic per 64 reads instead of one per read --, fewer when it has few: a batch
         // of 50 000 long reads claimed 64 at a time kept 781 of the 3 072 waves busy)
@@ -607,16 +608,9 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         __syncthreads();
         chunk_base = s_next;
         if (chunk_base >= rd.n) { out_of_reads = true; continue; }
-        bool todo = false;
+        // (k_cand ended the pass of every read it did not mark; 2 = left to the EXT launch by the first one)
         const uint32_t ri = chunk_base + (uint32_t)lane;
-        if ((uint32_t)lane < claim && ri < rd.n) {
-          RWork wi = rw[ri];
-          if (wi.strand_active && wi.search && wi.pass_n == (uint32_t)pass) {
-            RState si = work[ri];
-            if (si.hit_seeds >= (uint32_t)P.num_seeds && wi.hit_total > 0) todo = wi.pad_[0] == (EXT ? 2 : 1);      // marked by k_cand (the others ended their pass there); 2 = left to the EXT launch by the first one
-            else finish_read(ri, si, wi, 1, true);
-          }
-        }
+        const bool todo = (uint32_t)lane < claim && ri < rd.n && marks[ri] == (EXT ? 2 : 1);
         chunk_todo = __ballot(todo);
         if (chunk_todo == 0) continue;
       }
@@ -677,11 +671,12 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         uint32_t* const t_bloom = EXT ? xt : bloom;
         uint32_t* const t_skey = EXT ? xt + CH_EXT_CAP : skey;
         uint32_t* const t_scnt = EXT ? xt + 2 * CH_EXT_CAP : scnt;
-        const uint32_t t_cap = EXT ? CH_EXT_CAP : s_cap, t_mask = t_cap - 1;
+        // (the LDS table is cleared and scanned per read: a read with a few dozen positions -- the usual case -- takes a table of twice that, not all s_cap slots)
+        const uint32_t t_cap = EXT ? CH_EXT_CAP : min(s_cap, max(64u, (npos > 1 && npos < (1u << 20)) ? 1u << (32 - __clz((int)(2 * npos - 1))) : (npos > 1 ? s_cap : 64u))), t_mask = t_cap - 1;
         const bool set_ok = chain_build_set(sa, t_bloom, t_skey, t_scnt, t_cap, cap_err, ncand, keys);
         if (!set_ok) {
           if (!EXT && xt) {                                  // leave the read to the EXT launch: nothing of it is written but the mark
-            if (lane == 0) rw[r].pad_[0] = 2;
+            if (lane == 0) marks[r] = 2;
             continue;
           }
           if (lane == 0) atomicAdd(&ctr[C_ERR_SCAP], 1ull);

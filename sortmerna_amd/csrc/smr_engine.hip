@@ -45,6 +45,7 @@ struct Batch {
   uint32_t n = 0, max_len = 0, slots = 1;
   uint32_t* d_words = nullptr; uint64_t* d_rec_off = nullptr; uint32_t* d_len = nullptr;
   RState* d_saved = nullptr; RState* d_work = nullptr; RWork* d_rw = nullptr;
+  uint8_t* d_marks = nullptr;              // per read: k_chain has to walk it in this (strand, pass) (k_cand)
   AlignRec* d_saved_aln = nullptr; AlignRec* d_work_aln = nullptr;
   unsigned long long* d_ctr = nullptr;
   uint32_t* d_cigar = nullptr; uint64_t cigar_words = 0;
@@ -337,10 +338,10 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   uint8_t* const grd = c->b->max_len > SW_X4_MAX_ROWS ? c->d_rdq : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
-  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool);
+  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks);
   ev_mark(c, KP_CHAIN);
 #define CHAIN_ARGS(stab, t2) dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, \
-                             c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd
+                             c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks
   // (LONG: the batch has reads of more than one Smith-Waterman strip; the short-read instantiation carries none of their state)
   if (gb) hipLaunchKernelGGL((k_chain<false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
   else hipLaunchKernelGGL((k_chain<false, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
@@ -781,7 +782,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   for (int k = 0; k < SMR_MAX_BATCHES; k++) {
     Batch& B = c->bt[k];
     dev_free(&B.d_words); dev_free(&B.d_rec_off); dev_free(&B.d_len);
-    dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
+    dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_marks); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
   dev_free(&c->d_bound); dev_free(&c->d_rdq);
@@ -963,6 +964,7 @@ int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipS
     if ((rc = dev_alloc(c, &B.d_saved, nr))) return rc;
     if ((rc = dev_alloc(c, &B.d_work, nr))) return rc;
     if ((rc = dev_alloc(c, &B.d_rw, nr))) return rc;
+    if ((rc = dev_alloc(c, &B.d_marks, nr))) return rc;
     B.cap_reads = nr;
   }
   if (B.cap_aln < na) {
