@@ -836,11 +836,15 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         auto advance = [&](Walk& wk, bool real, SwTask& tk) -> int {
           for (;;) {
             if (!wk.started) {
+              TPH(5)
               const int lc = load_candidate(wk, real);
+              TPH(1)
               if (lc != 1) return lc;
               wk.started = 1;
             }
-            if (next_task(wk, tk)) return 1;
+            const bool got = next_task(wk, tk);
+            TPH(2)
+            if (got) return 1;
             wk.k++; wk.started = 0;
             __syncthreads();
           }
@@ -871,6 +875,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
             if (c2 == 0 && task_fits(t1)) {
               const uint32_t e = q_n;
               const uint32_t aval = (w.has_amb && !w.is04) ? 4u : (uint32_t)w.aval;             // read.flip34() before SSW (:360-361)
+              TPH(5)
               __syncthreads();
               uint8_t* rq = rdq + (size_t)lds_mq + (size_t)e * lds_mq;
               uint8_t* fq = wslot(4 + (int)e);
@@ -884,6 +889,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               }
               __syncthreads();
               q_n++;
+              TPH(4)
               if (q_n == 4) need_flush = true;
               parked = true;
               TST(3)

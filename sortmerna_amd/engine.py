@@ -323,6 +323,15 @@ class Engine:
     def records(self):
         return [self.record(i) for i in range(self.n_reads)]
 
+    def record_batch(self, batch, i):
+        """record of read i of batch `batch`, whichever batch is selected (smr_result_record_batch: a writer thread's call)"""
+        n = self.L.smr_result_record_batch(self.h, batch, i, None, 0)
+        if n == 0:
+            return b""
+        buf = C.create_string_buffer(n)
+        self.L.smr_result_record_batch(self.h, batch, i, buf, n)
+        return buf.raw
+
     def is_hit(self, i):
         return bool(self.L.smr_result_is_hit(self.h, i))
 

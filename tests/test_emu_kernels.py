@@ -182,6 +182,12 @@ def test_chunked_pipeline_equals_one_batch(emulator, wl):
         if t:
             t.join()
     assert got == whole and aligned == whole_ctr["num_aligned"]
+    # a writer thread's view: the records of an earlier chunk by batch number while another batch is the selected one (slots recycled by the
+    # streaming hosts: examples/smr_align_mgpu.cpp)
+    e.select_batch(4)
+    assert [e.record_batch(1, i) for i in range(chunks[0].count)] == whole[:cuts[1]]
+    assert [e.record_batch(3, i) for i in range(chunks[2].count)] == whole[cuts[2]:cuts[3]]
+    assert e.L.smr_device_count() >= 1
     with pytest.raises(smr.SmrError):
         e.upload_reads_batch(4, chunks[0], 1)                       # the selected batch must go through smr_reads_upload
     for c in chunks:

@@ -79,6 +79,13 @@ pacbio_phases)
     SMR_DEBUG_PHASES=1 timeout 600 python bench.py --workload pacbio5k --steps 1 --warmup 1 --resident-batches 2 --no-cpu-baseline --profile-run > $OUT/pacbio_phases.json 2> $OUT/pacbio_phases.err; grep "phase cycles" $OUT/pacbio_phases.err | tail -3 | cut -c1-400
     cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
   fi ;;
+phases)
+  # where a wave of k_chain spends its cycles on the headline workload (-DSMR_CHAIN_PHASES build of the library, 2 M-read batches)
+  if [ -f sortmerna_amd/lib/libsmr_hip_phases.so ]; then
+    cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp sortmerna_amd/lib/libsmr_hip_phases.so sortmerna_amd/lib/libsmr_hip.so
+    SMR_DEBUG_PHASES=1 timeout 300 python tools/hw_minibench.py > $OUT/minibench_phases.log 2>&1; grep -E "phase cycles|SW kernel" $OUT/minibench_phases.log | tail -8 | cut -c1-420
+    cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
+  fi ;;
 dropin)
   timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 mini)
