@@ -698,6 +698,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         // The results a read ends up with are those of the sequential walk; only the order of evaluation differs.
         struct Walk {                        // where the walk stands: candidate k, window iterators over its sorted pairs
           uint32_t k, np, it, ms_lo, ms_hi, begin_ref, begin_read;
+          uint64_t ref0, reflen;             // where candidate k's reference sequence starts, and its length (fetched while its pairs are being collected)
           int is_aligned, best, go_on;       // go_on = is_search_candidates
           int started, pending_pop, buf;     // buf: which pairs buffer holds candidate k (0/1: halves of l_pairs, 2: all of l_pairs, 3: global)
         };
@@ -715,6 +716,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           const uint32_t max_ref = (uint32_t)ck;
           const uint32_t max_occur = 0xFFFFFFFFu - (uint32_t)(ck >> 32);
           if (max_occur < (uint32_t)P.num_seeds) return 0;
+          const uint64_t r0_ = ix.ref_off[max_ref], r1_ = ix.ref_off[max_ref + 1];          // (used at the end: in flight during the rest)
           if (wk.is_aligned && P.min_lis > 0 && wk.k > 0 && max_occur < (0xFFFFFFFFu - (uint32_t)(keys[wk.k - 1] >> 32))) {   // :165-169
             --wk.best;
             if (wk.best < 1) return 0;
@@ -763,6 +765,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           wk.it = 0; wk.ms_lo = 0; wk.ms_hi = 0;
           wk.begin_ref = (uint32_t)(pairs[0] >> 32); wk.begin_read = (uint32_t)pairs[0];
           wk.pending_pop = 0;
+          wk.ref0 = r0_; wk.reflen = r1_ - r0_;
           return 1;
         };
 
@@ -776,7 +779,15 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               wk.pending_pop = 1;
               const uint64_t end_ref_max = (uint64_t)wk.begin_ref + len - wk.begin_read - P.lnwin + 1;
               int push = 0;
-              while (wk.it != np && (uint64_t)(uint32_t)(pairs[wk.it] >> 32) <= end_ref_max) { wk.ms_hi = ++wk.it; push = 1; }
+              // (the pairs are sorted by reference position: the ones to push are a prefix of what is left -- 64 looked at per trip, one per lane)
+              for (;;) {
+                const uint32_t pi = wk.it + (uint32_t)lane;
+                const bool okp = pi < np && (uint64_t)(uint32_t)(pairs[min(pi, np - 1)] >> 32) <= end_ref_max;
+                const unsigned long long pm = __ballot(okp);
+                const uint32_t pc = pm == ~0ull ? 64u : (uint32_t)__ffsll((long long)~pm) - 1u;
+                if (pc) { wk.it += pc; wk.ms_hi = wk.it; push = 1; }
+                if (pc < 64u) break;
+              }
               int skip_to_pop = 0;
               if (!push && wk.is_aligned) skip_to_pop = 1;        // heuristic 1 (:243-246)
               else wk.is_aligned = 0;
@@ -788,7 +799,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                 if (nl >= (uint32_t)P.min_lis) {
                   const uint32_t lcs_ref_start = (uint32_t)(pairs[wk.ms_lo + lis0] >> 32);
                   const uint32_t lcs_que_start = (uint32_t)pairs[wk.ms_lo + lis0];
-                  const uint64_t reflen = ix.ref_off[max_ref + 1] - ix.ref_off[max_ref];
+                  const uint64_t reflen = wk.reflen;
                   uint64_t head = 0, tail = 0, align_ref_start = 0, align_que_start = 0, align_length = 0;
                   uint32_t edges;
                   if (P.is_as_percent) edges = (uint32_t)((P.edges / 100.0) * (double)rlen);
@@ -816,7 +827,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                   }
                   tk.max_ref = max_ref; tk.align_ref_start = align_ref_start; tk.head = head; tk.align_que_start = align_que_start;
                   tk.m = (int)(align_length - head - tail); tk.nref = (int)align_length;
-                  tk.rf_start = ix.ref_off[max_ref] + align_ref_start - head;
+                  tk.rf_start = wk.ref0 + align_ref_start - head;
                   return true;
                 }
               }
@@ -854,7 +865,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 
         Walk R;
         R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0;
-        R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.buf = 0;
+        R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.buf = 0; R.ref0 = 0; R.reflen = 0;
         SwTask ctk[4]; SwRes cfw[4]; int cslot[4] = {0, 1, 2, 3}; int n_cached = 0;     // the batch cache: task, forward result, LDS slot of its reference window
         bool rdq_staged = false;
         bool immediate = mode == 1 || !x4_ok;

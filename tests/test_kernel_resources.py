@@ -51,7 +51,7 @@ def test_hot_kernels_use_no_scratch_and_stay_within_their_register_budget():
             assert k["vgpr"] <= max_vgpr, (parts, k)
     # k_chain is built for 3 waves per SIMD (168 VGPRs) and is allowed the spills DESIGN.md 3.2 accounts for
     for k in _find(md, "k_chainILb"):                 # <EXT, LONG>; the LONG instantiations (batches with reads of several strips) carry more state
-        assert k["vgpr"] <= 168 and k["spill"] <= 260, k
+        assert k["vgpr"] <= 168 and k["spill"] <= 300, k
     for k in _find(md, "k_chainILb0ELb0"):            # the instantiation of the short-read workloads
         assert k["spill"] <= 200, k
     # the stand-alone Smith-Waterman / begin-cell kernels: 4 waves per SIMD
