@@ -15,9 +15,9 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "config", "roofline", "cpu_baseline"]
 
 
-@pytest.mark.parametrize("steps,warmup,workload", [(2, 1, "illumina150"), (20, 5, "illumina150"), (2, 1, "refs8"), (2, 1, "pacbio5k")])          # (20, 5) = the driver's own command line of round 1, which aborted
+@pytest.mark.parametrize("steps,warmup,workload", [(2, 1, "illumina150"), (20, 5, "illumina150"), (1, 0, "refs8"), (2, 1, "pacbio5k")])          # (20, 5) = the driver's own command line of round 1, which aborted
 def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup, workload):
-    baseline = paths.have_ref_bin() and steps == 2               # with the reference binary at hand the CPU-baseline leg runs too
+    baseline = paths.have_ref_bin() and steps <= 2               # with the reference binary at hand the CPU-baseline leg runs too
     import torch
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
@@ -26,7 +26,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
     monkeypatch.setenv("SMR_BENCH_BACKEND", "gloo")          # the (world-size-1) reductions on CPU tensors
     import tempfile
     monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
-    nreads = 60 if workload == "pacbio5k" else 1500
+    nreads = 60 if workload == "pacbio5k" else (300 if steps > 2 else 1500)
     argv = ["bench.py", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch-reads", str(nreads), "--db-nt", "1000000" if workload == "refs8" else "150000",
             "--cpu-sample-reads", str(nreads), "--cpu-threads", "2", "--workload", workload, "--long-read-len", "600"]
     if not baseline:
