@@ -34,8 +34,8 @@ struct EvMark { hipEvent_t e; int kind; };        // kind < 0: end of a run of i
 
 #define SMR_MAX_BATCHES 16
 // kernel families timed apart (one HIP event between them on the engine's stream)
-enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_COUNT };
-static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_chain", "k_begins", "k_trace"};
+enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_QUAD, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_COUNT };
+static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_quad+k_park_sw", "k_chain", "k_begins", "k_trace"};
 
 // One resident read batch: packed reads + everything the reference keeps per read in the KVDB (read.cpp:429-539)
 // + its Readstats counter block + its CIGAR pool.  Several batches can be resident at once (the host uploads
@@ -87,6 +87,9 @@ struct smr_ctx {
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
   uint8_t* d_rdq = nullptr; size_t rdq_cap = 0;
+  // the 16-lane walk (smr_quad.hpp): list of marked reads, parked Smith-Waterman tasks, cursors
+  int quad = getenv("SMR_QUAD") ? atoi(getenv("SMR_QUAD")) : 1;
+  uint32_t* d_qlist = nullptr; QTask* d_qtasks = nullptr; uint32_t* d_qc = nullptr; size_t qlist_cap = 0, qtasks_cap = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
@@ -339,6 +342,30 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks);
+  if (c->quad && P.num_seeds >= 1) {
+    // the small majority of the marked reads, 16 lanes each: reads without any Smith-Waterman task end their pass, single tasks are scored four per wave
+    ev_mark(c, KP_QUAD);
+    const size_t want_t = std::max<size_t>((size_t)c->b->n / 4, 4096);
+    if (c->qlist_cap < c->b->n) { int rc = dev_alloc(c, &c->d_qlist, (size_t)c->b->n); if (rc) return rc; c->qlist_cap = c->b->n; }
+    if (c->qtasks_cap < want_t) { int rc = dev_alloc(c, &c->d_qtasks, want_t); if (rc) return rc; c->qtasks_cap = want_t; }
+    if (!c->d_qc) { int rc = dev_alloc(c, &c->d_qc, (size_t)QC_COUNT); if (rc) return rc; }
+    HIPCHK(c, hipMemsetAsync(c->d_qc, 0, QC_COUNT * 4, c->stream));
+    const uint32_t mq = std::min<uint32_t>(ml, SW_X4_MAX_ROWS);
+    hipLaunchKernelGGL(k_mark_list, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, c->b->n, (const uint8_t*)c->b->d_marks, c->d_qlist, c->d_qc);
+    hipLaunchKernelGGL(k_quad, dim3(std::min<uint32_t>((uint32_t)c->n_cu * 16u, (c->b->n + 3u) / 4u)), dim3(64), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand,
+                       c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, (const uint32_t*)c->d_qlist, c->d_qc, c->d_qtasks, (uint32_t)c->qtasks_cap, mq, rq);
+    hipLaunchKernelGGL(k_park_sw, dim3(std::min<uint32_t>((uint32_t)c->n_cu * 8u, (c->b->n + 3u) / 4u)), dim3(64), (size_t)4 * (mq + rq), c->stream, dreads(c), dindex(di), P, is_last_strand,
+                       c->b->d_work, c->b->d_rw, c->b->d_marks, (const uint32_t*)c->d_qc, (const QTask*)c->d_qtasks, (uint32_t)c->qtasks_cap, c->b->d_ctr, mq, rq);
+    if (getenv("SMR_QUAD_STATS")) {                        // debugging aid: what the 16-lane walk did with this launch's marked reads
+      uint32_t hq[QC_COUNT]; std::vector<uint8_t> hm(c->b->n);
+      HIPCHK(c, hipMemcpy(hq, c->d_qc, sizeof hq, hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(hm.data(), c->b->d_marks, c->b->n, hipMemcpyDeviceToHost));
+      size_t left[5] = {0, 0, 0, 0, 0};
+      for (uint8_t v : hm) if (v < 5) left[v]++;
+      fprintf(stderr, "[smr quad] pass %d: %u marked reads listed, %u parked tasks; after k_park_sw: %zu still marked, %zu for the sequential walk, %zu parked (must be 0)\n",
+              pass, hq[QC_LIST], hq[QC_TASKS], left[1], left[4], left[3]);
+    }
+  }
   ev_mark(c, KP_CHAIN);
 #define CHAIN_ARGS(stab, t2) dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, \
                              c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks
@@ -785,7 +812,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_marks); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
-  dev_free(&c->d_bound); dev_free(&c->d_rdq);
+  dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_qlist); dev_free(&c->d_qtasks); dev_free(&c->d_qc);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
   dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.fbits); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
@@ -1561,7 +1588,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
   o->seed_ms = c->kp_ms[KP_KEYS] + c->kp_ms[KP_SPLIT] + c->kp_ms[KP_BINS] + c->kp_ms[KP_PG0] + c->kp_ms[KP_PG1] + c->kp_ms[KP_FINISH]; o->seed_launches = c->kp_l[KP_KEYS];
-  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
+  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_QUAD] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
   o->trace_ms = c->kp_ms[KP_TRACE]; o->trace_launches = c->kp_l[KP_TRACE];
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];

@@ -86,6 +86,9 @@ phases)
     SMR_DEBUG_PHASES=1 timeout 300 python tools/hw_minibench.py > $OUT/minibench_phases.log 2>&1; grep -E "phase cycles|SW kernel" $OUT/minibench_phases.log | tail -8 | cut -c1-420
     cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so
   fi ;;
+quadab)
+  # the 16-lane walk of the small marked reads (smr_quad.hpp) on and off, same mini bench
+  for Q in 0 1; do SMR_QUAD=$Q timeout 300 python tools/hw_minibench.py > $OUT/minibench_quad$Q.log 2>&1; echo "== SMR_QUAD=$Q"; grep -E "SW kernel|kernels:" $OUT/minibench_quad$Q.log | tail -2 | cut -c1-900; done ;;
 dropin)
   timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 mini)
