@@ -556,7 +556,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   uint32_t q_n = 0, n_redo = 0, redo_slots = 0;          // parked tasks; parked reads to walk again (bit mask of their slots)
   bool q_hasn = false, need_flush = false, out_of_reads = false;
   uint32_t chunk_base = 0;                               // reads are claimed 64 at a time (one atomic per chunk: 31 k instead of 2 M same-address atomics per launch);
-  unsigned long long chunk_todo = 0, chunk_imm = 0;      // bit i: read chunk_base + i is still to be walked / ... in immediate mode
+  unsigned long long chunk_todo = 0;                     // bit i: read chunk_base + i is still to be walked
   for (;;) {
     uint32_t r;
     int mode = 0, seed_slot = -1;                         // mode 1: immediate (sequential walk), possibly seeded with the parked task's result
@@ -612,13 +612,11 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         const uint32_t ri = chunk_base + (uint32_t)lane;
         const uint32_t mk = ((uint32_t)lane < claim && ri < rd.n) ? marks[ri] : 0u;
         const bool todo = EXT ? mk == 2u : (mk == 1u || mk == 4u);
-        chunk_imm = EXT ? 0ull : __ballot(mk == 4u);          // 4: the 16-lane walk (k_quad) already knows that this read has to be walked sequentially
         chunk_todo = __ballot(todo);
         if (chunk_todo == 0) continue;
       }
       __syncthreads();
       r = chunk_base + (uint32_t)(__ffsll((long long)chunk_todo) - 1);
-      if (chunk_imm & chunk_todo & (0ull - chunk_todo)) mode = 1;
       chunk_todo &= chunk_todo - 1;
     }
     RWork w = rw[r];
@@ -688,8 +686,10 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         if (EXT && set_ok && ncand > 0 && !cap_err) chain_group_tuples(sa, t_scnt, xt + 3 * CH_EXT_CAP, t_cap, gt2);
         TPH(3)
         if (mode == 0 && ncand > 0) TST(2)
+#ifdef SMR_CHAIN_STATS
         if (mode == 0 && nh <= 32 && npos <= 64) TST(1)                       // census: small enough for a 16-lane walk
         if (mode == 0 && nh <= 32 && npos <= 64 && ncand <= 8 && (ncand == 0 || 0xFFFFFFFFu - (uint32_t)(keys[0] >> 32) <= 16u)) TST(6)
+#endif
         const uint32_t ntup = min(s_nt, pairs_cap);
 
         // 2. candidate loop (:150-508), organised as a GENERATOR of Smith-Waterman tasks.

@@ -345,7 +345,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   if (c->quad && P.num_seeds >= 1) {
     // the small majority of the marked reads, 16 lanes each: reads without any Smith-Waterman task end their pass, single tasks are scored four per wave
     ev_mark(c, KP_QUAD);
-    const size_t want_t = std::max<size_t>((size_t)c->b->n / 4, 4096);
+    const size_t want_t = std::max<size_t>((size_t)c->b->n / 4, 4096) & ~(size_t)(QD_SHARDS - 1);
     if (c->qlist_cap < c->b->n) { int rc = dev_alloc(c, &c->d_qlist, (size_t)c->b->n); if (rc) return rc; c->qlist_cap = c->b->n; }
     if (c->qtasks_cap < want_t) { int rc = dev_alloc(c, &c->d_qtasks, want_t); if (rc) return rc; c->qtasks_cap = want_t; }
     if (!c->d_qc) { int rc = dev_alloc(c, &c->d_qc, (size_t)QC_COUNT); if (rc) return rc; }
@@ -354,7 +354,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
     hipLaunchKernelGGL(k_mark_list, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, c->b->n, (const uint8_t*)c->b->d_marks, c->d_qlist, c->d_qc);
     hipLaunchKernelGGL(k_quad, dim3(std::min<uint32_t>((uint32_t)c->n_cu * 16u, (c->b->n + 3u) / 4u)), dim3(64), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand,
                        c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, (const uint32_t*)c->d_qlist, c->d_qc, c->d_qtasks, (uint32_t)c->qtasks_cap, mq, rq);
-    hipLaunchKernelGGL(k_park_sw, dim3(std::min<uint32_t>((uint32_t)c->n_cu * 8u, (c->b->n + 3u) / 4u)), dim3(64), (size_t)4 * (mq + rq), c->stream, dreads(c), dindex(di), P, is_last_strand,
+    hipLaunchKernelGGL(k_park_sw, dim3(std::max<uint32_t>(QD_SHARDS, (uint32_t)c->n_cu * 8u)), dim3(64), (size_t)4 * (mq + rq), c->stream, dreads(c), dindex(di), P, is_last_strand,
                        c->b->d_work, c->b->d_rw, c->b->d_marks, (const uint32_t*)c->d_qc, (const QTask*)c->d_qtasks, (uint32_t)c->qtasks_cap, c->b->d_ctr, mq, rq);
     if (getenv("SMR_QUAD_STATS")) {                        // debugging aid: what the 16-lane walk did with this launch's marked reads
       uint32_t hq[QC_COUNT]; std::vector<uint8_t> hm(c->b->n);
@@ -362,6 +362,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       HIPCHK(c, hipMemcpy(hm.data(), c->b->d_marks, c->b->n, hipMemcpyDeviceToHost));
       size_t left[5] = {0, 0, 0, 0, 0};
       for (uint8_t v : hm) if (v < 5) left[v]++;
+      for (uint32_t q = 1; q < QD_SHARDS; q++) hq[QC_TASKS] += hq[QC_TASKS + q];
       fprintf(stderr, "[smr quad] pass %d: %u marked reads listed, %u parked tasks; after k_park_sw: %zu still marked, %zu for the sequential walk, %zu parked (must be 0)\n",
               pass, hq[QC_LIST], hq[QC_TASKS], left[1], left[4], left[3]);
     }

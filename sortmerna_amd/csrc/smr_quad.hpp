@@ -25,7 +25,10 @@ namespace smr {
 #define QD_CAND 8u
 #define QD_PAIRS 16u
 enum { QM_NONE = 0, QM_MARKED = 1, QM_EXT = 2, QM_PARKED = 3, QM_IMMEDIATE = 4 };       // values of marks[]
-enum { QC_LIST = 0, QC_TASKS = 1, QC_NEXT_Q = 2, QC_NEXT_P = 3, QC_COUNT = 8 };         // u32 cursors of the stage
+// u32 cursors of the stage: the list of marked reads; the parked tasks in QD_SHARDS lists of their own (one cursor would take ~60 k returning
+// atomics on one address per launch: milliseconds)
+#define QD_SHARDS 64u
+enum { QC_LIST = 0, QC_TASKS = 16, QC_COUNT = 16 + 64 };
 
 struct QTask { uint32_t r, max_ref, ars, head, aq, m, nref, pad; unsigned long long rf_start; };     // 40 bytes
 
@@ -257,8 +260,9 @@ __global__ void __launch_bounds__(64) k_quad(DReads rd, DIndex ix, DParams P, in
       if (x4_ok && fits) park = true; else { alive = false; imm = true; }
     }
     const unsigned long long pb = __ballot(park && gl == 0);
+    const uint32_t shard = blockIdx.x & (QD_SHARDS - 1u), shard_cap = tasks_cap / QD_SHARDS;
     uint32_t tb = 0;
-    if (lane == 0 && pb) tb = atomicAdd(&qc[QC_TASKS], (uint32_t)__popcll(pb));
+    if (lane == 0 && pb) tb = atomicAdd(&qc[QC_TASKS + shard], (uint32_t)__popcll(pb));
     tb = (uint32_t)__shfl((int)tb, 0, 64);
     if (have && gl == 0) {
       if (alive && n_tasks == 0) {
@@ -267,7 +271,7 @@ __global__ void __launch_bounds__(64) k_quad(DReads rd, DIndex ix, DParams P, in
         marks[r] = QM_NONE;
       } else if (park) {
         const uint32_t ti = tb + (uint32_t)__popcll(pb & ((1ull << lane) - 1));
-        if (ti < tasks_cap) { tasks[ti] = T1; marks[r] = QM_PARKED; }
+        if (ti < shard_cap) { tasks[(size_t)shard * shard_cap + ti] = T1; marks[r] = QM_PARKED; }
         else marks[r] = QM_MARKED;                                              // list full: k_chain does it
       } else if (imm) marks[r] = QM_IMMEDIATE;
       // else: stays QM_MARKED
@@ -282,11 +286,14 @@ __global__ void __launch_bounds__(64) k_park_sw(DReads rd, DIndex ix, DParams P,
                                                 unsigned long long* __restrict__ ctr, uint32_t lds_mq, uint32_t lds_rq) {
   SMR_DYN_LDS(unsigned char, lds_raw);                    // 4 reads of lds_mq bytes | 4 reference windows of lds_rq bytes
   const int lane = lane_id(), g = lane >> 4, gl = lane & 15;
-  const uint32_t n_tasks = min(qc[QC_TASKS], tasks_cap);
+  // block b works on task list b % QD_SHARDS, every (gridDim / QD_SHARDS)-th quad of it
+  const uint32_t shard = blockIdx.x & (QD_SHARDS - 1u), shard_cap = tasks_cap / QD_SHARDS;
+  const uint32_t n_tasks = min(qc[QC_TASKS + shard], shard_cap);
+  tasks += (size_t)shard * shard_cap;
   uint8_t* rq = lds_raw + (size_t)g * lds_mq;
   uint8_t* fq = lds_raw + (size_t)4 * lds_mq + (size_t)g * lds_rq;
   unsigned long long n_fwd = 0, n_cells = 0;
-  for (uint32_t t0 = blockIdx.x * 4u; t0 < n_tasks; t0 += gridDim.x * 4u) {
+  for (uint32_t t0 = (blockIdx.x / QD_SHARDS) * 4u; t0 < n_tasks; t0 += max(gridDim.x / QD_SHARDS, 1u) * 4u) {
     const bool have = t0 + (uint32_t)g < n_tasks;
     QTask T; memset(&T, 0, sizeof T);
     RWork w; memset(&w, 0, sizeof w);
