@@ -87,8 +87,9 @@ struct smr_ctx {
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
   uint8_t* d_rdq = nullptr; size_t rdq_cap = 0;
-  // the 16-lane walk (smr_quad.hpp): list of marked reads, parked Smith-Waterman tasks, cursors
-  int quad = getenv("SMR_QUAD") ? atoi(getenv("SMR_QUAD")) : 1;
+  // the 16-lane walk (smr_quad.hpp): list of marked reads, parked Smith-Waterman tasks, cursors.  OFF by default: measured slower than leaving
+  // those reads to k_chain (2.48 + 4.35 vs 5.96 ms per 2 M-read launch, profiles/r3s17_*) -- SMR_QUAD=1 switches it on
+  int quad = getenv("SMR_QUAD") ? atoi(getenv("SMR_QUAD")) : 0;
   uint32_t* d_qlist = nullptr; QTask* d_qtasks = nullptr; uint32_t* d_qc = nullptr; size_t qlist_cap = 0, qtasks_cap = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;

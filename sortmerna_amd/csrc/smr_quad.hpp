@@ -16,6 +16,12 @@
 //
 // The records are those of the sequential walk: k_quad only decides WHICH reads need it, by the rules k_chain applies to park a read, and every
 // doubt is resolved towards k_chain.
+//
+// MEASURED AND NOT ADOPTED (round 3, MI355X, 2 M-read batches): with this stage k_chain drops from 5.96 to 4.35 ms per launch -- the 73 % of the
+// marked reads it is spared cost it only 1.6 ms; what is left are the reads sampled from the DB, whose 40-member families are walked candidate
+// by candidate -- while k_mark_list + k_quad + k_park_sw take 2.48 ms: four reads share an instruction stream, but the stream is as long as
+// the slowest of the four and its loops run to fixed bounds under predicates, ~2 400 wave-instructions per read, what k_chain spends on such a
+// read.  The stage stays in the library behind SMR_QUAD=1 (off by default), with its parity test (test_sixteen_lane_walk_on_and_off_...).
 #pragma once
 
 namespace smr {
