@@ -254,15 +254,20 @@ __device__ uint32_t serial_lis_first(const unsigned long long* a, uint32_t n, ui
 }
 
 // end of traverse() for one read: pass control (paralleltraversal.cpp:253-277), state write-back by the lane(s) with writer = true
+// (PASS_ONLY: the caller changed nothing of the read's transient state itself -- k_cand --, so only the pass control fields are written back)
+template <bool PASS_ONLY = false>
 __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_strand, uint32_t r, RState& st, RWork& w, int search, bool writer,
                                                   RState* __restrict__ work, RWork* __restrict__ rw) {
   uint32_t pass_n = w.pass_n;
   if (search) {
+    // (no P.skip[pass_n]: an index the compiler cannot resolve puts the three strides into private memory)
+    const uint32_t k0 = P.skip[0], k1 = P.skip[1], k2 = P.skip[2];
     if (pass_n == 2) search = 0;
     else {
-      while (pass_n < 2 && P.skip[pass_n] == P.skip[pass_n + 1]) ++pass_n;
+      if (pass_n == 0 && k0 == k1) pass_n = 1;               // equal consecutive strides are skipped (:269-272)
+      if (pass_n == 1 && k1 == k2) pass_n = 2;
       if (++pass_n > 2) search = 0;
-      else w.win_shift = P.skip[pass_n];
+      else w.win_shift = pass_n == 1 ? k1 : k2;
     }
   }
   w.pass_n = (uint8_t)pass_n; w.search = (uint8_t)search;
@@ -274,7 +279,11 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
     } else if (P.is_last_index_part && is_last_strand && st.n_align > 0) st.is_done = 1;
     w.strand_active = 0;
   }
-  if (writer) { work[r] = st; rw[r] = w; }
+  if (writer) {
+    work[r] = st;
+    if (PASS_ONLY) { RWork* d = rw + r; d->win_shift = w.win_shift; d->pass_n = w.pass_n; d->search = w.search; d->strand_active = w.strand_active; }
+    else rw[r] = w;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -287,12 +296,17 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 // only marks the read (one byte per read, `marks`) for k_chain, which does the exact work.  k_chain then walks the marked reads only.
 // ------------------------------------------------------------------------------------------------
 #define CAND_HITS 64u                 // seed hits per read handled here
-#define CAND_BLOOM_WORDS 512u         // 16 384 bits per read
+#define CAND_BLOOM_WORDS 512u         // most Bloom words per read: 16 384 bits
+// dynamic LDS bytes of a block (16 reads): Bloom words | prefix of the list lengths | list starts
+#define CAND_LDS_BYTES(bw) (16u * ((bw) + CAND_HITS + 1u + CAND_HITS) * 4u)
 __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
-                                              const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks) {
-  __shared__ uint32_t s_bloom[16][CAND_BLOOM_WORDS];
-  __shared__ uint32_t s_hp[16][CAND_HITS + 1], s_lo[16][CAND_HITS];
+                                              const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks, uint32_t bloom_words) {
+  SMR_DYN_LDS(uint32_t, cand_lds);
   const int lane = lane_id(), gl = lane & 15, g = (int)(threadIdx.x >> 4);
+  uint32_t* const bloom = cand_lds + (size_t)g * bloom_words;                                  // this read's 32 * bloom_words bits
+  uint32_t* const hp_ = cand_lds + 16u * bloom_words + (size_t)g * (CAND_HITS + 1u);
+  uint32_t* const lo_ = cand_lds + 16u * (bloom_words + CAND_HITS + 1u) + (size_t)g * CAND_HITS;
+  const uint32_t bshift = 32u - (5u + (uint32_t)__ffs((int)bloom_words) - 1u);
   const uint32_t r = blockIdx.x * 16u + (uint32_t)g;
   bool have = r < rd.n;
   RWork w; RState st;
@@ -303,7 +317,7 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
     if (have) {
       st = work[r];
       eligible = st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0;
-      if (!eligible) { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+      if (!eligible) { chain_finish_read<true>(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
     }
   }
   const uint32_t nh = eligible ? w.hit_total : 0u;
@@ -311,17 +325,16 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   const bool scan = eligible && !mark;
   // the group's hits: list start and length of each, prefix over the lengths (row-wise, 16 hits per round)
   uint32_t npos = 0;
-  if (scan) { for (uint32_t q = gl; q < CAND_BLOOM_WORDS; q += 16) s_bloom[g][q] = 0; }
+  if (scan) { for (uint32_t q = gl; q < bloom_words; q += 16) bloom[q] = 0; }
   for (uint32_t h0 = 0; h0 < CAND_HITS; h0 += 16) {
     const uint32_t h = h0 + (uint32_t)gl;
     uint32_t lo = 0, ln = 0;
     if (scan && h < nh) {
-      uint32_t o = h, id = 0;
-      for (uint32_t pp = 0; pp < 3; pp++) {                // the hit blocks of the passes run so far on this strand, concatenated
-        const uint32_t c = w.blk_cnt[pp];
-        if (o < c) { id = pool[w.blk_off[pp] + 2 * o]; break; }
-        o -= c;
-      }
+      // the hit blocks of the passes run so far on this strand, concatenated (no loop over the three: an index that the compiler cannot
+      // resolve sends the read's state to 12 KB of LDS per block)
+      const uint32_t c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
+      const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
+      const uint32_t id = pool[at];
       lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
     }
     uint32_t inc = ln;                                     // inclusive prefix inside the row of 16 lanes (row_shr:1/2/4/8)
@@ -330,10 +343,10 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, false); inc += v;
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, false); inc += v;
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, false); inc += v;
-    if (scan && h < nh) { s_hp[g][h] = npos + inc - ln; s_lo[g][h] = lo; }
+    if (scan && h < nh) { hp_[h] = npos + inc - ln; lo_[h] = lo; }
     npos += (uint32_t)__shfl((int)inc, 15, 16);
   }
-  if (scan && gl == 0) s_hp[g][nh] = npos;
+  if (scan && gl == 0) hp_[nh] = npos;
   __syncthreads();
   uint32_t rounds = scan ? (npos + 15u) / 16u : 0u;
   for (int d = 32; d > 0; d >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d, 64));
@@ -342,17 +355,17 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
     const uint32_t p = it * 16u + (uint32_t)gl;
     if (scan && p < npos) {
       uint32_t h = 0;
-      for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && s_hp[g][t] <= p) h = t; }
-      const uint32_t seq = ix.pos_arr[s_lo[g][h] + (p - s_hp[g][h])].y;
-      const uint32_t hb = (seq * 2654435761u) >> 18;                    // 14 bits
-      const uint32_t old = atomicOr(&s_bloom[g][hb >> 5], 1u << (hb & 31u));
+      for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp_[t] <= p) h = t; }
+      const uint32_t seq = ix.pos_arr[lo_[h] + (p - hp_[h])].y;
+      const uint32_t hb = (seq * 2654435761u) >> bshift;                // 14 bits for 512 words
+      const uint32_t old = atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
       hit |= ((old >> (hb & 31u)) & 1u) != 0;
     }
   }
   const unsigned long long hm = __ballot(hit);
   if (scan && ((hm >> (lane & 48)) & 0xFFFFull)) mark = true;
   if (eligible) {
-    if (!mark) { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+    if (!mark) { chain_finish_read<true>(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
   }
   // one byte per read says whether k_chain has to walk it: its waves claim reads by looking at 64 of these bytes, not at 64 per-read states
   if (r < rd.n && gl == 0) marks[r] = (eligible && mark) ? 1 : 0;
@@ -544,7 +557,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
 #else
 #define TST(i) {}
 #endif
-  auto finish_read = [&](uint32_t r, RState& st, RWork& w, int search, bool writer) { w.pad_[0] = 0; chain_finish_read(P, is_last_strand, r, st, w, search, writer, work, rw); };
+  auto finish_read = [&](uint32_t r, RState& st, RWork& w, int search, bool writer) { chain_finish_read(P, is_last_strand, r, st, w, search, writer, work, rw); };
   // Reads whose walk meets exactly ONE Smith-Waterman task (the usual case for a background read with a spurious candidate) are PARKED:
   // task and sequences go into one of four LDS slots, nothing is written back, the wave moves on to its next read.  Four parked tasks
   // of four different reads are scored by one pass of the four-problem kernel.  A result that is "no alignment" -- what the walk was

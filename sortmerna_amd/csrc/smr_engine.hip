@@ -72,6 +72,8 @@ struct smr_ctx {
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 4;                      // lane-local hit list capacity; doubles (and the part is redone) on overflow
   int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_pg (+ redo of the waves whose pool overflowed)
+  // Bloom words per read in k_cand (a power of two, 64..512): fewer = more blocks of k_cand per CU, but more reads marked for k_chain by a false collision
+  uint32_t cand_bloom = CAND_BLOOM_WORDS;
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
@@ -342,7 +344,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   uint8_t* const grd = c->b->max_len > SW_X4_MAX_ROWS ? c->d_rdq : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
-  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks);
+  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom);
   if (c->quad && P.num_seeds >= 1) {
     // the small majority of the marked reads, 16 lanes each: reads without any Smith-Waterman task end their pass, single tasks are scored four per wave
     ev_mark(c, KP_QUAD);
@@ -779,6 +781,7 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
     delete c; return SMR_ERR_DEVICE;
   }
   if (const char* e = getenv("SMR_SEED_EXACT")) c->seed_exact = atoi(e) != 0;
+  if (const char* e = getenv("SMR_CAND_BLOOM")) { uint32_t b = 64; while (b < CAND_BLOOM_WORDS && b < (uint32_t)atoi(e)) b <<= 1; c->cand_bloom = b; }      // measurement aid
   if (const char* e = getenv("SMR_PG_CAND_CAP")) c->ccap = std::min<uint32_t>(PG_CAND_CAP_MAX, std::max<uint32_t>(4u, (uint32_t)atoi(e)));      // test aid: a small candidate pool
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;

@@ -272,7 +272,6 @@ __global__ void __launch_bounds__(64) k_quad(DReads rd, DIndex ix, DParams P, in
     tb = (uint32_t)__shfl((int)tb, 0, 64);
     if (have && gl == 0) {
       if (alive && n_tasks == 0) {
-        w.pad_[0] = 0;
         chain_finish_read(P, is_last_strand, r, st, w, 1, true, work, rw);       // no ssw_align: the pass ends (paralleltraversal.cpp:253-277)
         marks[r] = QM_NONE;
       } else if (park) {
@@ -325,7 +324,6 @@ __global__ void __launch_bounds__(64) k_park_sw(DReads rd, DIndex ix, DParams P,
         // no alignment: the read ends as the sequential walk ends it -- one ssw_align call, nothing recorded
         RState st = work[T.r];
         if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; }
-        w.pad_[0] = 0;
         chain_finish_read(P, is_last_strand, T.r, st, w, 1, true, work, rw);
         marks[T.r] = QM_NONE;
         n_fwd++; n_cells += (unsigned long long)T.m * T.nref;

@@ -740,7 +740,9 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
         o += 2 * c;
       }
       w.aval = w.is04 ? 0 : w.aval; w.is04 = 0;
-      w.blk_off[pass] = base; w.blk_cnt[pass] = total; w.hit_total += total;
+      // (not w.blk_off[pass]: an index the compiler cannot resolve moves the whole state to LDS, 12 KB per block)
+      if (pass == 0) { w.blk_off[0] = base; w.blk_cnt[0] = total; } else if (pass == 1) { w.blk_off[1] = base; w.blk_cnt[1] = total; } else { w.blk_off[2] = base; w.blk_cnt[2] = total; }
+      w.hit_total += total;
       rw[r] = w;
       work[r].hit_seeds += seeds;
       hits = total; bytes = (len + 3) / 4;

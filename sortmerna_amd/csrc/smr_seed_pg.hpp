@@ -32,8 +32,37 @@ namespace smr {
 #ifndef PG_TRIP
 #define PG_TRIP 4
 #endif
-// dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16), chain heads of the 64 searches
-#define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap) + 64u)
+// dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16), chain heads of the 64 searches, the searches that start in a row of 64 strings
+#define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap) + 128u)
+
+// inclusive prefix sum / maximum over the 64 lanes in six DPP steps: row_shr:1/2/4/8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 (a lane without a source adds / compares 0)
+__device__ __forceinline__ uint32_t pg_scan_add(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+  return x;
+}
+__device__ __forceinline__ uint32_t pg_scan_max(uint32_t x) {
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false));
+  x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
+  return x;
+}
+// win_pos / stride for a window position, which is a multiple of the stride below 2^16: one reciprocal instead of an integer division
+__device__ __forceinline__ uint32_t pg_window_index(uint32_t win_pos, uint32_t stride) {
+#ifdef SMR_EMU
+  return win_pos / stride;
+#else
+  return (uint32_t)((float)win_pos * __builtin_amdgcn_rcpf((float)stride) + 0.5f);
+#endif
+}
 
 // the chars of a 2-bit packed string (char j at bits 2j) with char j moved to bits 30-2j: any run of chars is then a number with its
 // first char most significant
@@ -59,6 +88,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   uint32_t* cdv = cdk + ccap;                              // id
   uint32_t* cdn = cdv + ccap;                              // next record of the same search | kind << 16
   uint32_t* hd = cdn + ccap;                               // [64] newest record of each search
+  uint32_t* own = hd + 64;                                 // [64] 1 + the search whose strings start at string g0 + i of the wave (0: none does)
   __shared__ uint32_t s_ncand_[PG_WAVES];
   uint32_t& s_ncand = s_ncand_[threadIdx.x >> 6];
   const int lane = lane_id();
@@ -85,7 +115,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
     P9 = (uint32_t)(pl >> 40);
-    slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
+    slot = wseg_slot(sb, r, pg_window_index(win_pos, P.skip[pass]));
     if (DIR == 1 && wseg_has(sb, slot)) {                // the window's list so far = the forward search's hits (one bit per window says whether
       had_seg = true;
       const uint32_t seg = sb.wseg[slot];                //  there is one: the bitmap stays in the caches, the segment table would not)
@@ -125,32 +155,32 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     }
   }
   const uint32_t tot = rn0 + rn1 + rn2 + rn3;
-  unsigned long long w_node = 0, w_entry = 0;            // wave totals (uniform)
-  {
-    uint32_t wsum = tot, nsum = (mine && rt.x != NONE) ? (cA ? 4u : 1u) : 0u;
-    for (int d = 32; d > 0; d >>= 1) { wsum += __shfl_xor(wsum, d, 64); nsum += __shfl_xor(nsum, d, 64); }
-    w_entry = wsum; w_node = nsum;
-  }
+  // wave totals (uniform): directory ranges read (4 per search with directories, 1 without)
+  const bool srch = mine && rt.x != NONE;
+  const unsigned long long w_node = 4ull * (uint32_t)__popcll(__ballot(srch && cA)) + (uint32_t)__popcll(__ballot(srch && !cA));
   GPH(1)
   // ---- the strings of the wave's 64 searches, 64 at a time whichever search they belong to (a search has 5 strings on average, the
   // busiest of 64 about 13: lane = search would run the wave as long as that one).  String g of the wave belongs to the search s with
   // excl[s] <= g < excl[s] + tot[s]; its lane fetches what it needs of s's state with ds_bpermute ----
-  uint32_t sinc = tot;
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(sinc, d, 64); if (lane >= d) sinc += x; }
-  const uint32_t excl = sinc - tot, wtot = __shfl(sinc, 63, 64);
+  const uint32_t sinc = pg_scan_add(tot);
+  const uint32_t excl = sinc - tot, wtot = (uint32_t)__builtin_amdgcn_readlane((int)sinc, 63);
+  const unsigned long long w_entry = wtot;
   const uint32_t c1 = rn0, c2 = c1 + rn1, c3 = c2 + rn2;                 // where the ranges S0, S1, S2 begin in the search's own numbering
   const uint32_t u1 = n + rs1, u2 = n + rs2, u3 = n + rs3;               // ... and in the block's strings (TA TB)
   hd[lane] = PG_NIL;
+  uint32_t carry = 0;                                                    // 1 + the last search that starts before this row of 64 strings
   for (uint32_t g0 = 0; g0 < wtot; g0 += 64) {
     const uint32_t g = g0 + (uint32_t)lane;
-    uint32_t lo = 0, hi = 63;                                            // the last search whose strings start at or before g
-#pragma unroll
-    for (int it = 0; it < 6; it++) {
-      const uint32_t mid = (lo + hi + 1) >> 1;
-      const uint32_t v = __shfl(excl, (int)mid, 64);
-      if (v <= g) lo = mid; else hi = mid - 1;
-    }
-    const int s = (int)lo;
+    // the last search whose strings start at or before g: the searches that start inside the row leave their number at their first string,
+    // a prefix maximum spreads it to the strings behind (the searches are in the order of their first strings; one without strings starts
+    // where the next one does and loses against it)
+    own[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (tot && excl - g0 < 64u) own[excl - g0] = (uint32_t)lane + 1u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t ow = max(pg_scan_max(own[lane]), carry);
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
+    const int s = (int)ow - 1;
     const uint32_t oe = __shfl(excl, s, 64), oP = __shfl(P9, s, 64), om = __shfl(rt.y, s, 64), ob = __shfl(rt.x, s, 64);
     const uint32_t o0 = __shfl(rs0, s, 64), o1 = __shfl(u1, s, 64), o2 = __shfl(u2, s, 64), o3 = __shfl(u3, s, 64);
     const uint32_t oc1 = __shfl(c1, s, 64), oc2 = __shfl(c2, s, 64), oc3 = __shfl(c3, s, 64);
@@ -215,9 +245,8 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
   const bool wr = mine && (DIR == 0 ? nh > 0 : (zero || nh > n_prev));
   const uint32_t need = wr ? 2 + 2 * nh : 0;
-  uint32_t incl = need;
-  for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
-  const uint32_t total = __shfl(incl, 63, 64);
+  const uint32_t incl = pg_scan_add(need);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   uint32_t base = 0;
   if (total) {
     if (lane == 0) {
@@ -237,10 +266,10 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   // algorithmic bytes of this wave (C_B_PG0/1): per tuple 12 B + its block-table entry (8 B); a search with directories reads 8 directory
   // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; DIR 1 reads the window's bit and, where it is set, its slot and
   // the forward search's list (count word + its ids with their win_pos); the segment written (4 B per word) and the window slot pointing to it
-  unsigned long long w_bytes = (vb * 64u + lane < n_tup ? sizeof(SeedTmp) + 8u + (had_seg ? 8u + 8u * n_prev : 0u) : 0u) +
-                               ((mine && rt.x != NONE && cA) ? 32u : 0u) + 4ull * tot + 4ull * need + (wr ? 4u : 0u);
-  for (int d = 32; d > 0; d >>= 1) w_bytes += __shfl_xor(w_bytes, d, 64);
-  w_bytes += 8ull * min(s_ncand, ccap) + (DIR ? 8u : 0u);          // (DIR 1: one window bit per tuple)
+  // (what does not come out of the scans above is summed per lane: < 2^32 per wave)
+  const uint32_t lane_bytes = (vb * 64u + lane < n_tup ? (uint32_t)sizeof(SeedTmp) + 8u + (had_seg ? 8u + 8u * n_prev : 0u) : 0u) + ((srch && cA) ? 32u : 0u) + (wr ? 4u : 0u);
+  unsigned long long w_bytes = (uint32_t)__builtin_amdgcn_readlane((int)pg_scan_add(lane_bytes), 63);
+  w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + (DIR ? 8u : 0u);          // (DIR 1: one window bit per tuple)
   if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, w_bytes); }
 #ifdef SMR_SEED_PHASES
   GPH(5)

@@ -211,6 +211,21 @@ def test_pigeonhole_layout_built_on_the_device_equals_the_host_transform(emulato
     e.close()
 
 
+def test_a_small_bloom_bitmap_in_k_cand_only_marks_more_reads(emulator, tmp_path, monkeypatch):
+    """k_cand ends the pass of a read whose positions set no Bloom bit twice; a smaller bitmap (SMR_CAND_BLOOM words per read, 64 = 2 048 bits)
+    collides more often, which hands more reads to k_chain's exact walk and changes no record."""
+    from helpers.workload import Workload
+    w = Workload(str(tmp_path), db_nt=300_000, n_reads=2000, frac_db=0.1, seed=23, family_size=4)
+    exp, ctr = w.oracle_records()
+    for words in ("64", "512"):
+        monkeypatch.setenv("SMR_CAND_BLOOM", words)
+        e = smr.Engine(0)
+        got, c = w.gpu_records(e)
+        assert got == exp, "SMR_CAND_BLOOM=%s: %d records differ" % (words, sum(1 for a, b in zip(got, exp) if a != b))
+        assert c["num_aligned"] == ctr["num_aligned"]
+        e.close()
+
+
 def test_sixteen_lane_walk_on_and_off_give_the_oracle_records(emulator, tmp_path, monkeypatch):
     """smr_quad.hpp: most marked reads of a background-dominated sample are decided 16 lanes per read (no task: pass ends; one task: scored four
     per wave; else k_chain's sequential walk).  With the stage switched off (SMR_QUAD=0) k_chain does everything as in round 2.  Same records."""

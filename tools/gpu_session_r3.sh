@@ -89,6 +89,9 @@ phases)
 quadab)
   # the 16-lane walk of the small marked reads (smr_quad.hpp) on and off, same mini bench
   for Q in 0 1; do SMR_QUAD=$Q timeout 300 python tools/hw_minibench.py > $OUT/minibench_quad$Q.log 2>&1; echo "== SMR_QUAD=$Q"; grep -E "SW kernel|kernels:" $OUT/minibench_quad$Q.log | tail -2 | cut -c1-900; done ;;
+bloomab)
+  # k_cand's Bloom bitmap per read: 512 words (3 blocks of k_cand per CU), 256 (6), 128 (9) -- fewer words mark more reads for k_chain
+  for B in 512 256 128; do SMR_CAND_BLOOM=$B timeout 300 python tools/hw_minibench.py > $OUT/minibench_bloom$B.log 2>&1; echo "== SMR_CAND_BLOOM=$B"; grep -E "SW kernel|kernels:" $OUT/minibench_bloom$B.log | tail -2 | cut -c1-900; done ;;
 dropin)
   timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 mini)
