@@ -72,8 +72,10 @@ struct smr_ctx {
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
   uint32_t hcap = 4;                      // lane-local hit list capacity; doubles (and the part is redone) on overflow
   int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_pg (+ redo of the waves whose pool overflowed)
-  // Bloom words per read in k_cand (a power of two, 64..512): fewer = more blocks of k_cand per CU, but more reads marked for k_chain by a false collision
-  uint32_t cand_bloom = CAND_BLOOM_WORDS;
+  // Bloom words per read in k_cand (a power of two, 64..512): fewer = more blocks of k_cand per CU, but more reads marked for k_chain by a false
+  // collision.  Measured per 2 M-read launch (profiles/r3s18_*): 512 words k_cand 1.07 ms + k_chain 6.01 ms, 256: 0.59 + 6.06, 128: 0.48 + 6.07
+  // (16 KB of LDS per block: the 8 blocks per CU that the wave slots allow)
+  uint32_t cand_bloom = 128;
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;

@@ -73,6 +73,67 @@ __device__ __forceinline__ uint32_t pg_reversed(uint32_t s) {
 // chars from..from+cnt-1 (cnt >= 1) of a string given as pg_reversed
 __device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_t cnt) { return (rev >> (32u - 2u * (from + cnt))) & ((1u << (2u * cnt)) - 1u); }
 
+// One row of 64 strings of a wave's searches (see the string loop of k_seed_pg): what the lane that got string g of the wave knows about it.
+struct PgRow { uint32_t T, P, m, u, w; int s; const uint32_t* tt; bool have; };
+// the searches' state that a string's lane fetches from its owner
+struct PgOwn { uint32_t excl, tot, P9, rtx, rty, rs0, u1, u2, u3, c1, c2, c3; };
+
+// Row g0: find the owners, ISSUE the loads of the strings (nothing here waits for them).
+// The last search whose strings start at or before g: the searches that start inside the row leave their number at their first string, a
+// prefix maximum spreads it to the strings behind (the searches are in the order of their first strings; one without strings starts where
+// the next one does and loses against it); carry = 1 + the last search that starts before the row.
+__device__ __forceinline__ void pg_row_fetch(PgRow& R, uint32_t g0, uint32_t wtot, int lane, uint32_t* own, const PgOwn& O, uint32_t& carry, const uint32_t* pg) {
+  R.P = R.m = R.u = R.w = 0; R.s = 0; R.tt = pg; R.have = false;
+  if (g0 < wtot) {
+    const uint32_t g = g0 + (uint32_t)lane;
+    own[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (O.tot && O.excl - g0 < 64u) own[O.excl - g0] = (uint32_t)lane + 1u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t ow = max(pg_scan_max(own[lane]), carry);
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
+    const int s = (int)ow - 1;
+    const uint32_t oe = __shfl(O.excl, s, 64), oP = __shfl(O.P9, s, 64), om = __shfl(O.rty, s, 64), ob = __shfl(O.rtx, s, 64);
+    const uint32_t o0 = __shfl(O.rs0, s, 64), o1 = __shfl(O.u1, s, 64), o2 = __shfl(O.u2, s, 64), o3 = __shfl(O.u3, s, 64);
+    const uint32_t oc1 = __shfl(O.c1, s, 64), oc2 = __shfl(O.c2, s, 64), oc3 = __shfl(O.c3, s, 64);
+    if (g < wtot) {
+      const uint32_t j = g - oe;
+      uint32_t w = 0, u = o0 + j;
+      if (j >= oc1) { w = 1; u = o1 + (j - oc1); }
+      if (j >= oc2) { w = 2; u = o2 + (j - oc2); }
+      if (j >= oc3) { w = 3; u = o3 + (j - oc3); }
+      const uint32_t ocA = (om >> 24) & 15u, ocB = om >> 28;
+      R.tt = pg + (size_t)ob * 4 + (ocA ? (1u << (2 * ocA)) + (1u << (2 * ocB)) + 2u : 0u);
+      R.P = oP; R.m = om; R.u = u; R.w = w; R.s = s; R.have = true;
+    }
+  }
+  // exactly ONE load per call whatever the path (a lane without a string reads word 0 of the layout): only then can the compiler let the
+  // wave wait for the older of two loads in flight (s_waitcnt vmcnt(1)) instead of for all of them
+  R.T = R.tt[R.u];
+}
+// The automaton over the strings of a row; an accepted one becomes a candidate record of its search.
+__device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32_t h, bool full, uint32_t ccap, uint32_t* s_ncand,
+                                             uint32_t* cdk, uint32_t* cdv, uint32_t* cdn, uint32_t* hd) {
+  if (!R.have) return;
+  const uint32_t T = R.T, oP = R.P, u = R.u, w = R.w;
+  const uint32_t on = R.m & 0xFFFFFFu, ocA = (R.m >> 24) & 15u, ocB = R.m >> 28;
+  bool dup = false;                                    // reachable through an earlier key of its search?
+  if (w) {
+    const uint32_t mA = (1u << (2 * ocA)) - 1u, mB = (1u << (2 * ocB)) - 1u;
+    dup = ((T ^ oP) & mA) == 0;                        // under key A
+    if (w == 3) { const uint32_t tb = (T >> (2 * h)) & mB; dup = dup || tb == ((oP >> (2 * h)) & mB) || tb == ((oP >> (2 * h - 2)) & mB); }      // under S0 / S1
+  }
+  const uint32_t r = dup ? 0u : lev1_entry(oP, T, pw);
+  if (r & 1u) {
+    const uint32_t p = atomicAdd(s_ncand, 1u);
+    if (p < ccap) {
+      const uint32_t* ri = R.tt + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u;
+      cdk[p] = ri[0]; cdv[p] = ri[1];
+      cdn[p] = atomicExch(&hd[R.s], p) | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16);
+    }
+  }
+}
+
 template <int DIR>
 __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
                                                 uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
@@ -168,47 +229,17 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   const uint32_t c1 = rn0, c2 = c1 + rn1, c3 = c2 + rn2;                 // where the ranges S0, S1, S2 begin in the search's own numbering
   const uint32_t u1 = n + rs1, u2 = n + rs2, u3 = n + rs3;               // ... and in the block's strings (TA TB)
   hd[lane] = PG_NIL;
-  uint32_t carry = 0;                                                    // 1 + the last search that starts before this row of 64 strings
-  for (uint32_t g0 = 0; g0 < wtot; g0 += 64) {
-    const uint32_t g = g0 + (uint32_t)lane;
-    // the last search whose strings start at or before g: the searches that start inside the row leave their number at their first string,
-    // a prefix maximum spreads it to the strings behind (the searches are in the order of their first strings; one without strings starts
-    // where the next one does and loses against it)
-    own[lane] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (tot && excl - g0 < 64u) own[excl - g0] = (uint32_t)lane + 1u;
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t ow = max(pg_scan_max(own[lane]), carry);
-    carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
-    const int s = (int)ow - 1;
-    const uint32_t oe = __shfl(excl, s, 64), oP = __shfl(P9, s, 64), om = __shfl(rt.y, s, 64), ob = __shfl(rt.x, s, 64);
-    const uint32_t o0 = __shfl(rs0, s, 64), o1 = __shfl(u1, s, 64), o2 = __shfl(u2, s, 64), o3 = __shfl(u3, s, 64);
-    const uint32_t oc1 = __shfl(c1, s, 64), oc2 = __shfl(c2, s, 64), oc3 = __shfl(c3, s, 64);
-    if (g < wtot) {
-      const uint32_t j = g - oe;
-      uint32_t w = 0, u = o0 + j;
-      if (j >= oc1) { w = 1; u = o1 + (j - oc1); }
-      if (j >= oc2) { w = 2; u = o2 + (j - oc2); }
-      if (j >= oc3) { w = 3; u = o3 + (j - oc3); }
-      const uint32_t on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u, ocB = om >> 28;
-      const uint32_t* ott = ix.pg + (size_t)ob * 4 + (ocA ? (1u << (2 * ocA)) + (1u << (2 * ocB)) + 2u : 0u);
-      const uint32_t T = ott[u];
-      bool dup = false;                                    // reachable through an earlier key of its search?
-      if (w) {
-        const uint32_t mA = (1u << (2 * ocA)) - 1u, mB = (1u << (2 * ocB)) - 1u;
-        dup = ((T ^ oP) & mA) == 0;                        // under key A
-        if (w == 3) { const uint32_t tb = (T >> (2 * h)) & mB; dup = dup || tb == ((oP >> (2 * h)) & mB) || tb == ((oP >> (2 * h - 2)) & mB); }      // under S0 / S1
-      }
-      const uint32_t r = dup ? 0u : lev1_entry(oP, T, pw);
-      if (r & 1u) {
-        const uint32_t p = atomicAdd(&s_ncand, 1u);
-        if (p < ccap) {
-          const uint32_t* ri = ott + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u;
-          cdk[p] = ri[0]; cdv[p] = ri[1];
-          cdn[p] = atomicExch(&hd[s], p) | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16);
-        }
-      }
-    }
+  uint32_t carry = 0;
+  // The loop is pipelined by one row and unrolled by two (A and B take turns, nothing is copied): the loads of row i are issued, then the
+  // automaton runs over the strings of row i - 1, which were asked for a step earlier -- a wave waits for a string load once, not per row.
+  PgOwn O; O.excl = excl; O.tot = tot; O.P9 = P9; O.rtx = rt.x; O.rty = rt.y; O.rs0 = rs0; O.u1 = u1; O.u2 = u2; O.u3 = u3; O.c1 = c1; O.c2 = c2; O.c3 = c3;
+  PgRow A, B;
+  A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.tt = ix.pg; A.have = false;
+  for (uint32_t g0 = 0; g0 < wtot + 64u; g0 += 128) {
+    pg_row_fetch(B, g0, wtot, lane, own, O, carry, ix.pg);
+    pg_row_apply(A, pw, h, full, ccap, &s_ncand, cdk, cdv, cdn, hd);
+    pg_row_fetch(A, g0 + 64u, wtot, lane, own, O, carry, ix.pg);
+    pg_row_apply(B, pw, h, full, ccap, &s_ncand, cdk, cdv, cdn, hd);
   }
   __syncthreads();
   GPH(2)
