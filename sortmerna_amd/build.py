@@ -30,7 +30,7 @@ def build_library(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, "-o", LIB]
     cmd += os.environ.get("SMR_EXTRA_HIPCC_FLAGS", "").split()          # e.g. -DSMR_CHAIN_PHASES (debug instrumentation)
     cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-lpthread", "-lz"]
     if verbose:

@@ -1,0 +1,23 @@
+// smr_device_ops.hpp -- the few things the kernels ask of the gfx950 compiler beyond plain C++: dynamic LDS, packed 16-bit arithmetic
+// (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16), v_perm_b32, v_rcp_f32.  Included as <smr_device_ops.hpp> (build.py passes -I csrc): the
+// kernel emulator of the test suite puts its own file of this name in front (tests/emu/shim/smr_device_ops.hpp, scalar host code), so the
+// product sources carry no second implementation.
+#pragma once
+#include <stdint.h>
+
+#define SMR_DYN_LDS(type, name) extern __shared__ __align__(16) type name[]
+#define SMR_SW_SELFCHECK_CASES 512u                       // random problems smr_create runs through both Smith-Waterman kernels
+
+namespace smr {
+
+typedef short pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(pk16, v); }
+__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ pk16 pk_add(pk16 a, pk16 b) { return a + b; }
+__device__ __forceinline__ pk16 pk_sub(pk16 a, pk16 b) { return a - b; }
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+// n / d for n = k * d, k < 2^16: one reciprocal and a multiply (the error of v_rcp_f32 is far below the 0.5 that is added)
+__device__ __forceinline__ uint32_t div_multiple(uint32_t n, uint32_t d) { return (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d) + 0.5f); }
+
+}  // namespace smr

@@ -792,11 +792,7 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   c->b->used = true;
   if (c->sw_mode >= 1) {
     // the packed Smith-Waterman kernel must agree with the 32-bit kernel on this device, or it is not used
-#ifdef SMR_EMU
-    uint32_t cases = 8;
-#else
-    uint32_t cases = 512;
-#endif
+    uint32_t cases = SMR_SW_SELFCHECK_CASES;
     if (const char* e2 = getenv("SMR_SW_SELFCHECK")) cases = (uint32_t)atoi(e2);
     uint64_t bad = 0;
     if (cases > 0 && (smr_sw_selfcheck(c, cases, 20260926u, 700, &bad) != SMR_OK || bad != 0)) {

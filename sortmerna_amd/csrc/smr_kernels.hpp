@@ -24,12 +24,7 @@
 
 #include "smr_host.hpp"
 
-// dynamic LDS of a kernel.  (SMR_EMU is only ever defined by tests/emu, which compiles this file for the host.)
-#ifdef SMR_EMU
-#define SMR_DYN_LDS(type, name) type* const name = (type*)emu::dyn_lds()
-#else
-#define SMR_DYN_LDS(type, name) extern __shared__ __align__(16) type name[]
-#endif
+#include <smr_device_ops.hpp>      // SMR_DYN_LDS, packed 16-bit ops, v_perm_b32, v_rcp_f32 (the test suite's kernel emulator supplies its own)
 
 namespace smr {
 

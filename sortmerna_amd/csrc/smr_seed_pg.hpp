@@ -55,14 +55,6 @@ __device__ __forceinline__ uint32_t pg_scan_max(uint32_t x) {
   x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false));
   return x;
 }
-// win_pos / stride for a window position, which is a multiple of the stride below 2^16: one reciprocal instead of an integer division
-__device__ __forceinline__ uint32_t pg_window_index(uint32_t win_pos, uint32_t stride) {
-#ifdef SMR_EMU
-  return win_pos / stride;
-#else
-  return (uint32_t)((float)win_pos * __builtin_amdgcn_rcpf((float)stride) + 0.5f);
-#endif
-}
 
 // the chars of a 2-bit packed string (char j at bits 2j) with char j moved to bits 30-2j: any run of chars is then a number with its
 // first char most significant
@@ -176,7 +168,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
     win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
     P9 = (uint32_t)(pl >> 40);
-    slot = wseg_slot(sb, r, pg_window_index(win_pos, P.skip[pass]));
+    slot = wseg_slot(sb, r, div_multiple(win_pos, P.skip[pass]));
     if (DIR == 1 && wseg_has(sb, slot)) {                // the window's list so far = the forward search's hits (one bit per window says whether
       had_seg = true;
       const uint32_t seg = sb.wseg[slot];                //  there is one: the bitmap stays in the caches, the segment table would not)

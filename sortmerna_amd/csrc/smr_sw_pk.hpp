@@ -20,36 +20,7 @@
 
 namespace smr {
 
-#ifdef SMR_EMU
-struct pk16 { int16_t lo, hi; };
-__device__ inline pk16 pk_from(uint32_t v) { pk16 r; r.lo = (int16_t)(v & 0xFFFF); r.hi = (int16_t)(v >> 16); return r; }
-__device__ inline uint32_t pk_bits(pk16 v) { return (uint32_t)(uint16_t)v.lo | ((uint32_t)(uint16_t)v.hi << 16); }
-__device__ inline pk16 pk_add(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo + b.lo); r.hi = (int16_t)(a.hi + b.hi); return r; }
-__device__ inline pk16 pk_sub(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo - b.lo); r.hi = (int16_t)(a.hi - b.hi); return r; }
-__device__ inline pk16 pk_max(pk16 a, pk16 b) { pk16 r; r.lo = a.lo > b.lo ? a.lo : b.lo; r.hi = a.hi > b.hi ? a.hi : b.hi; return r; }
-__device__ inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {          // v_perm_b32: bytes 0-3 = s1, 4-7 = s0, 12 = 0x00, >= 13 = 0xFF
-  const unsigned long long src = ((unsigned long long)s0 << 32) | s1;
-  uint32_t r = 0;
-  for (int i = 0; i < 4; i++) {
-    const uint32_t s = (sel >> (8 * i)) & 0xFF;
-    uint32_t b;
-    if (s < 8) b = (uint32_t)(src >> (8 * s)) & 0xFF;
-    else if (s < 12) b = ((src >> (8 * (2 * (s - 8) + 1) + 7)) & 1) ? 0xFF : 0x00;
-    else if (s == 12) b = 0x00;
-    else b = 0xFF;
-    r |= b << (8 * i);
-  }
-  return r;
-}
-#else
-typedef short pk16 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ pk16 pk_from(uint32_t v) { return __builtin_bit_cast(pk16, v); }
-__device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(uint32_t, v); }
-__device__ __forceinline__ pk16 pk_add(pk16 a, pk16 b) { return a + b; }
-__device__ __forceinline__ pk16 pk_sub(pk16 a, pk16 b) { return a - b; }
-__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
-#endif
+// (pk16, pk_from / pk_bits / pk_add / pk_sub / pk_max and perm_b32: <smr_device_ops.hpp>)
 __device__ __forceinline__ pk16 pk_splat(int v) { return pk_from(((uint32_t)v & 0xFFFFu) * 0x00010001u); }
 
 #define PK_SEL_NONE 0x0C0Cu          // half selector: both bytes constant 0

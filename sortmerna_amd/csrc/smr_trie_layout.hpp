@@ -15,7 +15,7 @@
 #include "smr_host.hpp"
 
 #ifndef SMR_HD
-#if defined(__HIPCC__) || defined(SMR_EMU)
+#ifdef __HIPCC__
 #define SMR_HD __host__ __device__
 #else
 #define SMR_HD

@@ -1,0 +1,33 @@
+// TEST INFRASTRUCTURE: the emulator's stand-in for sortmerna_amd/csrc/smr_device_ops.hpp (found first: -I tests/emu/shim comes first).
+// Scalar host code with the semantics of the gfx950 instructions the product header maps to.
+#pragma once
+#include <stdint.h>
+
+#define SMR_DYN_LDS(type, name) type* const name = (type*)emu::dyn_lds()
+#define SMR_SW_SELFCHECK_CASES 8u
+
+namespace smr {
+
+struct pk16 { int16_t lo, hi; };
+inline pk16 pk_from(uint32_t v) { pk16 r; r.lo = (int16_t)(v & 0xFFFF); r.hi = (int16_t)(v >> 16); return r; }
+inline uint32_t pk_bits(pk16 v) { return (uint32_t)(uint16_t)v.lo | ((uint32_t)(uint16_t)v.hi << 16); }
+inline pk16 pk_add(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo + b.lo); r.hi = (int16_t)(a.hi + b.hi); return r; }      // v_pk_add_i16 (wraps)
+inline pk16 pk_sub(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo - b.lo); r.hi = (int16_t)(a.hi - b.hi); return r; }
+inline pk16 pk_max(pk16 a, pk16 b) { pk16 r; r.lo = a.lo > b.lo ? a.lo : b.lo; r.hi = a.hi > b.hi ? a.hi : b.hi; return r; }
+inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {          // v_perm_b32: bytes 0-3 = s1, 4-7 = s0, 8-11 = sign of a 16-bit half, 12 = 0x00, >= 13 = 0xFF
+  const unsigned long long src = ((unsigned long long)s0 << 32) | s1;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t s = (sel >> (8 * i)) & 0xFF;
+    uint32_t b;
+    if (s < 8) b = (uint32_t)(src >> (8 * s)) & 0xFF;
+    else if (s < 12) b = ((src >> (8 * (2 * (s - 8) + 1) + 7)) & 1) ? 0xFF : 0x00;
+    else if (s == 12) b = 0x00;
+    else b = 0xFF;
+    r |= b << (8 * i);
+  }
+  return r;
+}
+inline uint32_t div_multiple(uint32_t n, uint32_t d) { return n / d; }
+
+}  // namespace smr

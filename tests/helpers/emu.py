@@ -18,7 +18,8 @@ _bound = None
 
 
 def _sources():
-    src = [os.path.join(EMU, "emu_runtime.cpp"), os.path.join(EMU, "shim", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "smr_hip.h")]
+    src = [os.path.join(EMU, "emu_runtime.cpp"), os.path.join(EMU, "shim", "hip", "hip_runtime.h"), os.path.join(EMU, "shim", "smr_device_ops.hpp"),
+           os.path.join(ROOT, "include", "smr_hip.h")]
     src += [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))]
     return src
 

@@ -44,10 +44,13 @@ def test_product_never_touches_the_oracle():
 
 
 def test_product_has_no_route_to_the_kernel_emulator():
-    """tests/emu is a development aid: the product's Python never loads it, the hipcc build never defines SMR_EMU (the few
-    `#ifdef SMR_EMU` lines in csrc/ only replace compiler intrinsics when tests/emu compiles the kernel sources for the host), and
+    """tests/emu is a development aid: the product's Python never loads it, the product sources do not know it (the emulator puts ITS
+    smr_device_ops.hpp in front of csrc/'s when it compiles the kernel sources for the host: no `#ifdef` for it anywhere in csrc/), and
     libsmr_hip.so carries none of its symbols"""
     import subprocess
+    csrc = os.path.join(paths.REPO, "sortmerna_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "SMR_EMU" not in open(os.path.join(csrc, f)).read(), f
     for d, _, files in os.walk(os.path.join(paths.REPO, "sortmerna_amd")):
         for f in files:
             if f.endswith(".py"):

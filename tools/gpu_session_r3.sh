@@ -92,6 +92,12 @@ quadab)
 bloomab)
   # k_cand's Bloom bitmap per read: 512 words (3 blocks of k_cand per CU), 256 (6), 128 (9) -- fewer words mark more reads for k_chain
   for B in 512 256 128; do SMR_CAND_BLOOM=$B timeout 300 python tools/hw_minibench.py > $OUT/minibench_bloom$B.log 2>&1; echo "== SMR_CAND_BLOOM=$B"; grep -E "SW kernel|kernels:" $OUT/minibench_bloom$B.log | tail -2 | cut -c1-900; done ;;
+twoctx)
+  # two batches in flight on one GPU (two contexts, two streams) against one
+  for N in 1 2; do MB_CTX=$N timeout 300 python tools/hw_minibench2.py > $OUT/minibench_ctx$N.log 2>&1; grep -E "context" $OUT/minibench_ctx$N.log | tail -3 | cut -c1-300; done ;;
+twoctx8m)
+  MB_CTX=3 timeout 300 python tools/hw_minibench2.py > $OUT/minibench_ctx3.log 2>&1; grep -E "context" $OUT/minibench_ctx3.log | tail -2 | cut -c1-300
+  for N in 1 2; do MB_BATCH=8000000 MB_STEPS=2 MB_CTX=$N timeout 400 python tools/hw_minibench2.py > $OUT/minibench_8m_ctx$N.log 2>&1; grep -E "context" $OUT/minibench_8m_ctx$N.log | tail -2 | cut -c1-300; done ;;
 dropin)
   timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 mini)
