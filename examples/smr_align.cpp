@@ -128,6 +128,7 @@ int main(int argc, char** argv) {
 
   smr_ctx* gpu = nullptr;
   if (smr_create(device, &gpu, err, sizeof err) != SMR_OK) die(err);
+  if (smr_sw_mode(gpu, -1) == 0) fprintf(stderr, "smr_align: the 32-bit Smith-Waterman kernel is in use (packed kernel off or failed its self-check): expect about half the alignment rate\n");
   const uint32_t slots = base.num_alignments > 0 ? base.num_alignments : 256;
   for (size_t b = 0; b < rf.size(); b++)
     if (smr_batch_select(gpu, (int)b) != SMR_OK || smr_reads_upload(gpu, rf[b], slots) != SMR_OK) die(smr_last_error(gpu));

@@ -103,6 +103,7 @@ struct RankOut {
   uint64_t n_records = 0;
   std::vector<uint64_t> counters;      // reduced: identical on every rank
   double t_upload = 0, t_align = 0, t_fetch = 0, t_write = 0;
+  int sw_kernel = -1;                     // smr_sw_mode of the rank's context: 0 = 32-bit kernel only (the packed kernel failed its self-check or was switched off)
   uint32_t minimal_score0 = 0;
 };
 }  // namespace
@@ -218,6 +219,7 @@ int main(int argc, char** argv) {
     char e2[512] = "";
     smr_ctx* gpu = nullptr;
     if (smr_create(dev, &gpu, e2, sizeof e2) != SMR_OK) die(e2);
+    outs[rank].sw_kernel = smr_sw_mode(gpu, -1);
     // the read shard of this rank, in chunks (each chunk is one resident batch of the engine)
     uint64_t first = 0, count = 0;
     shard_range(n, rank, world, first, count);
@@ -424,6 +426,8 @@ int main(int argc, char** argv) {
   printf("[timing] ranks %d (%s reduction), reads %llu: parse+pack %.3f s alongside index load/build %.3f s = %.3f s, per-rank max: index upload + chunk uploads %.3f s (overlapped), align+traceback+fetch %.3f s, "
          "records%s %.3f s (overlapped), counter reduce + close %.3f s; rank stage %.3f s; end to end %.3f s = %.0f reads/s (rank stage alone: %.0f reads/s)\n",
          world, S.use_rccl ? "RCCL" : "host", (unsigned long long)n, t_reads, t_index, t_host, tu, ta, want_reports ? " + report rows" : "", tw, tf, t_ranks, t_all, n / t_all, n / t_ranks);
+  int swk = 2; for (auto& o : outs) swk = std::min(swk, o.sw_kernel);
+  printf("[kernels] Smith-Waterman: %s\n", swk >= 1 ? "packed 16-bit (four candidate windows per wave)" : "32-bit kernel ONLY on at least one rank (packed kernel off or failed its self-check): expect about half the alignment rate");
   printf("%llu reads, %llu aligned, %llu records, minimal_score %u -> %s\n", (unsigned long long)n, (unsigned long long)ctr[0], (unsigned long long)nrec, outs[0].minimal_score0, rp.c_str());
   for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
   smr_reads_free(all);
