@@ -632,11 +632,13 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
       r = chunk_base + (uint32_t)(__ffsll((long long)chunk_todo) - 1);
       chunk_todo &= chunk_todo - 1;
     }
+    // (all four loads before the first use of any: one round trip, not two -- a marked read is always active.  Tried and dropped: the
+    // 22 state words fetched one per lane and read back with v_readlane, the next marked read's a whole read ahead: k_chain 6.0 -> 6.3 ms)
     RWork w = rw[r];
-    if (!(w.strand_active && w.search && w.pass_n == (uint32_t)pass)) continue;
     RState st = work[r];
     const uint32_t len = rd.len[r];
     const uint32_t* rec = rd.words + rd.rec_off[r];
+    if (!(w.strand_active && w.search && w.pass_n == (uint32_t)pass)) continue;
     int search = 1;
     const uint32_t max_SW_score = len * (uint32_t)P.match;
     const bool x4_ok = P.sw_mode >= 1 && len <= SW_X4_MAX_ROWS && sw_pk_fits((int)len, (int)lds_rf, P.match, P.mismatch, P.score_N, P.gap_open);
