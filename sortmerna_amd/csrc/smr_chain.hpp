@@ -313,9 +313,9 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   bool eligible = false;
   if (have) {
     w = rw[r];
+    st = work[r];                                           // (asked for with w, not after it)
     have = w.strand_active && w.search && w.pass_n == (uint32_t)pass;
     if (have) {
-      st = work[r];
       eligible = st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0;
       if (!eligible) { chain_finish_read<true>(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
     }

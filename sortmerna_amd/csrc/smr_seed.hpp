@@ -223,9 +223,10 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     const uint32_t tid = tile * SEED_TILE + threadIdx.x;
     const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
     if (tile >= t1 || r >= rd.n) return;
-    const RWork w = rw[r];
-    const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
+    const RWork w = rw[r];                                 // (state, length and record offset asked for together: one round trip before the record's words, not two)
     const uint32_t len = rd.len[r];
+    const uint32_t* const rec = rd.words + rd.rec_off[r];
+    const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
     const uint32_t stride = P.skip[pass];
     const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
     bool mine = k < numwin;
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
     if (!mine) return;
     // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
     const uint32_t aval = w.is04 ? 0 : w.aval;
-    const unsigned long long wc = window_chars(rd.words + rd.rec_off[r], len, win_pos, L, w.reversed, aval);
+    const unsigned long long wc = window_chars(rec, len, win_pos, L, w.reversed, aval);
     const unsigned long long half = (1ull << (2 * pw)) - 1ull;
     // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
     const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
@@ -696,6 +697,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 // per read: copy the hit segments of this pass's windows into ONE contiguous block (k_chain then reads a strand's
 // cumulative hits with coalesced loads instead of chasing a list), count seeds/hits (++read.hit_seeds per window with
 // hits, paralleltraversal.cpp:242-249), make the 0..3 view persistent (Read::flip34, read.cpp:379-401)
+#define FIN_CHUNK 8u                                      // windows whose bits k_seed_finish asks for together (independent loads in flight per thread)
 __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
@@ -703,21 +705,39 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
   unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
   if (r < rd.n) {
     RWork w = rw[r];
+    const uint32_t len = rd.len[r];                        // (asked for with the state, not after it)
     moved = sizeof(RWork);
     kin = sizeof(RWork) + 4u;                              // k_seed_keys looks at every read's state and length ...
     if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
-      const uint32_t len = rd.len[r], stride = P.skip[pass];
+      const uint32_t stride = P.skip[pass];
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
       uint32_t seeds = 0, total = 0, rlook = 0, nsearched = 0;
-      for (uint32_t k = 0; k < numwin; k++) {
-        const size_t sl = wseg_slot(sb, r, k);
-        const uint32_t s = wseg_has(sb, sl) ? sb.wseg[sl] : NONE;
-        bool searched = true;                                // windows of this pass: not searched by an earlier pass (:128-131)
-        for (int q = 0; q < pass; q++) if ((k * stride) % P.skip[q] == 0) searched = false;
-        nsearched += searched ? 1u : 0u;
-        if (searched && !(s != NONE && (s & SEED_ZERO_BIT))) rlook++;     // the reverse lookup happens unless the forward search hit exactly (:188-198)
-        if (s == NONE) continue;
-        seeds++; total += pool[(s & ~SEED_ZERO_BIT) + 1];
+      // The windows are taken FIN_CHUNK at a time: their bits are asked for together (independent loads), and only the windows whose bit is set
+      // -- a tenth -- go on to their slot and their segment's count word.  (One window after the other, each a chain of up to three loads,
+      // this loop was the kernel's time: 45 windows x the memory latency per thread.)
+      const uint32_t k0s = P.skip[0], k1s = P.skip[1];
+      uint32_t rem0 = 0, rem1 = 0;                           // (k * stride) % skip[0], % skip[1], kept by addition
+      for (uint32_t kb = 0; kb < numwin; kb += FIN_CHUNK) {
+        const uint32_t nk = min((uint32_t)FIN_CHUNK, numwin - kb);
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < FIN_CHUNK; j++) m |= (wseg_has(sb, wseg_slot(sb, r, min(kb + j, numwin - 1))) ? 1u : 0u) << j;
+        if (nk < FIN_CHUNK) m &= (1u << nk) - 1u;
+        uint32_t srch = 0;                                   // windows of this pass: not searched by an earlier pass (:128-131)
+        for (uint32_t j = 0; j < nk; j++) {
+          const bool earlier = (pass >= 1 && rem0 == 0) || (pass >= 2 && rem1 == 0);
+          srch |= (earlier ? 0u : 1u) << j;
+          rem0 += stride; while (rem0 >= k0s) rem0 -= k0s;
+          rem1 += stride; while (rem1 >= k1s) rem1 -= k1s;
+        }
+        nsearched += (uint32_t)__popc(srch);
+        rlook += (uint32_t)__popc(srch & ~m);              // no segment: the reverse lookup happened (:188-198)
+        for (uint32_t mm = m; mm; mm &= mm - 1) {
+          const uint32_t j = (uint32_t)__ffs((int)mm) - 1u;
+          const uint32_t sg = sb.wseg[wseg_slot(sb, r, kb + j)];
+          if (((srch >> j) & 1u) && !(sg & SEED_ZERO_BIT)) rlook++;        // ... unless the forward search hit exactly
+          seeds++; total += pool[(sg & ~SEED_ZERO_BIT) + 1];
+        }
       }
       looks = rlook;
       kin += 8u + 4u * (((len + 15) >> 4) + ((len + 31) >> 5)) + 8ull * nsearched;      // ... of an active read also its record offset, its packed record, two lookup words per window
@@ -731,13 +751,17 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
         else base = shard * region + (uint32_t)old;
       }
       uint32_t o = base;
-      if (total) for (uint32_t k = 0; k < numwin; k++) {
-        const size_t sl = wseg_slot(sb, r, k);
-        if (!wseg_has(sb, sl)) continue;
-        const uint32_t s = sb.wseg[sl];
-        const uint32_t sg = s & ~SEED_ZERO_BIT, c = pool[sg + 1];
-        for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
-        o += 2 * c;
+      if (total) for (uint32_t kb = 0; kb < numwin; kb += FIN_CHUNK) {
+        const uint32_t nk = min((uint32_t)FIN_CHUNK, numwin - kb);
+        uint32_t m = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < FIN_CHUNK; j++) m |= (wseg_has(sb, wseg_slot(sb, r, min(kb + j, numwin - 1))) ? 1u : 0u) << j;
+        if (nk < FIN_CHUNK) m &= (1u << nk) - 1u;
+        for (uint32_t mm = m; mm; mm &= mm - 1) {
+          const uint32_t sg = sb.wseg[wseg_slot(sb, r, kb + (uint32_t)__ffs((int)mm) - 1u)] & ~SEED_ZERO_BIT, c = pool[sg + 1];
+          for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
+          o += 2 * c;
+        }
       }
       w.aval = w.is04 ? 0 : w.aval; w.is04 = 0;
       // (not w.blk_off[pass]: an index the compiler cannot resolve moves the whole state to LDS, 12 KB per block)
