@@ -697,11 +697,13 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 // per read: copy the hit segments of this pass's windows into ONE contiguous block (k_chain then reads a strand's
 // cumulative hits with coalesced loads instead of chasing a list), count seeds/hits (++read.hit_seeds per window with
 // hits, paralleltraversal.cpp:242-249), make the 0..3 view persistent (Read::flip34, read.cpp:379-401)
+#define FIN_KEEP 8u                                       // segments per read and pass whose place k_seed_finish remembers (16 KB of LDS per block; a read from the DB has one per window of the first pass)
 #define FIN_CHUNK 8u                                      // windows whose bits k_seed_finish asks for together (independent loads in flight per thread)
 __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t s_seg[FIN_KEEP][256], s_cnt[FIN_KEEP][256];            // the first segments a thread met: where, how many pairs (the copy below need not look for them again)
   unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
   if (r < rd.n) {
     RWork w = rw[r];
@@ -736,7 +738,9 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
           const uint32_t j = (uint32_t)__ffs((int)mm) - 1u;
           const uint32_t sg = sb.wseg[wseg_slot(sb, r, kb + j)];
           if (((srch >> j) & 1u) && !(sg & SEED_ZERO_BIT)) rlook++;        // ... unless the forward search hit exactly
-          seeds++; total += pool[(sg & ~SEED_ZERO_BIT) + 1];
+          const uint32_t cnt = pool[(sg & ~SEED_ZERO_BIT) + 1];
+          if (seeds < FIN_KEEP) { s_seg[seeds][threadIdx.x] = sg & ~SEED_ZERO_BIT; s_cnt[seeds][threadIdx.x] = cnt; }
+          seeds++; total += cnt;
         }
       }
       looks = rlook;
@@ -751,7 +755,13 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
         else base = shard * region + (uint32_t)old;
       }
       uint32_t o = base;
-      if (total) for (uint32_t kb = 0; kb < numwin; kb += FIN_CHUNK) {
+      if (total && seeds <= FIN_KEEP) {
+        for (uint32_t i = 0; i < seeds; i++) {
+          const uint32_t sg = s_seg[i][threadIdx.x], c = s_cnt[i][threadIdx.x];
+          for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
+          o += 2 * c;
+        }
+      } else if (total) for (uint32_t kb = 0; kb < numwin; kb += FIN_CHUNK) {
         const uint32_t nk = min((uint32_t)FIN_CHUNK, numwin - kb);
         uint32_t m = 0;
 #pragma unroll
