@@ -298,14 +298,21 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 #define CAND_HITS 64u                 // seed hits per read handled here
 #define CAND_BLOOM_WORDS 512u         // most Bloom words per read: 16 384 bits
 // dynamic LDS bytes of a block (16 reads): Bloom words | prefix of the list lengths | list starts
-#define CAND_LDS_BYTES(bw) (16u * ((bw) + CAND_HITS + 1u + CAND_HITS) * 4u)
+#define CAND_LDS_BYTES(bw) (16u * ((bw) + CAND_HITS + 1u + 2u * CAND_HITS) * 4u)
+#define CAND_REC_MAX 256u             // positions of a marked read that k_cand hands over to k_chain as a record
+// The hand-over (mrec != nullptr): k_cand has walked hit -> list bounds -> positions of every read it marks; k_chain would repeat those three
+// dependent gathers one read per wave.  So a marked read with at most CAND_REC_MAX positions leaves a RECORD in mpool -- npos reference
+// numbers | npos reference positions | npos window positions, in the order of the walk -- and {offset, npos} in mrec[r] ({NONE, 0}: none);
+// k_chain builds the read's candidate set from it with coalesced loads.
 __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
-                                              const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks, uint32_t bloom_words) {
+                                              const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks, uint32_t bloom_words,
+                                              uint2* __restrict__ mrec, uint32_t* __restrict__ mpool, uint32_t mpool_words, uint32_t* __restrict__ mcur) {
   SMR_DYN_LDS(uint32_t, cand_lds);
   const int lane = lane_id(), gl = lane & 15, g = (int)(threadIdx.x >> 4);
   uint32_t* const bloom = cand_lds + (size_t)g * bloom_words;                                  // this read's 32 * bloom_words bits
   uint32_t* const hp_ = cand_lds + 16u * bloom_words + (size_t)g * (CAND_HITS + 1u);
   uint32_t* const lo_ = cand_lds + 16u * (bloom_words + CAND_HITS + 1u) + (size_t)g * CAND_HITS;
+  uint32_t* const wn_ = cand_lds + 16u * (bloom_words + 2u * CAND_HITS + 1u) + (size_t)g * CAND_HITS;   // window position of every hit
   const uint32_t bshift = 32u - (5u + (uint32_t)__ffs((int)bloom_words) - 1u);
   const uint32_t r = blockIdx.x * 16u + (uint32_t)g;
   bool have = r < rd.n;
@@ -335,6 +342,7 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
       const uint32_t c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
       const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
       const uint32_t id = pool[at];
+      wn_[h] = pool[at + 1];
       lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
     }
     uint32_t inc = ln;                                     // inclusive prefix inside the row of 16 lanes (row_shr:1/2/4/8)
@@ -369,6 +377,26 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   }
   // one byte per read says whether k_chain has to walk it: its waves claim reads by looking at 64 of these bytes, not at 64 per-read states
   if (r < rd.n && gl == 0) marks[r] = (eligible && mark) ? 1 : 0;
+  if (mrec) {
+    const bool want = scan && mark && npos > 0 && npos <= CAND_REC_MAX;
+    uint32_t off = NONE;
+    if (want && gl == 0) {
+      const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = mpool_words / C_NSHARD;
+      const uint32_t old = atomicAdd(&mcur[shard], 3u * npos);
+      if (old + 3u * npos <= region) off = shard * region + old;
+    }
+    off = (uint32_t)__shfl((int)off, lane & 48, 64);
+    for (uint32_t it = 0; it < rounds; it++) {             // the positions once more (their lines are in the caches), this time kept
+      const uint32_t p = it * 16u + (uint32_t)gl;
+      if (want && off != NONE && p < npos) {
+        uint32_t h = 0;
+        for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp_[t] <= p) h = t; }
+        const uint2 pa = ix.pos_arr[lo_[h] + (p - hp_[h])];
+        mpool[off + p] = pa.y; mpool[off + npos + p] = pa.x; mpool[off + 2u * npos + p] = wn_[h];
+      }
+    }
+    if (r < rd.n && gl == 0) mrec[r] = (want && off != NONE) ? make_uint2(off, npos) : make_uint2(NONE, 0u);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,6 +407,7 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
 // (nothing usable was produced).  k_chain<false> runs it on the wave's LDS table, k_chain<true> on the block's global table.
 // ------------------------------------------------------------------------------------------------
 struct SetArgs {
+  const uint32_t* rec;               // k_cand's record of the read (see k_cand) or nullptr: then the positions are found through hits / hp / pos_arr
   const uint2* pos_arr; const uint2* hits; const uint32_t* hp; uint32_t nh, npos, num_seeds;
   unsigned long long* gt; uint32_t pairs_cap, keys_cap; unsigned long long* l_keys; unsigned long long* gk; unsigned long long* ctr;
   uint32_t* s_ns; uint32_t* s_nt; uint32_t* s_ncand;
@@ -396,9 +425,13 @@ __device__ __forceinline__ bool chain_build_set(const SetArgs& A, uint32_t* bl, 
   for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
     const uint32_t p = p0 + lane;
     if (p < npos) {
-      uint32_t h = 0;
-      for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
-      const uint32_t seq = A.pos_arr[A.hits[h].x + (p - A.hp[h])].y;
+      uint32_t seq;
+      if (A.rec) seq = A.rec[p];
+      else {
+        uint32_t h = 0;
+        for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
+        seq = A.pos_arr[A.hits[h].x + (p - A.hp[h])].y;
+      }
       const uint32_t hb = (seq * 2654435761u) >> bshift;
       const uint32_t old = atomicOr(&bl[hb >> 5], 1u << (hb & 31u));
       if (((old >> (hb & 31u)) & 1u) || A.num_seeds < 2) {
@@ -420,16 +453,20 @@ __device__ __forceinline__ bool chain_build_set(const SetArgs& A, uint32_t* bl, 
     for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
       const uint32_t p = p0 + lane;
       if (p < npos) {
-        uint32_t h = 0;
-        for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
-        const uint2 pa = A.pos_arr[A.hits[h].x + (p - A.hp[h])];
+        uint2 pa; uint32_t win;
+        if (A.rec) { pa = make_uint2(A.rec[npos + p], A.rec[p]); win = A.rec[2u * npos + p]; }
+        else {
+          uint32_t h = 0;
+          for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
+          pa = A.pos_arr[A.hits[h].x + (p - A.hp[h])]; win = A.hits[h].y;
+        }
         uint32_t sl = (pa.y * 0x9E3779B1u >> 7) & mask;
         for (;;) {
           const uint32_t o = sk[sl];
           if (o == pa.y + 1) {
             atomicAdd(&sc[sl], 1u);
             const uint32_t t = atomicAdd(A.s_nt, 1u);
-            if (t < A.pairs_cap) A.gt[t] = ((unsigned long long)pa.x << 32) | ((unsigned long long)sl << 16) | A.hits[h].y;
+            if (t < A.pairs_cap) A.gt[t] = ((unsigned long long)pa.x << 32) | ((unsigned long long)sl << 16) | win;
             break;
           }
           if (o == 0) break;
@@ -504,7 +541,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                                               unsigned long long* g_tuples, unsigned long long* g_keys, unsigned long long* g_pairs, uint32_t* g_lis,
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
                                               uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2,
-                                              uint32_t lds_rq, int* g_bound, uint8_t* g_rdq, uint8_t* __restrict__ marks) {
+                                              uint32_t lds_rq, int* g_bound, uint8_t* g_rdq, uint8_t* __restrict__ marks,
+                                              const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
@@ -638,6 +676,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
     RState st = work[r];
     const uint32_t len = rd.len[r];
     const uint32_t* rec = rd.words + rd.rec_off[r];
+    const uint2 mr = (!EXT && mrec) ? mrec[r] : make_uint2(NONE, 0u);       // k_cand's record of the read's positions, if it left one
     if (!(w.strand_active && w.search && w.pass_n == (uint32_t)pass)) continue;
     int search = 1;
     const uint32_t max_SW_score = len * (uint32_t)P.match;
@@ -656,8 +695,9 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
       bool cap_err = nh > hits_cap && nh > CH_HITS_LDS;
       if (cap_err) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); }
       else {
+        const bool from_rec = mr.x != NONE;
         uint32_t o = 0;
-        for (uint32_t pp = 0; pp < 3; pp++) {              // one contiguous block per pass run so far on this strand
+        if (!from_rec) for (uint32_t pp = 0; pp < 3; pp++) {              // one contiguous block per pass run so far on this strand
           const uint32_t c = w.blk_cnt[pp], bo = w.blk_off[pp];
           for (uint32_t q = lane; q < c; q += 64) hits[o + q] = make_uint2(pool[bo + 2 * q], pool[bo + 2 * q + 1]);
           o += c;
@@ -666,8 +706,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         // 1. per-reference counts of seed hits (:117-130)
         // prefix over the position-list lengths; hits[h].x becomes the list start
         uint32_t* hp = nh <= CH_HITS_LDS ? l_hp : gl;
-        uint32_t npos = 0;
-        for (uint32_t hb = 0; hb < nh; hb += 64) {
+        uint32_t npos = from_rec ? mr.y : 0u;
+        if (!from_rec) for (uint32_t hb = 0; hb < nh; hb += 64) {
           const uint32_t h = hb + lane;
           uint32_t lo = 0, ln = 0;
           if (h < nh) { const uint32_t id = hits[h].x; lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo; }
@@ -675,10 +715,11 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           if (h < nh) { hp[h] = npos + ex; hits[h].x = lo; }
           npos += tot;
         }
-        if (lane == 0) hp[nh] = npos;
+        if (lane == 0 && !from_rec) hp[nh] = npos;
         uint32_t ncand = 0;
         unsigned long long* keys = l_keys;
         SetArgs sa;
+        sa.rec = from_rec ? mpool + mr.x : nullptr;
         sa.pos_arr = ix.pos_arr; sa.hits = hits; sa.hp = hp; sa.nh = nh; sa.npos = npos; sa.num_seeds = (uint32_t)P.num_seeds;
         sa.gt = gt; sa.pairs_cap = pairs_cap; sa.keys_cap = keys_cap; sa.l_keys = l_keys; sa.gk = gk; sa.ctr = ctr;
         sa.s_ns = &s_ns; sa.s_nt = &s_nt; sa.s_ncand = &s_ncand;

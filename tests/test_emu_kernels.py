@@ -226,6 +226,23 @@ def test_a_small_bloom_bitmap_in_k_cand_only_marks_more_reads(emulator, tmp_path
         e.close()
 
 
+def test_candidate_sets_from_k_cand_records_and_from_the_position_lists_agree(emulator, tmp_path, monkeypatch):
+    """k_cand leaves the positions of a marked read as a record for k_chain (SMR_HANDOVER=1, the default); without it k_chain gathers them
+    itself through hits -> list bounds -> positions.  Same records."""
+    from helpers.workload import Workload
+    w = Workload(str(tmp_path), db_nt=300_000, n_reads=2500, frac_db=0.15, seed=29, family_size=8)
+    exp, ctr = w.oracle_records()
+    for h in ("1", "0"):
+        monkeypatch.setenv("SMR_HANDOVER", h)
+        e = smr.Engine(0)
+        got, c = w.gpu_records(e)
+        assert got == exp, "SMR_HANDOVER=%s: %d records differ" % (h, sum(1 for a, b in zip(got, exp) if a != b))
+        assert c["num_aligned"] == ctr["num_aligned"]
+        p = e.prof()
+        assert p.n_sw_fwd == ctr["n_sw_fwd"], (h, p.n_sw_fwd, ctr["n_sw_fwd"])
+        e.close()
+
+
 def test_sixteen_lane_walk_on_and_off_give_the_oracle_records(emulator, tmp_path, monkeypatch):
     """smr_quad.hpp: most marked reads of a background-dominated sample are decided 16 lanes per read (no task: pass ends; one task: scored four
     per wave; else k_chain's sequential walk).  With the stage switched off (SMR_QUAD=0) k_chain does everything as in round 2.  Same records."""

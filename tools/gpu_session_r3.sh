@@ -98,6 +98,9 @@ twoctx)
 twoctx8m)
   MB_CTX=3 timeout 300 python tools/hw_minibench2.py > $OUT/minibench_ctx3.log 2>&1; grep -E "context" $OUT/minibench_ctx3.log | tail -2 | cut -c1-300
   for N in 1 2; do MB_BATCH=8000000 MB_STEPS=2 MB_CTX=$N timeout 400 python tools/hw_minibench2.py > $OUT/minibench_8m_ctx$N.log 2>&1; grep -E "context" $OUT/minibench_8m_ctx$N.log | tail -2 | cut -c1-300; done ;;
+handab)
+  # k_cand's records of the marked reads' positions handed to k_chain (SMR_HANDOVER=1) against k_chain gathering them itself
+  for H in 0 1; do SMR_HANDOVER=$H timeout 300 python tools/hw_minibench.py > $OUT/minibench_handover$H.log 2>&1; echo "== SMR_HANDOVER=$H"; grep -E "SW kernel|kernels:" $OUT/minibench_handover$H.log | tail -2 | cut -c1-900; done ;;
 dropin)
   timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 mini)
