@@ -298,21 +298,24 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 #define CAND_HITS 64u                 // seed hits per read handled here
 #define CAND_BLOOM_WORDS 512u         // most Bloom words per read: 16 384 bits
 // dynamic LDS bytes of a block (16 reads): Bloom words | prefix of the list lengths | list starts
-#define CAND_LDS_BYTES(bw) (16u * ((bw) + CAND_HITS + 1u + 2u * CAND_HITS) * 4u)
-#define CAND_REC_MAX 256u             // positions of a marked read that k_cand hands over to k_chain as a record
+#define CAND_LDS_BYTES(bw, handover) (16u * ((bw) + CAND_HITS + 1u + ((handover) ? 2u : 1u) * CAND_HITS) * 4u)
+#define CAND_REC_MAX 64u              // positions of a marked read that k_cand hands over to k_chain as a record (99 % of the marked reads have no more)
+#define CAND_REC_WORDS 32u            // words of mpool per read of the batch (a block of 16 reads shares 512: room for its two or three marked reads)
 // The hand-over (mrec != nullptr): k_cand has walked hit -> list bounds -> positions of every read it marks; k_chain would repeat those three
 // dependent gathers one read per wave.  So a marked read with at most CAND_REC_MAX positions leaves a RECORD in mpool -- npos reference
 // numbers | npos reference positions | npos window positions, in the order of the walk -- and {offset, npos} in mrec[r] ({NONE, 0}: none);
 // k_chain builds the read's candidate set from it with coalesced loads.
 __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks, uint32_t bloom_words,
-                                              uint2* __restrict__ mrec, uint32_t* __restrict__ mpool, uint32_t mpool_words, uint32_t* __restrict__ mcur) {
+                                              uint2* __restrict__ mrec, uint32_t* __restrict__ mpool, size_t mpool_words) {
   SMR_DYN_LDS(uint32_t, cand_lds);
   const int lane = lane_id(), gl = lane & 15, g = (int)(threadIdx.x >> 4);
   uint32_t* const bloom = cand_lds + (size_t)g * bloom_words;                                  // this read's 32 * bloom_words bits
   uint32_t* const hp_ = cand_lds + 16u * bloom_words + (size_t)g * (CAND_HITS + 1u);
   uint32_t* const lo_ = cand_lds + 16u * (bloom_words + CAND_HITS + 1u) + (size_t)g * CAND_HITS;
   uint32_t* const wn_ = cand_lds + 16u * (bloom_words + 2u * CAND_HITS + 1u) + (size_t)g * CAND_HITS;   // window position of every hit
+  __shared__ uint32_t s_rec_cur;                            // words of the block's slice of mpool already given out
+  if (threadIdx.x == 0) s_rec_cur = 0;
   const uint32_t bshift = 32u - (5u + (uint32_t)__ffs((int)bloom_words) - 1u);
   const uint32_t r = blockIdx.x * 16u + (uint32_t)g;
   bool have = r < rd.n;
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
       const uint32_t c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
       const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
       const uint32_t id = pool[at];
-      wn_[h] = pool[at + 1];
+      if (mrec) wn_[h] = pool[at + 1];
       lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
     }
     uint32_t inc = ln;                                     // inclusive prefix inside the row of 16 lanes (row_shr:1/2/4/8)
@@ -359,12 +362,17 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   uint32_t rounds = scan ? (npos + 15u) / 16u : 0u;
   for (int d = 32; d > 0; d >>= 1) rounds = max(rounds, (uint32_t)__shfl_xor((int)rounds, d, 64));
   bool hit = false;
+  // (the first 64 positions of a read -- four rounds -- stay in registers with their hits: if the read is marked they become its record)
+  uint2 kp0 = make_uint2(0, 0), kp1 = kp0, kp2 = kp0, kp3 = kp0;
+  uint32_t kh0 = 0, kh1 = 0, kh2 = 0, kh3 = 0;
   for (uint32_t it = 0; it < rounds; it++) {
     const uint32_t p = it * 16u + (uint32_t)gl;
     if (scan && p < npos) {
       uint32_t h = 0;
       for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp_[t] <= p) h = t; }
-      const uint32_t seq = ix.pos_arr[lo_[h] + (p - hp_[h])].y;
+      const uint2 pa = ix.pos_arr[lo_[h] + (p - hp_[h])];
+      if (it == 0) { kp0 = pa; kh0 = h; } else if (it == 1) { kp1 = pa; kh1 = h; } else if (it == 2) { kp2 = pa; kh2 = h; } else if (it == 3) { kp3 = pa; kh3 = h; }
+      const uint32_t seq = pa.y;
       const uint32_t hb = (seq * 2654435761u) >> bshift;                // 14 bits for 512 words
       const uint32_t old = atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
       hit |= ((old >> (hb & 31u)) & 1u) != 0;
@@ -378,22 +386,21 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   // one byte per read says whether k_chain has to walk it: its waves claim reads by looking at 64 of these bytes, not at 64 per-read states
   if (r < rd.n && gl == 0) marks[r] = (eligible && mark) ? 1 : 0;
   if (mrec) {
+    // a block's records go into ITS slice of mpool (CAND_REC_WORDS per read of the block, placed by an LDS cursor: no atomic leaves the CU);
+    // a read that does not fit leaves no record
     const bool want = scan && mark && npos > 0 && npos <= CAND_REC_MAX;
     uint32_t off = NONE;
     if (want && gl == 0) {
-      const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = mpool_words / C_NSHARD;
-      const uint32_t old = atomicAdd(&mcur[shard], 3u * npos);
-      if (old + 3u * npos <= region) off = shard * region + old;
+      const uint32_t old = atomicAdd(&s_rec_cur, 3u * npos);
+      if (old + 3u * npos <= 16u * CAND_REC_WORDS && (size_t)(blockIdx.x + 1u) * 16u * CAND_REC_WORDS <= mpool_words) off = blockIdx.x * 16u * CAND_REC_WORDS + old;
     }
     off = (uint32_t)__shfl((int)off, lane & 48, 64);
-    for (uint32_t it = 0; it < rounds; it++) {             // the positions once more (their lines are in the caches), this time kept
-      const uint32_t p = it * 16u + (uint32_t)gl;
-      if (want && off != NONE && p < npos) {
-        uint32_t h = 0;
-        for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp_[t] <= p) h = t; }
-        const uint2 pa = ix.pos_arr[lo_[h] + (p - hp_[h])];
-        mpool[off + p] = pa.y; mpool[off + npos + p] = pa.x; mpool[off + 2u * npos + p] = wn_[h];
-      }
+    if (want && off != NONE) {
+      const uint32_t g0 = (uint32_t)gl;
+      if (g0 < npos) { mpool[off + g0] = kp0.y; mpool[off + npos + g0] = kp0.x; mpool[off + 2u * npos + g0] = wn_[kh0]; }
+      if (g0 + 16u < npos) { mpool[off + g0 + 16u] = kp1.y; mpool[off + npos + g0 + 16u] = kp1.x; mpool[off + 2u * npos + g0 + 16u] = wn_[kh1]; }
+      if (g0 + 32u < npos) { mpool[off + g0 + 32u] = kp2.y; mpool[off + npos + g0 + 32u] = kp2.x; mpool[off + 2u * npos + g0 + 32u] = wn_[kh2]; }
+      if (g0 + 48u < npos) { mpool[off + g0 + 48u] = kp3.y; mpool[off + npos + g0 + 48u] = kp3.x; mpool[off + 2u * npos + g0 + 48u] = wn_[kh3]; }
     }
     if (r < rd.n && gl == 0) mrec[r] = (want && off != NONE) ? make_uint2(off, npos) : make_uint2(NONE, 0u);
   }

@@ -94,9 +94,9 @@ struct smr_ctx {
   // the 16-lane walk (smr_quad.hpp): list of marked reads, parked Smith-Waterman tasks, cursors.  OFF by default: measured slower than leaving
   // those reads to k_chain (2.48 + 4.35 vs 5.96 ms per 2 M-read launch, profiles/r3s17_*) -- SMR_QUAD=1 switches it on
   int quad = getenv("SMR_QUAD") ? atoi(getenv("SMR_QUAD")) : 0;
-  // k_cand -> k_chain hand-over (smr_chain.hpp): {offset, npos} per read, the records, 64 sharded cursors (SMR_HANDOVER=0 switches it off)
+  // k_cand -> k_chain hand-over (smr_chain.hpp): {offset, npos} per read, the records (SMR_HANDOVER=0 switches it off)
   int handover = getenv("SMR_HANDOVER") ? atoi(getenv("SMR_HANDOVER")) : 1;
-  uint2* d_mrec = nullptr; uint32_t* d_mpool = nullptr; uint32_t* d_mcur = nullptr; size_t mrec_cap = 0, mpool_words = 0;
+  uint2* d_mrec = nullptr; uint32_t* d_mpool = nullptr; size_t mrec_cap = 0, mpool_words = 0;
   uint32_t* d_qlist = nullptr; QTask* d_qtasks = nullptr; uint32_t* d_qc = nullptr; size_t qlist_cap = 0, qtasks_cap = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
@@ -348,18 +348,16 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   int* const gb = c->b->max_len > SW_X4_MAX_ROWS ? c->d_bound : nullptr;
   uint8_t* const grd = c->b->max_len > SW_X4_MAX_ROWS ? c->d_rdq : nullptr;
   if (c->handover) {
-    // room for 24 words per read of the batch: a marked read leaves 3 words per position, an eighth of the reads are marked, ~40 positions each
-    const size_t want_w = (std::max<size_t>((size_t)c->b->n * 24, (size_t)1 << 20) + C_NSHARD - 1) / C_NSHARD * C_NSHARD;
+    // CAND_REC_WORDS words per read of the batch, one slice per block of k_cand
+    const size_t want_w = (size_t)((c->b->n + 15u) / 16u) * 16u * CAND_REC_WORDS;
     if (c->mrec_cap < c->b->n) { int rc = dev_alloc(c, &c->d_mrec, (size_t)c->b->n); if (rc) return rc; c->mrec_cap = c->b->n; }
     if (c->mpool_words < want_w) { int rc = dev_alloc(c, &c->d_mpool, want_w); if (rc) return rc; c->mpool_words = want_w; }
-    if (!c->d_mcur) { int rc = dev_alloc(c, &c->d_mcur, (size_t)C_NSHARD); if (rc) return rc; }
-    HIPCHK(c, hipMemsetAsync(c->d_mcur, 0, C_NSHARD * 4, c->stream));
   }
   uint2* const mrec = c->handover ? c->d_mrec : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
-  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
-                     mrec, c->d_mpool, (uint32_t)std::min<size_t>(c->mpool_words, 0xFFFFFFFFu), c->d_mcur);
+  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
+                     mrec, c->d_mpool, c->mpool_words);
   if (c->quad && P.num_seeds >= 1) {
     // the small majority of the marked reads, 16 lanes each: reads without any Smith-Waterman task end their pass, single tasks are scored four per wave
     ev_mark(c, KP_QUAD);
@@ -828,7 +826,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_marks); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
-  dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_qlist); dev_free(&c->d_qtasks); dev_free(&c->d_qc); dev_free(&c->d_mrec); dev_free(&c->d_mpool); dev_free(&c->d_mcur);
+  dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_qlist); dev_free(&c->d_qtasks); dev_free(&c->d_qc); dev_free(&c->d_mrec); dev_free(&c->d_mpool);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
   dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.fbits); dev_free(&c->sb.sn);
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
