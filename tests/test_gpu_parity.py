@@ -315,6 +315,21 @@ def test_pigeonhole_seed_kernel_equals_the_dfs_kernel(tmp_path, lnwin, db_nt, fa
     finally:
         e.close()
 
+@pytest.mark.parametrize("env", [("SMR_HANDOVER", "0"), ("SMR_CAND_BLOOM", "64"), ("SMR_QUAD", "1")], ids=lambda e: "%s=%s" % e)
+def test_optional_paths_of_the_candidate_stage_give_the_oracle_records(wl, monkeypatch, env):
+    """k_chain gathering a marked read's positions itself instead of taking k_cand's record; a 2 Kbit Bloom bitmap in k_cand (more reads
+    marked by false collisions); the 16-lane walk of small marked reads.  None of them may change a record (the emulator runs the same
+    three cases: tests/test_emu_kernels.py)."""
+    monkeypatch.setenv(*env)
+    e = smr.Engine(0)
+    try:
+        recs_o, ctr_o = wl.oracle_records()
+        recs_g, ctr_g = wl.gpu_records(e)
+        _compare(recs_g, recs_o, "%s=%s" % env)
+        assert ctr_g["num_aligned"] == ctr_o["num_aligned"]
+    finally:
+        e.close()
+
 
 def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
     """SMR_PG_CAND_CAP=8: most waves of k_seed_pg overflow their candidate pool and are searched again by the DFS kernel -- the records
