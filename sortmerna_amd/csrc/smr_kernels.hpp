@@ -14,9 +14,10 @@
 //  * integer work, VALU-issue / latency bound: no MFMA anywhere.
 //  * seed stage: the windows of the whole batch are binned by 9-mer key (counting sort) and searched in key order, one lane per
 //    search over the exact-key directories of the pigeonhole layout (k_seed_pg); lane-local hit lists in LDS.
-//  * k_cand: 16 lanes per read, four reads per wave.  k_chain: one wave per marked read, persistent blocks pulling chunks of 16 reads
-//    from an atomic counter (per-read work varies by orders of magnitude); the data-parallel pieces (position-list walks, bitonic
-//    sorts, LIS as patience piles across lanes, the SW systolic arrays) use all 64 lanes, control flow is wave-uniform.
+//  * k_cand: 16 lanes per read, four reads per wave; the positions of a read it marks are handed to k_chain as a record.  k_chain: one wave
+//    per marked read, persistent blocks claiming up to 64 reads at a time from an atomic counter (per-read work varies by orders of
+//    magnitude); the data-parallel pieces (position walks, bitonic sorts, LIS as patience piles across lanes, the SW systolic arrays) use
+//    all 64 lanes, control flow is wave-uniform.
 //  * k_trace_*: lanes across the band diagonals, one DP row per step; 4-bit direction flags in LDS (short reads) or a global tile.
 #pragma once
 #include <hip/hip_runtime.h>
