@@ -83,3 +83,19 @@ def test_unwrapped_multi_rank_command(tmp_path):
     assert out["config"]["nranks"] == 2
     r = out["roofline"]
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+def test_the_traffic_file_belongs_to_the_seed_kernels_in_the_tree():
+    """bench.py fills roofline.traffic from profiles/hbm_traffic.json only when the file's hash of the seed-stage sources is the tree's
+    (tools/pmc_traffic.py).  A stale file is not an error of the code -- the bench then prints traffic: null with a note -- so this only
+    warns: re-run `tools/gpu_session_r3.sh <tag> pmc` on the GPU box and copy <tag>/hbm_traffic.json into profiles/."""
+    import json
+    import sys
+    import warnings
+    sys.path.insert(0, os.path.join(paths.REPO, "tools"))
+    import pmc_traffic
+    tj = json.load(open(os.path.join(paths.REPO, "profiles", "hbm_traffic.json")))
+    assert set(tj["workload"]) == {"batch_reads", "read_len", "db_nt"} and tj["per_launch_bytes"]
+    if tj["kernel_src_sha"] != pmc_traffic.kernel_src_sha():
+        warnings.warn("profiles/hbm_traffic.json was measured on other seed-stage sources (%s, tree: %s): bench.py will print roofline.traffic = null"
+                      % (tj["kernel_src_sha"], pmc_traffic.kernel_src_sha()))
