@@ -363,12 +363,53 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   if (kb.size() < (size_t)nk * 4) { t_pos.join(); t_refs.join(); delete ix; set_err(err, errcap, "malformed kmer file: shorter than 4^(L/2) counts"); return SMR_ERR_IO; }
   for (uint32_t i = 0; i < nk && (size_t)(i + 1) * 4 <= kb.size(); i++) memcpy(&ix->lookup[i].count, kb.data() + (size_t)i * 4, 4);
   // mini-tries: one sequential walk over the BFS streams finds where each begins (the sizes in the file are the reference's in-memory
-  // sizes, index.cpp:178-190, not stream lengths), then key ranges are parsed and laid out by all threads into arenas of their own
+  // sizes, index.cpp:178-190, not stream lengths); the streams are parsed and laid out by all other threads WHILE that walk goes on --
+  // chunks of TRIE_CHUNK k-mers are handed out as soon as the walk has passed them, every chunk into a buffer of its own, and the arena is
+  // the chunks in k-mer order (so the layout does not depend on who parsed what)
   std::string why;
   bool tries_ok = true;
   {
     const uint8_t* b = tb.data(); const size_t bn = tb.size();
+    constexpr size_t TRIE_CHUNK = 256;
+    const size_t n_chunks = ((size_t)nk + TRIE_CHUNK - 1) / TRIE_CHUNK;
     std::vector<size_t> start(2 * (size_t)nk, (size_t)-1);
+    std::atomic<size_t> scanned{0};                        // k-mers whose stream boundaries are known
+    std::atomic<bool> scan_failed{false}, parse_failed{false};
+    std::atomic<size_t> next_chunk{0};
+    std::vector<std::vector<uint32_t>> local(n_chunks);
+    std::vector<size_t> rootw(2 * (size_t)nk, (size_t)-1), endw(2 * (size_t)nk, 0);     // word offsets inside the chunk's buffer
+    const uint32_t workers = std::max(1u, threads);
+    std::vector<TrieCounts> cnt(workers);
+    std::vector<std::string> twhy(workers);
+    auto work = [&](uint32_t tid) {
+      try {
+        std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::vector<uint8_t> flags;
+        for (;;) {
+          const size_t c = next_chunk.fetch_add(1);
+          if (c >= n_chunks) return;
+          const size_t lo = c * TRIE_CHUNK, hi = std::min((size_t)nk, lo + TRIE_CHUNK);
+          while (scanned.load(std::memory_order_acquire) < hi) {
+            if (scan_failed.load() || parse_failed.load()) return;
+            std::this_thread::yield();
+          }
+          std::vector<uint32_t>& buf = local[c];
+          for (size_t i = lo; i < hi; i++)
+            for (int j = 0; j < 2; j++) {
+              size_t o = start[2 * i + j];
+              if (o == (size_t)-1) continue;
+              if (!parse_bfs(b, bn, o, nodes, ents, flags) || !emit_minitrie(nodes, ents, buf, rootw[2 * i + j], cnt[tid], twhy[tid])) {
+                if (twhy[tid].empty()) twhy[tid] = "malformed stream";
+                parse_failed.store(true);
+                return;
+              }
+              endw[2 * i + j] = buf.size();
+            }
+          buf.resize((buf.size() + 3) & ~(size_t)3, 0);
+        }
+      } catch (const std::exception& e) { twhy[tid] = std::string("mini-tries: ") + e.what(); parse_failed.store(true); }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < workers; t++) th.emplace_back(work, t);
     {
       std::vector<uint8_t> flags;
       size_t o = 0;
@@ -377,55 +418,41 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
         if (o + 8 > bn) { tries_ok = false; why = "file ends before the last k-mer"; break; }      // the reference writes the two sizes for every k-mer (indexdb.cpp:719-742)
         memcpy(sz, b + o, 8);
         o += 8;
-        if (ix->lookup[i].count == 0) continue;       // index.cpp:190: tries are only read when count != 0
-        for (int j = 0; j < 2 && tries_ok; j++) {
-          if (sz[j] == 0) continue;
-          start[2 * (size_t)i + j] = o;
-          if (!skip_bfs(b, bn, o, flags)) { tries_ok = false; why = "truncated stream"; }
-        }
-      }
-    }
-    tm.lap("load: mini-trie boundaries");
-    std::vector<std::vector<uint32_t>> local(threads);
-    std::vector<TrieCounts> cnt(threads);
-    std::vector<size_t> t_lo(threads, 0), t_hi(threads, 0);
-    std::vector<size_t> rootw(2 * (size_t)nk, (size_t)-1), endw(2 * (size_t)nk, 0);     // thread-local word offsets
-    std::vector<std::string> twhy(threads);
-    if (tries_ok) parallel_for(threads, nk, [&](size_t lo, size_t hi, uint32_t tid) {
-      t_lo[tid] = lo; t_hi[tid] = hi;
-      std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::vector<uint8_t> flags;
-      for (size_t i = lo; i < hi; i++)
-        for (int j = 0; j < 2; j++) {
-          size_t o = start[2 * i + j];
-          if (o == (size_t)-1) continue;
-          if (!parse_bfs(b, bn, o, nodes, ents, flags) || !emit_minitrie(nodes, ents, local[tid], rootw[2 * i + j], cnt[tid], twhy[tid])) {
-            if (twhy[tid].empty()) twhy[tid] = "malformed stream";
-            return;
+        if (ix->lookup[i].count != 0)                   // index.cpp:190: tries are only read when count != 0
+          for (int j = 0; j < 2 && tries_ok; j++) {
+            if (sz[j] == 0) continue;
+            start[2 * (size_t)i + j] = o;
+            if (!skip_bfs(b, bn, o, flags)) { tries_ok = false; why = "truncated stream"; }
           }
-          endw[2 * i + j] = local[tid].size();
-        }
-      local[tid].resize((local[tid].size() + 3) & ~(size_t)3, 0);
-    });
-    for (uint32_t t = 0; t < threads && tries_ok; t++) if (!twhy[t].empty()) { tries_ok = false; why = twhy[t]; }
+        if (tries_ok && ((i + 1) % TRIE_CHUNK == 0 || i + 1 == nk)) scanned.store((size_t)i + 1, std::memory_order_release);
+        if (parse_failed.load(std::memory_order_relaxed)) break;
+      }
+      if (!tries_ok) scan_failed.store(true);
+    }
+    tm.lap("load: mini-trie boundaries (the streams behind the walk are being parsed meanwhile)");
+    work(0);                                               // the walking thread joins the others
+    for (auto& x : th) x.join();
+    for (uint32_t t = 0; t < workers && tries_ok; t++) if (!twhy[t].empty()) { tries_ok = false; why = twhy[t]; }
     size_t total = 0;
-    std::vector<size_t> tbase(threads, 0);
-    for (uint32_t t = 0; t < threads; t++) { tbase[t] = total; total += local[t].size(); }
+    std::vector<size_t> tbase(n_chunks, 0);
+    for (size_t c = 0; c < n_chunks; c++) { tbase[c] = total; total += local[c].size(); }
     if (tries_ok && total > 0xFFFFFFF0ull) { tries_ok = false; why = "trie arena exceeds 2^32 words"; }
     if (tries_ok) {
       ix->trie.resize(total);
-      parallel_for(threads, threads, [&](size_t lo, size_t hi, uint32_t) {
-        for (size_t t = lo; t < hi; t++) {
-          if (!local[t].empty()) memcpy(ix->trie.data() + tbase[t], local[t].data(), local[t].size() * 4);
-          for (size_t i = t_lo[t]; i < t_hi[t]; i++)
+      parallel_for(threads, n_chunks, [&](size_t lo, size_t hi, uint32_t) {
+        for (size_t c = lo; c < hi; c++) {
+          if (!local[c].empty()) memcpy(ix->trie.data() + tbase[c], local[c].data(), local[c].size() * 4);
+          std::vector<uint32_t>().swap(local[c]);
+          for (size_t i = c * TRIE_CHUNK; i < std::min((size_t)nk, (c + 1) * TRIE_CHUNK); i++)
             for (int j = 0; j < 2; j++) {
               if (rootw[2 * i + j] == (size_t)-1) continue;
-              const uint32_t root = (uint32_t)(tbase[t] + rootw[2 * i + j]), words = (uint32_t)(endw[2 * i + j] - rootw[2 * i + j]);
+              const uint32_t root = (uint32_t)(tbase[c] + rootw[2 * i + j]), words = (uint32_t)(endw[2 * i + j] - rootw[2 * i + j]);
               if (j == 0) { ix->lookup[i].rootF = root; ix->lookup[i].wordsF = words; }
               else { ix->lookup[i].rootR = root; ix->lookup[i].wordsR = words; }
             }
         }
       });
-      for (uint32_t t = 0; t < threads; t++) { ix->n_nodes += cnt[t].n_nodes; ix->n_buckets += cnt[t].n_buckets; ix->n_entries += cnt[t].n_entries; }
+      for (uint32_t t = 0; t < workers; t++) { ix->n_nodes += cnt[t].n_nodes; ix->n_buckets += cnt[t].n_buckets; ix->n_entries += cnt[t].n_entries; }
     }
   }
   tm.lap("load: mini-tries");
