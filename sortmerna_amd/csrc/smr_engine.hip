@@ -14,6 +14,7 @@
 #include "smr_kernels.hpp"
 #include "smr_ibuild.hpp"
 #include "smr_pgbuild.hpp"
+#include "smr_hostmem.hpp"
 
 using namespace smr;
 
@@ -560,6 +561,7 @@ int ib_part_device(void* user, const smr::IBuildInput& in, smr_index& ix, std::s
     hipLaunchKernelGGL(smr::k_ib_emit, dim3(gT), dim3(256), 0, c->stream, (const smr::u64*)d_ftail, (const smr::u64*)d_rtail, (const uint32_t*)d_fstart, (const uint32_t*)d_rstart,
                        NK, (int)T, burst_depth, (const smr::u64*)d_toff, d_trie, d_lookup);
     // back to the host object
+    reserve_huge(ix.trie, words); reserve_huge(ix.pos_arr, (size_t)2 * n_pos);      // (2 MB pages for the two GB-sized arrays that the copies below fill)
     ix.lookup.resize(NK); ix.trie.resize(words); ix.pos_off.resize((size_t)n_ids + 1); ix.pos_arr.resize((size_t)2 * n_pos);
     std::vector<uint32_t> hn((size_t)2 * NK), hb((size_t)2 * NK);
     HIPCHK(c, hipMemcpyAsync(ix.lookup.data(), d_lookup, (size_t)NK * sizeof(smr::Lookup), hipMemcpyDeviceToHost, c->stream));

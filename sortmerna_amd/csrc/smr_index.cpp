@@ -29,6 +29,7 @@
 
 #include "smr_host.hpp"
 #include "smr_trie_layout.hpp"
+#include "smr_hostmem.hpp"
 
 using namespace smr;
 
@@ -167,7 +168,7 @@ bool load_refs(const std::string& fasta, uint64_t start, uint32_t numseq, smr_in
   const uint8_t* b = mf.data();
   ix.ref_seq.clear(); ix.ref_off.assign(1, 0);
   size_t o = (size_t)start, n = mf.size();
-  ix.ref_seq.reserve(n > o ? n - o : 0);
+  reserve_huge(ix.ref_seq, n > o ? n - o : 0);
   bool have = false; uint32_t done = 0;
   while (o < n && done < numseq) {
     size_t e = o;
@@ -337,6 +338,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       if (total > 0xFFFFFFFFull) { pos_err = "more than 2^32 positions"; return; }
       ix->pos_off[i + 1] = (uint32_t)total;
     }
+    reserve_huge(ix->pos_arr, (size_t)total * 2);
     ix->pos_arr.resize((size_t)total * 2);
     parallel_for(std::max(1u, threads / 4), nid, [&](size_t lo, size_t hi, uint32_t) {
       std::vector<std::pair<uint32_t, uint32_t>> v;
@@ -432,13 +434,16 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
     tm.lap("load: mini-trie boundaries (the streams behind the walk are being parsed meanwhile)");
     work(0);                                               // the walking thread joins the others
     for (auto& x : th) x.join();
+    tm.lap("load: mini-tries parsed");
     for (uint32_t t = 0; t < workers && tries_ok; t++) if (!twhy[t].empty()) { tries_ok = false; why = twhy[t]; }
     size_t total = 0;
     std::vector<size_t> tbase(n_chunks, 0);
     for (size_t c = 0; c < n_chunks; c++) { tbase[c] = total; total += local[c].size(); }
     if (tries_ok && total > 0xFFFFFFF0ull) { tries_ok = false; why = "trie arena exceeds 2^32 words"; }
     if (tries_ok) {
+      reserve_huge(ix->trie, total);
       ix->trie.resize(total);
+      tm.lap("load: arena sized");
       parallel_for(threads, n_chunks, [&](size_t lo, size_t hi, uint32_t) {
         for (size_t c = lo; c < hi; c++) {
           if (!local[c].empty()) memcpy(ix->trie.data() + tbase[c], local[c].data(), local[c].size() * 4);
