@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "smr_host.hpp"
+#include "smr_hostmem.hpp"
 
 namespace {
 inline int code_of(unsigned char c) {
@@ -251,8 +252,10 @@ int load_fastx_impl(const char* path, uint32_t threads, bool keep_text, smr_read
   auto r = new smr_reads();
   r->n = (uint32_t)nrec[threads];
   r->fastq = fastq;
-  if (keep_text) { r->text_owner = bp; r->text = p; r->text_n = n; r->hdr_off.resize(r->n); r->seq_off.resize(r->n); }
-  r->len.resize(r->n); r->rec_off.resize((size_t)r->n + 1); r->words.resize(nword[threads]);   // value-initialised (zero); first touched below, in parallel
+  // (the arrays are value-initialised by the one thread that sizes them: 2 MB pages make that first touch cheap -- smr_hostmem.hpp)
+  if (keep_text) { r->text_owner = bp; r->text = p; r->text_n = n; smr::reserve_huge(r->hdr_off, r->n); smr::reserve_huge(r->seq_off, r->n); r->hdr_off.resize(r->n); r->seq_off.resize(r->n); }
+  smr::reserve_huge(r->len, r->n); smr::reserve_huge(r->rec_off, (size_t)r->n + 1); smr::reserve_huge(r->words, nword[threads]);
+  r->len.resize(r->n); r->rec_off.resize((size_t)r->n + 1); r->words.resize(nword[threads]);
   r->rec_off[0] = 0;
   uint32_t lo = 0xffffffffu, hi = 0;
   for (uint32_t t = 0; t < threads; t++) { r->total_len += tlen[t]; lo = std::min(lo, tmin[t]); hi = std::max(hi, tmax[t]); }
