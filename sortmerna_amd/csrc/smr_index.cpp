@@ -314,7 +314,8 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       !pb.open(std::string(prefix) + ".pos_" + p + ".dat")) {
     delete ix; set_err(err, errcap, "cannot read index part files"); return SMR_ERR_IO;
   }
-  const uint32_t threads = std::min<uint32_t>(64, std::max(1u, std::thread::hardware_concurrency()));
+  uint32_t threads = std::min<uint32_t>(64, std::max(1u, std::thread::hardware_concurrency()));
+  if (const char* e = getenv("SMR_LOAD_THREADS")) threads = std::min<uint32_t>(256, std::max(1, atoi(e)));      // test aid: many loader threads on a small machine
   // the reference sequences and the position lists load in threads of their own while the tries are parsed
   bool refs_ok = false;
   // (an exception inside a std::thread would end the process: the bodies catch and report -- a damaged file must come back as SMR_ERR_IO)
@@ -365,9 +366,12 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
   if (kb.size() < (size_t)nk * 4) { t_pos.join(); t_refs.join(); delete ix; set_err(err, errcap, "malformed kmer file: shorter than 4^(L/2) counts"); return SMR_ERR_IO; }
   for (uint32_t i = 0; i < nk && (size_t)(i + 1) * 4 <= kb.size(); i++) memcpy(&ix->lookup[i].count, kb.data() + (size_t)i * 4, 4);
   // mini-tries: one sequential walk over the BFS streams finds where each begins (the sizes in the file are the reference's in-memory
-  // sizes, index.cpp:178-190, not stream lengths); the streams are parsed and laid out by all other threads WHILE that walk goes on --
-  // chunks of TRIE_CHUNK k-mers are handed out as soon as the walk has passed them, every chunk into a buffer of its own, and the arena is
-  // the chunks in k-mer order (so the layout does not depend on who parsed what)
+  // sizes, index.cpp:178-190, not stream lengths); then the streams are parsed and laid out by all threads, chunks of TRIE_CHUNK k-mers
+  // handed out dynamically (the key ranges are far from equally heavy), every chunk into a vector of its exact size, and the arena is the
+  // chunks in k-mer order (so the layout does not depend on who parsed what).
+  // (Walk and parse side by side -- chunks handed out as soon as the walk had passed them -- was measured too: 4.3 s -> 2.0 s on 8 cores,
+  // but on the 64 loader threads of the GPU box the WALK went from 0.56 s to 4.3 s: its page faults on the mapped file queue behind the
+  // address-space lock that the parsers' allocations take for writing.  profiles/r3s29_e2e_quick.log)
   std::string why;
   bool tries_ok = true;
   {
@@ -375,26 +379,38 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
     constexpr size_t TRIE_CHUNK = 256;
     const size_t n_chunks = ((size_t)nk + TRIE_CHUNK - 1) / TRIE_CHUNK;
     std::vector<size_t> start(2 * (size_t)nk, (size_t)-1);
-    std::atomic<size_t> scanned{0};                        // k-mers whose stream boundaries are known
-    std::atomic<bool> scan_failed{false}, parse_failed{false};
+    {
+      std::vector<uint8_t> flags;
+      size_t o = 0;
+      for (uint32_t i = 0; i < nk && tries_ok; i++) {
+        uint32_t sz[2] = {0, 0};
+        if (o + 8 > bn) { tries_ok = false; why = "file ends before the last k-mer"; break; }      // the reference writes the two sizes for every k-mer (indexdb.cpp:719-742)
+        memcpy(sz, b + o, 8);
+        o += 8;
+        if (ix->lookup[i].count == 0) continue;       // index.cpp:190: tries are only read when count != 0
+        for (int j = 0; j < 2 && tries_ok; j++) {
+          if (sz[j] == 0) continue;
+          start[2 * (size_t)i + j] = o;
+          if (!skip_bfs(b, bn, o, flags)) { tries_ok = false; why = "truncated stream"; }
+        }
+      }
+    }
+    tm.lap("load: mini-trie boundaries");
+    std::atomic<bool> parse_failed{false};
     std::atomic<size_t> next_chunk{0};
     std::vector<std::vector<uint32_t>> local(n_chunks);
-    std::vector<size_t> rootw(2 * (size_t)nk, (size_t)-1), endw(2 * (size_t)nk, 0);     // word offsets inside the chunk's buffer
+    std::vector<size_t> rootw(2 * (size_t)nk, (size_t)-1), endw(2 * (size_t)nk, 0);     // word offsets inside the chunk's vector
     const uint32_t workers = std::max(1u, threads);
     std::vector<TrieCounts> cnt(workers);
     std::vector<std::string> twhy(workers);
     auto work = [&](uint32_t tid) {
       try {
-        std::vector<TmpNode> nodes; std::vector<uint32_t> ents; std::vector<uint8_t> flags;
+        std::vector<TmpNode> nodes; std::vector<uint32_t> ents, buf; std::vector<uint8_t> flags;
         for (;;) {
           const size_t c = next_chunk.fetch_add(1);
-          if (c >= n_chunks) return;
+          if (c >= n_chunks || parse_failed.load(std::memory_order_relaxed)) return;
           const size_t lo = c * TRIE_CHUNK, hi = std::min((size_t)nk, lo + TRIE_CHUNK);
-          while (scanned.load(std::memory_order_acquire) < hi) {
-            if (scan_failed.load() || parse_failed.load()) return;
-            std::this_thread::yield();
-          }
-          std::vector<uint32_t>& buf = local[c];
+          buf.clear();                                 // the thread's scratch keeps its capacity: one allocation per chunk (the exact copy below), not a series of regrowths
           for (size_t i = lo; i < hi; i++)
             for (int j = 0; j < 2; j++) {
               size_t o = start[2 * i + j];
@@ -407,33 +423,16 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
               endw[2 * i + j] = buf.size();
             }
           buf.resize((buf.size() + 3) & ~(size_t)3, 0);
+          local[c].assign(buf.begin(), buf.end());
         }
       } catch (const std::exception& e) { twhy[tid] = std::string("mini-tries: ") + e.what(); parse_failed.store(true); }
     };
-    std::vector<std::thread> th;
-    for (uint32_t t = 1; t < workers; t++) th.emplace_back(work, t);
-    {
-      std::vector<uint8_t> flags;
-      size_t o = 0;
-      for (uint32_t i = 0; i < nk && tries_ok; i++) {
-        uint32_t sz[2] = {0, 0};
-        if (o + 8 > bn) { tries_ok = false; why = "file ends before the last k-mer"; break; }      // the reference writes the two sizes for every k-mer (indexdb.cpp:719-742)
-        memcpy(sz, b + o, 8);
-        o += 8;
-        if (ix->lookup[i].count != 0)                   // index.cpp:190: tries are only read when count != 0
-          for (int j = 0; j < 2 && tries_ok; j++) {
-            if (sz[j] == 0) continue;
-            start[2 * (size_t)i + j] = o;
-            if (!skip_bfs(b, bn, o, flags)) { tries_ok = false; why = "truncated stream"; }
-          }
-        if (tries_ok && ((i + 1) % TRIE_CHUNK == 0 || i + 1 == nk)) scanned.store((size_t)i + 1, std::memory_order_release);
-        if (parse_failed.load(std::memory_order_relaxed)) break;
-      }
-      if (!tries_ok) scan_failed.store(true);
+    if (tries_ok) {
+      std::vector<std::thread> th;
+      for (uint32_t t = 1; t < workers; t++) th.emplace_back(work, t);
+      work(0);
+      for (auto& x : th) x.join();
     }
-    tm.lap("load: mini-trie boundaries (the streams behind the walk are being parsed meanwhile)");
-    work(0);                                               // the walking thread joins the others
-    for (auto& x : th) x.join();
     tm.lap("load: mini-tries parsed");
     for (uint32_t t = 0; t < workers && tries_ok; t++) if (!twhy[t].empty()) { tries_ok = false; why = twhy[t]; }
     size_t total = 0;
@@ -447,7 +446,6 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       parallel_for(threads, n_chunks, [&](size_t lo, size_t hi, uint32_t) {
         for (size_t c = lo; c < hi; c++) {
           if (!local[c].empty()) memcpy(ix->trie.data() + tbase[c], local[c].data(), local[c].size() * 4);
-          std::vector<uint32_t>().swap(local[c]);
           for (size_t i = c * TRIE_CHUNK; i < std::min((size_t)nk, (c + 1) * TRIE_CHUNK); i++)
             for (int j = 0; j < 2; j++) {
               if (rootw[2 * i + j] == (size_t)-1) continue;
