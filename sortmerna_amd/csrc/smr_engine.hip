@@ -78,6 +78,9 @@ struct smr_ctx {
   // (16 KB of LDS per block: the 8 blocks per CU that the wave slots allow)
   uint32_t cand_bloom = 128;
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
+  // k_seed_pg: waves of the launch (0: one per wave chunk the batch can have; else a wave walks chunks it, it + grid, ...), XCD-aware chunk order
+  uint32_t pg_grid = getenv("SMR_PG_GRID") ? (uint32_t)atoi(getenv("SMR_PG_GRID")) : 65536u;
+  int pg_swz = getenv("SMR_PG_SWZ") ? atoi(getenv("SMR_PG_SWZ")) : 0;
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
   uint32_t chain_blocks = 0;
@@ -124,6 +127,9 @@ namespace {
       return SMR_ERR_DEVICE;                                                                     \
     }                                                                                            \
   } while (0)
+
+// every write of the context's error string goes through here (smr_reads_upload_batch runs on a second host thread)
+void set_err(smr_ctx* c, const std::string& msg) { std::lock_guard<std::mutex> l_(c->err_m); c->err = msg; }
 
 template <class T> int dev_alloc(smr_ctx* c, T** p, size_t count) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -225,82 +231,114 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   for (int p = 0; p < 3; p++) mw = std::max(mw, num_windows(c->b->max_len, P.lnwin, P.skip[p]));
   const uint64_t slots = (uint64_t)std::max(c->b->n, 1u) * mw;
   const uint32_t nk = 2u << P.lnwin;                      // 2 x 4^(L/2) bins: forward and reverse keys
-  if (2 * slots >= 0xFFFFFF00ull) { c->err = "batch too large for the seed stage (reads x windows >= 2^31): use smaller batches"; return SMR_ERR_CAPACITY; }
+  if (2 * slots >= 0xFFFFFF00ull) { set_err(c, "batch too large for the seed stage (reads x windows >= 2^31): use smaller batches"); return SMR_ERR_CAPACITY; }
   int rc;
   if (c->sb_nk < nk) {
     if ((rc = dev_alloc(c, &c->sb.chist, (size_t)4096 + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 2))) return rc;
     if (!c->sb.rows && (rc = dev_alloc(c, &c->sb.rows, (size_t)SEED_KEY_BLOCKS * 4096))) return rc;
     if (!c->sb.bcnt && (rc = dev_alloc(c, &c->sb.bcnt, (size_t)SEED_KEY_BLOCKS))) return rc;
     if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
     if (!c->sb.sn && (rc = dev_alloc(c, &c->sb.sn, SN_COUNT))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.emap, (size_t)(nk / 2) / 16 + 1))) return rc;
     c->sb_nk = nk;
   }
   if (c->sb_slots < slots) {
-    // a forward and a reverse tuple per window; tmp is cut into one region per block of k_seed_keys (whole tiles: up to one tile per block more)
-    const size_t tmp_slots = 2 * (size_t)SEED_TILE * ((slots + SEED_TILE - 1) / SEED_TILE + SEED_KEY_BLOCKS);
-    if ((rc = dev_alloc(c, &c->sb.tmp, tmp_slots))) return rc;
+    // a forward and a reverse tuple per window; tmp is cut into one region per block of k_seed_keys (the slots of its reads)
+    if ((rc = dev_alloc(c, &c->sb.tmp, 2 * slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.mid, 2 * slots))) return rc;
     if ((rc = dev_alloc(c, &c->sb.srt, 2 * slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.wseg, slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.fbits, slots / 32 + 2))) return rc;
+    for (int d = 0; d < 2; d++) {
+      if ((rc = dev_alloc(c, &c->sb.wseg[d], slots))) return rc;
+      if ((rc = dev_alloc(c, &c->sb.fbits[d], slots / 32 + 2))) return rc;
+    }
+    if ((rc = dev_alloc(c, &c->sb.wbin, 2 * slots / 64 + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.zbits, slots / 32 + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.gflag, slots / 2048 + 2))) return rc;
     c->sb_slots = slots;
   }
   c->sb.nk = nk; c->sb.nkh = nk / 2;
   c->sb.fb = std::min<uint32_t>(9, P.lnwin); c->sb.nc = nk >> c->sb.fb;       // L <= 20: at most 4096 coarse bins
+  c->sb.cb = 2 * P.partialwin; c->sb.kbits = P.lnwin + 1;
   return SMR_OK;
 }
 
-// the seed stage of one (strand, pass): forward searches of all windows, then reverse searches (smr_seed.hpp)
+// the seed stage of one (strand, pass): the forward and reverse half-seed searches of all windows (smr_seed.hpp)
 int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   int rc = ensure_seed_bufs(c, P); if (rc) return rc;
-  if (c->b->n > 0xFFFFFFu || c->b->max_len > 0xFFFFu) { c->err = "seed stage limits: <= 16M reads per batch, reads <= 65535 nt"; return SMR_ERR_CAPACITY; }
+  if (c->b->max_len > 0xFFFFu) { set_err(c, "seed stage limit: reads <= 65535 nt"); return SMR_ERR_CAPACITY; }
+  if (di.n_ids >= 0x7FFFFFFFu) { set_err(c, "seed stage limit: < 2^31 - 1 distinct seeds per index part"); return SMR_ERR_CAPACITY; }
   SeedBufs sb = c->sb;
   sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
   const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
   sb.cap_tuples = (uint32_t)(2 * slots);
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
-  const uint32_t n_tiles = (uint32_t)((slots + SEED_TILE - 1) / SEED_TILE);
-  sb.kb = std::max<uint32_t>(1u, std::min<uint32_t>(n_tiles, SEED_KEY_BLOCKS));
-  sb.tpb = std::max<uint32_t>(1u, (n_tiles + sb.kb - 1) / sb.kb);
+  // k_seed_keys: reads per wave trip (a power of two; their packed records must fit the wave's LDS stage) and lanes per read; reads per block
+  const uint32_t rec_words = (c->b->max_len + 15) / 16 + (c->b->max_len + 31) / 32;
+  const bool staged = rec_words <= SEED_STAGE_WORDS;
+  uint32_t rwr = 64;
+  while (rwr > 1 && (uint64_t)rwr * rec_words > SEED_STAGE_WORDS) rwr >>= 1;
+  uint32_t gsh = 0;
+  while ((64u >> gsh) > rwr) gsh++;
+  sb.g_shift = gsh;
+  const uint32_t per_trip = SEED_WAVES * rwr;
+  const uint32_t trips = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)sb.n + (uint64_t)per_trip * SEED_KEY_BLOCKS - 1) / ((uint64_t)per_trip * SEED_KEY_BLOCKS)));
+  sb.rpb = trips * per_trip;
+  sb.kb = std::max<uint32_t>(1u, (sb.n + sb.rpb - 1) / sb.rpb);
+  if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
+  const bool mapped = (sb.nkh / 16) * 4 <= 64 * 1024;
+  const size_t lds_keys = (size_t)4 * (((sb.nc + 3u) & ~3u) + (mapped ? sb.nkh / 16 : 0u) + (staged ? SEED_WAVES * (SEED_STAGE_WORDS + 8u) : 0u));
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
-  const uint32_t pgw = (uint32_t)std::max<size_t>(1, std::min<size_t>(PG_WAVES, (60 * 1024) / lds_pg1));      // waves per block of k_seed_pg
-  const size_t lds_pg = lds_pg1 * pgw;
+  const size_t lds_pg = lds_pg1;
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((slots + 63) / 64));     // (every kernel checks its range: a batch without a single window launches one idle block each)
-  const size_t lds_split = (size_t)3 * sb.nc * 4 + (size_t)SEED_PIECE * sizeof(SeedTmp), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTmp);
+  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
+  const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
   if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     c->split_lds_attr = lds_split;
   }
+  // the instantiation of k_seed_keys for this batch
+  typedef void (*keys_fn)(DReads, DParams, int, SeedBufs, const RWork*, unsigned long long*);
+  keys_fn kf;
+  if (gsh == 0) kf = mapped ? k_seed_keys<true, true, true> : k_seed_keys<true, true, false>;
+  else if (staged) kf = mapped ? k_seed_keys<false, true, true> : k_seed_keys<false, true, false>;
+  else kf = mapped ? k_seed_keys<false, false, true> : k_seed_keys<false, false, false>;
+  if (lds_keys > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
   ev_mark(c, KP_KEYS);
   HIPCHK(c, hipMemsetAsync(sb.chist, 0, ((size_t)sb.nc + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(sb.fbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
-  hipLaunchKernelGGL(k_seed_keys, dim3(sb.kb), dim3(1024), (size_t)sb.nc * 4, c->stream, dreads(c), dindex(di), P, pass, sb, c->b->d_rw, c->b->d_ctr, n_tiles);
+  for (int d = 0; d < 2; d++) HIPCHK(c, hipMemsetAsync(sb.fbits[d], 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
+  HIPCHK(c, hipMemsetAsync(sb.zbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(sb.gflag, 0, (size_t)(slots / 2048 + 2) * 4, c->stream));
+  hipLaunchKernelGGL(k_seed_emap, dim3((sb.nkh / 16 + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)di.lkc, sb.nkh, P.minoccur, sb.emap);
+  hipLaunchKernelGGL(kf, dim3(sb.kb), dim3(64 * SEED_WAVES), lds_keys, c->stream, dreads(c), P, pass, sb, (const RWork*)c->b->d_rw, c->b->d_ctr);
   // the two-level sort of the stage's forward and reverse tuples (smr_seed.hpp)
   ev_mark(c, KP_SPLIT);                                    // (with the scans of the block histograms in front of it)
   hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
   hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_wbin, dim3((gw + 255) / 256), dim3(256), 0, c->stream, sb);
   hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
   ev_mark(c, KP_BINS);
   hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
-  for (int dir = 0; dir < 2; dir++) {
-    const uint32_t* no_redo = nullptr;
-    ev_mark(c, dir ? KP_PG1 : KP_PG0);
-    if (c->seed_exact) {
-      if (dir == 0) hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
-      else hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
-    } else {
-      // pigeonhole search; the (rare) waves whose candidate pool overflowed are searched again by the DFS kernel
-      const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
+  const uint32_t* no_redo = nullptr;
+  if (c->seed_exact) {
+    ev_mark(c, KP_PG0);
+    hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
+    ev_mark(c, KP_PG1);
+    hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
+  } else {
+    // pigeonhole search; the (rare) waves whose candidate pool overflowed are searched again by the DFS kernel
+    const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
+    const uint32_t gp = c->pg_grid ? std::min<uint32_t>((gw + 7u) & ~7u, c->pg_grid) : ((gw + 7u) & ~7u);
+    for (int dir = 0; dir < 2; dir++) {
       HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
+      ev_mark(c, dir ? KP_PG1 : KP_PG0);
       if (dir == 0) {
-        hipLaunchKernelGGL(k_seed_pg<0>, dim3((gw + pgw - 1) / pgw), dim3(64 * pgw), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       } else {
-        hipLaunchKernelGGL(k_seed_pg<1>, dim3((gw + pgw - 1) / pgw), dim3(64 * pgw), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr);
+        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       }
     }
@@ -830,7 +868,8 @@ extern "C" void smr_destroy(smr_ctx* c) {
   }
   dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_qlist); dev_free(&c->d_qtasks); dev_free(&c->d_qc); dev_free(&c->d_mrec); dev_free(&c->d_mpool);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
-  dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.wseg); dev_free(&c->sb.fbits); dev_free(&c->sb.sn);
+  dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
+  for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
   for (auto& m : c->events) (void)hipEventDestroy(m.e);
@@ -1626,8 +1665,8 @@ extern "C" int smr_prof_kernels(smr_ctx* c, smr_kprof* out, uint32_t cap, uint32
   }
   const unsigned long long T = h[C_TUP_ALL];
   unsigned long long bytes[KP_COUNT] = {};
-  bytes[KP_KEYS] = h[C_B_KEYS] + sizeof(SeedTmp) * T;                 // its inputs (counted by the kernel) + every tuple written once
-  bytes[KP_SPLIT] = bytes[KP_BINS] = 2 * sizeof(SeedTmp) * T;         // each of the two sort passes reads and writes every tuple once
+  bytes[KP_KEYS] = h[C_B_KEYS] + sizeof(SeedTup) * T;                 // its inputs (counted by the kernel) + every tuple written once
+  bytes[KP_SPLIT] = bytes[KP_BINS] = 2 * sizeof(SeedTup) * T;         // each of the two sort passes reads and writes every tuple once
   bytes[KP_PG0] = h[C_B_PG0]; bytes[KP_PG1] = h[C_B_PG1]; bytes[KP_FINISH] = h[C_B_FIN];
   uint32_t n = 0;
   for (int k = 0; k < KP_COUNT && n < cap; k++, n++) {

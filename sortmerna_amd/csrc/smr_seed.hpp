@@ -137,143 +137,214 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
 enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples
 
-struct SeedTmp { uint32_t key, lo, hi; };               // 12 bytes; payload = lo | hi << 32: read | win_pos << 24 | chars << 40
-__device__ __forceinline__ unsigned long long seed_payload(const SeedTmp& t) { return (unsigned long long)t.lo | ((unsigned long long)t.hi << 32); }
+// The tuples of the seed stage are 8 bytes (round 3: 12).  A tuple = one half-seed search of one window: its 9-mer key (direction in the top
+// bit: forward keys [0, nkh), reverse keys [nkh, 2 nkh)), the pw chars that feed the automaton, and the window's SLOT = read * maxwin +
+// window index (< 2^31: what wseg / fbits are indexed with -- nobody downstream needs read and window apart).  Key + chars + slot are
+// 2 L + 1 + 32 bits, too many; but a block of k_seed_keys owns a contiguous run of reads, so in ITS region of tmp the slot is stored relative
+// to the block's first slot, and from the first sort pass on the coarse key bits are implied by where the tuple lies:
+//   tmp        key (kbits = L + 1) | chars (cb = L) << kbits | block-relative slot << (kbits + cb)
+//   mid, srt   slot (32) | chars << 32 | fine key bits (fb) << (32 + cb)            coarse bin of srt[i]: wbin[i / 64], then cbase
+typedef unsigned long long SeedTup;
+struct SeedKey { uint32_t slot, chars, key; };          // a decoded tuple of srt
 
-#define SEED_KEY_BLOCKS 2048u                              // most blocks of k_seed_keys / k_seed_split (rows of the histogram matrix)
-#define SEED_TILE 1024u                                   // windows per tile of k_seed_keys
+#define SEED_KEY_BLOCKS 2048u                             // most blocks of k_seed_keys / k_seed_split (rows of the histogram matrix)
+#define SEED_WAVES 16u                                    // waves per block of k_seed_keys
+#define SEED_STAGE_WORDS 1280u                            // LDS words in which a wave of k_seed_keys stages the packed records of the reads of one trip (64 reads of <= 208 letters)
 #ifndef SEED_PIECE
 #define SEED_PIECE 4096u                                  // tuples a sort pass stages in LDS at a time
 #endif
+#define SEED_SEG_MERGED 0x80000000u                       // header bit of a reverse segment whose list is final (written by k_seed_search<1>: forward hits included)
+#define SEED_CAND_COND 0x80000000u                        // bit of an id in a reverse segment of k_seed_pg: this candidate is a 0-error match
 struct SeedBufs {
   uint32_t* chist;           // [nc + 1] tuples per COARSE bin (key >> fb)
   uint32_t* cbase;           // [nc + 1] exclusive scan of chist
   uint32_t* rows;            // [kb][nc] tuples of block b of k_seed_keys per coarse bin; after k_seed_colscan: where its first tuple of that bin goes in mid
-  uint32_t* bcnt;            // [kb] tuples block b wrote (at tmp[2 * SEED_TILE * tpb * b ...), compact)
-  SeedTmp* tmp;              // unsorted tuples, one compact region per block of k_seed_keys
-  SeedTmp* mid;              // tuples grouped by coarse bin
-  SeedTmp* srt;              // tuples in key order
-  uint32_t* wseg;            // [maxwin][n] (window-major: k_seed_finish's threads = reads read it coalesced) pool offset of the window's hit segment | SEED_ZERO_BIT; valid where the window's bit in fbits is set
-  uint32_t* fbits;           // [ceil(maxwin * n / 32)] bit per window slot: the window has a hit segment
+  uint32_t* bcnt;            // [kb] tuples block b wrote (at tmp[2 * rpb * maxwin * b ...), compact)
+  SeedTup* tmp;              // unsorted tuples, one compact region per block of k_seed_keys
+  SeedTup* mid;              // tuples grouped by coarse bin
+  SeedTup* srt;              // tuples in key order
+  uint32_t* wseg[2];         // [slot] pool offset of the window's forward / reverse hit segment | SEED_ZERO_BIT; valid where the slot's bit in fbits[d] is set
+  uint32_t* fbits[2];        // bit per slot (read-major: a read's windows are consecutive bits): the window has a forward / reverse segment
+  uint32_t* zbits;           // bit per slot: the window's forward search ended with a 0-error match (no reverse search, paralleltraversal.cpp:188)
+  uint32_t* gflag;           // bit per 64 slots: one of them has its zbit set (what a reverse search asks first: under a megabyte)
+  uint16_t* wbin;            // [ceil(tuples / 64)] coarse bin of srt[64 w]
+  uint32_t* emap;            // 2 bits per 9-mer: its forward / reverse tuple is emitted (lookup_tbl[kmer].count > minoccur and the mini-trie exists)
   uint32_t* sn;              // SN_* counters
   uint32_t* redo;            // waves of k_seed_pg to be searched again by k_seed_search
   uint32_t nk, nkh, maxwin, cap_tuples, cap_redo;     // nk = 2 * nkh bins: forward keys [0, nkh), reverse keys [nkh, 2 nkh)
   uint32_t fb, nc;           // fine bits (min(9, L): a coarse bin never mixes forward and reverse keys), nc = nk >> fb coarse bins (<= 4096)
   uint32_t n;                // reads in the batch
-  uint32_t kb, tpb;          // blocks of k_seed_keys / k_seed_split, tiles per block
+  uint32_t kb, rpb;          // blocks of k_seed_keys / k_seed_split, reads per block
+  uint32_t cb, kbits;        // bits of the automaton chars (2 pw = L) and of the key (L + 1)
+  uint32_t g_shift;          // k_seed_keys: log2 of the lanes per read (0: a lane walks all windows of its read; 6: one read per wave)
 };
-__device__ __forceinline__ size_t wseg_slot(const SeedBufs& sb, uint32_t r, uint32_t k) { return (size_t)k * sb.n + r; }
-__device__ __forceinline__ bool wseg_has(const SeedBufs& sb, size_t slot) { return (sb.fbits[slot >> 5] >> (slot & 31u)) & 1u; }
-__device__ __forceinline__ void wseg_put(const SeedBufs& sb, size_t slot, uint32_t v) { sb.wseg[slot] = v; atomicOr(&sb.fbits[slot >> 5], 1u << (slot & 31u)); }
+__device__ __forceinline__ bool wseg_has(const SeedBufs& sb, int d, uint32_t slot) { return (sb.fbits[d][slot >> 5] >> (slot & 31u)) & 1u; }
+__device__ __forceinline__ void wseg_put(const SeedBufs& sb, int d, uint32_t slot, uint32_t v, bool zero) {
+  sb.wseg[d][slot] = v; atomicOr(&sb.fbits[d][slot >> 5], 1u << (slot & 31u));
+  if (d == 0 && zero) { atomicOr(&sb.zbits[slot >> 5], 1u << (slot & 31u)); atomicOr(&sb.gflag[slot >> 11], 1u << ((slot >> 6) & 31u)); }
+}
+// tuple i of srt: its fields, the key completed from the position (wave chunk -> first coarse bin, then the bin boundaries)
+__device__ __forceinline__ SeedKey seed_decode(const SeedBufs& sb, uint32_t i) {
+  const SeedTup t = sb.srt[i];
+  uint32_t c = sb.wbin[i >> 6];
+  uint32_t nx = sb.cbase[c + 1];
+  while (i >= nx) { c++; nx = sb.cbase[c + 1]; }           // (i < cbase[nc]: ends; a chunk of 64 tuples rarely spans more than two bins)
+  SeedKey k;
+  k.slot = (uint32_t)t; k.chars = (uint32_t)(t >> 32) & ((1u << sb.cb) - 1u); k.key = (c << sb.fb) | (uint32_t)(t >> (32u + sb.cb));
+  return k;
+}
 
 // nbits <= 40 bits starting at bit `bit0` of a little-endian word stream (reads up to 2 words past the first)
-__device__ __forceinline__ unsigned long long extract_bits(const uint32_t* w, uint32_t bit0, uint32_t nbits) {
+template <class PTR>
+__device__ __forceinline__ unsigned long long extract_bits(PTR w, uint32_t bit0, uint32_t nbits) {
   const uint32_t i = bit0 >> 5, s = bit0 & 31u;
   unsigned long long v = ((unsigned long long)w[i] | ((unsigned long long)w[i + 1] << 32)) >> s;
   if (s) v |= (unsigned long long)w[i + 2] << (64 - s);
   return v & ((1ull << nbits) - 1ull);
 }
+// the 2-bit groups of the low 2n bits of x in reverse order
+__device__ __forceinline__ uint32_t rev_groups(uint32_t x, uint32_t n) {
+  uint32_t r = __brev(x) >> (32 - 2 * n);
+  return ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+}
+// bit i of m (i < 32) to bit 2 i
+__device__ __forceinline__ unsigned long long spread_bits(uint32_t m) {
+  unsigned long long v = m;
+  v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  v = (v | (v << 2)) & 0x3333333333333333ull;
+  v = (v | (v << 1)) & 0x5555555555555555ull;
+  return v;
+}
 
-// window content of a read in the CURRENT strand/encoding state: 2 bits per nt, char i at bits 2i.
-// Fast path: one 2L-bit extraction from the packed record (reverse strand: 2-bit groups reversed and complemented,
-// Read::revIntStr read.cpp:350-357); windows touching an ambiguous letter take the per-letter path.
-__device__ __forceinline__ unsigned long long window_chars(const uint32_t* rec, uint32_t len, uint32_t win_pos, uint32_t L,
-                                                           uint32_t reversed, uint32_t aval) {
+// window content of a read in the CURRENT strand/encoding state: 2 bits per nt, char i at bits 2i -- one 2L-bit extraction from the packed
+// record (reverse strand: 2-bit groups reversed and complemented, Read::revIntStr read.cpp:350-357); ambiguous letters (packed as code 0 +
+// mask bit) read as `aval` (Read::flip34, read.cpp:379-401), also one extraction.  Same values as L calls of read_nt.
+template <class PTR>
+__device__ __forceinline__ unsigned long long window_chars(PTR rec, uint32_t len, uint32_t win_pos, uint32_t L, uint32_t reversed, uint32_t aval) {
   const uint32_t cw = (len + 15) >> 4;
   const uint32_t j0 = reversed ? (len - win_pos - L) : win_pos;           // first read position covered, ascending
-  if (extract_bits(rec + cw, j0, L) == 0ull) {
-    unsigned long long x = extract_bits(rec, 2 * j0, 2 * L);
-    if (reversed) {
-      x = __brevll(x) >> (64 - 2 * L);                                      // reverse the bit order ...
-      x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);   // ... and restore each 2-bit group
-      x = ~x & ((1ull << (2 * L)) - 1ull);                                   // complement: 3 - code
-    }
-    return x;
+  uint32_t m = (uint32_t)extract_bits(rec + cw, j0, L);
+  unsigned long long x = extract_bits(rec, 2 * j0, 2 * L);
+  if (reversed) {
+    x = __brevll(x) >> (64 - 2 * L);                                      // reverse the bit order ...
+    x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);   // ... and restore each 2-bit group
+    x = ~x & ((1ull << (2 * L)) - 1ull);                                   // complement: 3 - code
+    m = __brev(m) >> (32 - L);
   }
-  unsigned long long wchars = 0;
-  for (uint32_t i = 0; i < L; i++) wchars |= (unsigned long long)read_nt(rec, len, win_pos + i, reversed, aval) << (2 * i);
-  return wchars;
+  if (m) { const unsigned long long sp = spread_bits(m); x = (x & ~(3ull * sp)) | (sp * aval); }
+  return x;
+}
+
+// 2 bits per 9-mer key for k_seed_keys: is the forward / the reverse tuple of a window with this key emitted?  (lookup_tbl[kmer].count > minoccur
+// and the mini-trie exists: paralleltraversal.cpp:155-160, 186-192.)  64 KB for L = 18: every block of k_seed_keys keeps a copy in LDS.
+__global__ void k_seed_emap(const uint32_t* __restrict__ lkc, uint32_t nkh, uint32_t minoccur, uint32_t* __restrict__ emap) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (16u * i >= nkh) return;
+  uint32_t w = 0;
+  for (uint32_t q = 0; q < 16; q++) {
+    const uint32_t key = 16u * i + q;
+    if (key >= nkh) break;
+    const uint32_t v = lkc[key];
+    const bool ok = (v & 0x3FFFFFFFu) > minoccur;
+    w |= ((ok && ((v >> 30) & 1u) ? 1u : 0u) | (ok && (v >> 31) ? 2u : 0u)) << (2 * q);
+  }
+  emap[i] = w;
 }
 
 // Both half-seed searches of a window become tuples in ONE pass (so the sort runs once per stage):
 //   forward: key = first 9-mer, automaton fed by chars [pw, 2pw)          (init_win_f bitvector.cpp:57-91)  -> bins [0, nkh)
 //   reverse: key = second 9-mer, automaton fed by chars pw-1 .. 0         (init_win_r :99-132)              -> bins [nkh, 2 nkh)
-// The reverse tuple is speculative: the reverse search kernel drops it when the forward search ended with a 0-error match
-// (accept_zero_kmer, paralleltraversal.cpp:188).
-// A block owns `tpb` consecutive tiles of SEED_TILE windows and writes its tuples compactly into ITS region of tmp (the slots of its
-// first window onwards: no allocation between blocks, no barrier inside the tile loop -- a wave reserves its slots with one LDS atomic).
-// It counts them per COARSE bin (key >> fb) in LDS and leaves that histogram as its row of sb.rows: the first sort pass needs no
-// counting pass of its own.
-__global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParams P, int pass, SeedBufs sb,
-                                                   const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, uint32_t n_tiles) {
-  SMR_DYN_LDS(uint32_t, lh);                              // [nc] this block's tuples per coarse bin
+// READ-centric (round 3: one thread per window slot, each running the chain state -> length / record offset -> record words -> two lookups):
+// a block owns `rpb` consecutive reads; per trip a wave takes 64 >> g_shift of them, asks for their states, lengths and record offsets
+// together, copies their packed records -- contiguous in the batch -- into LDS with 16-byte loads (STAGED; records too long for that are read
+// where they lie), and then 2^g_shift lanes per read (ONE: a lane per read) walk the read's windows: placement (paralleltraversal.cpp:118-131),
+// window extraction from LDS, both 9-mer keys, both emit bits from the block's LDS copy of emap (MAPPED) -- no global load depends on another
+// after the first three.  The tuples of a block go compactly into ITS region of tmp (a wave reserves its slots with one LDS atomic per window
+// round), counted per COARSE bin (key >> fb) in LDS; that histogram is the block's row of sb.rows: the first sort pass needs no counting pass.
+template <bool ONE, bool STAGED, bool MAPPED>
+__global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParams P, int pass, SeedBufs sb, const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr) {
+  SMR_DYN_LDS(uint32_t, lds);                             // lh [nc rounded to 4] | emap copy [nkh / 16] (MAPPED) | per wave SEED_STAGE_WORDS + 8 (STAGED)
   __shared__ uint32_t s_cur, s_win;
+  uint32_t* const lh = lds;
+  const uint32_t lh_words = (sb.nc + 3u) & ~3u, map_words = MAPPED ? sb.nkh >> 4 : 0u;
+  uint32_t* const map = lds + lh_words;
+  const uint32_t wv = threadIdx.x >> 6;
+  uint32_t* const stage = lds + lh_words + map_words + wv * (SEED_STAGE_WORDS + 8u);
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
+  if (MAPPED) for (uint32_t c = threadIdx.x; c < map_words; c += blockDim.x) map[c] = sb.emap[c];
   if (threadIdx.x == 0) { s_cur = 0; s_win = 0; }
   __syncthreads();
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, L = P.lnwin;
-  const uint32_t t0 = blockIdx.x * sb.tpb, t1 = min(t0 + sb.tpb, n_tiles);
-  SeedTmp* const region = sb.tmp + (size_t)2 * SEED_TILE * t0;
+  const uint32_t s0 = P.skip[0], s1 = P.skip[1], stride = pass == 0 ? s0 : pass == 1 ? s1 : P.skip[2];
+  const uint32_t rb0 = blockIdx.x * sb.rpb, rb1 = min(rb0 + sb.rpb, rd.n);
+  SeedTup* const region = sb.tmp + (size_t)2 * rb0 * sb.maxwin;
+  const uint32_t gsh = ONE ? 0u : sb.g_shift, G = 1u << gsh, RW = 64u >> gsh;
+  const uint32_t sub = ONE ? 0u : (uint32_t)lane & (G - 1u), rl = (uint32_t)lane >> gsh;
+  const uint32_t half = (1u << (2 * pw)) - 1u;
   uint32_t nwin = 0;                                      // windows of this wave (uniform)
-  struct Win { bool emit[2]; uint32_t key[2], is_win; unsigned long long payload[2]; };
-  // the window of this thread in `tile`: nothing but loads and arithmetic, so the loads of two tiles can be in flight together
-  auto window_of = [&](uint32_t tile, Win& W) {
-    W.emit[0] = W.emit[1] = false; W.key[0] = W.key[1] = 0; W.is_win = 0; W.payload[0] = W.payload[1] = 0;
-    const uint32_t tid = tile * SEED_TILE + threadIdx.x;
-    const uint32_t r = tid / sb.maxwin, k = tid % sb.maxwin;
-    if (tile >= t1 || r >= rd.n) return;
-    const RWork w = rw[r];                                 // (state, length and record offset asked for together: one round trip before the record's words, not two)
-    const uint32_t len = rd.len[r];
-    const uint32_t* const rec = rd.words + rd.rec_off[r];
-    const bool active = (w.strand_active && w.search && w.pass_n == (uint32_t)pass);
-    const uint32_t stride = P.skip[pass];
-    const uint32_t numwin = active ? (len - L + stride) / stride : 0;       // paralleltraversal.cpp:118-120
-    bool mine = k < numwin;
-    const uint32_t win_pos = k * stride;
-    if (mine) for (int q = 0; q < pass; q++) if (win_pos % P.skip[q] == 0) mine = false;   // read_pos_searched (:128-131)
-    if (!mine) return;
+  for (uint32_t rt0 = rb0 + wv * RW; rt0 < rb1; rt0 += SEED_WAVES * RW) {
+    const uint32_t r = rt0 + rl;
+    const bool have = r < rb1;
+    RWork w; w.strand_active = 0; w.search = 0; w.pass_n = 0; w.is04 = 0; w.aval = 0; w.reversed = 0;
+    uint32_t len = 0; uint64_t off = 0;
+    if (have) { w = rw[r]; len = rd.len[r]; off = rd.rec_off[r]; }       // (asked for together: one round trip)
+    const bool active = have && w.strand_active && w.search && w.pass_n == (uint32_t)pass;
+    if (!__any(active)) continue;
+    const uint32_t numwin = active ? (len - L + stride) / stride : 0u;     // paralleltraversal.cpp:118-120
+    const uint32_t* const grec = rd.words + off;
+    uint32_t* srec = stage;
+    if (STAGED) {
+      const uint64_t wb = rd.rec_off[rt0], we = rd.rec_off[min(rt0 + RW, rb1)];   // the records of the trip's reads: one contiguous run of words
+      const uint64_t a0 = wb & ~3ull;
+      const uint32_t sh = (uint32_t)(wb - a0), nq = (sh + (uint32_t)(we - wb) + 3u) >> 2;
+      const uint4* const src = reinterpret_cast<const uint4*>(rd.words + a0);
+      uint4* const dst = reinterpret_cast<uint4*>(stage);
+      __builtin_amdgcn_wave_barrier();                    // (the previous trip's extractions are done: LDS operations of a wave complete in order)
+      for (uint32_t q = (uint32_t)lane; q < nq; q += 64) dst[q] = src[q];
+      __builtin_amdgcn_wave_barrier();
+      srec = stage + sh + (uint32_t)(off - wb);
+    }
     // traverse(): `if (read.is04) read.flip34()` before every window (:126) -> ambiguous positions read as 0 / 3
-    const uint32_t aval = w.is04 ? 0 : w.aval;
-    const unsigned long long wc = window_chars(rec, len, win_pos, L, w.reversed, aval);
-    const unsigned long long half = (1ull << (2 * pw)) - 1ull;
-    // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
-    const uint32_t a = (uint32_t)(wc & half), b = (uint32_t)((wc >> (2 * pw)) & half);
-    uint32_t ra = __brev(a) >> (32 - 2 * pw), rb = __brev(b) >> (32 - 2 * pw);
-    ra = ((ra & 0x55555555u) << 1) | ((ra >> 1) & 0x55555555u);
-    rb = ((rb & 0x55555555u) << 1) | ((rb >> 1) & 0x55555555u);
-    W.is_win = 1;
-    const uint32_t lf = ix.lkc[ra], lr = ix.lkc[rb];          // lookup_tbl[kmer].count and the presence of trie_F / trie_R (paralleltraversal.cpp:155-160, 186-192)
-    W.emit[0] = (lf & 0x3FFFFFFFu) > P.minoccur && ((lf >> 30) & 1u);
-    W.emit[1] = (lr & 0x3FFFFFFFu) > P.minoccur && (lr >> 31);
-    W.key[0] = ra; W.key[1] = sb.nkh + rb;
-    const unsigned long long rw_ = (unsigned long long)r | ((unsigned long long)win_pos << 24);
-    W.payload[0] = rw_ | ((unsigned long long)b << 40);            // forward: second half in order
-    W.payload[1] = rw_ | ((unsigned long long)ra << 40);           // reverse: first half walked backwards
-  };
-  auto put = [&](const Win& W) {
-    const unsigned long long em0 = __ballot(W.emit[0]), em1 = __ballot(W.emit[1]);
-    nwin += (uint32_t)__popcll(__ballot(W.is_win));
-    const uint32_t c0 = (uint32_t)__popcll(em0), c1 = (uint32_t)__popcll(em1);
-    uint32_t base = 0;
-    if (lane == 0 && c0 + c1) base = atomicAdd(&s_cur, c0 + c1);       // the wave's slots in the block's region: its forward tuples, then its reverse tuples
-    base = (uint32_t)__shfl((int)base, 0, 64);
-#pragma unroll
-    for (int d = 0; d < 2; d++) {
-      if (W.emit[d]) {
-        const uint32_t idx = base + (d ? c0 : 0u) + (uint32_t)__popcll((d ? em1 : em0) & ((1ull << lane) - 1));
-        SeedTmp t; t.key = W.key[d]; t.lo = (uint32_t)W.payload[d]; t.hi = (uint32_t)(W.payload[d] >> 32);
-        region[idx] = t;
-        atomicAdd(&lh[W.key[d] >> sb.fb], 1u);
+    const uint32_t aval = w.is04 ? 0u : (uint32_t)w.aval;
+    const uint32_t rel0 = (r - rb0) * sb.maxwin;
+    for (uint32_t kk = 0; kk < sb.maxwin; kk += G) {
+      const uint32_t k = kk + sub, win_pos = k * stride;
+      bool mine = k < numwin;
+      if (pass >= 1 && win_pos % s0 == 0) mine = false;                     // read_pos_searched (:128-131)
+      if (pass >= 2 && win_pos % s1 == 0) mine = false;
+      if (!__any(mine)) continue;
+      bool e0 = false, e1 = false;
+      uint32_t ra = 0, rb = 0, a = 0, b = 0;
+      if (mine) {
+        const unsigned long long wc = STAGED ? window_chars(srec, len, win_pos, L, w.reversed, aval) : window_chars(grec, len, win_pos, L, w.reversed, aval);
+        // first / second 9-mer with char i at bits 2i; hashKmer is MSB-first (read.cpp:601-611) = the 2-bit groups reversed
+        a = (uint32_t)wc & half; b = (uint32_t)(wc >> (2 * pw)) & half;
+        ra = rev_groups(a, pw); rb = rev_groups(b, pw);
+        const uint32_t wa = MAPPED ? map[ra >> 4] : sb.emap[ra >> 4], wb_ = MAPPED ? map[rb >> 4] : sb.emap[rb >> 4];
+        e0 = (wa >> (2u * (ra & 15u))) & 1u;
+        e1 = (wb_ >> (2u * (rb & 15u) + 1u)) & 1u;
+      }
+      const unsigned long long em0 = __ballot(e0), em1 = __ballot(e1);
+      nwin += (uint32_t)__popcll(__ballot(mine));
+      const uint32_t c0 = (uint32_t)__popcll(em0), c1 = (uint32_t)__popcll(em1);
+      uint32_t base = 0;
+      if (lane == 0 && c0 + c1) base = atomicAdd(&s_cur, c0 + c1);         // the wave's slots in the block's region: its forward tuples, then its reverse tuples
+      base = (uint32_t)__shfl((int)base, 0, 64);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const unsigned long long relk = (unsigned long long)(rel0 + k) << (sb.kbits + sb.cb);
+      if (e0) {                                            // forward: second half in order
+        region[base + (uint32_t)__popcll(em0 & below)] = (unsigned long long)ra | ((unsigned long long)b << sb.kbits) | relk;
+        atomicAdd(&lh[ra >> sb.fb], 1u);
+      }
+      if (e1) {                                            // reverse: first half walked backwards
+        const uint32_t key = sb.nkh + rb;
+        region[base + c0 + (uint32_t)__popcll(em1 & below)] = (unsigned long long)key | ((unsigned long long)ra << sb.kbits) | relk;
+        atomicAdd(&lh[key >> sb.fb], 1u);
       }
     }
-  };
-  for (uint32_t tile = t0; tile < t1; tile += 2) {
-    Win A, B;
-    window_of(tile, A);
-    window_of(tile + 1, B);
-    put(A);
-    if (tile + 1 < t1) put(B);
   }
   if (lane == 0 && nwin) atomicAdd(&s_win, nwin);
   __syncthreads();
@@ -286,12 +357,13 @@ __global__ void __launch_bounds__(1024) k_seed_keys(DReads rd, DIndex ix, DParam
 }
 
 // The tuples are brought into key order by a two-level counting sort.  No pass writes a tuple with a store of its own lane's choosing
-// (scattered 12-byte stores run at 0.9 TB/s on the MI355X whatever the run length, coalesced ones at 5.6 TB/s; profiles/r03a_pmc_calibration_*):
+// (scattered stores run at 0.9 TB/s on the MI355X whatever the run length, coalesced ones at 5.6 TB/s; profiles/r03a_pmc_calibration_*):
 // a pass stages SEED_PIECE tuples in LDS in bin order and copies them out with consecutive lanes on consecutive tuples.
 //   k_seed_keys     leaves per block the number of its tuples per COARSE bin (key >> fb, <= 4096 bins)       -> rows, chist
 //   k_seed_cscan    exclusive scan of the coarse counts (one block)                                            -> cbase, SN_TUPLES, SN_FWD
 //   k_seed_colscan  rows[b][c] = cbase[c] + the tuples of bin c in the rows above: where block b's tuples of bin c go
-//   k_seed_split    block b reads ITS tuples once, piece by piece, and moves them to their coarse bins
+//   k_seed_wbin     coarse bin of every 64th tuple of the sorted array (the key of a sorted tuple = its bin | its fine bits)
+//   k_seed_split    block b reads ITS tuples once, piece by piece, and moves them to their coarse bins (block-relative slot -> slot, key -> fine bits)
 //   k_seed_bins     one block per coarse bin: histogram of the fine key bits (<= 512 bins), then the same staged move to the final places
 // History per 60 M tuples on the MI355X: one counting sort with a returning global atomic per tuple 2.4 + 1.9 ms; two-level with LDS
 // atomics and per-lane stores 1.3 + 0.9 + 1.0 ms (HBM writes 3.0 x and 2.7 x the tuple bytes, profiles/r03a_sort_variants_*).
@@ -332,6 +404,17 @@ __global__ void __launch_bounds__(1024) k_seed_colscan(SeedBufs sb) {
   for (uint32_t r = r0; r < r1; r++) { const size_t o = (size_t)r * sb.nc + c; const uint32_t v = sb.rows[o]; sb.rows[o] = run; run += v; }
 }
 
+// wbin[w] = the coarse bin of sorted tuple 64 w: the last bin that begins at or before it (empty bins begin where the next one does)
+__global__ void __launch_bounds__(256) k_seed_wbin(SeedBufs sb) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples);
+  if ((unsigned long long)w * 64ull >= n_all) return;
+  const uint32_t pos = w * 64u;
+  uint32_t lo = 0, hi = sb.nc;                            // cbase[0] = 0 <= pos < n_all = cbase[nc]
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sb.cbase[mid] <= pos) lo = mid; else hi = mid; }
+  sb.wbin[w] = (uint16_t)lo;
+}
+
 // exclusive prefix of cnt[0..nb) (nb <= 4096, block of 1024 threads) into out[], plus `add`; all threads must call it
 __device__ __forceinline__ void block_excl_scan(const uint32_t* cnt, uint32_t* out, uint32_t nb, uint32_t* s_part /* [16] */) {
   const uint32_t t = threadIdx.x;
@@ -351,20 +434,21 @@ __device__ __forceinline__ void block_excl_scan(const uint32_t* cnt, uint32_t* o
 
 // One staged move of the tuples src[i0, i1) into `nb` bins whose next free places are cur[] (LDS, global indices into dst): piece by piece --
 // load (each tuple once), take a place in its bin (LDS atomic), put the piece into LDS in bin order, copy it out with consecutive lanes on
-// consecutive staged tuples (lanes of one bin's run write neighbouring addresses).  LDS: cur / pc0 / pst [nb], stage [SEED_PIECE].
-template <class BINOF>
-__device__ __forceinline__ void staged_move(const SeedTmp* __restrict__ src, uint32_t i0, uint32_t i1, SeedTmp* __restrict__ dst, uint32_t nb,
-                                            uint32_t* cur, uint32_t* pc0, uint32_t* pst, SeedTmp* stage, uint32_t* s_part, BINOF binof) {
+// consecutive staged tuples (lanes of one bin's run write neighbouring addresses), rewritten by `conv` on the way.
+// LDS: cur / pc0 / pst [nb], stage [SEED_PIECE].
+template <class BINOF, class CONV>
+__device__ __forceinline__ void staged_move(const SeedTup* __restrict__ src, uint32_t i0, uint32_t i1, SeedTup* __restrict__ dst, uint32_t nb,
+                                            uint32_t* cur, uint32_t* pc0, uint32_t* pst, SeedTup* stage, uint32_t* s_part, BINOF binof, CONV conv) {
   constexpr int PER = SEED_PIECE / 1024;
   for (uint32_t p0 = i0; p0 < i1; p0 += SEED_PIECE) {
     const uint32_t np = min(SEED_PIECE, i1 - p0);
     for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pc0[q] = cur[q];
     __syncthreads();
-    SeedTmp mine[PER]; uint32_t place[PER];
+    SeedTup mine[PER]; uint32_t place[PER];
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
-      if (i < np) { mine[j] = src[p0 + i]; place[j] = atomicAdd(&cur[binof(mine[j].key)], 1u); }
+      if (i < np) { mine[j] = src[p0 + i]; place[j] = atomicAdd(&cur[binof(mine[j])], 1u); }
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pst[q] = cur[q] - pc0[q];      // the piece's tuples per bin ...
@@ -373,47 +457,54 @@ __device__ __forceinline__ void staged_move(const SeedTmp* __restrict__ src, uin
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
-      if (i < np) { const uint32_t f = binof(mine[j].key); stage[pst[f] + (place[j] - pc0[f])] = mine[j]; }
+      if (i < np) { const uint32_t f = binof(mine[j]); stage[pst[f] + (place[j] - pc0[f])] = mine[j]; }
     }
     __syncthreads();
     for (uint32_t sidx = threadIdx.x; sidx < np; sidx += blockDim.x) {
-      const SeedTmp t = stage[sidx];
-      const uint32_t f = binof(t.key);
-      dst[pc0[f] + (sidx - pst[f])] = t;
+      const SeedTup t = stage[sidx];
+      const uint32_t f = binof(t);
+      dst[pc0[f] + (sidx - pst[f])] = conv(t);
     }
     __syncthreads();
   }
 }
 
 __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
-  SMR_DYN_LDS(uint32_t, lds);                             // cur | pc0 | pst [nc each] | stage
+  SMR_DYN_LDS(uint32_t, lds);                             // cur | pc0 | pst [nc each, rounded to an even number of words] | stage
   __shared__ uint32_t s_part[16];
-  uint32_t* cur = lds; uint32_t* pc0 = lds + sb.nc; uint32_t* pst = lds + 2 * sb.nc;
-  SeedTmp* stage = reinterpret_cast<SeedTmp*>(lds + 3 * sb.nc);
+  const uint32_t ncw = (sb.nc + 1u) & ~1u;
+  uint32_t* cur = lds; uint32_t* pc0 = lds + ncw; uint32_t* pst = lds + 2 * ncw;
+  SeedTup* stage = reinterpret_cast<SeedTup*>(lds + 3 * ncw);
   const uint32_t nmine = sb.bcnt[blockIdx.x];
   if (nmine == 0) return;
   const uint32_t* row = sb.rows + (size_t)blockIdx.x * sb.nc;
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) cur[c] = row[c];
   __syncthreads();
-  const uint32_t fb = sb.fb;
-  staged_move(sb.tmp + (size_t)2 * SEED_TILE * sb.tpb * blockIdx.x, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part, [fb](uint32_t key) { return key >> fb; });
+  const uint32_t fb = sb.fb, kbits = sb.kbits, cb = sb.cb;
+  const uint32_t slot0 = blockIdx.x * sb.rpb * sb.maxwin;                  // the block's first slot
+  staged_move(sb.tmp + (size_t)2 * slot0, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part,
+              [fb, kbits](SeedTup t) { return ((uint32_t)t & ((1u << kbits) - 1u)) >> fb; },
+              [fb, kbits, cb, slot0](SeedTup t) {
+                const uint32_t key = (uint32_t)t & ((1u << kbits) - 1u), chars = (uint32_t)(t >> kbits) & ((1u << cb) - 1u), rel = (uint32_t)(t >> (kbits + cb));
+                return (unsigned long long)(slot0 + rel) | ((unsigned long long)chars << 32) | ((unsigned long long)(key & ((1u << fb) - 1u)) << (32u + cb));
+              });
 }
 
 __global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
   __shared__ uint32_t cur[512], pc0[512], pst[512], s_part[16];
   SMR_DYN_LDS(uint32_t, lds);
-  SeedTmp* stage = reinterpret_cast<SeedTmp*>(lds);
+  SeedTup* stage = reinterpret_cast<SeedTup*>(lds);
   const uint32_t c = blockIdx.x, lo = sb.cbase[c], hi = sb.cbase[c + 1];
   if (lo == hi) return;
-  const uint32_t t = threadIdx.x, nf = 1u << sb.fb, fm = nf - 1u;
+  const uint32_t t = threadIdx.x, nf = 1u << sb.fb, sh = 32u + sb.cb;
   if (t < 512) pst[t] = 0;
   __syncthreads();
-  for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&pst[sb.mid[i].key & fm], 1u);
+  for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&pst[(uint32_t)(sb.mid[i] >> sh)], 1u);
   __syncthreads();
   block_excl_scan(pst, cur, nf, s_part);
   if (t < nf) cur[t] += lo;                               // the next free place of every fine bin
   __syncthreads();
-  staged_move(sb.mid, lo, hi, sb.srt, nf, cur, pc0, pst, stage, s_part, [fm](uint32_t key) { return key & fm; });
+  staged_move(sb.mid, lo, hi, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
 }
 
 struct SeedLane {           // per-lane search result
@@ -598,13 +689,14 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ ar
   out.nh = nh; out.zero = zero; out.overflow = overflow; out.n_node = n_node; out.n_entry = n_entry;
 }
 
+// DIR 0: the forward searches of a wave chunk of the sorted tuples, DIR 1: its reverse searches (the lanes of the other direction idle: the
+// chunk that holds the last forward and the first reverse tuple is the only mixed one).  The reverse search starts from the window's forward
+// list and leaves the FINAL list of the window (SEED_SEG_MERGED), as the reference's two calls of traversetrie_align on one list do.
 template <int DIR>
 __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap,
                                                     uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr,
                                                     const uint32_t* __restrict__ redo) {
-  // this phase's tuples: forward bins first, reverse bins after them
-  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_all);
-  const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
+  const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples);
   uint32_t wave = blockIdx.x;
   if (redo) {                                            // only the waves listed by k_seed_pg (its candidate pool overflowed)
     if (blockIdx.x >= min(sb.sn[SN_REDO], sb.cap_redo)) return;
@@ -625,28 +717,30 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   __shared__ unsigned long long s_row[LEV_ROWS];
   const int lane = lane_id();
   build_lev_rows(s_row);
-  const uint32_t pos = first + wave * 64u + lane;
-  bool mine = wave * 64u + lane < n_tup;
-  uint32_t r = 0, win_pos = 0, chars = 0;
-  uint32_t root = 0;
-  size_t slot = 0;
+  const uint32_t pos = wave * 64u + lane;
+  bool mine = pos < n_tup;
+  uint32_t chars = 0, root = 0, slot = 0;
   SeedLane sl; sl.nh = 0; sl.zero = false; sl.overflow = false; sl.n_node = 0; sl.n_entry = 0;
   uint32_t n_prev = 0;
+  bool counted = false;                                  // a tuple of this direction (its algorithmic bytes are counted here)
   if (mine) {
-    const SeedTmp tp = sb.srt[pos];
-    const unsigned long long pl = seed_payload(tp);
-    const Lookup lk = ix.lookup[tp.key - (DIR ? sb.nkh : 0u)];
-    root = DIR == 0 ? lk.rootF : lk.rootR;
-    r = (uint32_t)(pl & 0xFFFFFFull); win_pos = (uint32_t)((pl >> 24) & 0xFFFFull); chars = (uint32_t)(pl >> 40);
-    slot = wseg_slot(sb, r, win_pos / P.skip[pass]);
-    if (DIR == 1 && wseg_has(sb, slot)) {                // the window's list so far = the forward search's hits
-      const uint32_t seg = sb.wseg[slot];
-      if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
-      else {
-        n_prev = pool[seg + 1];
-        for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
-        if (n_prev > hcap) { sl.overflow = true; n_prev = hcap; }
-        sl.nh = n_prev;
+    if ((pos >= min(sb.sn[SN_FWD], n_tup)) != (DIR == 1)) mine = false;      // the forward tuples lie in front
+    else {
+      const SeedKey tk = seed_decode(sb, pos);
+      counted = true;
+      const Lookup lk = ix.lookup[tk.key - (DIR ? sb.nkh : 0u)];
+      root = DIR == 0 ? lk.rootF : lk.rootR;
+      chars = tk.chars; slot = tk.slot;
+      if (DIR == 1 && wseg_has(sb, 0, slot)) {             // the window's list so far = the forward search's hits
+        const uint32_t seg = sb.wseg[0][slot];
+        if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+        else {
+          const uint32_t o = seg & ~SEED_ZERO_BIT;
+          n_prev = pool[o] & 0xFFFFu;
+          for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[o + 1 + q];
+          if (n_prev > hcap) { sl.overflow = true; n_prev = hcap; }
+          sl.nh = n_prev;
+        }
       }
     }
   }
@@ -657,9 +751,9 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 #else
   seed_search_wave(ix.trie, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
 #endif
-  // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
+  // ---- write the windows' hit segments: [count (| SEED_SEG_MERGED), id x count] ----
   const bool wr = mine && (DIR == 0 ? sl.nh > 0 : (sl.zero || sl.nh > n_prev));
-  const uint32_t need = wr ? 2 + 2 * sl.nh : 0;
+  const uint32_t need = wr ? 1 + sl.nh : 0;
   uint32_t incl = need;
   for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
   const uint32_t total = __shfl(incl, 63, 64);
@@ -674,15 +768,15 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   }
   if (wr && base != NONE) {
     const uint32_t o = base + incl - need;
-    pool[o] = NONE; pool[o + 1] = sl.nh;
-    for (uint32_t q = 0; q < sl.nh; q++) { pool[o + 2 + 2 * q] = hl[q * 64 + lane]; pool[o + 3 + 2 * q] = win_pos; }
-    wseg_put(sb, slot, o | (sl.zero ? SEED_ZERO_BIT : 0u));
+    pool[o] = sl.nh | (DIR ? SEED_SEG_MERGED : 0u);
+    for (uint32_t q = 0; q < sl.nh; q++) pool[o + 1 + q] = hl[q * 64 + lane];
+    wseg_put(sb, DIR, slot, o | (sl.zero ? SEED_ZERO_BIT : 0u), sl.zero);
   }
   if (__any(sl.overflow) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
   // algorithmic bytes of this wave (C_B_PG0/1): tuple + lookup entry per search, 16 B per node, 8 B per entry, the forward list read (DIR 1),
   // the segment written + its window slot
   unsigned long long v[3] = {sl.n_node, sl.n_entry, 0};
-  v[2] = (wave * 64u + lane < n_tup ? sizeof(SeedTmp) + sizeof(Lookup) + (DIR ? 1u + (n_prev ? 8u + 8u * n_prev : 0u) : 0u) : 0u) + 16ull * sl.n_node + 8ull * sl.n_entry + 4ull * need + (wr ? 4u : 0u);
+  v[2] = (counted ? sizeof(SeedTup) + sizeof(Lookup) + (DIR ? 1u + (n_prev ? 8u + 4u * n_prev : 0u) : 0u) : 0u) + 16ull * sl.n_node + 8ull * sl.n_entry + 4ull * need + (wr ? 4u : 0u);
   for (int c = 0; c < 3; c++) {
     unsigned long long x = v[c];
     for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
@@ -694,37 +788,65 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 #endif
 }
 
-// per read: copy the hit segments of this pass's windows into ONE contiguous block (k_chain then reads a strand's
-// cumulative hits with coalesced loads instead of chasing a list), count seeds/hits (++read.hit_seeds per window with
-// hits, paralleltraversal.cpp:242-249), make the 0..3 view persistent (Read::flip34, read.cpp:379-401)
-#define FIN_KEEP 8u                                       // segments per read and pass whose place k_seed_finish remembers (16 KB of LDS per block; a read from the DB has one per window of the first pass)
-#define FIN_CHUNK 8u                                      // windows whose bits k_seed_finish asks for together (independent loads in flight per thread)
+// per read: merge the forward and reverse hit segments of this pass's windows into ONE contiguous block of (id, win_pos) pairs (k_chain then
+// reads a strand's cumulative hits with coalesced loads instead of chasing a list), count seeds/hits (++read.hit_seeds per window with hits,
+// paralleltraversal.cpp:242-249), make the 0..3 view persistent (Read::flip34, read.cpp:379-401).
+// The window's list is what the reference's two searches leave on one list (traverse_bursttrie.cpp:256-277): the forward hits; nothing more if
+// the forward search ended with a 0-error match (:188); else the reverse search's candidates in its DFS order -- one already present is
+// skipped, a 0-error candidate (SEED_CAND_COND) that is not present REPLACES the list and ends the window, any other is appended.  A reverse
+// segment marked SEED_SEG_MERGED (k_seed_search<1>) is that final list already.
+#define FIN_KEEP 8u                                       // segments per read and pass whose place k_seed_finish remembers (24 KB of LDS per block; a read from the DB has one per window of the first pass)
 __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ uint32_t s_seg[FIN_KEEP][256], s_cnt[FIN_KEEP][256];            // the first segments a thread met: where, how many pairs (the copy below need not look for them again)
+  __shared__ uint32_t s_sf[FIN_KEEP][256], s_sr[FIN_KEEP][256], s_k[FIN_KEEP][256];     // the first windows with segments a thread met: forward / reverse segment (NONE: none), window
   unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
   if (r < rd.n) {
     RWork w = rw[r];
     const uint32_t len = rd.len[r];                        // (asked for with the state, not after it)
     moved = sizeof(RWork);
-    kin = sizeof(RWork) + 4u;                              // k_seed_keys looks at every read's state and length ...
+    kin = sizeof(RWork) + 12u;                             // k_seed_keys looks at every read's state, length and record offset ...
     if (w.strand_active && w.search && w.pass_n == (uint32_t)pass) {
-      const uint32_t stride = P.skip[pass];
+      const uint32_t k0s = P.skip[0], k1s = P.skip[1], stride = pass == 0 ? k0s : pass == 1 ? k1s : P.skip[2];
       const uint32_t numwin = (len - P.lnwin + stride) / stride;
-      uint32_t seeds = 0, total = 0, rlook = 0, nsearched = 0;
-      // The windows are taken FIN_CHUNK at a time: their bits are asked for together (independent loads), and only the windows whose bit is set
-      // -- a tenth -- go on to their slot and their segment's count word.  (One window after the other, each a chain of up to three loads,
-      // this loop was the kernel's time: 45 windows x the memory latency per thread.)
-      const uint32_t k0s = P.skip[0], k1s = P.skip[1];
+      const uint32_t slot0 = r * sb.maxwin;
+      uint32_t seeds = 0, upper = 0, rlook = 0, nsearched = 0;
       uint32_t rem0 = 0, rem1 = 0;                           // (k * stride) % skip[0], % skip[1], kept by addition
-      for (uint32_t kb = 0; kb < numwin; kb += FIN_CHUNK) {
-        const uint32_t nk = min((uint32_t)FIN_CHUNK, numwin - kb);
-        uint32_t m = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < FIN_CHUNK; j++) m |= (wseg_has(sb, wseg_slot(sb, r, min(kb + j, numwin - 1))) ? 1u : 0u) << j;
-        if (nk < FIN_CHUNK) m &= (1u << nk) - 1u;
+      // the windows' bits, 32 at a time: a read's windows are consecutive bits of fbits[0] / fbits[1]
+      auto bits32 = [&](int d, uint32_t b0) -> uint32_t {
+        const uint32_t i = b0 >> 5, s = b0 & 31u;
+        const uint32_t lo = sb.fbits[d][i], hi = sb.fbits[d][i + 1];
+        return s ? (lo >> s) | (hi << (32u - s)) : lo;
+      };
+      // the merged list of window k (segments sf / sr, NONE = none) appended at pool[o...] as (id, win_pos) pairs when o != NONE; returns its length
+      auto merge = [&](uint32_t sf, uint32_t sr, uint32_t win_pos, uint32_t o) -> uint32_t {
+        uint32_t n = 0;
+        const bool fzero = sf != NONE && (sf & SEED_ZERO_BIT);
+        const uint32_t of = sf & ~SEED_ZERO_BIT, orv = sr & ~SEED_ZERO_BIT;
+        const uint32_t hr = sr != NONE ? pool[orv] : 0u;
+        const uint32_t nf = sf != NONE ? (pool[of] & 0xFFFFu) : 0u, nr = hr & 0xFFFFu;
+        if (sr != NONE && (hr & SEED_SEG_MERGED) && !fzero) {
+          for (uint32_t q = 0; q < nr; q++) { if (o != NONE) { pool[o + 2 * n] = pool[orv + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
+          return n;
+        }
+        for (uint32_t q = 0; q < nf; q++) { if (o != NONE) { pool[o + 2 * n] = pool[of + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
+        if (fzero || sr == NONE) return n;
+        for (uint32_t q = 0; q < nr; q++) {
+          const uint32_t c = pool[orv + 1 + q], id = c & ~SEED_CAND_COND;
+          bool present = false;
+          for (uint32_t f = 0; f < nf; f++) if (pool[of + 1 + f] == id) { present = true; break; }
+          if (present) continue;
+          if (c & SEED_CAND_COND) { if (o != NONE) { pool[o] = id; pool[o + 1] = win_pos; } return 1u; }
+          if (o != NONE) { pool[o + 2 * n] = id; pool[o + 2 * n + 1] = win_pos; }
+          n++;
+        }
+        return n;
+      };
+      for (uint32_t kb = 0; kb < numwin; kb += 32) {
+        const uint32_t nk = min(32u, numwin - kb);
+        const uint32_t vm = nk < 32 ? (1u << nk) - 1u : 0xFFFFFFFFu;
+        const uint32_t mf = bits32(0, slot0 + kb) & vm, mr = bits32(1, slot0 + kb) & vm;
         uint32_t srch = 0;                                   // windows of this pass: not searched by an earlier pass (:128-131)
         for (uint32_t j = 0; j < nk; j++) {
           const bool earlier = (pass >= 1 && rem0 == 0) || (pass >= 2 && rem1 == 0);
@@ -733,46 +855,44 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
           rem1 += stride; while (rem1 >= k1s) rem1 -= k1s;
         }
         nsearched += (uint32_t)__popc(srch);
-        rlook += (uint32_t)__popc(srch & ~m);              // no segment: the reverse lookup happened (:188-198)
-        for (uint32_t mm = m; mm; mm &= mm - 1) {
-          const uint32_t j = (uint32_t)__ffs((int)mm) - 1u;
-          const uint32_t sg = sb.wseg[wseg_slot(sb, r, kb + j)];
-          if (((srch >> j) & 1u) && !(sg & SEED_ZERO_BIT)) rlook++;        // ... unless the forward search hit exactly
-          const uint32_t cnt = pool[(sg & ~SEED_ZERO_BIT) + 1];
-          if (seeds < FIN_KEEP) { s_seg[seeds][threadIdx.x] = sg & ~SEED_ZERO_BIT; s_cnt[seeds][threadIdx.x] = cnt; }
-          seeds++; total += cnt;
+        rlook += (uint32_t)__popc(srch & ~mf);             // no forward segment: the reverse lookup happened (:188-198)
+        for (uint32_t mm = mf | mr; mm; mm &= mm - 1) {
+          const uint32_t j = (uint32_t)__ffs((int)mm) - 1u, k = kb + j;
+          const uint32_t sf = ((mf >> j) & 1u) ? sb.wseg[0][slot0 + k] : NONE, sr = ((mr >> j) & 1u) ? sb.wseg[1][slot0 + k] : NONE;
+          if (sf != NONE && ((srch >> j) & 1u) && !(sf & SEED_ZERO_BIT)) rlook++;        // ... unless the forward search hit exactly
+          const uint32_t cf = sf != NONE ? (pool[sf & ~SEED_ZERO_BIT] & 0xFFFFu) : 0u, cr = sr != NONE ? (pool[sr & ~SEED_ZERO_BIT] & 0xFFFFu) : 0u;
+          if (seeds < FIN_KEEP) { s_sf[seeds][threadIdx.x] = sf; s_sr[seeds][threadIdx.x] = sr; s_k[seeds][threadIdx.x] = k; }
+          seeds++; upper += cf + cr;
         }
       }
       looks = rlook;
-      kin += 8u + 4u * (((len + 15) >> 4) + ((len + 31) >> 5)) + 8ull * nsearched;      // ... of an active read also its record offset, its packed record, two lookup words per window
-      // length, one window bit per window, per segment its count word, every (id, win_pos) pair read and written, per-read state written, hit_seeds
-      moved += 4u + (numwin + 7u) / 8u + 8ull * seeds + 16ull * total + sizeof(RWork) + 8u;
-      uint32_t base = 0;
-      if (total) {
+      kin += 4u * (((len + 15) >> 4) + ((len + 31) >> 5));      // ... and of an active read its packed record
+      uint32_t base = 0, total = 0;
+      if (upper) {                                           // room for the longest the merged lists can be; blk_cnt is what they are
         const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
-        const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], 2ull * total);
-        if (old + 2ull * total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); total = 0; seeds = 0; }
+        const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], 2ull * upper);
+        if (old + 2ull * upper > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); upper = 0; seeds = 0; }
         else base = shard * region + (uint32_t)old;
       }
-      uint32_t o = base;
-      if (total && seeds <= FIN_KEEP) {
+      unsigned long long segw = 0;                           // segment words read
+      if (upper && seeds <= FIN_KEEP) {
         for (uint32_t i = 0; i < seeds; i++) {
-          const uint32_t sg = s_seg[i][threadIdx.x], c = s_cnt[i][threadIdx.x];
-          for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
-          o += 2 * c;
+          const uint32_t sf = s_sf[i][threadIdx.x], sr = s_sr[i][threadIdx.x];
+          total += merge(sf, sr, s_k[i][threadIdx.x] * stride, base + 2 * total);
         }
-      } else if (total) for (uint32_t kb = 0; kb < numwin; kb += FIN_CHUNK) {
-        const uint32_t nk = min((uint32_t)FIN_CHUNK, numwin - kb);
-        uint32_t m = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < FIN_CHUNK; j++) m |= (wseg_has(sb, wseg_slot(sb, r, min(kb + j, numwin - 1))) ? 1u : 0u) << j;
-        if (nk < FIN_CHUNK) m &= (1u << nk) - 1u;
-        for (uint32_t mm = m; mm; mm &= mm - 1) {
-          const uint32_t sg = sb.wseg[wseg_slot(sb, r, kb + (uint32_t)__ffs((int)mm) - 1u)] & ~SEED_ZERO_BIT, c = pool[sg + 1];
-          for (uint32_t q = 0; q < 2 * c; q++) pool[o + q] = pool[sg + 2 + q];
-          o += 2 * c;
+      } else if (upper) for (uint32_t kb = 0; kb < numwin; kb += 32) {
+        const uint32_t nk = min(32u, numwin - kb);
+        const uint32_t vm = nk < 32 ? (1u << nk) - 1u : 0xFFFFFFFFu;
+        const uint32_t mf = bits32(0, slot0 + kb) & vm, mr = bits32(1, slot0 + kb) & vm;
+        for (uint32_t mm = mf | mr; mm; mm &= mm - 1) {
+          const uint32_t j = (uint32_t)__ffs((int)mm) - 1u, k = kb + j;
+          const uint32_t sf = ((mf >> j) & 1u) ? sb.wseg[0][slot0 + k] : NONE, sr = ((mr >> j) & 1u) ? sb.wseg[1][slot0 + k] : NONE;
+          total += merge(sf, sr, k * stride, base + 2 * total);
         }
       }
+      segw = upper + seeds;
+      // length, two bits per window, per segment its slot and its words, every (id, win_pos) pair written, per-read state written, hit_seeds
+      moved += 4u + (numwin + 3u) / 4u + 8ull * seeds + 4ull * segw + 8ull * total + sizeof(RWork) + 8u;
       w.aval = w.is04 ? 0 : w.aval; w.is04 = 0;
       // (not w.blk_off[pass]: an index the compiler cannot resolve moves the whole state to LDS, 12 KB per block)
       if (pass == 0) { w.blk_off[0] = base; w.blk_cnt[0] = total; } else if (pass == 1) { w.blk_off[1] = base; w.blk_cnt[1] = total; } else { w.blk_off[2] = base; w.blk_cnt[2] = total; }

@@ -26,9 +26,7 @@ namespace smr {
 #define PG_CAND_CAP0 256u                                 // initial pool size
 #define PG_CAND_CAP_MAX 2048u
 #define PG_NIL 0xFFFFu
-#ifndef PG_WAVES
-#define PG_WAVES 1
-#endif
+#define PG_WAVES 1                                        // (measured in round 2: 4 waves per block 1.70 ms, one wave per block 1.57 ms; the chunk loop of k_seed_pg assumes one)
 #ifndef PG_TRIP
 #define PG_TRIP 4
 #endif
@@ -126,15 +124,21 @@ __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32
   }
 }
 
+// DIR 0: the forward searches (the sorted tuples in front of SN_FWD), DIR 1: the reverse searches, launched after them.  Round 3's reverse
+// search started from the window's forward list: per tuple a random probe for the window's segment, then the list itself.  A reverse search
+// does not need the forward list to FIND its candidates, only to apply them; so it leaves them, in its DFS order and without repeats, as the
+// window's reverse segment (a 0-error candidate carries SEED_CAND_COND), and k_seed_finish, which walks the windows of a read anyway,
+// applies them to the forward list (see there).  What it does need to know is whether the forward search ended with a 0-error match -- then
+// there is no reverse search (paralleltraversal.cpp:188), and those are exactly the searches with many accepted strings --: one bit per
+// window (zbits), asked for only where the bit of the window's group of 64 slots is set (gflag: under a megabyte, stays in the L2s).
+// `swz`: wave it works on chunk (it % 8) * ceil(chunks / 8) + it / 8 -- blocks run on XCD b % 8, so every XCD's L2 sees one contiguous
+// eighth of the key range.
 template <int DIR>
 __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
-                                                uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr) {
-  // this phase's tuples: forward bins first, reverse bins after them
-  const uint32_t n_all = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_all);
-  const uint32_t first = DIR ? n_fwd : 0u, n_tup = DIR ? n_all - n_fwd : n_fwd;
-  // up to PG_WAVES independent waves per block, as many as the LDS of a block allows (measured: 4 waves per block 1.70 ms, one wave per block 1.57 ms)
-  const uint32_t vb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);          // this wave's 64 tuples
-  if (vb * 64u >= n_tup) return;
+                                                uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr, int swz) {
+  const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_tup);
+  // this launch's wave chunks of 64 tuples: [c0, c0 + nw) (the chunk that holds the last forward and the first reverse tuple belongs to both)
+  const uint32_t c0 = DIR ? n_fwd >> 6 : 0u, nw = (DIR ? (n_tup + 63u) >> 6 : (n_fwd + 63u) >> 6) - c0, per = (nw + 7u) >> 3;
   SMR_DYN_LDS(uint32_t, lds_dyn);
   uint32_t* hl = lds_dyn + (threadIdx.x >> 6) * PG_LDS_WORDS(hcap, ccap);
   uint32_t* cdk = hl + 64 * hcap;                          // rank in the reference's traversal order
@@ -154,32 +158,26 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
 #define GPH(i)
 #endif
 
+  // A wave takes the chunks it, it + stride, ... (stride = all waves of the launch): the grid is a few waves per wave slot of the machine, not
+  // one block per chunk the batch COULD have (most of which would find nothing to do: the number of tuples is only known on the device).
+  for (uint32_t it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ; it += gridDim.x * (blockDim.x >> 6)) {
+  uint32_t vb = it;                                        // this wave's 64 tuples
+  if (swz) { if ((it >> 3) >= per) break; vb = (it & 7u) * per + (it >> 3); if (vb >= nw) continue; }
+  else if (vb >= nw) break;
+  vb += c0;
+  __syncthreads();                                         // (the previous chunk's LDS is free)
   // ---- the wave's 64 searches ----
-  const uint32_t pos = first + vb * 64u + lane;
-  bool mine = vb * 64u + lane < n_tup;
-  uint32_t win_pos = 0, nh = 0, n_prev = 0, P9 = 0;
+  const uint32_t pos = vb * 64u + lane;
+  bool mine = DIR ? (pos >= n_fwd && pos < n_tup) : pos < n_fwd;
+  const bool counted = mine;
+  uint32_t nh = 0, P9 = 0, slot = 0;
   uint2 rt = make_uint2(NONE, 0);
-  size_t slot = 0;
-  bool hl_over = false, had_seg = false;
+  bool hl_over = false;
   if (mine) {
-    const SeedTmp tp = sb.srt[pos];
-    const unsigned long long pl = seed_payload(tp);
-    rt = ix.root3[2 * (tp.key - (DIR ? sb.nkh : 0u)) + DIR];
-    const uint32_t r = (uint32_t)(pl & 0xFFFFFFull);
-    win_pos = (uint32_t)((pl >> 24) & 0xFFFFull);
-    P9 = (uint32_t)(pl >> 40);
-    slot = wseg_slot(sb, r, div_multiple(win_pos, P.skip[pass]));
-    if (DIR == 1 && wseg_has(sb, slot)) {                // the window's list so far = the forward search's hits (one bit per window says whether
-      had_seg = true;
-      const uint32_t seg = sb.wseg[slot];                //  there is one: the bitmap stays in the caches, the segment table would not)
-      if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
-      else {
-        n_prev = pool[seg + 1];
-        for (uint32_t q = 0; q < n_prev && q < hcap; q++) hl[q * 64 + lane] = pool[seg + 2 + 2 * q];
-        if (n_prev > hcap) { hl_over = true; n_prev = hcap; }
-        nh = n_prev;
-      }
-    }
+    const SeedKey tk = seed_decode(sb, pos);
+    rt = ix.root3[2 * (tk.key - (DIR ? sb.nkh : 0u)) + DIR];
+    P9 = tk.chars; slot = tk.slot;
+    if (DIR == 1 && ((sb.gflag[slot >> 11] >> ((slot >> 6) & 31u)) & 1u) && ((sb.zbits[slot >> 5] >> (slot & 31u)) & 1u)) mine = false;   // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
   }
   if (lane == 0) s_ncand = 0;
   __syncthreads();
@@ -205,6 +203,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
       rs1 = b0; rn1 = b1 - b0;
       if (kb1 != kb0) { rs2 = c0; rn2 = c1 - c0; }
       rs3 = d0; rn3 = d1 - d0;
+      (void)nB;
     }
   }
   const uint32_t tot = rn0 + rn1 + rn2 + rn3;
@@ -241,9 +240,11 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
       const uint32_t p = atomicAdd(&sb.sn[SN_REDO], 1u);
       if (p < sb.cap_redo) sb.redo[p] = vb; else atomicAdd(&ctr[C_ERR_REDO], 1ull);
     }
-    return;
+    continue;
   }
-  // ---------- every search applies its candidates in DFS order (selection by increasing rank) ----------
+  // ---------- every search takes its candidates in DFS order (selection by increasing rank).  Forward: applied to its list -- the window's
+  // list so far -- with the reference's rules.  Reverse: collected without repeats, the kind of the first occurrence kept (a later occurrence
+  // of an id changes nothing whatever the forward list holds: the id is present by then, or the list was replaced and the search over) ----------
   bool zero = false;
   {
     const uint32_t head = hd[lane];
@@ -258,16 +259,16 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
       if (!more || best == 0xFFFFFFFFu) { more = false; continue; }
       const uint32_t idc = cdv[bi], kc = cdn[bi] >> 16;
       bool present = false;
-      for (uint32_t f = 0; f < nh; f++) if (hl[f * 64 + lane] == idc) { present = true; break; }
-      if (kc == CK_COND && !present) { hl[lane] = idc; nh = 1; zero = true; more = false; }
-      else if (!present) { if (nh < hcap) { hl[nh * 64 + lane] = idc; nh++; } else hl_over = true; }
+      for (uint32_t f = 0; f < nh; f++) if ((hl[f * 64 + lane] & ~SEED_CAND_COND) == idc) { present = true; break; }
+      if (DIR == 0 && kc == CK_COND && !present) { hl[lane] = idc; nh = 1; zero = true; more = false; }
+      else if (!present) { if (nh < hcap) { hl[nh * 64 + lane] = idc | ((DIR && kc == CK_COND) ? SEED_CAND_COND : 0u); nh++; } else hl_over = true; }
       last = best + 1;
     }
   }
   GPH(4)
-  // ---- write the windows' hit segments: [unused, count, (id, win_pos) x count] ----
-  const bool wr = mine && (DIR == 0 ? nh > 0 : (zero || nh > n_prev));
-  const uint32_t need = wr ? 2 + 2 * nh : 0;
+  // ---- write the windows' hit segments: [count, id x count] ----
+  const bool wr = mine && nh > 0;
+  const uint32_t need = wr ? 1 + nh : 0;
   const uint32_t incl = pg_scan_add(need);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   uint32_t base = 0;
@@ -281,23 +282,23 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   }
   if (wr && base != NONE) {
     const uint32_t o = base + incl - need;
-    pool[o] = NONE; pool[o + 1] = nh;
-    for (uint32_t q = 0; q < nh; q++) { pool[o + 2 + 2 * q] = hl[q * 64 + lane]; pool[o + 3 + 2 * q] = win_pos; }
-    wseg_put(sb, slot, o | (zero ? SEED_ZERO_BIT : 0u));
+    pool[o] = nh;
+    for (uint32_t q = 0; q < nh; q++) pool[o + 1 + q] = hl[q * 64 + lane];
+    wseg_put(sb, DIR, slot, o | (zero ? SEED_ZERO_BIT : 0u), zero);
   }
   if (__any(hl_over) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
-  // algorithmic bytes of this wave (C_B_PG0/1): per tuple 12 B + its block-table entry (8 B); a search with directories reads 8 directory
-  // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; DIR 1 reads the window's bit and, where it is set, its slot and
-  // the forward search's list (count word + its ids with their win_pos); the segment written (4 B per word) and the window slot pointing to it
-  // (what does not come out of the scans above is summed per lane: < 2^32 per wave)
-  const uint32_t lane_bytes = (vb * 64u + lane < n_tup ? (uint32_t)sizeof(SeedTmp) + 8u + (had_seg ? 8u + 8u * n_prev : 0u) : 0u) + ((srch && cA) ? 32u : 0u) + (wr ? 4u : 0u);
+  // algorithmic bytes of this wave (C_B_PG0/1): per tuple 8 B + its block-table entry (8 B); a search with directories reads 8 directory
+  // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; the segment written (4 B per word) and the window slot pointing
+  // to it; the chunk's coarse bin; DIR 1: the window's group bit (what does not come out of the scans above is summed per lane: < 2^32 per wave)
+  const uint32_t lane_bytes = (counted ? (uint32_t)sizeof(SeedTup) + 8u + (DIR ? 1u : 0u) : 0u) + ((srch && cA) ? 32u : 0u) + (wr ? 4u : 0u);
   unsigned long long w_bytes = (uint32_t)__builtin_amdgcn_readlane((int)pg_scan_add(lane_bytes), 63);
-  w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + (DIR ? 8u : 0u);          // (DIR 1: one window bit per tuple)
+  w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + 2u;
   if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, w_bytes); }
 #ifdef SMR_SEED_PHASES
   GPH(5)
-  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) atomicAdd(&ctr[C_SHARDS + (vb & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], tph[q]);
+  if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) { atomicAdd(&ctr[C_SHARDS + (vb & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], tph[q]); tph[q] = 0; }
 #endif
+  }
 }
 
 }  // namespace smr
