@@ -25,9 +25,11 @@ collectives are the two tiny all-reduces the reference's semantics need: global 
 minimal_score, refstats.cpp:247-265) and the Readstats counters after (RCCL).
 
 The JSON line also carries
-  roofline      seed stage (k_seed_keys/scan/scatter/pg/finish = "k_seed"): algorithmic bytes (SURVEY.md 8d formula, from exact
-                device work counters of an untimed counting pass over the same batches) / HIP-event time of its launches in the
-                timed steps, against the 8 TB/s HBM3E peak
+  roofline      the seed-stage kernel with the most time in the timed steps: the algorithmic HBM bytes THAT kernel counts for itself on the
+                device (smr_prof_kernels: tuples, directory words, strings looked at, accepted {rank, id}, hit segments) / its own HIP-event
+                time, against the 8 TB/s HBM3E peak; `kernels` has every seed-stage kernel, `seed_stage` their sum, `counters` the issue-side
+                view (VALU issue fraction, LDS bank conflicts) from profiles/sq_counters.json when it was measured on these sources; what
+                the REFERENCE's traversal would move for the same reads (SURVEY.md 8d formula) only as `equivalent_rate`
   kernels       HIP-event time and launch count of each kernel family in the timed region
   cpu_baseline  the UNMODIFIED reference (oracle/_ref/sortmerna_ref) timed on this host's cores on a bounded sample of
                 the same reads with the same index files (rank 0, N=1 only)
@@ -270,8 +272,26 @@ def make_batch(args, synth, codes, offs, n, seed):
     if args.workload == "pacbio5k":
         L = args.long_read_len
         return synth.make_long_reads(codes, offs, n, mean_len=L, sd_len=L // 10, min_len=L // 5, max_len=6 * L, seed=seed)
-    letters = synth.make_reads(codes, offs, n, read_len=args.read_len, frac_db=0.10, seed=seed, sub=0.005, indel=0.0001, n_rate=0.001)
+    letters = synth.make_reads_fast(codes, offs, n, read_len=args.read_len, frac_db=0.10, seed=seed, sub=0.005, indel=0.0001, n_rate=0.001)
     return letters.tobytes(), (np.arange(n + 1, dtype=np.uint64) * np.uint64(args.read_len))
+
+
+def make_shard(args, synth, codes, offs, rank, world):
+    """--scaling strong: the job is ONE fixed read set of --total-reads reads, made of 8 seeded units (N units when 8 is not a multiple of N);
+    rank r of N takes the units [r U / N, (r + 1) U / N) -- contiguous record ranges of the same file whatever N is, like the reference's
+    split of a reads file over its threads (readfeed.cpp:1253-1277)"""
+    import numpy as np
+    units = 8 if 8 % world == 0 else world
+    per = args.total_reads // units
+    mine = range(rank * units // world, (rank + 1) * units // world)
+    blobs, offl, base = [], [np.zeros(1, dtype=np.uint64)], 0
+    for u in mine:
+        n = per + (args.total_reads - per * units if u == units - 1 else 0)
+        b, o = make_batch(args, synth, codes, offs, n, 777 + u)
+        blobs.append(b)
+        offl.append(o[1:] + np.uint64(base))
+        base += int(o[-1])
+    return b"".join(blobs), np.concatenate(offl)
 
 
 def self_launch(n):
@@ -300,7 +320,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="illumina150")
-    ap.add_argument("--batch-reads", type=int, default=0, help="reads per resident batch (0 = the workload's default: 2 M short reads, 50 k long reads)")
+    ap.add_argument("--batch-reads", type=int, default=0, help="reads per resident batch (0 = the workload's default: 8 M short reads, 50 k long reads)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--long-read-len", type=int, default=5000, help="pacbio5k: mean read length (sd = a tenth of it, clipped to [a fifth, six times])")
     ap.add_argument("--db-nt", type=int, default=0, help="size of the synthetic DB (0 = the workload's: 140 Mnt; pacbio5k 14 Mnt; refs8 scales its 7 synthetic members by db_nt / 140 M)")
@@ -310,6 +330,11 @@ def main():
     ap.add_argument("--no-cigar", action="store_true", help="skip the banded traceback (not the reference's behaviour)")
     ap.add_argument("--profile-run", action="store_true",
                     help="for rocprofv3 counter passes: only warm-up + timed steps (no exact-count pass, no PCIe leg, no CPU baseline), so every dispatch is a timed-path dispatch")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank aligns its own batches of --batch-reads reads; strong: ONE job of --total-reads reads (BASELINE configs[3]: 10 M) is split over the ranks, "
+                         "a step = one pass of every rank over its shard")
+    ap.add_argument("--total-reads", type=int, default=10_000_000, help="--scaling strong: reads of the whole job")
+    ap.add_argument("--n1-value", type=float, default=0.0, help="--scaling strong: the value of the same command at --gpus 1; the line then carries efficiency_vs_n1 = value / (N x that)")
     ap.add_argument("--resident-batches", type=int, default=0,
                     help="distinct read batches kept resident in HBM (1..%d); step i runs on batch i %% this; 0 = as many as hold 16 M reads, between 2 and 8" % MAX_RESIDENT)
     args = ap.parse_args()
@@ -325,6 +350,10 @@ def main():
     args.warmup = max(args.warmup, 0)
     W = WORKLOADS[args.workload]
     args.batch_reads = args.batch_reads or W["batch_reads"]
+    if args.scaling == "strong":
+        units = 8 if 8 % world == 0 else world
+        args.batch_reads = (args.total_reads // units) * (units // world) + args.total_reads % units      # the last rank's shard (the largest); config.batch_reads reports it
+        args.resident_batches = 1
     args.cpu_sample_reads = args.cpu_sample_reads or W["cpu_sample_reads"]
     args.db_nt = args.db_nt or (14_000_000 if args.workload == "pacbio5k" else 140_000_000)
     if args.resident_batches <= 0:
@@ -405,13 +434,19 @@ def main():
     tot_reads = tot_len = 0
     min_len, max_len = 1 << 30, 0
     import ctypes as C
+    shard_reads = []                                         # reads of every resident batch of this rank
     for b in range(nb):
-        blob, o = make_batch(args, synth, codes, offs, args.batch_reads, 1234 + 1000 * rank + b)
+        if args.scaling == "strong":
+            blob, o = make_shard(args, synth, codes, offs, rank, world)
+        else:
+            blob, o = make_batch(args, synth, codes, offs, args.batch_reads, 1234 + 1000 * rank + b)
+        nrb = len(o) - 1
+        shard_reads.append(nrb)
         if b == 0:
-            ns = min(args.batch_reads, args.cpu_sample_reads)
+            ns = min(nrb, args.cpu_sample_reads)
             sample0 = (blob[:int(o[ns])], o[:ns + 1].copy())
         h = C.c_void_p()
-        rc = eng.L.smr_reads_pack(blob, o.ctypes.data, args.batch_reads, C.byref(h))
+        rc = eng.L.smr_reads_pack(blob, o.ctypes.data, nrb, C.byref(h))
         assert rc == 0
         r = smr.Reads(h)
         eng.select_batch(b)
@@ -424,7 +459,8 @@ def main():
         else:
             r.free()
     del codes, offs
-    log("%d batches of %d reads resident, %.0f nt per read (%.1fs)" % (nb, args.batch_reads, tot_len / max(tot_reads, 1), time.time() - t0))
+    log("%d batch(es) of %s reads resident, %.0f nt per read (%.1fs)" % (nb, "/".join(str(x) for x in sorted(set(shard_reads))), tot_len / max(tot_reads, 1), time.time() - t0))
+    reads_per_step = shard.reduce_counters([shard_reads[0]], device=cdev)[0] if args.scaling == "strong" else args.gpus * args.batch_reads
 
     # C1: global read totals -> the same minimal_score (per DB) on every rank (refstats.cpp:247-265)
     g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, min_len, max_len, device=cdev)
@@ -496,11 +532,11 @@ def main():
         eng.upload_reads(last_packed, 1)
         smr.align_resident(eng, idx_slots, plist, with_cigar=not args.no_cigar)
     torch.cuda.synchronize()
-    pcie_rate = None if args.profile_run else 2 * args.batch_reads / (time.perf_counter() - t0)
+    pcie_rate = None if args.profile_run else 2 * shard_reads[nb - 1] / (time.perf_counter() - t0)
     last_packed.free()
 
     if rank == 0:
-        reads_timed = args.gpus * args.steps * args.batch_reads
+        reads_timed = args.steps * int(reads_per_step)
         seed_ms, chain_ms, trace_ms, seed_l, chain_l, trace_l = prof[0:6]
         n_lookup, n_node, n_entry, n_hit, n_read_bytes = prof[7], prof[8], prof[9], prof[10], prof[11]
         # what the reference's traversal would have moved (SURVEY.md 8d formula on the exact counters of the DFS kernel): reported as an
@@ -566,7 +602,7 @@ def main():
             "metric": {"illumina150": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "refs8": "reads/sec (150 bp vs the 8-ref rRNA set)",
                        "pacbio5k": "reads/sec (5 kb PacBio-like reads vs a 28S-like DB, every alignment with its CIGAR)"}[args.workload], "value": reads_timed / dt, "unit": "reads/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/i32", "data": "synthetic",
             "config": {"workload": {
                 "illumina150": "BASELINE configs[2]: synthetic 150-nt Illumina-like reads (10%% from DB, 90%% background) vs seeded synthetic rRNA-like DB "
                                "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); " % args.db_nt,
@@ -576,6 +612,9 @@ def main():
                             "of %d nt (silva-euk-28s-id98 is absent offline); " % args.db_nt}[args.workload] + W["options"],
                        "name": args.workload, "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": (args.read_len if args.workload != "pacbio5k" else mean_len), "db_nt": args.db_nt, "index_parts": len(parts),
                        "n_dbs": n_db, "db_seqs": sum(int(i.numseq) for i in infos), "minimal_score": [int(x) for x in mss] if n_db > 1 else int(ms), "sharding": "reads, %d rank(s), index replicated" % args.gpus, "nranks": (dist.get_world_size() if dist is not None else 1),
+                       "collectives": {"backend": (backend if dist is not None else None), "what": "all-reduce of the read totals before, of the Readstats counters after; none on the data path",
+                                       "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None)},
+                       "total_reads": (args.total_reads if args.scaling == "strong" else None),
                        "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": "packed 16-bit (v_pk): candidate windows scored ahead four per wave, single problems on 128 virtual lanes" if eng.sw_mode() >= 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
@@ -597,6 +636,8 @@ def main():
                                             "four-problem kernel's model when the reads fit it"},
                         "k_trace": {"ms": trace_ms / args.gpus, "launches": trace_l / args.gpus}},
         }
+        if args.scaling == "strong" and args.n1_value > 0:
+            out["efficiency_vs_n1"] = out["value"] / (args.gpus * args.n1_value)
         if args.gpus == 1 and not args.no_cpu_baseline and not args.profile_run:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, dbs, parts_per_db, sample0, smr, eng, idx_slots)

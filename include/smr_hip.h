@@ -21,6 +21,17 @@
  *                    traverse_bursttrie.cpp:100-298, alignment.cpp:100-509, ssw.c:834-941
  *   smr_result_*     Read::toBinString() / kvdb.put()         read.cpp:429-462, processor.cpp:150-155
  *   smr_counters     Readstats atomics                        readstats.hpp:77-85
+ *
+ * Hard limits of this build (each is an explicit error -- SMR_ERR_CAPACITY / SMR_ERR_ARG with a message --, never a silent difference):
+ *   reads                 <= 65 535 letters each; reads x windows of the finest pass < 2^31 per batch (150-nt reads: ~47 M; the benches use 8 M)
+ *   resident batches      16 per context (smr_batch_select), resident index parts 64 per context (smr_index_upload slot 0..63)
+ *   seed length           8..20, even; < 2^31 - 1 distinct seeds (ids) per index part
+ *   seed hits             <= 128 distinct 18-mers within one error of ONE seed window (the lane-local hit lists double up to that)
+ *   candidate references  <= 49 152 references sharing seeds with ONE read on one strand (the per-block global table of k_chain<EXT>)
+ *   alignments per read   max_alignments_per_read given to smr_reads_upload (the reference's -num_alignments, or 256 for "all")
+ *   scoring               match <= 127, mismatch >= -127, |score_N| <= 127, gaps <= 255, and 2 * gap_open, 2 * gap_ext >= |mismatch|
+ *                         (under that condition the affine recurrence here equals the reference's striped kernels cell for cell, ssw.c:267,496)
+ *   pools                 seed-hit pool <= 8 GiB, CIGAR pool < 2^32 words, pigeonhole arena < 2^34 words per part (all grown on demand)
  */
 #ifndef SMR_HIP_H
 #define SMR_HIP_H

@@ -6,7 +6,7 @@
 // (index, part), processor.cpp:93-168,248-256) through the C ABI of libsmr_hip (include/smr_hip.h).  oracle/Makefile (target `dropin`)
 // compiles the reference's processor.cpp with its own align() renamed out of the way and links this file in its place:
 //     oracle/_ref/sortmerna_gpu  =  the reference with the GPU in the middle.
-// tests/test_dropin_gpu.py runs it next to the unmodified binary on the reference's test inputs and compares every output file.
+// tests/test_dropin.py runs it next to the unmodified binary on the reference's test inputs and compares every output file.
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -39,10 +39,10 @@ struct Chunk {
 	smr_reads* packed = nullptr;
 	std::vector<std::pair<size_t, std::string>> records;     // (position in ids, Read::toBinString bytes)
 };
-template <class T> struct Queue {                            // unbounded hand-over between the stages; a null pointer ends it
-	std::mutex m; std::condition_variable cv; std::deque<T> q;
-	void push(T v) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(v)); } cv.notify_one(); }
-	T pop() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty(); }); T v = std::move(q.front()); q.pop_front(); return v; }
+template <class T> struct Queue {                            // hand-over between the stages, at most `cap` chunks waiting (a fast reader or a slow KVDB must
+	std::mutex m; std::condition_variable cv, cv_room; std::deque<T> q; size_t cap = 4;      //  not hold the whole read set in memory); a null pointer ends it
+	void push(T v) { { std::unique_lock<std::mutex> l(m); cv_room.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); } cv.notify_one(); }
+	T pop() { T v; { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return !q.empty(); }); v = std::move(q.front()); q.pop_front(); } cv_room.notify_one(); return v; }
 };
 }
 
@@ -87,9 +87,11 @@ void align(Readfeed& readfeed, Readstats& readstats, Index& index, KeyValueDatab
 			p.is_last_index_part = (idx_num == opts.indexfiles.size() - 1 && part == refstats.num_index_parts[idx_num] - 1);
 			parts.push_back(P);
 		}
-	if (parts.size() > 64) { ERR("more than 64 index parts in total: the engine keeps 64 resident"); exit(EXIT_FAILURE); }
+	// the engine keeps up to 64 parts resident on a GPU; a run with more (a small -m, many -ref) streams them through slot 0 per chunk instead
+	const bool resident = parts.size() <= 64;
 
 	Queue<std::unique_ptr<Chunk>> to_gpu, to_db;
+	to_gpu.cap = to_db.cap = (size_t)n_gpu + 2;
 	std::mutex cm;
 	std::vector<uint64_t> ctr(2 + opts.indexfiles.size(), 0);
 	uint64_t n_reads = 0, n_chunks = 0;
@@ -127,7 +129,7 @@ void align(Readfeed& readfeed, Readstats& readstats, Index& index, KeyValueDatab
 		char e2[512] = "";
 		smr_ctx* gpu = nullptr;
 		if (smr_create(g, &gpu, e2, sizeof e2) != SMR_OK) { ERR(e2); exit(EXIT_FAILURE); }   // no CPU fallback
-		for (size_t k = 0; k < parts.size(); k++) if (smr_index_upload(gpu, parts[k].ix, (int)k) != SMR_OK) die_gpu(gpu, "smr_index_upload");
+		if (resident) for (size_t k = 0; k < parts.size(); k++) if (smr_index_upload(gpu, parts[k].ix, (int)k) != SMR_OK) die_gpu(gpu, "smr_index_upload");
 		std::vector<uint64_t> mine(ctr.size(), 0), c1(ctr.size());
 		std::vector<uint8_t> buf;
 		for (;;) {
@@ -135,8 +137,11 @@ void align(Readfeed& readfeed, Readstats& readstats, Index& index, KeyValueDatab
 			if (!ch) break;
 			if (smr_reads_upload(gpu, ch->packed, slots) != SMR_OK) die_gpu(gpu, "smr_reads_upload");
 			for (size_t k = 0; k < parts.size(); k++) {      // the (index, part) loop of processor.cpp:219-277 for this chunk
-				if (smr_align_part(gpu, (int)k, &parts[k].p) != SMR_OK) die_gpu(gpu, "smr_align_part");    // = the N x align2() threads of this part
-				if (smr_traceback(gpu, (int)k, &parts[k].p)  != SMR_OK) die_gpu(gpu, "smr_traceback");     // CIGARs (ssw.c:577-773)
+				const int sl = resident ? (int)k : 0;
+				if (!resident && smr_index_upload(gpu, parts[k].ix, 0) != SMR_OK) die_gpu(gpu, "smr_index_upload");
+				if (smr_align_part(gpu, sl, &parts[k].p) != SMR_OK) die_gpu(gpu, "smr_align_part");    // = the N x align2() threads of this part
+				if (smr_traceback(gpu, sl, &parts[k].p)  != SMR_OK) die_gpu(gpu, "smr_traceback");     // CIGARs (ssw.c:577-773)
+				if (!resident && smr_index_unload(gpu, 0) != SMR_OK) die_gpu(gpu, "smr_index_unload");
 			}
 			if (smr_results_fetch(gpu) != SMR_OK) die_gpu(gpu, "smr_results_fetch");
 			for (uint32_t i = 0; i < ch->ids.size(); ++i) {

@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         // (k_cand ended the pass of every read it did not mark; 2 = left to the EXT launch by the first one)
         const uint32_t ri = chunk_base + (uint32_t)lane;
         const uint32_t mk = ((uint32_t)lane < claim && ri < rd.n) ? marks[ri] : 0u;
-        const bool todo = EXT ? mk == 2u : (mk == 1u || mk == 4u);
+        const bool todo = EXT ? mk == 2u : mk == 1u;
         chunk_todo = __ballot(todo);
         if (chunk_todo == 0) continue;
       }

@@ -17,6 +17,22 @@ __device__ __forceinline__ pk16 pk_add(pk16 a, pk16 b) { return a + b; }
 __device__ __forceinline__ pk16 pk_sub(pk16 a, pk16 b) { return a - b; }
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+// A value that is the same in every lane of the wave, said so to the compiler (v_readfirstlane_b32): it then lives in a scalar register, costs
+// no vector register across a call and is worked on by the scalar unit.  The kernel emulator's version checks that the lanes do agree.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long v) { return (unsigned long long)uni((uint32_t)v) | ((unsigned long long)uni((uint32_t)(v >> 32)) << 32); }
+__device__ __forceinline__ unsigned long uni(unsigned long v) { return (unsigned long)uni((unsigned long long)v); }
+template <class T> __device__ __forceinline__ T uni_words(const T& v) {      // a struct of whole 32-bit words
+  static_assert(sizeof(T) % 4 == 0, "uni_words: whole words only");
+  uint32_t w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = uni(w[i]);
+  T o;
+  __builtin_memcpy(&o, w, sizeof(T));
+  return o;
+}
 // n / d for n = k * d, k < 2^16: one reciprocal and a multiply (the error of v_rcp_f32 is far below the 0.5 that is added)
 __device__ __forceinline__ uint32_t div_multiple(uint32_t n, uint32_t d) { return (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d) + 0.5f); }
 

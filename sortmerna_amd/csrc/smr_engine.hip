@@ -35,8 +35,8 @@ struct EvMark { hipEvent_t e; int kind; };        // kind < 0: end of a run of i
 
 #define SMR_MAX_BATCHES 16
 // kernel families timed apart (one HIP event between them on the engine's stream)
-enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_QUAD, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_COUNT };
-static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_quad+k_park_sw", "k_chain", "k_begins", "k_trace"};
+enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_COUNT };
+static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_chain", "k_begins", "k_trace"};
 
 // One resident read batch: packed reads + everything the reference keeps per read in the KVDB (read.cpp:429-539)
 // + its Readstats counter block + its CIGAR pool.  Several batches can be resident at once (the host uploads
@@ -79,7 +79,7 @@ struct smr_ctx {
   uint32_t cand_bloom = 128;
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
   // k_seed_pg: waves of the launch (0: one per wave chunk the batch can have; else a wave walks chunks it, it + grid, ...), XCD-aware chunk order
-  uint32_t pg_grid = getenv("SMR_PG_GRID") ? (uint32_t)atoi(getenv("SMR_PG_GRID")) : 65536u;
+  uint32_t pg_grid = getenv("SMR_PG_GRID") ? (uint32_t)atoi(getenv("SMR_PG_GRID")) : 262144u;
   int pg_swz = getenv("SMR_PG_SWZ") ? atoi(getenv("SMR_PG_SWZ")) : 0;
   SeedBufs sb = {};                       // seed-stage scratch (smr_seed.hpp)
   uint64_t sb_slots = 0; uint32_t sb_nk = 0;
@@ -95,13 +95,9 @@ struct smr_ctx {
   unsigned long long* d_pairs = nullptr; uint32_t* d_lis = nullptr; uint32_t pairs_cap = 0;
   uint2* d_hits = nullptr; uint32_t hits_cap = 0;
   uint8_t* d_rdq = nullptr; size_t rdq_cap = 0;
-  // the 16-lane walk (smr_quad.hpp): list of marked reads, parked Smith-Waterman tasks, cursors.  OFF by default: measured slower than leaving
-  // those reads to k_chain (2.48 + 4.35 vs 5.96 ms per 2 M-read launch, profiles/r3s17_*) -- SMR_QUAD=1 switches it on
-  int quad = getenv("SMR_QUAD") ? atoi(getenv("SMR_QUAD")) : 0;
   // k_cand -> k_chain hand-over (smr_chain.hpp): {offset, npos} per read, the records (SMR_HANDOVER=0 switches it off)
   int handover = getenv("SMR_HANDOVER") ? atoi(getenv("SMR_HANDOVER")) : 1;
   uint2* d_mrec = nullptr; uint32_t* d_mpool = nullptr; size_t mrec_cap = 0, mpool_words = 0;
-  uint32_t* d_qlist = nullptr; QTask* d_qtasks = nullptr; uint32_t* d_qc = nullptr; size_t qlist_cap = 0, qtasks_cap = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
@@ -158,18 +154,18 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
 }
 
 int check_params(smr_ctx* c, const smr_params* p) {
-  if (!p) { c->err = "null params"; return SMR_ERR_ARG; }
-  if (p->index_num >= 64) { c->err = "index_num must be < 64"; return SMR_ERR_ARG; }
-  if ((uint64_t)p->minoccur >= 0x3FFFFFFFull) { c->err = "minoccur must be < 2^30 - 1"; return SMR_ERR_ARG; }
-  if (p->num_seeds < 1 || p->gap_open < 0 || p->gap_ext < 0 || p->match <= 0 || p->mismatch > 0) { c->err = "bad scoring/seed options"; return SMR_ERR_ARG; }
+  if (!p) { set_err(c, "null params"); return SMR_ERR_ARG; }
+  if (p->index_num >= 64) { set_err(c, "index_num must be < 64"); return SMR_ERR_ARG; }
+  if ((uint64_t)p->minoccur >= 0x3FFFFFFFull) { set_err(c, "minoccur must be < 2^30 - 1"); return SMR_ERR_ARG; }
+  if (p->num_seeds < 1 || p->gap_open < 0 || p->gap_ext < 0 || p->match <= 0 || p->mismatch > 0) { set_err(c, "bad scoring/seed options"); return SMR_ERR_ARG; }
   // the reference's scoring matrix is int8_t (ssw_init, ssw.h:88); the SW kernel keeps a row's scores as 4 signed bytes
-  if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { c->err = "scores must fit int8 / gaps uint8 like the reference's"; return SMR_ERR_ARG; }
+  if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { set_err(c, "scores must fit int8 / gaps uint8 like the reference's"); return SMR_ERR_ARG; }
   // The reference's striped kernels never open a gap in one sequence directly after a gap in the other when the
   // second gap would cross a SIMD stripe (ssw.c:267,496).  Under 2*gap_open >= |mismatch| and 2*gap_ext >= |mismatch|
   // such paths are never optimal and the standard affine recurrence computed here is cell-for-cell identical.
   int mm = std::max(-p->mismatch, -std::min(p->score_N, 0));
-  if (2 * p->gap_open < mm || 2 * p->gap_ext < mm) { c->err = "scoring scheme outside the supported range (2*gap_open and 2*gap_ext must be >= |mismatch|)"; return SMR_ERR_ARG; }
-  if (p->num_alignments > 0 && p->num_alignments > c->b->slots) { c->err = "num_alignments exceeds max_alignments_per_read given to smr_reads_upload"; return SMR_ERR_ARG; }
+  if (2 * p->gap_open < mm || 2 * p->gap_ext < mm) { set_err(c, "scoring scheme outside the supported range (2*gap_open and 2*gap_ext must be >= |mismatch|)"); return SMR_ERR_ARG; }
+  if (p->num_alignments > 0 && p->num_alignments > c->b->slots) { set_err(c, "num_alignments exceeds max_alignments_per_read given to smr_reads_upload"); return SMR_ERR_ARG; }
   return SMR_OK;
 }
 
@@ -216,6 +212,12 @@ void ev_collect(smr_ctx* c) {
     float ms = 0;
     if (k >= 0 && hipEventElapsedTime(&ms, c->events[i].e, c->events[i + 1].e) == hipSuccess) { c->kp_ms[k] += ms; c->kp_l[k]++; }
   }
+  for (auto& m : c->events) c->ev_pool.push_back(m.e);
+  c->events.clear();
+}
+// marks a call that failed half-way left behind (an error return between ev_mark and ev_stop): dropped at the start of the next timed call, or
+// ev_collect would pair the dangling mark with the first one of an unrelated run and charge the gap to a kernel family
+void ev_drop(smr_ctx* c) {
   for (auto& m : c->events) c->ev_pool.push_back(m.e);
   c->events.clear();
 }
@@ -397,31 +399,6 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
                      mrec, c->d_mpool, c->mpool_words);
-  if (c->quad && P.num_seeds >= 1) {
-    // the small majority of the marked reads, 16 lanes each: reads without any Smith-Waterman task end their pass, single tasks are scored four per wave
-    ev_mark(c, KP_QUAD);
-    const size_t want_t = std::max<size_t>((size_t)c->b->n / 4, 4096) & ~(size_t)(QD_SHARDS - 1);
-    if (c->qlist_cap < c->b->n) { int rc = dev_alloc(c, &c->d_qlist, (size_t)c->b->n); if (rc) return rc; c->qlist_cap = c->b->n; }
-    if (c->qtasks_cap < want_t) { int rc = dev_alloc(c, &c->d_qtasks, want_t); if (rc) return rc; c->qtasks_cap = want_t; }
-    if (!c->d_qc) { int rc = dev_alloc(c, &c->d_qc, (size_t)QC_COUNT); if (rc) return rc; }
-    HIPCHK(c, hipMemsetAsync(c->d_qc, 0, QC_COUNT * 4, c->stream));
-    const uint32_t mq = std::min<uint32_t>(ml, SW_X4_MAX_ROWS);
-    hipLaunchKernelGGL(k_mark_list, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, c->b->n, (const uint8_t*)c->b->d_marks, c->d_qlist, c->d_qc);
-    hipLaunchKernelGGL(k_quad, dim3(std::min<uint32_t>((uint32_t)c->n_cu * 16u, (c->b->n + 3u) / 4u)), dim3(64), 0, c->stream, dreads(c), dindex(di), P, pass, is_last_strand,
-                       c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, (const uint32_t*)c->d_qlist, c->d_qc, c->d_qtasks, (uint32_t)c->qtasks_cap, mq, rq);
-    hipLaunchKernelGGL(k_park_sw, dim3(std::max<uint32_t>(QD_SHARDS, (uint32_t)c->n_cu * 8u)), dim3(64), (size_t)4 * (mq + rq), c->stream, dreads(c), dindex(di), P, is_last_strand,
-                       c->b->d_work, c->b->d_rw, c->b->d_marks, (const uint32_t*)c->d_qc, (const QTask*)c->d_qtasks, (uint32_t)c->qtasks_cap, c->b->d_ctr, mq, rq);
-    if (getenv("SMR_QUAD_STATS")) {                        // debugging aid: what the 16-lane walk did with this launch's marked reads
-      uint32_t hq[QC_COUNT]; std::vector<uint8_t> hm(c->b->n);
-      HIPCHK(c, hipMemcpy(hq, c->d_qc, sizeof hq, hipMemcpyDeviceToHost));
-      HIPCHK(c, hipMemcpy(hm.data(), c->b->d_marks, c->b->n, hipMemcpyDeviceToHost));
-      size_t left[5] = {0, 0, 0, 0, 0};
-      for (uint8_t v : hm) if (v < 5) left[v]++;
-      for (uint32_t q = 1; q < QD_SHARDS; q++) hq[QC_TASKS] += hq[QC_TASKS + q];
-      fprintf(stderr, "[smr quad] pass %d: %u marked reads listed, %u parked tasks; after k_park_sw: %zu still marked, %zu for the sequential walk, %zu parked (must be 0)\n",
-              pass, hq[QC_LIST], hq[QC_TASKS], left[1], left[4], left[3]);
-    }
-  }
   ev_mark(c, KP_CHAIN);
 #define CHAIN_ARGS(stab, t2) dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, \
                              c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks, (const uint2*)mrec, (const uint32_t*)c->d_mpool
@@ -474,7 +451,7 @@ struct DevPool {                         // device buffers of one build; freed t
   ~DevPool() { for (void* p : ptrs) (void)hipFree(p); }
   template <class T> T* get(smr_ctx* c, size_t count) {
     void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { c->err = "hipMalloc failed in the index build"; return nullptr; }
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { set_err(c, "hipMalloc failed in the index build"); return nullptr; }
     ptrs.push_back(p);
     return (T*)p;
   }
@@ -593,8 +570,8 @@ int ib_part_device(void* user, const smr::IBuildInput& in, smr_index& ix, std::s
     uint32_t status = 0;
     HIPCHK(c, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (status != smr::TRIE_OK) { c->err = status == smr::TRIE_ERR_BUCKET ? "bucket with more than 255 entries" : "mini-trie larger than 2^22 words"; return SMR_ERR_IO; }
-    if (words > 0xFFFFFFF0ull) { c->err = "trie arena exceeds 2^32 words"; return SMR_ERR_IO; }
+    if (status != smr::TRIE_OK) { set_err(c, status == smr::TRIE_ERR_BUCKET ? "bucket with more than 255 entries" : "mini-trie larger than 2^22 words"); return SMR_ERR_IO; }
+    if (words > 0xFFFFFFF0ull) { set_err(c, "trie arena exceeds 2^32 words"); return SMR_ERR_IO; }
     IB_GET(d_trie, uint32_t, words); IB_GET(d_lookup, smr::Lookup, NK);
     hipLaunchKernelGGL(smr::k_ib_emit, dim3(gT), dim3(256), 0, c->stream, (const smr::u64*)d_ftail, (const smr::u64*)d_rtail, (const uint32_t*)d_fstart, (const uint32_t*)d_rstart,
                        NK, (int)T, burst_depth, (const smr::u64*)d_toff, d_trie, d_lookup);
@@ -698,7 +675,7 @@ extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uin
   unsigned long long h[3] = {0, 0, 0};
   HIPCHK(c, hipMemcpyAsync(h, d, 3 * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (h[0] != 2ull * n_cases) { c->err = "SW self-check did not run all cases"; return SMR_ERR_DEVICE; }
+  if (h[0] != 2ull * n_cases) { set_err(c, "SW self-check did not run all cases"); return SMR_ERR_DEVICE; }
   *n_bad = h[1];
   return SMR_OK;
 }
@@ -779,7 +756,7 @@ extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads,
   for (uint32_t i = 0; i < n_pairs; i++) { mx_m = std::max(mx_m, read_off[i + 1] - read_off[i]); mx_n = std::max(mx_n, ref_off[i + 1] - ref_off[i]); }
   const uint32_t lm = (uint32_t)((mx_m + 15) & ~15ull), ln = (uint32_t)((mx_n + 15) & ~15ull);
   const size_t lds = (size_t)lm + ln + (size_t)2 * ln * 4;
-  if (lds > 60 * 1024) { c->err = "smr_ssw_batch: sequences too long for one LDS tile (read + 9 x reference window <= 60 KB)"; return SMR_ERR_CAPACITY; }
+  if (lds > 60 * 1024) { set_err(c, "smr_ssw_batch: sequences too long for one LDS tile (read + 9 x reference window <= 60 KB)"); return SMR_ERR_CAPACITY; }
   DevPool pool;
   IB_GET(d_reads, uint8_t, read_off[n_pairs] + 1); IB_GET(d_refs, uint8_t, ref_off[n_pairs] + 1);
   IB_GET(d_ro, unsigned long long, (size_t)n_pairs + 1); IB_GET(d_fo, unsigned long long, (size_t)n_pairs + 1);
@@ -792,7 +769,7 @@ extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads,
     for (uint32_t i = 0; i < n_pairs; i++) {
       const uint64_t m = read_off[i + 1] - read_off[i], n = ref_off[i + 1] - ref_off[i];
       if (m > SW_X4_MAX_ROWS || !((long long)m * match + 255 < 32768 && n + 128 <= 8191 && gap_open + mismatch >= 0 && gap_open + score_N >= 0 && match + gap_open <= 255 && score_N + gap_open <= 255)) {
-        c->err = "smr_ssw_batch mode 3: a pair is outside the range of the four-problem kernel"; return SMR_ERR_ARG;
+        set_err(c, "smr_ssw_batch mode 3: a pair is outside the range of the four-problem kernel"); return SMR_ERR_ARG;
       }
     }
     hipLaunchKernelGGL(k_ssw_batch_x4, dim3(std::min<uint32_t>((n_pairs + 3) / 4, (uint32_t)c->n_cu * 8u)), dim3(64), (size_t)4 * (lm + ln), c->stream, n_pairs, (const uint8_t*)d_reads,
@@ -866,7 +843,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_saved); dev_free(&B.d_work); dev_free(&B.d_rw); dev_free(&B.d_marks); dev_free(&B.d_saved_aln); dev_free(&B.d_work_aln); dev_free(&B.d_ctr);
     dev_free(&B.d_cigar);
   }
-  dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_qlist); dev_free(&c->d_qtasks); dev_free(&c->d_qc); dev_free(&c->d_mrec); dev_free(&c->d_mpool);
+  dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_mrec); dev_free(&c->d_mpool);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
   dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
   for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
@@ -897,7 +874,7 @@ int build_pigeonhole_device(smr_ctx* c, DevIndex& d, uint32_t nk, uint32_t pw) {
   hipLaunchKernelGGL(smr::k_pgb_sizes, dim3((nb + 255) / 256), dim3(256), 0, c->stream, (const Lookup*)d.lookup, (const uint32_t*)d.trie, nk, pw, cnt, words);
   smr::u64 W = 0;
   int rc = dev_scan<smr::u64>(c, pool, words, woff, nb, &W); if (rc) return rc;
-  if (W / 3 > 0xFFFFFFF0ull || W / 4 > 0xFFFFFFF0ull) { c->err = "pigeonhole arena exceeds 2^34 words"; return SMR_ERR_CAPACITY; }
+  if (W / 3 > 0xFFFFFFF0ull || W / 4 > 0xFFFFFFF0ull) { set_err(c, "pigeonhole arena exceeds 2^34 words"); return SMR_ERR_CAPACITY; }
   uint32_t E = 0;
   if ((rc = dev_scan<uint32_t>(c, pool, cnt, eoff, nb, &E))) return rc;
   if ((rc = dev_alloc(c, &d.pg, (size_t)W + 4))) return rc;
@@ -907,6 +884,10 @@ int build_pigeonhole_device(smr_ctx* c, DevIndex& d, uint32_t nk, uint32_t pw) {
   IB_GET(k0, smr::u64, E); IB_GET(k1, smr::u64, E); IB_GET(v0, uint32_t, E); IB_GET(v1, uint32_t, E);
   hipLaunchKernelGGL(smr::k_pgb_collect, dim3((nb + 255) / 256), dim3(256), 0, c->stream, (const Lookup*)d.lookup, (const uint32_t*)d.trie, nk, pw,
                      (const uint32_t*)cnt, (const uint32_t*)eoff, (const smr::u64*)woff, d.root3, d.pg, estr, eid, eblk, derr);
+  uint32_t herr = 0;                                       // (a block k_pgb_collect refused has no entries written: nothing below may run on them)
+  HIPCHK(c, hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (herr) { set_err(c, (herr & 1u) ? "a mini-trie is too large for the pigeonhole layout" : "pigeonhole arena exceeds 2^34 words"); return SMR_ERR_CAPACITY; }
   int blockbits = 1; while ((1u << blockbits) < nb) blockbits++;
   const uint32_t gE = (uint32_t)(((smr::u64)E + 255) / 256);
   for (int order = 0; order < 2 && E; order++) {
@@ -920,11 +901,8 @@ int build_pigeonhole_device(smr_ctx* c, DevIndex& d, uint32_t nk, uint32_t pw) {
     else hipLaunchKernelGGL(smr::k_pgb_emit<1>, dim3(gE), dim3(256), 0, c->stream, (const smr::u64*)ka, (const uint32_t*)va, (smr::u64)E, pw, kbits,
                             (const uint32_t*)estr, (const uint32_t*)eid, (const uint32_t*)eoff, (const uint32_t*)d.root3, d.pg);
   }
-  uint32_t herr = 0;
-  HIPCHK(c, hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
-  if (herr) { c->err = (herr & 1u) ? "a mini-trie is too large for the pigeonhole layout" : "pigeonhole arena exceeds 2^34 words"; return SMR_ERR_CAPACITY; }
   d.pg_words = W;
   return SMR_OK;
 }
@@ -946,10 +924,11 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   HIPCHK(c, hipMemcpyAsync(d.trie, ix->trie.data(), ix->trie.size() * 4, hipMemcpyHostToDevice, c->stream));
   // The pigeonhole layout of the tries (what k_seed_pg reads) is built on the device from the arena just uploaded (smr_pgbuild.hpp).  An index
   // that already carries the host-built layout (smr_index_selfcheck, SMR_PG_HOST=1) is uploaded as it is.
-  const bool host_pg = !ix->root3.empty() || (getenv("SMR_PG_HOST") && atoi(getenv("SMR_PG_HOST")));
+  bool host_pg = getenv("SMR_PG_HOST") && atoi(getenv("SMR_PG_HOST"));
+  { std::lock_guard<std::mutex> l_(const_cast<smr_index*>(ix)->pg_mutex); host_pg = host_pg || !ix->root3.empty(); }     // (another context may be inside smr_build_pigeonhole on the same host index)
   if (host_pg) {
     std::string why;
-    if (!smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
+    if (!smr_build_pigeonhole(*const_cast<smr_index*>(ix), 0, why)) { set_err(c, why); return SMR_ERR_CAPACITY; }
     if ((rc = dev_alloc(c, &d.pg, ix->pg.size()))) return rc;
     if ((rc = dev_alloc(c, &d.root3, ix->root3.size()))) return rc;
     HIPCHK(c, hipMemcpyAsync(d.pg, ix->pg.data(), ix->pg.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -977,13 +956,13 @@ extern "C" int smr_index_check_device(smr_ctx* c, int slot, smr_index* ix) {
   HIPCHK(c, hipSetDevice(c->device));
   const DevIndex& d = c->idx[slot];
   std::string why;
-  if (!smr_build_pigeonhole(*ix, 0, why)) { c->err = why; return SMR_ERR_CAPACITY; }
-  if (ix->pg.size() != d.pg_words + 4) { c->err = "pigeonhole layout: the device arena has " + std::to_string(d.pg_words) + " words, the host's " + std::to_string(ix->pg.size() - 4); return SMR_ERR_STATE; }
+  if (!smr_build_pigeonhole(*ix, 0, why)) { set_err(c, why); return SMR_ERR_CAPACITY; }
+  if (ix->pg.size() != d.pg_words + 4) { set_err(c, "pigeonhole layout: the device arena has " + std::to_string(d.pg_words) + " words, the host's " + std::to_string(ix->pg.size() - 4)); return SMR_ERR_STATE; }
   std::vector<uint32_t> r3(ix->root3.size()), pg(ix->pg.size());
   HIPCHK(c, hipMemcpy(r3.data(), d.root3, r3.size() * 4, hipMemcpyDeviceToHost));
   HIPCHK(c, hipMemcpy(pg.data(), d.pg, pg.size() * 4, hipMemcpyDeviceToHost));
-  for (size_t q = 0; q < r3.size(); q++) if (r3[q] != ix->root3[q]) { c->err = "pigeonhole layout: block table differs at word " + std::to_string(q); return SMR_ERR_STATE; }
-  for (size_t q = 0; q < pg.size(); q++) if (pg[q] != ix->pg.data()[q]) { c->err = "pigeonhole layout: arena differs at word " + std::to_string(q); return SMR_ERR_STATE; }
+  for (size_t q = 0; q < r3.size(); q++) if (r3[q] != ix->root3[q]) { set_err(c, "pigeonhole layout: block table differs at word " + std::to_string(q)); return SMR_ERR_STATE; }
+  for (size_t q = 0; q < pg.size(); q++) if (pg[q] != ix->pg.data()[q]) { set_err(c, "pigeonhole layout: arena differs at word " + std::to_string(q)); return SMR_ERR_STATE; }
   return SMR_OK;
 }
 
@@ -1107,16 +1086,17 @@ __global__ void k_ctr_begin(unsigned long long* __restrict__ ctr, const unsigned
 
 extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->b->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
+  if (!c->idx[slot].used || !c->b->d_saved) { set_err(c, "index slot empty or no reads uploaded"); return SMR_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_params(c, p); if (rc) return rc;
   const DevIndex& di = c->idx[slot];
-  if (di.lnwin < 8 || di.lnwin > 20) { c->err = "unsupported seed length"; return SMR_ERR_ARG; }
+  if (di.lnwin < 8 || di.lnwin > 20) { set_err(c, "unsupported seed length"); return SMR_ERR_ARG; }
   DParams P = make_dparams(c, di, p);
   uint32_t ml, rf; size_t lds; chain_lds(c, P, ml, rf, lds);
-  if (lds > 150 * 1024) { c->err = "reads too long for this build of the SW kernel (LDS)"; return SMR_ERR_CAPACITY; }
+  if (lds > 150 * 1024) { set_err(c, "reads too long for this build of the SW kernel (LDS)"); return SMR_ERR_CAPACITY; }
   c->b->last_num_alignments = p->num_alignments;
   c->b->fetched = false;
+  ev_drop(c);
   if (c->b->n == 0) return SMR_OK;
   if ((rc = ensure_pool(c))) return rc;
   std::vector<unsigned long long> h;
@@ -1144,12 +1124,12 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if ((rc = read_ctr(c, h))) return rc;
     ev_collect(c);
     bool retry = false;
-    if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { c->err = "more than 128 distinct seed hits in one window"; return SMR_ERR_CAPACITY; } }
-    if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0x7FFFFFF0ull) { c->err = "seed-hit pool exceeds 8 GiB"; return SMR_ERR_CAPACITY; }
+    if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { set_err(c, "more than 128 distinct seed hits in one window"); return SMR_ERR_CAPACITY; } }
+    if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0x7FFFFFF0ull) { set_err(c, "seed-hit pool exceeds 8 GiB"); return SMR_ERR_CAPACITY; }
       if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (h[C_ERR_PAIRS]) {
       c->pairs_cap *= 4; c->hits_cap *= 4; dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits); dev_free(&c->d_tuples); dev_free(&c->d_tuples2);
-      if (c->pairs_cap > (1u << 22)) { c->err = "per-read candidate scratch exceeds capacity"; return SMR_ERR_CAPACITY; }
+      if (c->pairs_cap > (1u << 22)) { set_err(c, "per-read candidate scratch exceeds capacity"); return SMR_ERR_CAPACITY; }
       retry = true;
     }
     if (h[C_ERR_REDO]) { c->seed_exact = 1; retry = true; }     // too many overflowing waves for the redo list: use the DFS kernel throughout
@@ -1167,13 +1147,13 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if (h[C_ERR_SCAP]) {
       // a read shares seeds with more references than the LDS table of its wave holds (384): from now on such reads build their set in a
       // per-block table in global memory; the candidate keys need room for as many members
-      if (c->chain_ext) { c->err = "more than 49152 references share seeds with one read (candidate set capacity)"; return SMR_ERR_CAPACITY; }
+      if (c->chain_ext) { set_err(c, "more than 49152 references share seeds with one read (candidate set capacity)"); return SMR_ERR_CAPACITY; }
       c->chain_ext = true; retry = true;
       if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: a read shares seeds with more references than its wave's LDS table holds: per-block global candidate tables enabled (%.1f GB)\n",
                                          (double)c->chain_blocks * (4.0 * CH_EXT_CAP * 4 + (double)c->pairs_cap * 8 + (double)CH_EXT_CAP * 8) / 1e9);
       if (c->keys_cap < CH_EXT_CAP) { dev_free(&c->d_keys); c->keys_cap = 0; c->keys_need = CH_EXT_CAP; }
     }
-    if (h[C_ERR_SLOTS]) { c->err = "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"; return SMR_ERR_CAPACITY; }
+    if (h[C_ERR_SLOTS]) { set_err(c, "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"); return SMR_ERR_CAPACITY; }
     if (retry) kp_restore(c, kp0);   // timings of a discarded attempt
     if (!retry) {
       // the begin cells of the alignments that are still stored (k_chain records the accepted ones "begin pending"): four reverse passes per wave
@@ -1211,7 +1191,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       return SMR_OK;
     }
   }
-  c->err = "capacity retries exhausted";
+  set_err(c, "capacity retries exhausted");
   return SMR_ERR_CAPACITY;
 }
 
@@ -1231,6 +1211,7 @@ __global__ void k_trace_collect(uint32_t n, uint32_t slots, const RState* __rest
 // CIGARs for every stored alignment of the selected batch that lacks one and belongs to (p->index_num, p->part), whose reference sequences are di's
 static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
   int rc;
+  ev_drop(c);
   DParams P = make_dparams(c, di, p);
   c->b->fetched = false;
   const uint64_t ntot = (uint64_t)c->b->n * c->b->slots;
@@ -1257,11 +1238,11 @@ static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
     HIPCHK(c, hipGetLastError());
     int r2 = read_ctr(c, h); if (r2) return r2;
     ev_collect(c);
-    if (h[C_ERR_TRACE]) { c->err = "banded traceback left the band for some alignments (internal error)"; return SMR_ERR_CAPACITY; }
+    if (h[C_ERR_TRACE]) { set_err(c, "banded traceback left the band for some alignments (internal error)"); return SMR_ERR_CAPACITY; }
     if (h[C_ERR_CIGAR]) {
       // grow the CIGAR pool, keeping what is already there; the failed claims moved the cursor past the end: back to the old capacity
       const uint64_t w = c->b->cigar_words * 2; uint32_t* nw = nullptr;
-      if (w > 0xFFFFFFF0ull) { c->err = "CIGAR pool exceeds 2^32 words"; return SMR_ERR_CAPACITY; }
+      if (w > 0xFFFFFFF0ull) { set_err(c, "CIGAR pool exceeds 2^32 words"); return SMR_ERR_CAPACITY; }
       HIPCHK(c, hipMalloc((void**)&nw, w * 4));
       HIPCHK(c, hipMemcpy(nw, c->b->d_cigar, c->b->cigar_words * 4, hipMemcpyDeviceToDevice));
       (void)hipFree(c->b->d_cigar); c->b->d_cigar = nw;
@@ -1319,15 +1300,15 @@ static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
     }
     if (st < 0) return st;
     if (st == 0) return SMR_OK;
-    if (st == 1) { c->err = "banded traceback did not reach the alignment score within the widest band (internal error)"; return SMR_ERR_CAPACITY; }
+    if (st == 1) { set_err(c, "banded traceback did not reach the alignment score within the widest band (internal error)"); return SMR_ERR_CAPACITY; }
   }
-  c->err = "CIGAR pool regrow attempts exhausted";
+  set_err(c, "CIGAR pool regrow attempts exhausted");
   return SMR_ERR_CAPACITY;
 }
 
 extern "C" int smr_traceback(smr_ctx* c, int slot, const smr_params* p) {
   if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->b->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
+  if (!c->idx[slot].used || !c->b->d_saved) { set_err(c, "index slot empty or no reads uploaded"); return SMR_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_params(c, p); if (rc) return rc;
   if (c->b->n == 0) return SMR_OK;
@@ -1356,7 +1337,7 @@ extern "C" int smr_cigar_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* read
   uint32_t max_len = 1; uint64_t max_ref = 1;
   for (uint32_t i = 0; i < n_pairs; i++) {
     const uint64_t m = read_off[i + 1] - read_off[i], n = ref_off[i + 1] - ref_off[i];
-    if (m == 0 || n == 0 || m > 0xFFFFu) { c->err = "smr_cigar_batch: empty or oversized pair"; return SMR_ERR_ARG; }
+    if (m == 0 || n == 0 || m > 0xFFFFu) { set_err(c, "smr_cigar_batch: empty or oversized pair"); return SMR_ERR_ARG; }
     const uint32_t cw = (uint32_t)((m + 15) >> 4), mw = (uint32_t)((m + 31) >> 5);
     rec_off[i] = words.size();
     words.resize(words.size() + cw + mw, 0u);
@@ -1405,7 +1386,7 @@ extern "C" int smr_cigar_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* read
     HIPCHK(c, hipStreamSynchronize(c->stream));
     uint64_t o = 0;
     for (uint32_t i = 0; i < n_pairs; i++) {
-      if (!al[i].has_cigar) { c->err = "smr_cigar_batch: an alignment was left without a CIGAR"; return SMR_ERR_STATE; }
+      if (!al[i].has_cigar) { set_err(c, "smr_cigar_batch: an alignment was left without a CIGAR"); return SMR_ERR_STATE; }
       for (uint32_t q = 0; q < al[i].cigar_len; q++, o++) if (cigar_out && o < cigar_cap) cigar_out[o] = pool[(size_t)al[i].cigar_off + q];
       cigar_off_out[i + 1] = o;
     }
@@ -1557,12 +1538,13 @@ __global__ void k_force_pass(uint32_t n, DParams P, int pass, const uint32_t* __
 
 extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int strand, int pass, uint64_t* n_hits_out) {
   if (!c || slot < 0 || slot >= 64 || pass < 0 || pass > 2) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->b->d_saved) { c->err = "index slot empty or no reads uploaded"; return SMR_ERR_STATE; }
+  if (!c->idx[slot].used || !c->b->d_saved) { set_err(c, "index slot empty or no reads uploaded"); return SMR_ERR_STATE; }
   HIPCHK(c, hipSetDevice(c->device));
   int rc = check_params(c, p); if (rc) return rc;
   const DevIndex& di = c->idx[slot];
   DParams P = make_dparams(c, di, p);
   if ((rc = ensure_pool(c))) return rc;
+  ev_drop(c);
   const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   std::vector<unsigned long long> h;
   for (int attempt = 0; attempt < 8; attempt++) {
@@ -1579,11 +1561,11 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
     if ((rc = read_ctr(c, h))) return rc;
     ev_collect(c);
     bool retry = false;
-    if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { c->err = "more than 128 distinct seed hits in one window"; return SMR_ERR_CAPACITY; } }
+    if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { set_err(c, "more than 128 distinct seed hits in one window"); return SMR_ERR_CAPACITY; } }
     if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (!retry) { if (n_hits_out) *n_hits_out = h[C_HIT]; return SMR_OK; }
   }
-  c->err = "capacity retries exhausted";
+  set_err(c, "capacity retries exhausted");
   return SMR_ERR_CAPACITY;
 }
 
@@ -1643,7 +1625,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
   o->seed_ms = c->kp_ms[KP_KEYS] + c->kp_ms[KP_SPLIT] + c->kp_ms[KP_BINS] + c->kp_ms[KP_PG0] + c->kp_ms[KP_PG1] + c->kp_ms[KP_FINISH]; o->seed_launches = c->kp_l[KP_KEYS];
-  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_QUAD] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
+  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
   o->trace_ms = c->kp_ms[KP_TRACE]; o->trace_launches = c->kp_l[KP_TRACE];
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];

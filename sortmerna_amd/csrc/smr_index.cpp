@@ -445,7 +445,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       tm.lap("load: arena sized");
       parallel_for(threads, n_chunks, [&](size_t lo, size_t hi, uint32_t) {
         for (size_t c = lo; c < hi; c++) {
-          if (!local[c].empty()) memcpy(ix->trie.data() + tbase[c], local[c].data(), local[c].size() * 4);
+          if (!local[c].empty()) { memcpy(ix->trie.data() + tbase[c], local[c].data(), local[c].size() * 4); std::vector<uint32_t>().swap(local[c]); }   // (freed as it goes: the peak is not twice the arena)
           for (size_t i = c * TRIE_CHUNK; i < std::min((size_t)nk, (c + 1) * TRIE_CHUNK); i++)
             for (int j = 0; j < 2; j++) {
               if (rootw[2 * i + j] == (size_t)-1) continue;

@@ -151,7 +151,7 @@ struct SeedKey { uint32_t slot, chars, key; };          // a decoded tuple of sr
 #define SEED_WAVES 16u                                    // waves per block of k_seed_keys
 #define SEED_STAGE_WORDS 1280u                            // LDS words in which a wave of k_seed_keys stages the packed records of the reads of one trip (64 reads of <= 208 letters)
 #ifndef SEED_PIECE
-#define SEED_PIECE 4096u                                  // tuples a sort pass stages in LDS at a time
+#define SEED_PIECE 8192u                                  // tuples a sort pass stages in LDS at a time
 #endif
 #define SEED_SEG_MERGED 0x80000000u                       // header bit of a reverse segment whose list is final (written by k_seed_search<1>: forward hits included)
 #define SEED_CAND_COND 0x80000000u                        // bit of an id in a reverse segment of k_seed_pg: this candidate is a 0-error match

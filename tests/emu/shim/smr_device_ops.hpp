@@ -29,5 +29,25 @@ inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {          // v
   return r;
 }
 inline uint32_t div_multiple(uint32_t n, uint32_t d) { return n / d; }
+// uni(): v_readfirstlane_b32 of a value the kernel claims to be wave-uniform -- here the claim is CHECKED: every active lane must hold the
+// value of the first one
+inline uint32_t uni(uint32_t v) {
+  const unsigned long long m = __ballot(1);
+  const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_ctzll(m));
+  if (!__all(f == v)) { fprintf(stderr, "emu: uni() of a value that differs between the lanes of a wave (%u vs %u)\n", f, v); abort(); }
+  return f;
+}
+inline int uni(int v) { return (int)uni((uint32_t)v); }
+inline unsigned long long uni(unsigned long long v) { return (unsigned long long)uni((uint32_t)v) | ((unsigned long long)uni((uint32_t)(v >> 32)) << 32); }
+inline unsigned long uni(unsigned long v) { return (unsigned long)uni((unsigned long long)v); }
+template <class T> inline T uni_words(const T& v) {
+  static_assert(sizeof(T) % 4 == 0, "uni_words: whole words only");
+  uint32_t w[sizeof(T) / 4];
+  __builtin_memcpy(w, &v, sizeof(T));
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = uni(w[i]);
+  T o;
+  __builtin_memcpy(&o, w, sizeof(T));
+  return o;
+}
 
 }  // namespace smr

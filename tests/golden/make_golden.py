@@ -45,6 +45,12 @@ SYN_CASES = [
     # no "-passes a,b,c" case: the reference's parser of that option (options.cpp:704-732) never stores the three
     # strides per index (it emplaces vectors of that SIZE), so the run silently uses the defaults {L, L/2, 3}.
     ("syn_multipart", ["-m", "0.15"], {"max_mb": 0.15}),
+    # round 4: the rest of the option space of the hot path (added with `make_golden.py --only ...`: the cases above were not re-run)
+    ("syn_seeds1", ["-num_seeds", "1"], {"num_seeds": 1}),
+    ("syn_minlis3", ["-min_lis", "3"], {"min_lis": 3}),        # (the reference refuses -min_lis together with -num_alignments, options.cpp:1656)
+    ("syn_minlis1", ["-min_lis", "1"], {"min_lis": 1}),
+    ("syn_N0", ["-N", "0"], {"score_N": 0}),
+    ("syn_gaps32", ["-gap_open", "3", "-gap_ext", "2"], {"gap_open": 3, "gap_ext": 2}),
 ]
 
 
@@ -92,8 +98,27 @@ def run_case(name, refs, reads, n_reads, extra, tmp, with_reports=True):
     return out
 
 
+def only(names):
+    """`make_golden.py --only case,case`: run the reference for these synthetic cases alone (committed syn_db.fasta / syn_reads.fasta) and add them
+    to golden.json; nothing else is rewritten"""
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    G = json.load(open(os.path.join(HERE, "golden.json")))
+    db, reads = os.path.join(HERE, "syn_db.fasta"), os.path.join(HERE, "syn_reads.fasta")
+    n = sum(1 for l in open(reads) if l.startswith(">"))
+    for name, extra, params in SYN_CASES:
+        if name not in names:
+            continue
+        G[name] = run_case(name, [db], [reads], n, extra, tmp, with_reports=False)
+        G[name]["params"] = params
+        print(name, "aligned", G[name]["log"].get("num_aligned"), "records", G[name]["n_records"], "parts", G[name]["index_parts"])
+    json.dump(G, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     assert paths.have_reference() and paths.have_ref_bin(), "needs /root/reference and oracle/_ref/sortmerna_ref (make -C oracle)"
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        return only(sys.argv[2].split(","))
     tmp = tempfile.mkdtemp(prefix="golden_")
     G = {}
     # ---- the reference's own test inputs ----

@@ -6,7 +6,7 @@ import sortmerna_amd as smr
 from . import golden, orc
 
 CASES = ["t0", "t9", "syn_default", "syn_all", "syn_best3", "syn_nobest2", "syn_F", "syn_R", "syn_full_search",
-         "syn_seeds3_edges10", "syn_multipart", "real_default", "real_all", "two_db_default", "two_db_all"]
+         "syn_seeds3_edges10", "syn_multipart", "syn_seeds1", "syn_minlis3", "syn_minlis1", "syn_N0", "syn_gaps32", "real_default", "real_all", "two_db_default", "two_db_all"]
 
 
 def build_case(case, tmpdir):

@@ -43,7 +43,8 @@ class Workload:
 
     def oracle_records(self, **kw):
         """Run the CPU oracle over all parts; returns (records, counters)."""
-        p = orc.default_params(minimal_score=self.minimal_score, **kw)
+        kw = dict(kw)
+        p = orc.default_params(minimal_score=kw.pop("minimal_score", self.minimal_score), **kw)
         if "skiplengths" not in kw:
             p.lnwin = self.lnwin
             p.skiplengths[0], p.skiplengths[1], p.skiplengths[2] = self.lnwin, self.lnwin // 2, 3      # refstats.cpp:159-166
@@ -61,7 +62,8 @@ class Workload:
         return recs, out
 
     def gpu_records(self, engine, with_cigar=True, **kw):
-        p = smr.default_params(minimal_score=self.minimal_score, **kw)
+        kw = dict(kw)
+        p = smr.default_params(minimal_score=kw.pop("minimal_score", self.minimal_score), **kw)
         smr.align(engine, self.reads, [self.parts], [p], with_cigar=with_cigar)
         return engine.records(), engine.counters(1)
 

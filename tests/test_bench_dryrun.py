@@ -85,6 +85,30 @@ def test_unwrapped_multi_rank_command(tmp_path):
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
 
 
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_strong_scaling_splits_one_job_over_the_ranks(tmp_path, ranks):
+    """`--scaling strong --total-reads T`: the job is the same T reads whatever the number of ranks (8 seeded units, contiguous unit ranges per
+    rank); the line says "strong", counts T reads per step, and the Readstats counters of the 2-rank run equal those of the 1-rank run."""
+    import subprocess
+    emu.build()
+    env = dict(os.environ, TMPDIR=str(tmp_path), SMR_BENCH_BACKEND="gloo", SMR_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(paths.REPO, "tests", "helpers", "bench_on_emu.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
+           "--scaling", "strong", "--total-reads", "2403", "--db-nt", "150000", "--no-cpu-baseline", "--n1-value", "1000.0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["scaling"] == "strong" and out["n_gpus"] == ranks and out["counters"]["reads"] == 2403 and out["config"]["total_reads"] == 2403
+    assert abs(out["efficiency_vs_n1"] - out["value"] / (ranks * 1000.0)) < 1e-9
+    ref = tmp_path.parent / "strong_num_aligned.txt"         # the first of the two runs leaves its count for the second
+    if ref.exists():
+        assert int(ref.read_text()) == out["counters"]["num_aligned"] > 0
+    else:
+        ref.write_text(str(out["counters"]["num_aligned"]))
+
+
 def test_the_traffic_file_belongs_to_the_seed_kernels_in_the_tree():
     """bench.py fills roofline.traffic from profiles/hbm_traffic.json only when the file's hash of the seed-stage sources is the tree's
     (tools/pmc_traffic.py).  A stale file is not an error of the code -- the bench then prints traffic: null with a note -- so this only

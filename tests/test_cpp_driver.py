@@ -204,3 +204,21 @@ def test_mgpu_host_shards_and_chunks_on_one_device(case, ranks, chunk, tmp_path)
     record-range shards, any number of chunks streamed through three recycled batch slots (upload | align | records + report rows overlapped),
     counters summed over chunks on the device and over ranks, records and report files concatenated in rank order"""
     _check_mgpu(case, tmp_path, ["--gpus", str(ranks), "--devices", ",".join(["0"] * ranks), "--reduce", "host", "--chunk-reads", str(chunk)])
+
+
+def _device_count():
+    import sortmerna_amd.capi as capi
+    return int(capi.load().smr_device_count())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,chunk", [("syn_default", 0), ("syn_all", 40), ("two_db_default", 64)])
+def test_mgpu_host_all_devices_rccl(case, chunk, tmp_path):
+    """On a node with more than one GPU: one rank per device, the read totals and the counter block reduced by ncclAllReduce with world > 1 (the
+    one-device box of the builder only ever runs world 1: this test is for the driver's multi-GPU node).  Records, counters and the merged
+    report files must still be the reference's own."""
+    n = _device_count()
+    if n < 2:
+        pytest.skip("one GPU: RCCL with more than one rank needs a device per rank (%d visible)" % n)
+    out = _check_mgpu(case, tmp_path, ["--gpus", str(n), "--reduce", "rccl", "--chunk-reads", str(chunk)])
+    assert "RCCL reduction" in out and "ranks %d" % n in out

@@ -81,6 +81,20 @@ def test_reads_stream_through_the_gpu_in_chunks(case, chunk, tmp_path):
     compare(REF_GPU, case, tmp_path, {"SMR_DROPIN_CHUNK": str(chunk)}, min_chunks=4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,chunk", [("real_two_db", 50), ("paired", 32)])
+def test_dropin_spreads_chunks_over_all_devices(case, chunk, tmp_path):
+    """On a node with more than one GPU the binding starts one worker per visible device (smr_device_count) and hands the chunks round; the
+    outputs must not depend on which device aligned which chunk.  Skipped on the builder's one-GPU box."""
+    import sortmerna_amd.capi as capi
+    n = int(capi.load().smr_device_count())
+    if n < 2:
+        pytest.skip("one GPU visible")
+    if not (os.path.isfile(REF_GPU) and os.path.isfile(paths.REF_BIN)):
+        pytest.skip("oracle/_ref/sortmerna_gpu / sortmerna_ref are not in this snapshot")
+    compare(REF_GPU, case, tmp_path, {"SMR_DROPIN_CHUNK": str(chunk)}, min_chunks=4)
+
+
 @pytest.mark.skipif(not (paths.have_reference() and paths.have_ref_bin()), reason="needs /root/reference and `make -C oracle ref`")
 @pytest.mark.parametrize("case,chunk", [("t0", 0), ("paired", 0), ("paired", 64)])
 def test_reference_cli_with_the_kernel_emulator_in_the_middle(case, chunk, tmp_path):

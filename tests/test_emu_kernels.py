@@ -244,18 +244,3 @@ def test_candidate_sets_from_k_cand_records_and_from_the_position_lists_agree(em
         e.close()
 
 
-def test_sixteen_lane_walk_on_and_off_give_the_oracle_records(emulator, tmp_path, monkeypatch):
-    """smr_quad.hpp: most marked reads of a background-dominated sample are decided 16 lanes per read (no task: pass ends; one task: scored four
-    per wave; else k_chain's sequential walk).  With the stage switched off (SMR_QUAD=0) k_chain does everything as in round 2.  Same records."""
-    from helpers.workload import Workload
-    w = Workload(str(tmp_path), db_nt=400_000, n_reads=3000, frac_db=0.08, seed=21, family_size=6)
-    exp, ctr = w.oracle_records()
-    for q in ("1", "0"):
-        monkeypatch.setenv("SMR_QUAD", q)
-        e = smr.Engine(0)
-        got, c = w.gpu_records(e)
-        assert got == exp, "SMR_QUAD=%s: %d records differ" % (q, sum(1 for a, b in zip(got, exp) if a != b))
-        assert c["num_aligned"] == ctr["num_aligned"]
-        p = e.prof()
-        assert p.n_sw_fwd == ctr["n_sw_fwd"], (q, p.n_sw_fwd, ctr["n_sw_fwd"])       # the sequential walk's ssw_align calls, whoever scored them
-        e.close()

@@ -82,8 +82,20 @@ def test_seed_scan_matches_oracle(engine, wl):
     {"is_forward": 0},
     {"is_full_search": 1},
     {"num_seeds": 3, "edges": 10},
-], ids=["default", "all", "best3", "nobest2", "F", "R", "full_search", "seeds3_edges10"])
+    # the rest of the option space of the path (alignment.cpp:134-169,251-261, options.cpp:1566-1758, read.cpp:274-288)
+    {"num_seeds": 1},                                # every reference with ONE seed hit is a candidate (k_cand only marks the read)
+    {"min_lis": 1},
+    {"min_lis": 3, "num_alignments": 2},
+    {"score_N": 0},                                  # -N
+    {"gap_open": 3, "gap_ext": 2},
+    {"match": 3, "mismatch": -4, "gap_open": 6, "gap_ext": 3, "score_N": -1},
+    {"minoccur": 2},
+    {"minimal_score_delta": 30},                     # a stricter -e
+], ids=["default", "all", "best3", "nobest2", "F", "R", "full_search", "seeds3_edges10", "seeds1", "min_lis1", "min_lis3_best2", "N0", "gaps_3_2", "score_3_4_6_3", "minoccur2", "stricter_e"])
 def test_align_records_match_oracle(engine, wl, opts):
+    opts = dict(opts)
+    if "minimal_score_delta" in opts:
+        opts["minimal_score"] = wl.minimal_score + opts.pop("minimal_score_delta")
     recs_o, ctr_o = wl.oracle_records(**opts)
     recs_g, ctr_g = wl.gpu_records(engine, **opts)
     _compare(recs_g, recs_o, str(opts))
@@ -315,11 +327,10 @@ def test_pigeonhole_seed_kernel_equals_the_dfs_kernel(tmp_path, lnwin, db_nt, fa
     finally:
         e.close()
 
-@pytest.mark.parametrize("env", [("SMR_HANDOVER", "0"), ("SMR_CAND_BLOOM", "64"), ("SMR_QUAD", "1")], ids=lambda e: "%s=%s" % e)
+@pytest.mark.parametrize("env", [("SMR_HANDOVER", "0"), ("SMR_CAND_BLOOM", "64")], ids=lambda e: "%s=%s" % e)
 def test_optional_paths_of_the_candidate_stage_give_the_oracle_records(wl, monkeypatch, env):
     """k_chain gathering a marked read's positions itself instead of taking k_cand's record; a 2 Kbit Bloom bitmap in k_cand (more reads
-    marked by false collisions); the 16-lane walk of small marked reads.  None of them may change a record (the emulator runs the same
-    three cases: tests/test_emu_kernels.py)."""
+    marked by false collisions).  Neither may change a record (the emulator runs the same cases: tests/test_emu_kernels.py)."""
     monkeypatch.setenv(*env)
     e = smr.Engine(0)
     try:

@@ -1,3 +1,5 @@
+// NOT PART OF libsmr_hip (round 4): measured slower than leaving these reads to k_chain (2.48 + 4.35 vs 5.96 ms per 2 M-read launch,
+// profiles/r3s17_*); kept as the record of the experiment.  The engine side (k_mark_list / k_quad / k_park_sw launches) is in the history: 2b0b0d8.
 // smr_quad.hpp -- part of the HIP kernels of libsmr_hip (included by smr_kernels.hpp after smr_chain.hpp).
 //
 // Four reads per wave for the small majority of compute_lis_alignment (alignment.cpp:100-509).  Census of the bench workload
