@@ -19,7 +19,7 @@
 //          --fastx / --other / --blast / --sam the reference's report files (aligned.fq, other.fq, aligned.blast, aligned.sam): every rank
 //          writes its shard's files into <out>/rank<r>/, rank order concatenation = Report::merge (report.cpp:56-97).
 // Build:   hipcc -std=c++17 -O2 examples/smr_align_mgpu.cpp -Iinclude -Lsortmerna_amd/lib -lsmr_hip -lrccl -Wl,-rpath,$PWD/sortmerna_amd/lib -o smr_align_mgpu
-// Options: --ref DB.fasta [--idx PREFIX] --gumbel LAMBDA K  [--ref ...]  --reads READS[.gz]  --out DIR
+// Options: --ref DB.fasta [--idx PREFIX] --gumbel LAMBDA K  [--ref ...]  --reads READS[.gz]  --out DIR  [--idx-flat DIR]
 //          --gpus N            ranks (default: all visible devices)
 //          --devices a,b,..    device of every rank (default 0,1,..,N-1)
 //          --reduce rccl|host  how C1 / C2 are reduced; `host` (a mutex-protected sum between the rank threads) exists for dry
@@ -49,7 +49,17 @@
 namespace {
 [[noreturn]] void die(const std::string& m) { fprintf(stderr, "ERROR: %s\n", m.c_str()); exit(EXIT_FAILURE); }
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-struct Db { std::string fasta, idx_prefix; double lambda = 0, K = 0; bool has_gumbel = false; std::vector<smr_index*> parts; };
+struct Db { std::string fasta, idx_prefix; double lambda = 0, K = 0; bool has_gumbel = false; std::vector<smr_index*> parts; bool from_flat = false; };
+
+// the key of a flat index cache: size and mtime of the reference FASTA and of the first reference-format index file (when there is one)
+uint64_t file_stamp(const std::string& fasta, const std::string& idx_prefix) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { for (int q = 0; q < 8; q++) { h ^= (v >> (8 * q)) & 0xFF; h *= 1099511628211ull; } };
+  struct stat st;
+  if (stat(fasta.c_str(), &st) == 0) { mix((uint64_t)st.st_size); mix((uint64_t)st.st_mtime); }
+  if (!idx_prefix.empty() && stat((idx_prefix + ".kmer_0.dat").c_str(), &st) == 0) { mix((uint64_t)st.st_size); mix((uint64_t)st.st_mtime); }
+  return h;
+}
 
 // contiguous record range of a rank (sortmerna_amd/shard.py: shard_range)
 void shard_range(uint64_t n, int rank, int world, uint64_t& first, uint64_t& count) {
@@ -109,8 +119,9 @@ struct RankOut {
 }  // namespace
 
 int main(int argc, char** argv) {
+  const double t_main = now_s();
   std::vector<Db> dbs;
-  std::string reads_path, out_dir = ".", reduce = "rccl", devlist;
+  std::string reads_path, out_dir = ".", reduce = "rccl", devlist, flat_dir;
   smr_params base; smr_params_default(&base);
   double evalue = 1.0;
   int world = 0;
@@ -121,6 +132,7 @@ int main(int argc, char** argv) {
     auto val = [&]() -> std::string { if (i + 1 >= argc) die("missing value after " + a); return argv[++i]; };
     if (a == "-ref" || a == "--ref") { Db d; d.fasta = val(); dbs.push_back(d); }
     else if (a == "-idx" || a == "--idx") { if (dbs.empty()) die("--idx before --ref"); dbs.back().idx_prefix = val(); }
+    else if (a == "-idx-flat" || a == "--idx-flat") flat_dir = val();
     else if (a == "-gumbel" || a == "--gumbel") { if (dbs.empty()) die("--gumbel before --ref"); dbs.back().lambda = atof(val().c_str()); dbs.back().K = atof(val().c_str()); dbs.back().has_gumbel = true; }
     else if (a == "-reads" || a == "--reads") reads_path = val();
     else if (a == "-out" || a == "--out") out_dir = val();
@@ -158,8 +170,16 @@ int main(int argc, char** argv) {
   if (S.use_rccl) {
     for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (S.devices[a] == S.devices[b]) die("RCCL needs one device per rank: use --reduce host for a dry run with shared devices");
     S.comms.resize(world);
-    if (ncclCommInitAll(S.comms.data(), world, S.devices.data()) != ncclSuccess) die("ncclCommInitAll failed");
   }
+  // the communicators are made while the index and the reads are being loaded (RCCL's initialisation takes seconds and nothing needs it before
+  // the first reduction)
+  double t_rccl = 0;
+  std::thread rccl_thread([&] {
+    if (!S.use_rccl) return;
+    const double t = now_s();
+    if (ncclCommInitAll(S.comms.data(), world, S.devices.data()) != ncclSuccess) die("ncclCommInitAll failed");
+    t_rccl = now_s() - t;
+  });
   Barrier bar(world); S.bar = &bar;
   char err[512] = "";
 
@@ -176,7 +196,30 @@ int main(int argc, char** argv) {
     reads_rc = want_reports ? smr_reads_load_fastx_text(reads_path.c_str(), 0, &all, rerr, sizeof rerr) : smr_reads_load_fastx_mt(reads_path.c_str(), 0, &all, rerr, sizeof rerr);
     t_reads = now_s() - t0;
   });
+  auto flat_path = [&](const Db& d, uint32_t part) {
+    const size_t sl = d.fasta.find_last_of('/');
+    return flat_dir + "/" + (sl == std::string::npos ? d.fasta : d.fasta.substr(sl + 1)) + "." + std::to_string(part) + ".flat";
+  };
   for (auto& d : dbs) {
+    // --idx-flat DIR: the parts as flat files of the host layout (smr_index_save), keyed by size + mtime of the reference files; loaded at
+    // memory speed when they are there and current, written after this run's slow load / build otherwise
+    if (!flat_dir.empty()) {
+      const uint64_t stamp = file_stamp(d.fasta, d.idx_prefix);
+      smr_index* p0 = nullptr;
+      if (smr_index_load_flat(flat_path(d, 0).c_str(), stamp, &p0, err, sizeof err) == SMR_OK) {
+        smr_index_info info; smr_index_get_info(p0, &info);
+        d.parts.push_back(p0);
+        bool all_ok = true;
+        for (uint32_t k = 1; k < info.n_parts && all_ok; k++) {
+          smr_index* pk = nullptr;
+          all_ok = smr_index_load_flat(flat_path(d, k).c_str(), stamp, &pk, err, sizeof err) == SMR_OK;
+          if (all_ok) d.parts.push_back(pk);
+        }
+        if (all_ok) { d.from_flat = true; continue; }
+        for (auto* ix : d.parts) smr_index_free(ix);
+        d.parts.clear();
+      }
+    }
     if (!d.idx_prefix.empty()) {
       smr_index* p0 = nullptr;
       if (smr_index_load_files(d.idx_prefix.c_str(), 0, d.fasta.c_str(), &p0, err, sizeof err) != SMR_OK) die(err);
@@ -199,7 +242,20 @@ int main(int argc, char** argv) {
     }
   }
   const double t_index = now_s() - t0;
+  // (the flat cache of what was loaded the slow way is written beside the alignment, by a thread of its own)
+  std::thread flat_thread([&] {
+    if (flat_dir.empty()) return;
+    mkdir(flat_dir.c_str(), 0755);
+    char e2[512] = "";
+    for (auto& d : dbs) {
+      if (d.from_flat) continue;
+      const uint64_t stamp = file_stamp(d.fasta, d.idx_prefix);
+      for (size_t k = 0; k < d.parts.size(); k++)
+        if (smr_index_save(d.parts[k], flat_path(d, (uint32_t)k).c_str(), stamp, e2, sizeof e2) != SMR_OK) { fprintf(stderr, "smr_align_mgpu: %s (the run goes on without the cache)\n", e2); return; }
+    }
+  });
   reads_thread.join();
+  rccl_thread.join();
   if (reads_rc != SMR_OK) die(rerr);
   const uint64_t n = smr_reads_count(all);
   const int is_fastq = want_reports ? smr_reads_is_fastq(all) : 0;
@@ -369,7 +425,7 @@ int main(int argc, char** argv) {
   for (int r = 0; r < world; r++) th.emplace_back(rank_main, r);
   for (auto& t : th) t.join();
   const double t_ranks = now_s() - t_start;
-  if (S.use_rccl) for (auto& c : S.comms) ncclCommDestroy(c);
+  // (the communicators are not destroyed: the process ends with _exit below)
 
   // ---- report files: the shards' files concatenated in rank order (Report::merge, report.cpp:56-97) ----
   if (want_reports) {
@@ -429,7 +485,9 @@ int main(int argc, char** argv) {
   int swk = 2; for (auto& o : outs) swk = std::min(swk, o.sw_kernel);
   printf("[kernels] Smith-Waterman: %s\n", swk >= 1 ? "packed 16-bit (four candidate windows per wave)" : "32-bit kernel ONLY on at least one rank (packed kernel off or failed its self-check): expect about half the alignment rate");
   printf("%llu reads, %llu aligned, %llu records, minimal_score %u -> %s\n", (unsigned long long)n, (unsigned long long)ctr[0], (unsigned long long)nrec, outs[0].minimal_score0, rp.c_str());
-  for (auto& d : dbs) for (auto* ix : d.parts) smr_index_free(ix);
-  smr_reads_free(all);
-  return 0;
+  flat_thread.join();
+  printf("[timing] process: %.3f s from main() to here (options + device discovery %.3f s, RCCL communicators %.3f s alongside the loading); the host copies of index and reads are "
+         "left to the operating system\n", now_s() - t_main, t0 - t_main, t_rccl);
+  fflush(stdout); fflush(stderr);
+  _exit(0);                                                // (no teardown of GBs of host arrays, device memory and communicators at the end of a command-line run)
 }

@@ -99,6 +99,13 @@ int smr_index_build(const char* ref_fasta, uint32_t seed_win_len, double max_fil
 /* Write one part in the REFERENCE's on-disk format (so the reference binary can consume our index). */
 int smr_index_write_files(const smr_index* const* parts, uint32_t n_parts, const char* ref_fasta, const char* prefix,
                           char* err, size_t errcap);
+/* Flat cache of one part's HOST layout (header + the arrays as they lie in memory, page aligned): smr_index_load_flat maps the file and
+ * copies the arrays with all cores -- the reference-format files store no stream lengths (index.cpp:176-316) and cost a sequential walk
+ * over GBs plus a parse (1.3 s for the 140 Mnt DB, 0.3 s from the cache).  `stamp` is the caller's key for "these reference files" (size
+ * and mtime, a hash ...): load returns SMR_ERR_STATE when the file was written under another stamp, SMR_ERR_IO when it is absent or damaged;
+ * the caller then loads the reference's files (or builds) and saves the cache for the next run. */
+int smr_index_save(const smr_index*, const char* path, uint64_t stamp, char* err, size_t errcap);
+int smr_index_load_flat(const char* path, uint64_t stamp, smr_index** out, char* err, size_t errcap);
 /* Consistency check of the two device layouts of the mini-tries (reference-shaped arena for k_seed_search, pigeonhole arena for
  * k_seed_pg): the second must hold the same (candidate string, id) entries with their ranks in the DFS order of the first, sorted by its
  * two keys, under consistent directories.  0 = ok. */

@@ -58,7 +58,7 @@ class Kprof(C.Structure):
 
 
 EXPORTS = [
-    "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_selfcheck", "smr_index_free",
+    "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_save", "smr_index_load_flat", "smr_index_selfcheck", "smr_index_free",
     "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free", "smr_reads_slice",
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_device_count", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_check_device", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
@@ -98,6 +98,10 @@ def bind(L):
     L.smr_index_build_gpu.argtypes = [vp, cp, u32, C.c_double, u32, C.POINTER(vp), u32, C.POINTER(u32), cp, C.c_size_t]
     L.smr_index_write_files.restype = i32
     L.smr_index_write_files.argtypes = [C.POINTER(vp), u32, cp, cp, cp, C.c_size_t]
+    L.smr_index_save.restype = i32
+    L.smr_index_save.argtypes = [vp, cp, u64, cp, C.c_size_t]
+    L.smr_index_load_flat.restype = i32
+    L.smr_index_load_flat.argtypes = [cp, u64, C.POINTER(vp), cp, C.c_size_t]
     L.smr_index_selfcheck.restype = i32
     L.smr_index_selfcheck.argtypes = [vp, cp, C.c_size_t]
     L.smr_index_free.argtypes = [vp]

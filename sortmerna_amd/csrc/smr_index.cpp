@@ -1087,3 +1087,124 @@ extern "C" int smr_index_write_files(const smr_index* const* parts, uint32_t n_p
   }
   return SMR_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Flat index cache.  The reference's four files per part store no stream lengths (index.cpp:176-316): loading them means one sequential
+// walk over GBs to find where every mini-trie begins, then a parse.  smr_index_save writes the HOST layout of a loaded / built part as it
+// lies in memory -- header, then every array 4096-byte aligned -- and smr_index_load_flat maps the file and copies the arrays with all
+// cores: the index is ready at memory speed.  `stamp` is the caller's key (e.g. size and mtime of the reference FASTA and of the
+// reference-format files): load fails with SMR_ERR_STATE when the file's stamp is another, and the caller falls back to the slow path.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct FlatHeader {
+  char magic[8];                                          // "SMRFLAT1"
+  uint32_t version, lnwin, part, n_parts;
+  uint64_t stamp;
+  uint64_t n_nodes, n_buckets, n_entries, full_len, numseq, filesize;
+  double bg[4];
+  uint64_t n_lookup, n_trie, n_pos_off, n_pos_arr, n_ref_seq, n_ref_off, n_lkc, n_parts_stats, n_sq_bytes;      // element counts (sq: bytes)
+  uint64_t off[9];                                        // byte offsets of the sections, in this order
+  uint64_t total_bytes;
+};
+const uint64_t FLAT_ALIGN = 4096;
+
+void par_copy(void* dst, const void* src, size_t n, uint32_t threads) {
+  const size_t CH = (size_t)8 << 20;
+  const size_t nch = (n + CH - 1) / CH;
+  if (nch <= 1) { if (n) memcpy(dst, src, n); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < std::min<size_t>(threads, nch); t++)
+    th.emplace_back([&] { for (size_t c; (c = next.fetch_add(1)) < nch;) memcpy((char*)dst + c * CH, (const char*)src + c * CH, std::min(CH, n - c * CH)); });
+  for (auto& x : th) x.join();
+}
+}  // namespace
+
+extern "C" int smr_index_save(const smr_index* ix, const char* path, uint64_t stamp, char* err, size_t errcap) {
+  if (!ix || !path) { set_err(err, errcap, "smr_index_save: null argument"); return SMR_ERR_ARG; }
+  std::string sq;
+  for (auto& h : ix->sq_header) { const uint32_t l = (uint32_t)h.first.size(); sq.append((const char*)&l, 4); sq.append(h.first); sq.append((const char*)&h.second, 4); }
+  FlatHeader H; memset(&H, 0, sizeof H);
+  memcpy(H.magic, "SMRFLAT1", 8);
+  H.version = 1; H.lnwin = ix->lnwin; H.part = ix->part; H.n_parts = ix->n_parts; H.stamp = stamp;
+  H.n_nodes = ix->n_nodes; H.n_buckets = ix->n_buckets; H.n_entries = ix->n_entries; H.full_len = ix->full_len; H.numseq = ix->numseq; H.filesize = ix->filesize;
+  for (int q = 0; q < 4; q++) H.bg[q] = ix->bg[q];
+  H.n_lookup = ix->lookup.size(); H.n_trie = ix->trie.size(); H.n_pos_off = ix->pos_off.size(); H.n_pos_arr = ix->pos_arr.size();
+  H.n_ref_seq = ix->ref_seq.size(); H.n_ref_off = ix->ref_off.size(); H.n_lkc = ix->lkc.size(); H.n_parts_stats = ix->parts.size(); H.n_sq_bytes = sq.size();
+  const void* src[9] = {ix->lookup.data(), ix->trie.data(), ix->pos_off.data(), ix->pos_arr.data(), ix->ref_seq.data(), ix->ref_off.data(), ix->lkc.data(), ix->parts.data(), sq.data()};
+  const uint64_t bytes[9] = {H.n_lookup * sizeof(Lookup), H.n_trie * 4, H.n_pos_off * 4, H.n_pos_arr * 4, H.n_ref_seq, H.n_ref_off * 8, H.n_lkc * 4, H.n_parts_stats * sizeof(PartStats), H.n_sq_bytes};
+  uint64_t o = FLAT_ALIGN;
+  for (int q = 0; q < 9; q++) { H.off[q] = o; o = (o + bytes[q] + FLAT_ALIGN - 1) & ~(FLAT_ALIGN - 1); }
+  H.total_bytes = o;
+  const std::string tmp = std::string(path) + ".tmp";
+  int fd = open(tmp.c_str(), O_CREAT | O_TRUNC | O_RDWR, 0644);
+  if (fd < 0) { set_err(err, errcap, "smr_index_save: cannot create " + tmp); return SMR_ERR_IO; }
+  bool ok = ftruncate(fd, (off_t)o) == 0;
+  void* m = ok ? mmap(nullptr, o, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+  ok = ok && m != MAP_FAILED;
+  if (ok) {
+    const uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    memcpy(m, &H, sizeof H);
+    for (int q = 0; q < 9; q++) par_copy((char*)m + H.off[q], src[q], bytes[q], threads);
+    munmap(m, o);
+  }
+  close(fd);
+  if (!ok || rename(tmp.c_str(), path) != 0) { unlink(tmp.c_str()); set_err(err, errcap, std::string("smr_index_save: cannot write ") + path); return SMR_ERR_IO; }
+  return SMR_OK;
+}
+
+extern "C" int smr_index_load_flat(const char* path, uint64_t stamp, smr_index** out, char* err, size_t errcap) {
+  if (!path || !out) { set_err(err, errcap, "smr_index_load_flat: null argument"); return SMR_ERR_ARG; }
+  *out = nullptr;
+  StageTimer tm;
+  int fd = open(path, O_RDONLY);
+  if (fd < 0) { set_err(err, errcap, std::string("no flat index at ") + path); return SMR_ERR_IO; }
+  struct stat st;
+  if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < sizeof(FlatHeader)) { close(fd); set_err(err, errcap, std::string(path) + ": not a flat index"); return SMR_ERR_IO; }
+  const size_t n = (size_t)st.st_size;
+  void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { set_err(err, errcap, std::string("cannot map ") + path); return SMR_ERR_IO; }
+  struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n); } } um{m, n};
+  FlatHeader H; memcpy(&H, m, sizeof H);
+  const uint64_t bytes[9] = {H.n_lookup * sizeof(Lookup), H.n_trie * 4, H.n_pos_off * 4, H.n_pos_arr * 4, H.n_ref_seq, H.n_ref_off * 8, H.n_lkc * 4, H.n_parts_stats * sizeof(PartStats), H.n_sq_bytes};
+  bool ok = memcmp(H.magic, "SMRFLAT1", 8) == 0 && H.version == 1 && H.total_bytes == n && H.lnwin >= 8 && H.lnwin <= 20 && H.n_lookup == (1ull << H.lnwin);
+  for (int q = 0; q < 9 && ok; q++) ok = H.off[q] % FLAT_ALIGN == 0 && H.off[q] <= n && bytes[q] <= n - H.off[q];
+  if (!ok) { set_err(err, errcap, std::string(path) + ": damaged or foreign flat index"); return SMR_ERR_IO; }
+  if (H.stamp != stamp) { set_err(err, errcap, std::string(path) + ": the flat index was written for other reference files (stamp)"); return SMR_ERR_STATE; }
+  (void)madvise(m, n, MADV_WILLNEED);
+  std::unique_ptr<smr_index> ix(new smr_index);
+  ix->lnwin = H.lnwin; ix->part = H.part; ix->n_parts = H.n_parts;
+  ix->n_nodes = H.n_nodes; ix->n_buckets = H.n_buckets; ix->n_entries = H.n_entries; ix->full_len = H.full_len; ix->numseq = H.numseq; ix->filesize = H.filesize;
+  for (int q = 0; q < 4; q++) ix->bg[q] = H.bg[q];
+  const char* base = (const char*)m;
+  try {
+    // the arrays are sized side by side (a vector zero-fills what it is resized to: one thread per array, 2 MB pages), then filled by all cores
+    std::vector<std::thread> th;
+    th.emplace_back([&] { reserve_huge(ix->trie, H.n_trie); ix->trie.resize(H.n_trie); });
+    th.emplace_back([&] { reserve_huge(ix->pos_arr, H.n_pos_arr); ix->pos_arr.resize(H.n_pos_arr); });
+    th.emplace_back([&] { reserve_huge(ix->pos_off, H.n_pos_off); ix->pos_off.resize(H.n_pos_off); });
+    th.emplace_back([&] { reserve_huge(ix->ref_seq, H.n_ref_seq); ix->ref_seq.resize(H.n_ref_seq); ix->ref_off.resize(H.n_ref_off); ix->lookup.resize(H.n_lookup); ix->lkc.resize(H.n_lkc); ix->parts.resize(H.n_parts_stats); });
+    for (auto& x : th) x.join();
+  } catch (const std::exception& e) { set_err(err, errcap, std::string("smr_index_load_flat: ") + e.what()); return SMR_ERR_IO; }
+  tm.lap("load flat: arrays sized");
+  const uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  void* dst[8] = {ix->lookup.data(), ix->trie.data(), ix->pos_off.data(), ix->pos_arr.data(), ix->ref_seq.data(), ix->ref_off.data(), ix->lkc.data(), ix->parts.data()};
+  for (int q = 0; q < 8; q++) par_copy(dst[q], base + H.off[q], bytes[q], threads);
+  const char* sp = base + H.off[8]; const char* se = sp + bytes[8];
+  while (sp + 4 <= se) {
+    uint32_t l; memcpy(&l, sp, 4); sp += 4;
+    if (sp + l + 4 > se) { set_err(err, errcap, std::string(path) + ": damaged sequence table"); return SMR_ERR_IO; }
+    uint32_t ln; memcpy(&ln, sp + l, 4);
+    ix->sq_header.emplace_back(std::string(sp, l), ln);
+    sp += l + 4;
+  }
+  // what the other loaders guarantee, checked here too: offsets inside the arrays
+  if (ix->pos_off.empty() || ix->pos_off.back() * 2ull != ix->pos_arr.size() || ix->ref_off.empty() || ix->ref_off.back() != ix->ref_seq.size()) {
+    set_err(err, errcap, std::string(path) + ": inconsistent flat index"); return SMR_ERR_IO;
+  }
+  tm.lap("load flat: arrays copied");
+  *out = ix.release();
+  return SMR_OK;
+}

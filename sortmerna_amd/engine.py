@@ -82,6 +82,22 @@ class Index:
         if rc != 0:
             raise SmrError("smr_index_write_files: %s (rc=%d)" % (err.value.decode(), rc))
 
+    def save(self, path, stamp=0):
+        """flat cache of this part's host layout (smr_index_save)"""
+        err = C.create_string_buffer(512)
+        rc = capi.load().smr_index_save(self.h, path.encode(), stamp, err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_save: %s (rc=%d)" % (err.value.decode(), rc))
+
+    @staticmethod
+    def load_flat(path, stamp=0):
+        h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = capi.load().smr_index_load_flat(path.encode(), stamp, C.byref(h), err, 512)
+        if rc != 0:
+            raise SmrError("smr_index_load_flat: %s (rc=%d)" % (err.value.decode(), rc))
+        return Index(h)
+
     def selfcheck(self):
         """the pigeonhole device layout holds the same entries, with their DFS ranks, as the reference-shaped one"""
         err = C.create_string_buffer(512)

@@ -244,3 +244,39 @@ def test_reference_index_files_round_trip_byte_exact(tmp_path):
         assert getattr(a, f) == getattr(b, f), f
     assert abs(a.n_nodes - b.n_nodes) < 0.01 * a.n_nodes
     assert list(a.bg) == list(b.bg)
+
+
+def test_flat_index_cache_round_trip(tmp_path):
+    """smr_index_save / smr_index_load_flat: the part that comes back writes byte-identical reference-format files (every array and every
+    statistic survived), a wrong stamp and a damaged file are refused"""
+    import hashlib
+    import sortmerna_amd as smr
+    from sortmerna_amd import synth
+    db = str(tmp_path / "db.fasta")
+    synth.make_db(db, 300_000, seed=9, family_size=6, mean_len=1300)
+    parts = smr.Index.build(db, 18, 0.8, 10000, 0)
+    assert len(parts) >= 2
+    flats = []
+    for k, ix in enumerate(parts):
+        f = str(tmp_path / ("part%d.flat" % k))
+        ix.save(f, stamp=77 + k)
+        flats.append(smr.Index.load_flat(f, stamp=77 + k))
+    smr.Index.write_files(parts, db, str(tmp_path / "a"))
+    smr.Index.write_files(flats, db, str(tmp_path / "b"))
+    names = sorted(n[2:] for n in os.listdir(tmp_path) if n.startswith("a."))
+    assert len(names) >= 1 + 3 * len(parts)
+    for n in names:
+        da, dbb = open(tmp_path / ("a." + n), "rb").read(), open(tmp_path / ("b." + n), "rb").read()
+        assert hashlib.sha1(da).digest() == hashlib.sha1(dbb).digest(), n
+    i0, i1 = parts[0].info(), flats[0].info()
+    assert (i0.n_ids, i0.n_pos, i0.trie_words, i0.numseq, i0.full_len, i0.n_parts) == (i1.n_ids, i1.n_pos, i1.trie_words, i1.numseq, i1.full_len, i1.n_parts)
+    with pytest.raises(smr.SmrError, match="stamp"):
+        smr.Index.load_flat(str(tmp_path / "part0.flat"), stamp=1)
+    blob = open(tmp_path / "part0.flat", "rb").read()
+    open(tmp_path / "cut.flat", "wb").write(blob[:len(blob) // 2])
+    with pytest.raises(smr.SmrError, match="damaged"):
+        smr.Index.load_flat(str(tmp_path / "cut.flat"), stamp=77)
+    with pytest.raises(smr.SmrError):
+        smr.Index.load_flat(str(tmp_path / "absent.flat"), stamp=77)
+    for ix in parts + flats:
+        ix.free()

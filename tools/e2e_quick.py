@@ -46,11 +46,14 @@ for x in th:
     x.start()
 for x in th:
     x.join()
-out = os.path.join(d, "out")
-os.makedirs(out)
 exe = os.path.join(ROOT, "examples", "build", "smr_align_mgpu")
-t = time.time()
-p = subprocess.run([exe, "--ref", db, "--idx", prefix, "--gumbel", "0.618874", "0.343238", "--reads", fq, "--out", out, "--gpus", "1", "--chunk-reads", "2000000", "--fastx"],
-                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, SMR_IB_TIMING="1"))
-print(p.stdout.decode()[-3000:])
-print("[run] wall %.1f s, rc %d; total %.1f s" % (time.time() - t, p.returncode, time.time() - T0), flush=True)
+flat = os.path.join(d, "flat")
+# run 1: reference-format index files (the slow load), writes the flat cache beside the alignment; run 2: the same command, index from the cache
+for run in (1, 2):
+    out = os.path.join(d, "out%d" % run)
+    os.makedirs(out)
+    t = time.time()
+    p = subprocess.run([exe, "--ref", db, "--idx", prefix, "--idx-flat", flat, "--gumbel", "0.618874", "0.343238", "--reads", fq, "--out", out, "--gpus", "1", "--chunk-reads", "2000000", "--fastx"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, SMR_IB_TIMING="1"))
+    print(p.stdout.decode()[-3000:])
+    print("[run %d] wall %.1f s, rc %d; total %.1f s" % (run, time.time() - t, p.returncode, time.time() - T0), flush=True)
