@@ -556,6 +556,16 @@ def main():
                 traffic_note = tj["note"]
         except Exception:
             pass
+        counters_all, counters_note = None, "no counter pass for these kernel sources and this workload (profiles/sq_counters.json)"
+        try:
+            import pmc_traffic
+            sj = json.load(open(os.path.join(HERE, "profiles", "sq_counters.json")))
+            w = sj["workload"]
+            if (w["read_len"], w["db_nt"], w["batch_reads"]) == (args.read_len, args.db_nt, args.batch_reads) and sj.get("kernel_src_sha") == pmc_traffic.kernel_src_sha():
+                counters_all = sj["per_kernel"]
+                counters_note = sj["source"]
+        except Exception:
+            pass
         seed_k = [k for k in kp if k.startswith("k_seed")]
         rk = {}
         for k in seed_k:
@@ -564,12 +574,17 @@ def main():
                 continue
             gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
             rk[k] = {"avg_launch_ms": v["ms"] / v["launches"], "launches": v["launches"] / args.gpus, "algorithmic_bytes_per_launch": v["bytes"] / v["launches"],
-                     "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": (traffic_all or {}).get(k)}
+                     "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": (traffic_all or {}).get(k), "counters": (counters_all or {}).get(k)}
         dom = max(rk, key=lambda k: rk[k]["avg_launch_ms"] * rk[k]["launches"]) if rk else None
         st_bytes = sum(kp[k]["bytes"] for k in seed_k)
         st_ms = sum(kp[k]["ms"] for k in seed_k)
         roof = {"kernel": dom, "bound": "hbm", "achieved": rk[dom]["achieved"] if dom else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (rk[dom]["achieved"] / HBM_PEAK_GBS) if dom else 0.0, "traffic": rk[dom]["traffic"] if dom else None, "traffic_note": traffic_note,
+                # the issue side of the same kernel (rocprofv3 derived metrics, tools/pmc_sq.py): % of cycles its vector / scalar ALUs issue, lane utilisation, LDS bank conflicts
+                "valu_issue_frac": (rk[dom]["counters"]["VALUBusy"] / 100.0) if dom and rk[dom]["counters"] and "VALUBusy" in rk[dom]["counters"] else None,
+                "lds_bank_conflict_frac": (rk[dom]["counters"]["LDSBankConflict"] / 100.0) if dom and rk[dom]["counters"] and "LDSBankConflict" in rk[dom]["counters"] else None,
+                "counters": rk[dom]["counters"] if dom else None, "counters_note": counters_note,
+                "other_kernels_counters": {k: v for k, v in (counters_all or {}).items() if not k.startswith("k_seed")} or None,
                 "algorithmic_bytes_per_launch": rk[dom]["algorithmic_bytes_per_launch"] if dom else 0.0, "avg_launch_ms": rk[dom]["avg_launch_ms"] if dom else 0.0,
                 "kernels": rk,
                 "seed_stage": {"achieved": st_bytes / max(st_ms * 1e-3, 1e-12) / 1e9, "frac": st_bytes / max(st_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,

@@ -121,7 +121,7 @@ struct RankOut {
 int main(int argc, char** argv) {
   const double t_main = now_s();
   std::vector<Db> dbs;
-  std::string reads_path, out_dir = ".", reduce = "rccl", devlist, flat_dir;
+  std::string reads_path, out_dir = ".", reduce = "auto", devlist, flat_dir;
   smr_params base; smr_params_default(&base);
   double evalue = 1.0;
   int world = 0;
@@ -165,8 +165,10 @@ int main(int argc, char** argv) {
   if (devlist.empty()) for (int r = 0; r < world; r++) S.devices.push_back(r % ndev);
   else { size_t p = 0; while (p <= devlist.size()) { size_t q = devlist.find(',', p); if (q == std::string::npos) q = devlist.size(); S.devices.push_back(atoi(devlist.substr(p, q - p).c_str())); p = q + 1; } }
   if ((int)S.devices.size() != world) die("--devices must list one device per rank");
+  // auto: RCCL when there is more than one rank (a reduction over one rank is the identity, and making a communicator takes seconds)
+  if (reduce == "auto") reduce = world > 1 ? "rccl" : "host";
   S.use_rccl = reduce == "rccl";
-  if (!S.use_rccl && reduce != "host") die("--reduce rccl|host");
+  if (!S.use_rccl && reduce != "host") die("--reduce auto|rccl|host");
   if (S.use_rccl) {
     for (int a = 0; a < world; a++) for (int b = a + 1; b < world; b++) if (S.devices[a] == S.devices[b]) die("RCCL needs one device per rank: use --reduce host for a dry run with shared devices");
     S.comms.resize(world);

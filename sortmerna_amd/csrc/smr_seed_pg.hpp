@@ -63,6 +63,8 @@ __device__ __forceinline__ uint32_t pg_reversed(uint32_t s) {
 // chars from..from+cnt-1 (cnt >= 1) of a string given as pg_reversed
 __device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_t cnt) { return (rev >> (32u - 2u * (from + cnt))) & ((1u << (2u * cnt)) - 1u); }
 
+struct __attribute__((aligned(4))) PgPair { uint32_t lo, hi; };       // two neighbouring directory words (4-byte aligned: global_load_dwordx2 takes that)
+
 // One row of 64 strings of a wave's searches (see the string loop of k_seed_pg): what the lane that got string g of the wave knows about it.
 struct PgRow { uint32_t T, P, m, u, w; int s; const uint32_t* tt; bool have; };
 // the searches' state that a string's lane fetches from its owner
@@ -198,10 +200,12 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
       uint32_t lo2, hi2;
       if (cB == pw - h) { const uint32_t k2 = pg_rkey(rev, h + 1, cB - 1); lo2 = 4 * k2; hi2 = lo2 + 4; }      // T[pw-1] is free under S2
       else { lo2 = pg_rkey(rev, h + 1, cB); hi2 = lo2 + 1; }
-      const uint32_t a0 = dirA[kA], a1 = dirA[kA + 1], b0 = dirB[kb0], b1 = dirB[kb0 + 1], c0 = dirB[kb1], c1 = dirB[kb1 + 1], d0 = dirB[lo2], d1 = dirB[hi2];
-      rs0 = a0; rn0 = a1 - a0;
-      rs1 = b0; rn1 = b1 - b0;
-      if (kb1 != kb0) { rs2 = c0; rn2 = c1 - c0; }
+      // (a range = two neighbouring directory words: one 8-byte load each -- five gathers per search instead of eight)
+      const PgPair pa = *reinterpret_cast<const PgPair*>(dirA + kA), pb = *reinterpret_cast<const PgPair*>(dirB + kb0), pc = *reinterpret_cast<const PgPair*>(dirB + kb1);
+      const uint32_t d0 = dirB[lo2], d1 = dirB[hi2];
+      rs0 = pa.lo; rn0 = pa.hi - pa.lo;
+      rs1 = pb.lo; rn1 = pb.hi - pb.lo;
+      if (kb1 != kb0) { rs2 = pc.lo; rn2 = pc.hi - pc.lo; }
       rs3 = d0; rn3 = d1 - d0;
       (void)nB;
     }

@@ -49,9 +49,14 @@ pmc)
   python tools/pmc_traffic.py $F $W 8000000 150 140000000 $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt 2>&1; cat $OUT/hbm_traffic.txt | head -40
   rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
 sq)
-  ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > /dev/null 2> $ROOT/$OUT/pmc_sq.err )
-  find $OUT/pmc_sq -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmc_sq.txt 2>&1; head -16 $OUT/pmc_sq.txt
-  rm -rf $OUT/pmc_sq ;;
+  # the issue-side counters (rocprofv3 derived metrics, at most three per pass) -> sq_counters.json
+  FILES=""
+  for SET in "VALUBusy SALUBusy LDSBankConflict" "MemUnitStalled VALUUtilization"; do N=$(echo $SET | cut -c1-8)
+    ( cd /tmp && timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > /dev/null 2> $ROOT/$OUT/pmc_sq_$N.err )
+    FILES="$FILES $(find $OUT/pmc_sq_$N -name "*counter_collection.csv" | head -1)"
+  done
+  ( cd tools && python pmc_sq.py $ROOT/$OUT/sq_counters.json 8000000 150 140000000 $(for F in $FILES; do echo $ROOT/$F; done) ) > $OUT/sq_counters.txt 2>&1; cat $OUT/sq_counters.txt
+  rm -rf $OUT/pmc_sq_* ;;
 sqi)
   ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sqi -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_sqi.json 2> $ROOT/$OUT/pmc_sqi.err )
   find $OUT/pmc_sqi -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmc_sqi.txt 2>&1; head -18 $OUT/pmc_sqi.txt
