@@ -119,9 +119,27 @@ __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32
   if (r & 1u) {
     const uint32_t p = atomicAdd(s_ncand, 1u);
     if (p < ccap) {
-      const uint32_t* ri = R.tt + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u;
-      cdk[p] = ri[0]; cdv[p] = ri[1];
+      // (only WHERE its {rank, id} lies: the load itself would sit in the pipelined loop and make the wave wait for it -- and, loads
+      // completing in order, for the next row's strings -- in every row with an accepted string; pg_resolve fetches them all at once)
+      cdk[p] = u | ((uint32_t)R.s << 25);
       cdn[p] = atomicExch(&hd[R.s], p) | ((((r & 2u) && !full) ? CK_COND : CK_PLAIN) << 16);
+    }
+  }
+}
+
+// The {DFS rank, id} of every accepted string of the wave, 64 records per trip: record p holds its string's number in the block and its
+// search; the search's lane has the block ({offset, n | cA << 24 | cB << 28}).
+__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t rtx, uint32_t rty, const uint32_t* pg, uint32_t* cdk, uint32_t* cdv) {
+  for (uint32_t p0 = 0; p0 < nrec; p0 += 64) {
+    const uint32_t p = p0 + (uint32_t)lane;
+    const uint32_t rec = p < nrec ? cdk[p] : 0u;
+    const int s = (int)(rec >> 25) & 63;
+    const uint32_t ob = __shfl(rtx, s, 64), om = __shfl(rty, s, 64);
+    if (p < nrec) {
+      const uint32_t u = rec & 0x1FFFFFFu, on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u, ocB = om >> 28;
+      const uint32_t* tt = pg + (size_t)ob * 4 + (ocA ? (1u << (2 * ocA)) + (1u << (2 * ocB)) + 2u : 0u);
+      const PgPair ri = *reinterpret_cast<const PgPair*>(tt + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u);
+      cdk[p] = ri.lo; cdv[p] = ri.hi;
     }
   }
 }
@@ -232,9 +250,13 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.tt = ix.pg; A.have = false;
   for (uint32_t g0 = 0; g0 < wtot + 64u; g0 += 128) {
     pg_row_fetch(B, g0, wtot, lane, own, O, carry, ix.pg);
+    GPH(2)
     pg_row_apply(A, pw, h, full, ccap, &s_ncand, cdk, cdv, cdn, hd);
+    GPH(3)
     pg_row_fetch(A, g0 + 64u, wtot, lane, own, O, carry, ix.pg);
+    GPH(2)
     pg_row_apply(B, pw, h, full, ccap, &s_ncand, cdk, cdv, cdn, hd);
+    GPH(3)
   }
   __syncthreads();
   GPH(2)
@@ -246,6 +268,9 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     }
     continue;
   }
+  pg_resolve(s_ncand, lane, rt.x, rt.y, ix.pg, cdk, cdv);
+  __syncthreads();
+  GPH(6)
   // ---------- every search takes its candidates in DFS order (selection by increasing rank).  Forward: applied to its list -- the window's
   // list so far -- with the reference's rules.  Reverse: collected without repeats, the kind of the first occurrence kept (a later occurrence
   // of an id changes nothing whatever the forward list holds: the id is present by then, or the list was replaced and the search over) ----------
