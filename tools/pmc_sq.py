@@ -25,7 +25,7 @@ def main():
         for r in csv.DictReader(open(path)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("smr::", "")
             fam = pmc_traffic.family_of(name)
-            if fam is None or name.startswith("k_seed_search") or name.startswith("k_seed_cscan") or name.startswith("k_seed_colscan"):
+            if fam is None or name.startswith("k_seed_search") or name.startswith("k_seed_cscan") or name.startswith("k_seed_colscan") or name.startswith("k_seed_emap") or name.startswith("k_seed_wbin"):
                 continue                                        # (the families' minor kernels would dilute the averages)
             a = acc[fam][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"])

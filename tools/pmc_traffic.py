@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 SEED_SOURCES = ["smr_seed.hpp", "smr_seed_pg.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
-FAMILY = [("k_seed_keys", "k_seed_keys"), ("k_seed_cscan", "k_seed_split"), ("k_seed_colscan", "k_seed_split"), ("k_seed_split", "k_seed_split"),
+FAMILY = [("k_seed_keys", "k_seed_keys"), ("k_seed_emap", "k_seed_keys"), ("k_seed_wbin", "k_seed_split"), ("k_seed_cscan", "k_seed_split"), ("k_seed_colscan", "k_seed_split"), ("k_seed_split", "k_seed_split"),
           ("k_seed_bins", "k_seed_bins"), ("k_seed_pg<0>", "k_seed_pg<0>"), ("k_seed_search<0>", "k_seed_pg<0>"), ("k_seed_pg<1>", "k_seed_pg<1>"),
           ("k_seed_search<1>", "k_seed_pg<1>"), ("k_seed_finish", "k_seed_finish"), ("k_cand", "k_cand"), ("k_chain", "k_chain"), ("k_begins", "k_begins"),
           ("k_trace", "k_trace")]
