@@ -538,6 +538,8 @@ __device__ __forceinline__ void chain_group_tuples(const SetArgs& A, uint32_t* s
 //   Bloom words + counts while the candidate set is built | hits[CH_HITS_LDS] uint2 | hp[CH_HITS_LDS + 8] u32 | skey[s_cap] u32
 // Candidate references (alignment.cpp:117-148) without a per-reference counter array: see chain_build_set.  EXT = true is the second
 // instantiation for the reads whose set outgrew the LDS table (global table of the block, tuples grouped by member).
+// one Smith-Waterman task of the candidate walk: reference, window geometry (alignment.cpp:271-357)
+struct SwTask { uint32_t max_ref; uint64_t rf_start, align_ref_start, head, align_que_start; int m, nref; };
 #ifndef SMR_CHAIN_WAVES_PER_SIMD
 #define SMR_CHAIN_WAVES_PER_SIMD 3
 #endif
@@ -576,6 +578,11 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   uint32_t* l_hp = (uint32_t*)(l_hits + CH_HITS_LDS);
   uint32_t* skey = l_hp + CH_HITS_LDS + 8;
   __shared__ uint32_t s_ns, s_nt;
+  // the batch cache of the walk (tasks scored together, their forward results, the LDS slot of each reference window): indexed with run-time
+  // values, so as local arrays they lived in private memory (scratch loads and stores on every look-up) -- a wave's LDS is the place
+  __shared__ SwTask s_ctk[4];
+  __shared__ SwRes s_cfw[4];
+  __shared__ int s_cslot[4];
   const uint32_t s_mask = s_cap - 1;
 
   unsigned long long* gt = g_tuples + (size_t)blockIdx.x * pairs_cap;
@@ -770,7 +777,6 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           int is_aligned, best, go_on;       // go_on = is_search_candidates
           int started, pending_pop, buf;     // buf: which pairs buffer holds candidate k (0/1: halves of l_pairs, 2: all of l_pairs, 3: global)
         };
-        struct SwTask { uint32_t max_ref; uint64_t rf_start, align_ref_start, head, align_que_start; int m, nref; };
         uint32_t buf_tag[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, buf_np[2] = {0, 0};
         int real_buf = 0;                                                     // the buffer the real walk's current candidate lives in
         const uint64_t rlen = len;
@@ -934,7 +940,10 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         Walk R;
         R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0;
         R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.buf = 0; R.ref0 = 0; R.reflen = 0;
-        SwTask ctk[4]; SwRes cfw[4]; int cslot[4] = {0, 1, 2, 3}; int n_cached = 0;     // the batch cache: task, forward result, LDS slot of its reference window
+        SwTask* const ctk = s_ctk; SwRes* const cfw = s_cfw; int* const cslot = s_cslot; int n_cached = 0;     // the batch cache: task, forward result, LDS slot of its reference window
+        // (every lane writes the same values; the wave barriers keep a lane that runs ahead from rewriting an entry that another is still reading)
+        __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < 4; e++) cslot[e] = e;
         bool rdq_staged = false;
         bool immediate = mode == 1 || !x4_ok;
         if (mode == 1 && seed_slot >= 0) {
@@ -943,6 +952,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
           cfw[0].score = q_score[seed_slot]; cfw[0].end_ref = q_eref[seed_slot]; cfw[0].end_read = q_eread[seed_slot];
           cslot[0] = 4 + seed_slot; n_cached = 1;
         }
+        __builtin_amdgcn_wave_barrier();
         if (!immediate) {
           // run the walk ahead assuming that nothing aligns: no task -> the read is finished; exactly one -> park it; more -> walk it now
           Walk L = R;
@@ -995,6 +1005,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
               if (ctk[e].max_ref == tk.max_ref && ctk[e].rf_start == tk.rf_start && ctk[e].align_que_start == tk.align_que_start && ctk[e].m == m && ctk[e].nref == nref) { ce = e; break; }
             if (ce < 0) {
               // a new batch: this task, and the tasks the walk would reach next if this one and they do not align
+              __builtin_amdgcn_wave_barrier();
               ctk[0] = tk; n_cached = 1;
               for (int e = 0; e < 4; e++) cslot[e] = e;
               if (x4_ok) {

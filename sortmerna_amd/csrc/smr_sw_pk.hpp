@@ -261,11 +261,14 @@ __device__ __forceinline__ SwRes sw_wave_pk_x4(const uint8_t* rdq, int m, int rd
 
 // the largest read span the four-problem kernel takes, and whether a problem's numbers fit the packed representation at all
 #define SW_X4_MAX_ROWS 256
+#ifndef SW_X4_INLINE
+#define SW_X4_INLINE __attribute__((noinline))
+#endif
 __device__ __forceinline__ bool sw_pk_fits(int m, int n, int match, int mismatch, int scoreN, int go) {
   return (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255;
 }
 // max_m: the longest read span among the wave's problems (wave-uniform), hasn: some reference window holds an N (wave-uniform)
-__device__ __attribute__((noinline)) SwRes sw_wave_x4(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+__device__ SW_X4_INLINE SwRes sw_wave_x4(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                                       int match, int mismatch, int scoreN, int go, int ge, int max_m, bool hasn) {
 #define X4_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, match, mismatch, scoreN, go, ge
   if (hasn) {
