@@ -1287,27 +1287,18 @@ static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
       const bool rows_lds = (size_t)wcap * 8 + TR_CIG_STAGE * 4 <= 64 * 1024 && !getenv("SMR_TRACE_GLOBAL_ROWS");     // (the variable: debugging aid, forces the wide-band variant)
       const uint64_t flags_cap = (uint64_t)std::max(c->b->max_len, 1u) * (wcap / 2);
       const uint64_t per_block = flags_cap + (rows_lds ? 0 : (uint64_t)wcap * 8);
-      static const int tw_bpc = getenv("SMR_TRACE_BPC") ? atoi(getenv("SMR_TRACE_BPC")) : 32, tw_seq = getenv("SMR_TRACE_SEQ_LDS") ? atoi(getenv("SMR_TRACE_SEQ_LDS")) : 0;
-      // (measured on 5 kb reads, k_trace per 50 000-read step: 8 blocks per CU 762 ms; 16: 496; 32: 459; with the sequences in LDS -- 19 KB per block, 8 blocks per CU -- 658:
-      //  the kernel lives on waves in flight, profiles/r4s10_*)
+      // (measured on 5 kb reads, k_trace per 50 000-read step: 8 blocks per CU 762 ms; 16: 496; 32: 459: the kernel lives on waves in flight, profiles/r4s10_*)
+      static const int tw_bpc = getenv("SMR_TRACE_BPC") ? atoi(getenv("SMR_TRACE_BPC")) : 32;
       uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((16ull << 30) / per_block, 1), (uint64_t)c->n_cu * tw_bpc);
       blocks = std::min(blocks, n_tasks);
-      // LDS: CIGAR stage | DP rows (bands that fit) | the alignment's read letters and reference window (as much as fits next to the rows)
-      const size_t lds_fix = (size_t)TR_CIG_STAGE * 4 + (rows_lds ? (size_t)wcap * 8 : 0);
-      const uint32_t seq_want = (std::max(ml, rf) + 15u) & ~15u;
-      const uint32_t seq_cap = !tw_seq ? 0u : lds_fix + 2 * (size_t)seq_want <= 150 * 1024 ? seq_want : (uint32_t)(((150 * 1024 - lds_fix) / 2) & ~(size_t)15);
-      const size_t lds_tw = lds_fix + 2 * (size_t)seq_cap;
-      if (lds_tw > 64 * 1024) {
-        if (rows_lds) HIPCHK(c, hipFuncSetAttribute((const void*)k_trace_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tw));
-        else HIPCHK(c, hipFuncSetAttribute((const void*)k_trace_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tw));
-      }
+      const size_t lds_tw = (size_t)TR_CIG_STAGE * 4 + (rows_lds ? (size_t)wcap * 8 : 0);
       if (c->trflags_bytes < (uint64_t)blocks * flags_cap) { if ((rc = dev_alloc(c, &c->d_trflags, (size_t)blocks * flags_cap))) return rc; c->trflags_bytes = (uint64_t)blocks * flags_cap; }
       if (!rows_lds && c->trrows_ints < (uint64_t)blocks * 2 * wcap) { if ((rc = dev_alloc(c, &c->d_trrows, (size_t)blocks * 2 * wcap))) return rc; c->trrows_ints = (uint64_t)blocks * 2 * wcap; }
       if ((rc = before())) return rc;
       if (rows_lds) hipLaunchKernelGGL(k_trace_wide<true>, dim3(blocks), dim3(64), lds_tw, c->stream, dreads(c), dindex(di), P, (const uint32_t*)t_in, n_tasks,
-                                       c->b->d_saved_aln, c->b->d_cigar, pool_words, c->b->d_ctr, t_out, (int)band, c->d_trflags, (unsigned long long)flags_cap, c->d_trrows, wcap, seq_cap);
+                                       c->b->d_saved_aln, c->b->d_cigar, pool_words, c->b->d_ctr, t_out, (int)band, c->d_trflags, (unsigned long long)flags_cap, c->d_trrows, wcap);
       else hipLaunchKernelGGL(k_trace_wide<false>, dim3(blocks), dim3(64), lds_tw, c->stream, dreads(c), dindex(di), P, (const uint32_t*)t_in, n_tasks,
-                              c->b->d_saved_aln, c->b->d_cigar, pool_words, c->b->d_ctr, t_out, (int)band, c->d_trflags, (unsigned long long)flags_cap, c->d_trrows, wcap, seq_cap);
+                              c->b->d_saved_aln, c->b->d_cigar, pool_words, c->b->d_ctr, t_out, (int)band, c->d_trflags, (unsigned long long)flags_cap, c->d_trrows, wcap);
       st = after(n_tasks);
     }
     if (st < 0) return st;

@@ -210,21 +210,19 @@ __global__ void __launch_bounds__(64) k_trace_band(DReads rd, DIndex ix, DParams
 // k_trace_wide: one wave per alignment, bands up to band_cap.  DP rows (H and E of the previous row, updated in place strip by
 // strip, left to right: a strip reads its right neighbour's first diagonal before that strip overwrites it): 2 x wcap ints, in
 // dynamic LDS (ROWS_LDS) or at g_rows + block * 2 * wcap.  Flags: g_flags + block * flags_cap bytes, row i at i * (wp / 2), two
-// neighbouring diagonals per byte.  The read's letters and the reference window of an alignment are put into LDS first when they fit
-// (seq_cap bytes each; round 3 fetched a letter per DP row and a reference letter per lane and strip from global memory inside the row loop --
-// with two waves per SIMD nothing hid that latency: 195 GCUPS on 5 kb reads).
+// neighbouring diagonals per byte.  The kernel lives on waves in flight (a letter of the read per DP row and a reference letter per lane and
+// strip come from global memory inside the row loop): 32 blocks per CU, 64 VGPRs; staging both sequences in LDS first (19 KB per block: 8 blocks
+// per CU) was slower than leaving that latency to the other waves (round 4, profiles/r4s10_*).
 // ------------------------------------------------------------------------------------------------
 template <bool ROWS_LDS>
-__global__ void __launch_bounds__(64) k_trace_wide(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, uint32_t n_tasks,
+__global__ void __launch_bounds__(64, 8) k_trace_wide(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, uint32_t n_tasks,
                                                    AlignRec* __restrict__ aln, uint32_t* __restrict__ cigar_pool, uint32_t cigar_words,
                                                    unsigned long long* __restrict__ ctr, uint32_t* __restrict__ tasks_out, int band_cap,
-                                                   uint8_t* __restrict__ g_flags, unsigned long long flags_cap, int* g_rows, uint32_t wcap, uint32_t seq_cap) {
+                                                   uint8_t* __restrict__ g_flags, unsigned long long flags_cap, int* g_rows, uint32_t wcap) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   uint32_t* stage = (uint32_t*)lds_raw;
   int* rowH = ROWS_LDS ? (int*)(lds_raw + TR_CIG_STAGE * 4) : g_rows + (size_t)blockIdx.x * 2 * wcap;
   int* rowE = rowH + wcap;
-  uint8_t* const rd_l = lds_raw + TR_CIG_STAGE * 4 + (ROWS_LDS ? (size_t)wcap * 8 : 0);      // [seq_cap] the read's letters (0..4) of the alignment's span
-  uint8_t* const rf_l = rd_l + seq_cap;                                                        // [seq_cap] its reference window
   uint8_t* fl = g_flags + (size_t)blockIdx.x * flags_cap;
   const int lane = lane_id();
   const int go = P.gap_open, ge = P.gap_ext;
@@ -239,13 +237,6 @@ __global__ void __launch_bounds__(64) k_trace_wide(DReads rd, DIndex ix, DParams
     const uint8_t* ref = ix.ref_seq + ix.ref_off[al.ref_num] + al.ref_begin1;
     int bw = max(abs(refLen - readLen) + 1, (int)al.cigar_len);
     int mx = 0, state = 0, wp = 64;
-    const bool staged = seq_cap && (uint32_t)readLen <= seq_cap && (uint32_t)refLen <= seq_cap;
-    if (staged) {
-      __syncthreads();
-      for (int q = lane; q < readLen; q += 64) rd_l[q] = (uint8_t)read_nt(rec, len, (uint32_t)(al.read_begin1 + q), reversed, 4u);
-      for (int q = lane; q < refLen; q += 64) rf_l[q] = ref[q];
-      __syncthreads();
-    }
     while (state == 0) {
       wp = (2 * bw + 1 + 63) & ~63;
       if (bw > band_cap || (uint32_t)wp > wcap || (unsigned long long)readLen * (wp / 2) > flags_cap) { state = 2; break; }
@@ -253,7 +244,7 @@ __global__ void __launch_bounds__(64) k_trace_wide(DReads rd, DIndex ix, DParams
       for (int k = lane; k < wp; k += 64) { rowH[k] = 0; rowE[k] = 0; }
       __syncthreads();
       for (int i = 0; i < readLen; i++) {
-        const int rnt = staged ? (int)rd_l[i] : (int)read_nt(rec, len, (uint32_t)(al.read_begin1 + i), reversed, 4u);
+        const int rnt = (int)read_nt(rec, len, (uint32_t)(al.read_begin1 + i), reversed, 4u);
         const int klo = max(0, bw - i), khi = min(2 * bw, refLen - 1 - i + bw);
         const bool edge_row = i <= bw + 1 && refLen - 1 < i + bw;
         int carry = TR_NEG, last_h = 0, last_f = 0;                     // scan prefix and exact H, F of the previous strip's last diagonal
@@ -265,7 +256,7 @@ __global__ void __launch_bounds__(64) k_trace_wide(DReads rd, DIndex ix, DParams
           int hup = k + 1 < wp ? rowH[k + 1] : 0, eup = k + 1 < wp ? rowE[k + 1] : 0;
           if (k >= 2 * bw || i == 0 || (edge_row && j == refLen - 1)) { hup = 0; eup = 0; }
           const int hd = (i > 0 && j > 0) ? hown : 0;
-          const int fnt = cell ? (staged ? (int)rf_l[j] : (int)ref[j]) : 4;
+          const int fnt = cell ? ref[j] : 4;
           const int sc = (rnt == 4 || fnt == 4) ? P.score_N : (rnt == fnt ? P.match : P.mismatch);
           const TrCell c = tr_cell_open(hup, eup, hd, sc, go, ge);
           int hc = c.hq, f, f1, x;
