@@ -150,12 +150,29 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
 #include "smr_sw_pk.hpp"
 namespace smr {
 
-// reads of more than 512 letters (mode 2): strips of 128 x 8 rows.  A function of its own so that its registers (8 rows of state per lane) are not
-// the footprint of every other call of sw_wave
-__device__ __attribute__((noinline)) SwRes sw_wave_long(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
-                                              int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
+// reads of more than 512 letters (mode 2): strips of 128 virtual lanes x R rows, R = 8 or 16.  The per-step overhead (hand-over between lanes,
+// inputs of lane 0, the boundary row for the next strip: 78 instructions) is paid per 128 R cells, so more rows per lane are cheaper per cell
+// (9 R + 78 instructions per step) -- as long as the last strip is not mostly empty: a read of m rows takes ceil(m / 128 R) strips of n + 127
+// steps.  5 kb reads: 5 strips x 150 = 750 per column with R = 8, 3 x 222 = 666 with R = 16.  Functions of their own so that their registers
+// (16 rows of state per lane) are not the footprint of every other call of sw_wave
+#ifndef SW_LONG_R2
+#define SW_LONG_R2 16
+#endif
+__device__ __attribute__((noinline)) SwRes sw_wave_long8(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                               int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
   if (hn) return sw_wave_pk_r<8, true, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
   return sw_wave_pk_r<8, false, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+}
+__device__ __attribute__((noinline)) SwRes sw_wave_long16(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                                int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
+  if (hn) return sw_wave_pk_r<SW_LONG_R2, true, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  return sw_wave_pk_r<SW_LONG_R2, false, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+}
+__device__ __forceinline__ SwRes sw_wave_long(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                              int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
+  const int c8 = ((m + 1023) / 1024) * (9 * 8 + 78), c16 = ((m + 128 * SW_LONG_R2 - 1) / (128 * SW_LONG_R2)) * (9 * SW_LONG_R2 + 78);
+  if (c16 < c8) return sw_wave_long16(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, hn);
+  return sw_wave_long8(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, hn);
 }
 
 // mode 1 / 2: the packed 16-bit kernel (smr_sw_pk.hpp; 2 = its wave_ror variant) where its preconditions hold; mode 0: always the 32-bit kernel
