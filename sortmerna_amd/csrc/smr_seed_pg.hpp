@@ -180,11 +180,22 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
 
   // A wave takes the chunks it, it + stride, ... (stride = all waves of the launch): the grid is a few waves per wave slot of the machine, not
   // one block per chunk the batch COULD have (most of which would find nothing to do: the number of tuples is only known on the device).
-  for (uint32_t it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ; it += gridDim.x * (blockDim.x >> 6)) {
-  uint32_t vb = it;                                        // this wave's 64 tuples
-  if (swz) { if ((it >> 3) >= per) break; vb = (it & 7u) * per + (it >> 3); if (vb >= nw) continue; }
-  else if (vb >= nw) break;
-  vb += c0;
+  // chunk of walk step `it`: 1 = vb is it, 2 = none at this step (the XCD's share is shorter), 0 = the walk is over
+  auto chunk_of = [&](uint32_t it, uint32_t& vb) -> int {
+    if (swz) { if ((it >> 3) >= per) return 0; vb = (it & 7u) * per + (it >> 3); if (vb >= nw) return 2; }
+    else { vb = it; if (vb >= nw) return 0; }
+    vb += c0;
+    return 1;
+  };
+  // The next chunk's tuple and its coarse bin are asked for while this chunk's candidates are being sorted out (pf_*): the head of the
+  // dependency chain tuple -> bin boundaries -> block table of the next walk step is under way before the step begins
+  bool pf = false, pf_bounds = false;
+  uint32_t pf_vb = 0, pf_c = 0, pf_nx = 0;
+  SeedTup pf_t = 0;
+  const uint32_t stride = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ; it += stride) {
+  uint32_t vb = 0;                                         // this wave's 64 tuples
+  { const int ck = chunk_of(it, vb); if (ck == 0) break; if (ck == 2) continue; }
   __syncthreads();                                         // (the previous chunk's LDS is free)
   // ---- the wave's 64 searches ----
   const uint32_t pos = vb * 64u + lane;
@@ -193,10 +204,21 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   uint32_t nh = 0, P9 = 0, slot = 0;
   uint2 rt = make_uint2(NONE, 0);
   bool hl_over = false;
+  {
+    const bool hit = pf && pf_vb == vb;
+    const SeedTup t = hit ? pf_t : (pos < n_tup ? sb.srt[pos] : 0ull);
+    uint32_t c = hit ? pf_c : (uint32_t)sb.wbin[vb];
+    uint32_t nx = (hit && pf_bounds) ? pf_nx : sb.cbase[c + 1];
+    pf = false; pf_bounds = false;
+    if (mine) {
+      while (pos >= nx) { c++; nx = sb.cbase[c + 1]; }          // (pos < cbase[nc]: ends; a chunk of 64 tuples rarely spans more than two bins)
+      SeedKey tk;
+      tk.slot = (uint32_t)t; tk.chars = (uint32_t)(t >> 32) & ((1u << sb.cb) - 1u); tk.key = (c << sb.fb) | (uint32_t)(t >> (32u + sb.cb));
+      rt = ix.root3[2 * (tk.key - (DIR ? sb.nkh : 0u)) + DIR];
+      P9 = tk.chars; slot = tk.slot;
+    }
+  }
   if (mine) {
-    const SeedKey tk = seed_decode(sb, pos);
-    rt = ix.root3[2 * (tk.key - (DIR ? sb.nkh : 0u)) + DIR];
-    P9 = tk.chars; slot = tk.slot;
     if (DIR == 1 && ((sb.gflag[slot >> 11] >> ((slot >> 6) & 31u)) & 1u) && ((sb.zbits[slot >> 5] >> (slot & 31u)) & 1u)) mine = false;   // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
   }
   if (lane == 0) s_ncand = 0;
@@ -260,6 +282,15 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   }
   __syncthreads();
   GPH(2)
+  {                                                 // the next walk step's tuple and coarse bin (see pf_* above)
+    uint32_t nvb = 0;
+    if (chunk_of(it + stride, nvb) == 1) {
+      const uint32_t npos = nvb * 64u + lane;
+      pf_t = npos < n_tup ? sb.srt[npos] : 0ull;
+      pf_c = sb.wbin[nvb];                          // (its bin's upper boundary is asked for once this has arrived: after the selection below)
+      pf_vb = nvb; pf = true;
+    }
+  }
   if (s_ncand > ccap) {                             // hand the wave to k_seed_search
     if (lane == 0) {
       atomicAdd(&ctr[C_SEED_REDO], 1ull);
@@ -295,6 +326,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     }
   }
   GPH(4)
+  if (pf) { pf_nx = sb.cbase[pf_c + 1]; pf_bounds = true; }
   // ---- write the windows' hit segments: [count, id x count] ----
   const bool wr = mine && nh > 0;
   const uint32_t need = wr ? 1 + nh : 0;
