@@ -296,6 +296,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
   const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
+  if (lds_bins > 60 * 1024) { static size_t bins_lds_attr = 0; if (lds_bins > bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); bins_lds_attr = lds_bins; } }
   if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     c->split_lds_attr = lds_split;
