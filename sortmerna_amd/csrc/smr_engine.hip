@@ -1196,17 +1196,31 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   return SMR_ERR_CAPACITY;
 }
 
+// Append from a wave with ONE returning atomic: the lanes that take a place count themselves with a ballot (same-address atomics serialise
+// at their L2 channel).  All 64 lanes must call it.
+__device__ __forceinline__ uint32_t wave_append(unsigned long long* counter, bool take) {
+  const unsigned long long m = __ballot(take);
+  uint32_t base = 0;
+  const int lane = (int)(threadIdx.x & 63u);
+  if (m) {
+    const int first = __ffsll((long long)m) - 1;
+    if (lane == first) base = (uint32_t)atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = (uint32_t)__shfl((int)base, first, 64);
+  }
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 // collect alignments of (index_num, part) that still need a CIGAR
 __global__ void k_trace_collect(uint32_t n, uint32_t slots, const RState* __restrict__ saved, const AlignRec* __restrict__ aln, uint32_t index_num, uint32_t part,
                                 uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * slots) return;
-  uint32_t r = i / slots, k = i % slots;
-  if (k >= saved[r].n_align) return;
-  const AlignRec& a = aln[i];
-  if (a.has_cigar || a.index_num != index_num || a.part != part) return;
-  unsigned long long o = atomicAdd(&ctr[C_TRACE_NEXT], 1ull);
-  tasks[o] = i;
+  bool take = false;
+  if (i < n * slots) {
+    uint32_t r = i / slots, k = i % slots;
+    if (k < saved[r].n_align) { const AlignRec& a = aln[i]; take = !(a.has_cigar || a.index_num != index_num || a.part != part); }
+  }
+  const uint32_t o = wave_append(&ctr[C_TRACE_NEXT], take);
+  if (take) tasks[o] = i;
 }
 
 // CIGARs for every stored alignment of the selected batch that lacks one and belongs to (p->index_num, p->part), whose reference sequences are di's
@@ -1438,10 +1452,10 @@ extern "C" int smr_counters_accumulate(smr_ctx* c, void* d_acc, uint32_t n_u64) 
 __global__ void k_results_compact(uint32_t n, uint32_t slots, const RState* __restrict__ saved, const AlignRec* __restrict__ saved_aln,
                                   uint32_t* __restrict__ out_idx, RState* __restrict__ out_state, AlignRec* __restrict__ out_aln, unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  const RState s = saved[r];
+  RState s; s.n_align = 0;
+  if (r < n) s = saved[r];
+  const uint32_t p = wave_append(&ctr[C_FETCH_N], s.n_align != 0);
   if (s.n_align == 0) return;
-  const uint32_t p = (uint32_t)atomicAdd(&ctr[C_FETCH_N], 1ull);
   out_idx[p] = r; out_state[p] = s;
   for (uint32_t k = 0; k < s.n_align && k < slots; k++) out_aln[(size_t)p * slots + k] = saved_aln[(size_t)r * slots + k];
 }
