@@ -10,6 +10,7 @@
 //   positions           indexdb.cpp:318-349,1716-1723 (file order, truncated at max_pos)
 //   minimal score       refstats.cpp:238-265
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -952,7 +953,15 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
   for (auto& r : recs) {
     if (r.len < W) { set_err(err, errcap, "at least one sequence is shorter than the seed length " + std::to_string(W)); return SMR_ERR_IO; }
     full_len += r.len;
-    for (uint32_t k = 0; k < r.len; k++) { int c = raw[r.seq_begin + k]; if (c != 'N') bgc[nt_index(c)]++; }
+  }
+  {                                                          // (all cores: one thread counting 140 M letters was a third of a device build)
+    std::vector<std::array<uint64_t, 4>> cnt(threads, std::array<uint64_t, 4>{0, 0, 0, 0});
+    parallel_for(threads, recs.size(), [&](size_t lo, size_t hi, uint32_t t) {
+      uint64_t c4[4] = {0, 0, 0, 0};
+      for (size_t q = lo; q < hi; q++) { const SeqRec& r = recs[q]; for (uint32_t k = 0; k < r.len; k++) { const int c = raw[r.seq_begin + k]; if (c != 'N') c4[nt_index(c)]++; } }
+      for (int k = 0; k < 4; k++) cnt[t][k] += c4[k];
+    });
+    for (auto& c4 : cnt) for (int k = 0; k < 4; k++) bgc[k] += (double)c4[k];
   }
   double tot = bgc[0] + bgc[1] + bgc[2] + bgc[3];
   // part split (indexdb.cpp:1384-1420)
