@@ -88,7 +88,8 @@ void align(Readfeed& readfeed, Readstats& readstats, Index& index, KeyValueDatab
 			parts.push_back(P);
 		}
 	// the engine keeps up to 64 parts resident on a GPU; a run with more (a small -m, many -ref) streams them through slot 0 per chunk instead
-	const bool resident = parts.size() <= 64;
+	const size_t max_resident = getenv("SMR_DROPIN_MAX_RESIDENT") ? (size_t)std::min(64, std::max(0, atoi(getenv("SMR_DROPIN_MAX_RESIDENT")))) : 64;   // (the variable: test aid)
+	const bool resident = parts.size() <= max_resident;
 
 	Queue<std::unique_ptr<Chunk>> to_gpu, to_db;
 	to_gpu.cap = to_db.cap = (size_t)n_gpu + 2;

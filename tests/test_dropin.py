@@ -96,10 +96,14 @@ def test_dropin_spreads_chunks_over_all_devices(case, chunk, tmp_path):
 
 
 @pytest.mark.skipif(not (paths.have_reference() and paths.have_ref_bin()), reason="needs /root/reference and `make -C oracle ref`")
-@pytest.mark.parametrize("case,chunk", [("t0", 0), ("paired", 0), ("paired", 64)])
+@pytest.mark.parametrize("case,chunk", [("t0", 0), ("paired", 0), ("paired", 64), ("real_two_db", -1)])
 def test_reference_cli_with_the_kernel_emulator_in_the_middle(case, chunk, tmp_path):
-    """(chunk 64: the 200 mate pairs stream through the emulator in 7 chunks)"""
+    """(chunk 64: the 200 mate pairs stream through the emulator in 7 chunks; chunk -1: more index parts than the binding keeps resident --
+    SMR_DROPIN_MAX_RESIDENT=1 for the two DBs of this case -- so every part is uploaded, used and unloaded per chunk of 300 reads)"""
     from helpers import emu
     lib = emu.build()
     subprocess.check_call(["make", "-s", "-j8", "-C", paths.ORACLE_DIR, "dropin", "SMRLIB=" + os.path.dirname(lib), "SMRNAME=smr_emu", "DROPIN_BIN=sortmerna_gpu_emu"])
+    if chunk < 0:
+        compare(os.path.join(paths.ORACLE_DIR, "_ref", "sortmerna_gpu_emu"), case, tmp_path, {"SMR_DROPIN_CHUNK": "300", "SMR_DROPIN_MAX_RESIDENT": "1"}, min_chunks=2)
+        return
     compare(os.path.join(paths.ORACLE_DIR, "_ref", "sortmerna_gpu_emu"), case, tmp_path, {"SMR_DROPIN_CHUNK": str(chunk)} if chunk else None, min_chunks=4 if chunk else 1)
