@@ -1162,16 +1162,8 @@ __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __res
     const uint32_t r = i / slots, k = i % slots;
     take = rw[r].is_new_hit && k < work[r].n_align && work_aln[i].has_cigar == 2;
   }
-  // (one returning atomic per wave, not per task: same-address atomics serialise at their L2 channel -- 1.5 ms for the 800 000 of a bench step)
-  const unsigned long long m = __ballot(take);
-  uint32_t base = 0;
-  const int lane = lane_id();
-  if (m) {
-    const int first = __ffsll((long long)m) - 1;
-    if (lane == first) base = (uint32_t)atomicAdd(&ctr[C_BEGIN_N], (unsigned long long)__popcll(m));
-    base = (uint32_t)__shfl((int)base, first, 64);
-  }
-  if (take) tasks[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+  const uint32_t o = block_append(&ctr[C_BEGIN_N], take);
+  if (take) tasks[o] = i;
 }
 
 template <bool LONG>
@@ -1190,11 +1182,16 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
   uint8_t* rfq_l = lds_raw + (size_t)per * lds_m + (size_t)g * lds_n;
   int* bound = g_bound ? g_bound + (size_t)blockIdx.x * 2 * lds_n : nullptr;          // strip boundaries (single-problem mode, reads of more than one strip)
   unsigned long long n_rev = 0, n_cells = 0;
+  uint32_t c_next = 0, c_end = 0;                            // tasks claimed and not yet taken
   for (;;) {
     __syncthreads();
-    if (lane == 0) s_t0 = (uint32_t)atomicAdd(&ctr[C_BEGIN_NEXT], (unsigned long long)per);
-    __syncthreads();
-    const uint32_t t0 = s_t0;
+    if (c_next >= c_end) {                                  // (eight rounds per claim: a returning atomic per round of four tasks made the counter a queue -- 200 000 per bench step at ~88 per microsecond)
+      if (lane == 0) s_t0 = (uint32_t)atomicAdd(&ctr[C_BEGIN_NEXT], (unsigned long long)(8 * per));
+      __syncthreads();
+      c_next = s_t0; c_end = c_next + 8u * (uint32_t)per;
+    }
+    const uint32_t t0 = c_next;
+    c_next += (uint32_t)per;
     if (t0 >= n_tasks) break;
     const uint32_t t = t0 + (uint32_t)g;
     const bool have = t < n_tasks;

@@ -428,7 +428,7 @@ void fold_shards(std::vector<unsigned long long>& h) {
       h[C_SHARDS + C_SHARD_W * s + k] = 0;
     }
   unsigned long long mx = 0;
-  for (int s = 0; s < C_NSHARD; s++) mx = std::max(mx, h[C_PCUR + s]);
+  for (int s = 0; s < C_NSHARD; s++) mx = std::max(mx, h[C_PCUR + s * C_PCUR_STRIDE]);
   h[C_POOL_CURSOR] = mx;
 }
 
@@ -1002,7 +1002,7 @@ int reset_batch(smr_ctx* c, Batch& B, hipStream_t st) {
   // their shards) keep accumulating until smr_prof_reset, like the kernel times do
   HIPCHK(c, hipMemsetAsync(B.d_ctr, 0, (size_t)C_WINDOWS * 8, st));
   HIPCHK(c, hipMemsetAsync(B.d_ctr + C_ERR_HITCAP, 0, (size_t)(C_SW_SPEC - C_ERR_HITCAP) * 8, st));
-  HIPCHK(c, hipMemsetAsync(B.d_ctr + C_PCUR, 0, (size_t)C_NSHARD * 8, st));
+  HIPCHK(c, hipMemsetAsync(B.d_ctr + C_PCUR, 0, (size_t)C_NSHARD * C_PCUR_STRIDE * 8, st));
   HIPCHK(c, hipStreamSynchronize(st));
   B.fetched = false;
   return SMR_OK;
@@ -1114,7 +1114,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
     for (int count = 0; count < num_strands; count++) {
       hipLaunchKernelGGL(k_begin_strand, dim3(nb), dim3(tb), 0, c->stream, c->b->n, P, count, c->b->d_work, c->b->d_rw);
-      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * 8, c->stream));
+      HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * C_PCUR_STRIDE * 8, c->stream));
       for (int pass = 0; pass < 3; pass++) {
         if (pass > 0 && P.skip[pass] == P.skip[pass - 1]) continue;     // equal strides are skipped (paralleltraversal.cpp:269-272)
         if ((rc = launch_seed(c, di, P, pass))) return rc;
@@ -1176,7 +1176,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
         }
         HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_BEGIN_N], 0, 16, c->stream));       // C_BEGIN_N, C_BEGIN_NEXT
         ev_mark(c, KP_BEGINS);
-        hipLaunchKernelGGL(k_begins_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->b->n, c->b->slots, (const RState*)c->b->d_work, (const RWork*)c->b->d_rw,
+        hipLaunchKernelGGL(k_begins_collect, dim3((uint32_t)((ntot + 1023) / 1024)), dim3(1024), 0, c->stream, c->b->n, c->b->slots, (const RState*)c->b->d_work, (const RWork*)c->b->d_rw,
                            (const AlignRec*)c->b->d_work_aln, c->d_tasks, c->b->d_ctr);
         if (c->b->max_len > SW_X4_MAX_ROWS)
           hipLaunchKernelGGL(k_begins<true>, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, c->d_bound, c->d_rdq);
@@ -1196,20 +1196,6 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   return SMR_ERR_CAPACITY;
 }
 
-// Append from a wave with ONE returning atomic: the lanes that take a place count themselves with a ballot (same-address atomics serialise
-// at their L2 channel).  All 64 lanes must call it.
-__device__ __forceinline__ uint32_t wave_append(unsigned long long* counter, bool take) {
-  const unsigned long long m = __ballot(take);
-  uint32_t base = 0;
-  const int lane = (int)(threadIdx.x & 63u);
-  if (m) {
-    const int first = __ffsll((long long)m) - 1;
-    if (lane == first) base = (uint32_t)atomicAdd(counter, (unsigned long long)__popcll(m));
-    base = (uint32_t)__shfl((int)base, first, 64);
-  }
-  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
-
 // collect alignments of (index_num, part) that still need a CIGAR
 __global__ void k_trace_collect(uint32_t n, uint32_t slots, const RState* __restrict__ saved, const AlignRec* __restrict__ aln, uint32_t index_num, uint32_t part,
                                 uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
@@ -1219,7 +1205,7 @@ __global__ void k_trace_collect(uint32_t n, uint32_t slots, const RState* __rest
     uint32_t r = i / slots, k = i % slots;
     if (k < saved[r].n_align) { const AlignRec& a = aln[i]; take = !(a.has_cigar || a.index_num != index_num || a.part != part); }
   }
-  const uint32_t o = wave_append(&ctr[C_TRACE_NEXT], take);
+  const uint32_t o = block_append(&ctr[C_TRACE_NEXT], take);
   if (take) tasks[o] = i;
 }
 
@@ -1273,7 +1259,7 @@ static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
   for (int attempt = 0; attempt < 40; attempt++) {
     t_in = c->d_tasks; t_out = c->d_tasks + ntot;
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_TRACE_NEXT], 0, 8, c->stream));
-    hipLaunchKernelGGL(k_trace_collect, dim3((uint32_t)((ntot + 255) / 256)), dim3(256), 0, c->stream, c->b->n, c->b->slots, c->b->d_saved, c->b->d_saved_aln, P.index_num, P.part, t_in, c->b->d_ctr);
+    hipLaunchKernelGGL(k_trace_collect, dim3((uint32_t)((ntot + 1023) / 1024)), dim3(1024), 0, c->stream, c->b->n, c->b->slots, c->b->d_saved, c->b->d_saved_aln, P.index_num, P.part, t_in, c->b->d_ctr);
     if ((rc = read_ctr(c, h))) return rc;
     uint32_t n_tasks = (uint32_t)h[C_TRACE_NEXT];
     if (n_tasks == 0) return SMR_OK;
@@ -1454,7 +1440,7 @@ __global__ void k_results_compact(uint32_t n, uint32_t slots, const RState* __re
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   RState s; s.n_align = 0;
   if (r < n) s = saved[r];
-  const uint32_t p = wave_append(&ctr[C_FETCH_N], s.n_align != 0);
+  const uint32_t p = block_append(&ctr[C_FETCH_N], s.n_align != 0);
   if (s.n_align == 0) return;
   out_idx[p] = r; out_state[p] = s;
   for (uint32_t k = 0; k < s.n_align && k < slots; k++) out_aln[(size_t)p * slots + k] = saved_aln[(size_t)r * slots + k];
@@ -1475,7 +1461,7 @@ extern "C" int smr_results_fetch(smr_ctx* c) {
   }
   if (c->fetch_cap_a < need_a) { if ((rc = dev_alloc(c, &c->d_faln, need_a))) return rc; c->fetch_cap_a = need_a; }
   HIPCHK(c, hipMemsetAsync(&B.d_ctr[C_FETCH_N], 0, 8, c->stream));
-  if (B.n) hipLaunchKernelGGL(k_results_compact, dim3((B.n + 255) / 256), dim3(256), 0, c->stream, B.n, B.slots, (const RState*)B.d_saved, (const AlignRec*)B.d_saved_aln,
+  if (B.n) hipLaunchKernelGGL(k_results_compact, dim3((B.n + 1023) / 1024), dim3(1024), 0, c->stream, B.n, B.slots, (const RState*)B.d_saved, (const AlignRec*)B.d_saved_aln,
                               c->d_fidx, c->d_fstate, c->d_faln, B.d_ctr);
   std::vector<unsigned long long> h;
   rc = read_ctr(c, h); if (rc) return rc;
@@ -1567,7 +1553,7 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
   std::vector<unsigned long long> h;
   for (int attempt = 0; attempt < 8; attempt++) {
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_HITCAP], 0, 16, c->stream));          // HITCAP, POOL
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * C_PCUR_STRIDE * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_HIT], 0, 8, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_SHARDS], 0, C_SHARD_W * C_NSHARD * 8, c->stream));
     // fresh per-part/strand state: forward, or reverse-complement with ambiguous letters complemented (aval 0 -> 3)

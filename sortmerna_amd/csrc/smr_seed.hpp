@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   if (total) {
     if (lane == 0) {                                     // the pool is split into C_NSHARD regions, each with its own cursor
       const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
-      const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], (unsigned long long)total);
+      const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard * C_PCUR_STRIDE], (unsigned long long)total);
       if (old + total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = shard * region + (uint32_t)old;
     }
     base = __shfl(base, 0, 64);
@@ -869,7 +869,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       uint32_t base = 0, total = 0;
       if (upper) {                                           // room for the longest the merged lists can be; blk_cnt is what they are
         const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
-        const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], 2ull * upper);
+        const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard * C_PCUR_STRIDE], 2ull * upper);
         if (old + 2ull * upper > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); upper = 0; seeds = 0; }
         else base = shard * region + (uint32_t)old;
       }

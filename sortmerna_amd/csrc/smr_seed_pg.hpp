@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   if (total) {
     if (lane == 0) {
       const uint32_t shard = vb & (C_NSHARD - 1), region = pool_words / C_NSHARD;
-      const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard], (unsigned long long)total);
+      const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard * C_PCUR_STRIDE], (unsigned long long)total);
       if (old + total > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); base = NONE; } else base = shard * region + (uint32_t)old;
     }
     base = __shfl(base, 0, 64);
