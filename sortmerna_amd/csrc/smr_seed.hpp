@@ -800,6 +800,9 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ uint32_t s_sf[FIN_KEEP][256], s_sr[FIN_KEEP][256], s_k[FIN_KEEP][256];     // the first windows with segments a thread met: forward / reverse segment (NONE: none), window
+  __shared__ unsigned long long s_st[5];
+  if (threadIdx.x < 5) s_st[threadIdx.x] = 0;
+  __syncthreads();
   unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
   if (r < rd.n) {
     RWork w = rw[r];
@@ -902,7 +905,13 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
     }
   }
   for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); moved += __shfl_down(moved, d, 64); kin += __shfl_down(kin, d, 64); }
-  if (lane_id() == 0) { if (hits) ctr_add(ctr, C_HIT, hits); if (bytes) ctr_add(ctr, C_READ_BYTES, bytes); if (looks) ctr_add(ctr, C_LOOKUP, looks); if (moved) ctr_add(ctr, C_B_FIN, moved); if (kin) ctr_add(ctr, C_B_KEYS, kin); }
+  // the block's five sums leave with one atomic each (not one per wave)
+  if (lane_id() == 0) { atomicAdd(&s_st[0], hits); atomicAdd(&s_st[1], bytes); atomicAdd(&s_st[2], looks); atomicAdd(&s_st[3], moved); atomicAdd(&s_st[4], kin); }
+  __syncthreads();
+  if (threadIdx.x < 5 && s_st[threadIdx.x]) {
+    const int which = threadIdx.x == 0 ? C_HIT : threadIdx.x == 1 ? C_READ_BYTES : threadIdx.x == 2 ? C_LOOKUP : threadIdx.x == 3 ? C_B_FIN : C_B_KEYS;
+    ctr_add(ctr, which, s_st[threadIdx.x]);
+  }
 }
 
 }  // namespace smr

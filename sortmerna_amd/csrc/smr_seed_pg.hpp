@@ -193,6 +193,10 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   uint32_t pf_vb = 0, pf_c = 0, pf_nx = 0;
   SeedTup pf_t = 0;
   const uint32_t stride = gridDim.x * (blockDim.x >> 6);
+  // the wave's work counters: summed in LDS (not in registers: the kernel sits on its 64-VGPR budget), added to the shard once after its last chunk
+  __shared__ unsigned long long s_acc[PG_WAVES][3];
+  unsigned long long* acc = s_acc[threadIdx.x >> 6];
+  if (lane == 0) { acc[0] = 0; acc[1] = 0; acc[2] = 0; }
   for (uint32_t it = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ; it += stride) {
   uint32_t vb = 0;                                         // this wave's 64 tuples
   { const int ck = chunk_of(it, vb); if (ck == 0) break; if (ck == 2) continue; }
@@ -354,12 +358,13 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   const uint32_t lane_bytes = (counted ? (uint32_t)sizeof(SeedTup) + 8u + (DIR ? 1u : 0u) : 0u) + ((srch && cA) ? 32u : 0u) + (wr ? 4u : 0u);
   unsigned long long w_bytes = (uint32_t)__builtin_amdgcn_readlane((int)pg_scan_add(lane_bytes), 63);
   w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + 2u;
-  if (lane == 0) { if (w_node) ctr_add(ctr, C_NODE, w_node); if (w_entry) ctr_add(ctr, C_ENTRY, w_entry); ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, w_bytes); }
+  if (lane == 0) { acc[0] += w_node; acc[1] += w_entry; acc[2] += w_bytes; }
 #ifdef SMR_SEED_PHASES
   GPH(5)
   if (lane == 0) for (int q = 0; q < 7; q++) if (tph[q]) { atomicAdd(&ctr[C_SHARDS + (vb & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], tph[q]); tph[q] = 0; }
 #endif
   }
+  if (lane == 0) { if (acc[0]) ctr_add(ctr, C_NODE, acc[0]); if (acc[1]) ctr_add(ctr, C_ENTRY, acc[1]); if (acc[2]) ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, acc[2]); }
 }
 
 }  // namespace smr
