@@ -309,7 +309,6 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   else kf = mapped ? k_seed_keys<false, false, true> : k_seed_keys<false, false, false>;
   if (lds_keys > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
   ev_mark(c, KP_KEYS);
-  HIPCHK(c, hipMemsetAsync(sb.chist, 0, ((size_t)sb.nc + 1) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
   for (int d = 0; d < 2; d++) HIPCHK(c, hipMemsetAsync(sb.fbits[d], 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
   HIPCHK(c, hipMemsetAsync(sb.zbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));
@@ -318,8 +317,8 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   hipLaunchKernelGGL(kf, dim3(sb.kb), dim3(64 * SEED_WAVES), lds_keys, c->stream, dreads(c), P, pass, sb, (const RWork*)c->b->d_rw, c->b->d_ctr);
   // the two-level sort of the stage's forward and reverse tuples (smr_seed.hpp)
   ev_mark(c, KP_SPLIT);                                    // (with the scans of the block histograms in front of it)
-  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
   hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
   hipLaunchKernelGGL(k_seed_wbin, dim3((gw + 255) / 256), dim3(256), 0, c->stream, sb);
   hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
   ev_mark(c, KP_BINS);

@@ -157,7 +157,7 @@ struct SeedKey { uint32_t slot, chars, key; };          // a decoded tuple of sr
 struct SeedBufs {
   uint32_t* chist;           // [nc + 1] tuples per COARSE bin (key >> fb)
   uint32_t* cbase;           // [nc + 1] exclusive scan of chist
-  uint32_t* rows;            // [kb][nc] tuples of block b of k_seed_keys per coarse bin; after k_seed_colscan: where its first tuple of that bin goes in mid
+  uint32_t* rows;            // [kb][nc] tuples of block b of k_seed_keys per coarse bin; after k_seed_colscan: where its first tuple of that bin goes in mid, counted from the bin's base
   uint32_t* bcnt;            // [kb] tuples block b wrote (at tmp[2 * rpb * maxwin * b ...), compact)
   SeedTup* tmp;              // unsorted tuples, one compact region per block of k_seed_keys
   SeedTup* mid;              // tuples grouped by coarse bin
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
   if (lane == 0 && nwin) atomicAdd(&s_win, nwin);
   __syncthreads();
   uint32_t* const row = sb.rows + (size_t)blockIdx.x * sb.nc;
-  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) { const uint32_t v = lh[c]; row[c] = v; if (v) atomicAdd(&sb.chist[c], v); }
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) row[c] = lh[c];       // (the bins' totals are k_seed_colscan's column sums: no atomics here)
   if (threadIdx.x == 0) {
     sb.bcnt[blockIdx.x] = s_cur;
     if (s_win) { ctr_add(ctr, C_WINDOWS, s_win); ctr_add(ctr, C_LOOKUP, s_win); }     // the forward lookups; the reverse ones are counted by k_seed_finish
@@ -358,9 +358,9 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
 // The tuples are brought into key order by a two-level counting sort.  No pass writes a tuple with a store of its own lane's choosing
 // (scattered stores run at 0.9 TB/s on the MI355X whatever the run length, coalesced ones at 5.6 TB/s; profiles/r03a_pmc_calibration_*):
 // a pass stages SEED_PIECE tuples in LDS in bin order and copies them out with consecutive lanes on consecutive tuples.
-//   k_seed_keys     leaves per block the number of its tuples per COARSE bin (key >> fb, <= 4096 bins)       -> rows, chist
+//   k_seed_keys     leaves per block the number of its tuples per COARSE bin (key >> fb, <= 4096 bins)       -> rows
+//   k_seed_colscan  rows[b][c] = the tuples of bin c in the rows above (where block b's tuples of bin c go inside the bin), the bin's total -> chist
 //   k_seed_cscan    exclusive scan of the coarse counts (one block)                                            -> cbase, SN_TUPLES, SN_FWD
-//   k_seed_colscan  rows[b][c] = cbase[c] + the tuples of bin c in the rows above: where block b's tuples of bin c go
 //   k_seed_wbin     coarse bin of every 64th tuple of the sorted array (the key of a sorted tuple = its bin | its fine bits)
 //   k_seed_split    block b reads ITS tuples once, piece by piece, and moves them to their coarse bins (block-relative slot -> slot, key -> fine bits)
 //   k_seed_bins     one block per coarse bin: histogram of the fine key bits (<= 512 bins), then the same staged move to the final places
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long 
 }
 
 // one block per 64 coarse bins (lane = bin); wave w takes the rows [w * kb / 16, (w + 1) * kb / 16): their sum, then -- offset by the waves
-// above and the bin's base -- the running place of every row
+// above -- the running place of every row inside its bin; the column's sum is the bin's size
 __global__ void __launch_bounds__(1024) k_seed_colscan(SeedBufs sb) {
   __shared__ uint32_t s_sum[16][64];
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -398,8 +398,9 @@ __global__ void __launch_bounds__(1024) k_seed_colscan(SeedBufs sb) {
   s_sum[wv][lane] = sum;
   __syncthreads();
   if (c >= sb.nc) return;
-  uint32_t run = sb.cbase[c];
+  uint32_t run = 0;
   for (uint32_t q = 0; q < wv; q++) run += s_sum[q][lane];
+  if (wv == 15) sb.chist[c] = run + sum;
   for (uint32_t r = r0; r < r1; r++) { const size_t o = (size_t)r * sb.nc + c; const uint32_t v = sb.rows[o]; sb.rows[o] = run; run += v; }
 }
 
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
   const uint32_t nmine = sb.bcnt[blockIdx.x];
   if (nmine == 0) return;
   const uint32_t* row = sb.rows + (size_t)blockIdx.x * sb.nc;
-  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) cur[c] = row[c];
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) cur[c] = sb.cbase[c] + row[c];
   __syncthreads();
   const uint32_t fb = sb.fb, kbits = sb.kbits, cb = sb.cb;
   const uint32_t slot0 = blockIdx.x * sb.rpb * sb.maxwin;                  // the block's first slot
