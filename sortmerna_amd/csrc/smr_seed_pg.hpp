@@ -26,6 +26,9 @@ namespace smr {
 #define PG_CAND_CAP0 256u                                 // initial pool size
 #define PG_CAND_CAP_MAX 2048u
 #define PG_NIL 0xFFFFu
+#ifndef PG_OCC
+#define PG_OCC 8                                          // waves per SIMD the kernel is compiled for (64 VGPRs, 96 SGPRs)
+#endif
 #define PG_WAVES 1                                        // (measured in round 2: 4 waves per block 1.70 ms, one wave per block 1.57 ms; the chunk loop of k_seed_pg assumes one)
 #ifndef PG_TRIP
 #define PG_TRIP 4
@@ -66,42 +69,45 @@ __device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_
 struct __attribute__((aligned(4))) PgPair { uint32_t lo, hi; };       // two neighbouring directory words (4-byte aligned: global_load_dwordx2 takes that)
 
 // One row of 64 strings of a wave's searches (see the string loop of k_seed_pg): what the lane that got string g of the wave knows about it.
-struct PgRow { uint32_t T, P, m, u, w; int s; const uint32_t* tt; bool have; };
-// the searches' state that a string's lane fetches from its owner
-struct PgOwn { uint32_t excl, tot, P9, rtx, rty, rs0, u1, u2, u3, c1, c2, c3; };
+struct PgRow { uint32_t T, P, m, u, w; int s; unsigned long long at; bool have; };     // at: the string's word in the layout
+// the searches' state that a string's lane fetches from its owner, prepared so that the lane has little left to do: string g of the wave is
+// string g + d[w] of the search's block, w = the number of thresholds t1 <= t2 <= t3 (first wave string of the ranges S0, S1, S2) that g has
+// reached; the block's strings begin at word blo | (bhi & 3) << 32 of the layout (bit 31 of bhi: the search has strings at all)
+struct PgOwn { uint32_t excl, P9, rty, blo, bhi, t1, t2, t3, d0, d1, d2, d3; };
+// where the strings of a block begin: behind its two directories when it has them
+__device__ __forceinline__ unsigned long long pg_strings_at(uint32_t rtx, uint32_t rty) {
+  const uint32_t cA = (rty >> 24) & 15u, cB = rty >> 28;
+  return (unsigned long long)rtx * 4ull + (cA ? (1u << (2 * cA)) + (1u << (2 * cB)) + 2u : 0u);
+}
 
 // Row g0: find the owners, ISSUE the loads of the strings (nothing here waits for them).
 // The last search whose strings start at or before g: the searches that start inside the row leave their number at their first string, a
 // prefix maximum spreads it to the strings behind (the searches are in the order of their first strings; one without strings starts where
 // the next one does and loses against it); carry = 1 + the last search that starts before the row.
 __device__ __forceinline__ void pg_row_fetch(PgRow& R, uint32_t g0, uint32_t wtot, int lane, uint32_t* own, const PgOwn& O, uint32_t& carry, const uint32_t* pg) {
-  R.P = R.m = R.u = R.w = 0; R.s = 0; R.tt = pg; R.have = false;
+  R.P = R.m = R.u = R.w = 0; R.s = 0; R.at = 0; R.have = false;
   if (g0 < wtot) {
     const uint32_t g = g0 + (uint32_t)lane;
     own[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    if (O.tot && O.excl - g0 < 64u) own[O.excl - g0] = (uint32_t)lane + 1u;
+    if ((O.bhi >> 31) && O.excl - g0 < 64u) own[O.excl - g0] = (uint32_t)lane + 1u;
     __builtin_amdgcn_wave_barrier();
     const uint32_t ow = max(pg_scan_max(own[lane]), carry);
     carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
     const int s = (int)ow - 1;
-    const uint32_t oe = __shfl(O.excl, s, 64), oP = __shfl(O.P9, s, 64), om = __shfl(O.rty, s, 64), ob = __shfl(O.rtx, s, 64);
-    const uint32_t o0 = __shfl(O.rs0, s, 64), o1 = __shfl(O.u1, s, 64), o2 = __shfl(O.u2, s, 64), o3 = __shfl(O.u3, s, 64);
-    const uint32_t oc1 = __shfl(O.c1, s, 64), oc2 = __shfl(O.c2, s, 64), oc3 = __shfl(O.c3, s, 64);
+    const uint32_t oP = __shfl(O.P9, s, 64), om = __shfl(O.rty, s, 64), olo = __shfl(O.blo, s, 64), ohi = __shfl(O.bhi, s, 64);
+    const uint32_t t1 = __shfl(O.t1, s, 64), t2 = __shfl(O.t2, s, 64), t3 = __shfl(O.t3, s, 64);
+    const uint32_t d0 = __shfl(O.d0, s, 64), d1 = __shfl(O.d1, s, 64), d2 = __shfl(O.d2, s, 64), d3 = __shfl(O.d3, s, 64);
     if (g < wtot) {
-      const uint32_t j = g - oe;
-      uint32_t w = 0, u = o0 + j;
-      if (j >= oc1) { w = 1; u = o1 + (j - oc1); }
-      if (j >= oc2) { w = 2; u = o2 + (j - oc2); }
-      if (j >= oc3) { w = 3; u = o3 + (j - oc3); }
-      const uint32_t ocA = (om >> 24) & 15u, ocB = om >> 28;
-      R.tt = pg + (size_t)ob * 4 + (ocA ? (1u << (2 * ocA)) + (1u << (2 * ocB)) + 2u : 0u);
-      R.P = oP; R.m = om; R.u = u; R.w = w; R.s = s; R.have = true;
+      const bool p1 = g >= t1, p2 = g >= t2, p3 = g >= t3;
+      const uint32_t u = g + (p3 ? d3 : p2 ? d2 : p1 ? d1 : d0);
+      R.at = ((unsigned long long)(ohi & 3u) << 32 | olo) + u;
+      R.P = oP; R.m = om; R.u = u; R.w = p3 ? 3u : p2 ? 2u : p1 ? 1u : 0u; R.s = s; R.have = true;
     }
   }
   // exactly ONE load per call whatever the path (a lane without a string reads word 0 of the layout): only then can the compiler let the
   // wave wait for the older of two loads in flight (s_waitcnt vmcnt(1)) instead of for all of them
-  R.T = R.tt[R.u];
+  R.T = pg[R.at];
 }
 // The automaton over the strings of a row; an accepted one becomes a candidate record of its search.
 __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32_t h, bool full, uint32_t ccap, uint32_t* s_ncand,
@@ -129,15 +135,15 @@ __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32
 
 // The {DFS rank, id} of every accepted string of the wave, 64 records per trip: record p holds its string's number in the block and its
 // search; the search's lane has the block ({offset, n | cA << 24 | cB << 28}).
-__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t rtx, uint32_t rty, const uint32_t* pg, uint32_t* cdk, uint32_t* cdv) {
+__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo, uint32_t bhi, uint32_t rty, const uint32_t* pg, uint32_t* cdk, uint32_t* cdv) {
   for (uint32_t p0 = 0; p0 < nrec; p0 += 64) {
     const uint32_t p = p0 + (uint32_t)lane;
     const uint32_t rec = p < nrec ? cdk[p] : 0u;
     const int s = (int)(rec >> 25) & 63;
-    const uint32_t ob = __shfl(rtx, s, 64), om = __shfl(rty, s, 64);
+    const uint32_t olo = __shfl(blo, s, 64), ohi = __shfl(bhi, s, 64), om = __shfl(rty, s, 64);
     if (p < nrec) {
-      const uint32_t u = rec & 0x1FFFFFFu, on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u, ocB = om >> 28;
-      const uint32_t* tt = pg + (size_t)ob * 4 + (ocA ? (1u << (2 * ocA)) + (1u << (2 * ocB)) + 2u : 0u);
+      const uint32_t u = rec & 0x1FFFFFFu, on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u;
+      const uint32_t* tt = pg + ((unsigned long long)(ohi & 3u) << 32 | olo);
       const PgPair ri = *reinterpret_cast<const PgPair*>(tt + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u);
       cdk[p] = ri.lo; cdv[p] = ri.hi;
     }
@@ -154,7 +160,7 @@ __device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t rtx
 // `swz`: wave it works on chunk (it % 8) * ceil(chunks / 8) + it / 8 -- blocks run on XCD b % 8, so every XCD's L2 sees one contiguous
 // eighth of the key range.
 template <int DIR>
-__global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
+__global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
                                                 uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr, int swz) {
   const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_tup);
   // this launch's wave chunks of 64 tuples: [c0, c0 + nw) (the chunk that holds the last forward and the first reverse tuple belongs to both)
@@ -271,9 +277,12 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   uint32_t carry = 0;
   // The loop is pipelined by one row and unrolled by two (A and B take turns, nothing is copied): the loads of row i are issued, then the
   // automaton runs over the strings of row i - 1, which were asked for a step earlier -- a wave waits for a string load once, not per row.
-  PgOwn O; O.excl = excl; O.tot = tot; O.P9 = P9; O.rtx = rt.x; O.rty = rt.y; O.rs0 = rs0; O.u1 = u1; O.u2 = u2; O.u3 = u3; O.c1 = c1; O.c2 = c2; O.c3 = c3;
+  PgOwn O; O.excl = excl; O.P9 = P9; O.rty = rt.y;
+  { const unsigned long long at = pg_strings_at(rt.x, rt.y); O.blo = (uint32_t)at; O.bhi = (uint32_t)(at >> 32) | (tot ? 0x80000000u : 0u); }
+  O.t1 = excl + c1; O.t2 = excl + c2; O.t3 = excl + c3;
+  O.d0 = rs0 - excl; O.d1 = u1 - O.t1; O.d2 = u2 - O.t2; O.d3 = u3 - O.t3;
   PgRow A, B;
-  A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.tt = ix.pg; A.have = false;
+  A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.at = 0; A.have = false;
   for (uint32_t g0 = 0; g0 < wtot + 64u; g0 += 128) {
     pg_row_fetch(B, g0, wtot, lane, own, O, carry, ix.pg);
     GPH(2)
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
     }
     continue;
   }
-  pg_resolve(s_ncand, lane, rt.x, rt.y, ix.pg, cdk, cdv);
+  pg_resolve(s_ncand, lane, O.blo, O.bhi, rt.y, ix.pg, cdk, cdv);
   __syncthreads();
   GPH(6)
   // ---------- every search takes its candidates in DFS order (selection by increasing rank).  Forward: applied to its list -- the window's
@@ -355,8 +364,8 @@ __global__ void __launch_bounds__(64 * PG_WAVES, 8 / PG_WAVES) k_seed_pg(DIndex 
   // algorithmic bytes of this wave (C_B_PG0/1): per tuple 8 B + its block-table entry (8 B); a search with directories reads 8 directory
   // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; the segment written (4 B per word) and the window slot pointing
   // to it; the chunk's coarse bin; DIR 1: the window's group bit (what does not come out of the scans above is summed per lane: < 2^32 per wave)
-  const uint32_t lane_bytes = (counted ? (uint32_t)sizeof(SeedTup) + 8u + (DIR ? 1u : 0u) : 0u) + ((srch && cA) ? 32u : 0u) + (wr ? 4u : 0u);
-  unsigned long long w_bytes = (uint32_t)__builtin_amdgcn_readlane((int)pg_scan_add(lane_bytes), 63);
+  unsigned long long w_bytes = (uint32_t)__popcll(__ballot(counted)) * ((uint32_t)sizeof(SeedTup) + 8u + (DIR ? 1u : 0u))
+                             + 32u * (uint32_t)__popcll(__ballot(srch && cA)) + 4u * (uint32_t)__popcll(__ballot(wr));
   w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + 2u;
   if (lane == 0) { acc[0] += w_node; acc[1] += w_entry; acc[2] += w_bytes; }
 #ifdef SMR_SEED_PHASES
