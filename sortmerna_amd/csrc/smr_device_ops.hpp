@@ -6,6 +6,9 @@
 #include <stdint.h>
 
 #define SMR_DYN_LDS(type, name) extern __shared__ __align__(16) type name[]
+// a pointer into global memory that was put together from integers: without the address space the compiler emits FLAT loads, which count
+// against the LDS counter as well and make every LDS wait a wait for memory
+#define SMR_GLOBAL_U32 const uint32_t __attribute__((address_space(1)))
 #define SMR_SW_SELFCHECK_CASES 512u                       // random problems smr_create runs through both Smith-Waterman kernels
 
 namespace smr {

@@ -27,8 +27,8 @@ namespace smr {
 #define PG_CAND_CAP_MAX 2048u
 #define PG_NIL 0xFFFFu
 #ifndef PG_OCC
-#define PG_OCC 8                                          // waves per SIMD the kernel is compiled for (64 VGPRs, 96 SGPRs)
-#endif
+#define PG_OCC 7                                          // waves per SIMD the kernel is compiled for: at 8 its ~115 wave-uniform values do not fit the 96 SGPRs a wave
+#endif                                                    // then gets (37 spilled to VGPR lanes, 124 v_readlane / v_writelane): 7 x 112 SGPRs was 1.5 - 3 % faster (r4s41, r4s42)
 #define PG_WAVES 1                                        // (measured in round 2: 4 waves per block 1.70 ms, one wave per block 1.57 ms; the chunk loop of k_seed_pg assumes one)
 #ifndef PG_TRIP
 #define PG_TRIP 4
@@ -69,58 +69,57 @@ __device__ __forceinline__ uint32_t pg_rkey(uint32_t rev, uint32_t from, uint32_
 struct __attribute__((aligned(4))) PgPair { uint32_t lo, hi; };       // two neighbouring directory words (4-byte aligned: global_load_dwordx2 takes that)
 
 // One row of 64 strings of a wave's searches (see the string loop of k_seed_pg): what the lane that got string g of the wave knows about it.
-struct PgRow { uint32_t T, P, m, u, w; int s; unsigned long long at; bool have; };     // at: the string's word in the layout
+struct PgRow { uint32_t T, P, m, u, w; int s; SMR_GLOBAL_U32* tt; bool have; };     // tt: the strings of the search's block
 // the searches' state that a string's lane fetches from its owner, prepared so that the lane has little left to do: string g of the wave is
 // string g + d[w] of the search's block, w = the number of thresholds t1 <= t2 <= t3 (first wave string of the ranges S0, S1, S2) that g has
-// reached; the block's strings begin at word blo | (bhi & 3) << 32 of the layout (bit 31 of bhi: the search has strings at all)
-struct PgOwn { uint32_t excl, P9, rty, blo, bhi, t1, t2, t3, d0, d1, d2, d3; };
+// reached; blo / bhi: the ADDRESS of the block's strings; mab: the masks of the two directory keys (cA, cB <= 8 chars: 16 bits each);
+// exm: the first wave string of the search, 2^31 when it has none
+struct PgOwn { uint32_t exm, P9, mab, blo, bhi, t1, t2, t3, d0, d1, d2, d3; };
 // where the strings of a block begin: behind its two directories when it has them
-__device__ __forceinline__ unsigned long long pg_strings_at(uint32_t rtx, uint32_t rty) {
+__device__ __forceinline__ const uint32_t* pg_strings_at(const uint32_t* pg, uint32_t rtx, uint32_t rty) {
   const uint32_t cA = (rty >> 24) & 15u, cB = rty >> 28;
-  return (unsigned long long)rtx * 4ull + (cA ? (1u << (2 * cA)) + (1u << (2 * cB)) + 2u : 0u);
+  return pg + (size_t)rtx * 4 + (cA ? (1u << (2 * cA)) + (1u << (2 * cB)) + 2u : 0u);
 }
+__device__ __forceinline__ SMR_GLOBAL_U32* pg_ptr(uint32_t lo, uint32_t hi) { return (SMR_GLOBAL_U32*)((unsigned long long)hi << 32 | lo); }
 
 // Row g0: find the owners, ISSUE the loads of the strings (nothing here waits for them).
 // The last search whose strings start at or before g: the searches that start inside the row leave their number at their first string, a
 // prefix maximum spreads it to the strings behind (the searches are in the order of their first strings; one without strings starts where
 // the next one does and loses against it); carry = 1 + the last search that starts before the row.
 __device__ __forceinline__ void pg_row_fetch(PgRow& R, uint32_t g0, uint32_t wtot, int lane, uint32_t* own, const PgOwn& O, uint32_t& carry, const uint32_t* pg) {
-  R.P = R.m = R.u = R.w = 0; R.s = 0; R.at = 0; R.have = false;
+  R.P = R.m = R.u = R.w = 0; R.s = 0; R.tt = (SMR_GLOBAL_U32*)pg; R.have = false;
   if (g0 < wtot) {
     const uint32_t g = g0 + (uint32_t)lane;
     own[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    if ((O.bhi >> 31) && O.excl - g0 < 64u) own[O.excl - g0] = (uint32_t)lane + 1u;
+    if (O.exm - g0 < 64u) own[O.exm - g0] = (uint32_t)lane + 1u;
     __builtin_amdgcn_wave_barrier();
     const uint32_t ow = max(pg_scan_max(own[lane]), carry);
     carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
     const int s = (int)ow - 1;
-    const uint32_t oP = __shfl(O.P9, s, 64), om = __shfl(O.rty, s, 64), olo = __shfl(O.blo, s, 64), ohi = __shfl(O.bhi, s, 64);
+    const uint32_t oP = __shfl(O.P9, s, 64), om = __shfl(O.mab, s, 64), olo = __shfl(O.blo, s, 64), ohi = __shfl(O.bhi, s, 64);
     const uint32_t t1 = __shfl(O.t1, s, 64), t2 = __shfl(O.t2, s, 64), t3 = __shfl(O.t3, s, 64);
     const uint32_t d0 = __shfl(O.d0, s, 64), d1 = __shfl(O.d1, s, 64), d2 = __shfl(O.d2, s, 64), d3 = __shfl(O.d3, s, 64);
     if (g < wtot) {
       const bool p1 = g >= t1, p2 = g >= t2, p3 = g >= t3;
-      const uint32_t u = g + (p3 ? d3 : p2 ? d2 : p1 ? d1 : d0);
-      R.at = ((unsigned long long)(ohi & 3u) << 32 | olo) + u;
-      R.P = oP; R.m = om; R.u = u; R.w = p3 ? 3u : p2 ? 2u : p1 ? 1u : 0u; R.s = s; R.have = true;
+      R.u = g + (p3 ? d3 : p2 ? d2 : p1 ? d1 : d0);
+      R.tt = pg_ptr(olo, ohi);
+      R.P = oP; R.m = om; R.w = p3 ? 3u : p2 ? 2u : p1 ? 1u : 0u; R.s = s; R.have = true;
     }
   }
   // exactly ONE load per call whatever the path (a lane without a string reads word 0 of the layout): only then can the compiler let the
   // wave wait for the older of two loads in flight (s_waitcnt vmcnt(1)) instead of for all of them
-  R.T = pg[R.at];
+  R.T = R.tt[R.u];
 }
 // The automaton over the strings of a row; an accepted one becomes a candidate record of its search.
 __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32_t h, bool full, uint32_t ccap, uint32_t* s_ncand,
                                              uint32_t* cdk, uint32_t* cdv, uint32_t* cdn, uint32_t* hd) {
   if (!R.have) return;
   const uint32_t T = R.T, oP = R.P, u = R.u, w = R.w;
-  const uint32_t on = R.m & 0xFFFFFFu, ocA = (R.m >> 24) & 15u, ocB = R.m >> 28;
-  bool dup = false;                                    // reachable through an earlier key of its search?
-  if (w) {
-    const uint32_t mA = (1u << (2 * ocA)) - 1u, mB = (1u << (2 * ocB)) - 1u;
-    dup = ((T ^ oP) & mA) == 0;                        // under key A
-    if (w == 3) { const uint32_t tb = (T >> (2 * h)) & mB; dup = dup || tb == ((oP >> (2 * h)) & mB) || tb == ((oP >> (2 * h - 2)) & mB); }      // under S0 / S1
-  }
+  const uint32_t mA = R.m & 0xFFFFu, mB = R.m >> 16;
+  // reachable through an earlier key of its search?  Ranges S0, S1, S2: under key A; S2: also under S0 / S1
+  const uint32_t tb = (T >> (2 * h)) & mB;
+  const bool dup = (w != 0 && ((T ^ oP) & mA) == 0) || (w == 3 && (tb == ((oP >> (2 * h)) & mB) || tb == ((oP >> (2 * h - 2)) & mB)));
   const uint32_t r = dup ? 0u : lev1_entry(oP, T, pw);
   if (r & 1u) {
     const uint32_t p = atomicAdd(s_ncand, 1u);
@@ -135,7 +134,7 @@ __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32
 
 // The {DFS rank, id} of every accepted string of the wave, 64 records per trip: record p holds its string's number in the block and its
 // search; the search's lane has the block ({offset, n | cA << 24 | cB << 28}).
-__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo, uint32_t bhi, uint32_t rty, const uint32_t* pg, uint32_t* cdk, uint32_t* cdv) {
+__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo, uint32_t bhi, uint32_t rty, uint32_t* cdk, uint32_t* cdv) {
   for (uint32_t p0 = 0; p0 < nrec; p0 += 64) {
     const uint32_t p = p0 + (uint32_t)lane;
     const uint32_t rec = p < nrec ? cdk[p] : 0u;
@@ -143,9 +142,8 @@ __device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo
     const uint32_t olo = __shfl(blo, s, 64), ohi = __shfl(bhi, s, 64), om = __shfl(rty, s, 64);
     if (p < nrec) {
       const uint32_t u = rec & 0x1FFFFFFu, on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u;
-      const uint32_t* tt = pg + ((unsigned long long)(ohi & 3u) << 32 | olo);
-      const PgPair ri = *reinterpret_cast<const PgPair*>(tt + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u);
-      cdk[p] = ri.lo; cdv[p] = ri.hi;
+      SMR_GLOBAL_U32* ri = pg_ptr(olo, ohi) + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u;      // (two neighbouring words: one 8-byte load)
+      cdk[p] = ri[0]; cdv[p] = ri[1];
     }
   }
 }
@@ -277,12 +275,16 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   uint32_t carry = 0;
   // The loop is pipelined by one row and unrolled by two (A and B take turns, nothing is copied): the loads of row i are issued, then the
   // automaton runs over the strings of row i - 1, which were asked for a step earlier -- a wave waits for a string load once, not per row.
-  PgOwn O; O.excl = excl; O.P9 = P9; O.rty = rt.y;
-  { const unsigned long long at = pg_strings_at(rt.x, rt.y); O.blo = (uint32_t)at; O.bhi = (uint32_t)(at >> 32) | (tot ? 0x80000000u : 0u); }
+  PgOwn O; O.exm = tot ? excl : 0x80000000u; O.P9 = P9;
+  {
+    const uint32_t* at = pg_strings_at(ix.pg, rt.x == NONE ? 0u : rt.x, rt.y);
+    O.blo = (uint32_t)(unsigned long long)at; O.bhi = (uint32_t)((unsigned long long)at >> 32);
+    O.mab = ((1u << (2 * cA)) - 1u) | (((1u << (2 * cB)) - 1u) << 16);
+  }
   O.t1 = excl + c1; O.t2 = excl + c2; O.t3 = excl + c3;
   O.d0 = rs0 - excl; O.d1 = u1 - O.t1; O.d2 = u2 - O.t2; O.d3 = u3 - O.t3;
   PgRow A, B;
-  A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.at = 0; A.have = false;
+  A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.tt = (SMR_GLOBAL_U32*)ix.pg; A.have = false;
   for (uint32_t g0 = 0; g0 < wtot + 64u; g0 += 128) {
     pg_row_fetch(B, g0, wtot, lane, own, O, carry, ix.pg);
     GPH(2)
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
     }
     continue;
   }
-  pg_resolve(s_ncand, lane, O.blo, O.bhi, rt.y, ix.pg, cdk, cdv);
+  pg_resolve(s_ncand, lane, O.blo, O.bhi, rt.y, cdk, cdv);
   __syncthreads();
   GPH(6)
   // ---------- every search takes its candidates in DFS order (selection by increasing rank).  Forward: applied to its list -- the window's

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define SMR_DYN_LDS(type, name) type* const name = (type*)emu::dyn_lds()
+#define SMR_GLOBAL_U32 const uint32_t
 #define SMR_SW_SELFCHECK_CASES 8u
 
 namespace smr {
