@@ -51,6 +51,15 @@ SYN_CASES = [
     ("syn_minlis1", ["-min_lis", "1"], {"min_lis": 1}),
     ("syn_N0", ["-N", "0"], {"score_N": 0}),
     ("syn_gaps32", ["-gap_open", "3", "-gap_ext", "2"], {"gap_open": 3, "gap_ext": 2}),
+    # ... a seed length of 14 (its own index: passes L, L/2, 3 -- options.cpp), another scoring scheme (its own Gumbel lambda / K and minimal
+    # score), the (inert) -passes option, a stricter E-value ("evalue" is not a Params field: the tests take the minimal score computed from it)
+    ("syn_L14", ["-L", "14"], {"lnwin": 14, "skiplengths": [14, 7, 3]}),
+    ("syn_score3463", ["-match", "3", "-mismatch", "-4", "-gap_open", "6", "-gap_ext", "3"], {"match": 3, "mismatch": -4, "score_N": -4, "gap_open": 6, "gap_ext": 3}),      # (without -N the N penalty IS the mismatch: options.cpp:1707-1708)
+    # `-passes 18,6,2` does NOT reach the hot path in the reference: opt_passes (options.cpp:704-732) does skiplengths.emplace_back(18) on a
+    # vector<vector<uint32_t>> -- a vector of 18 zeros --, never parses the last number, and refstats.cpp:159-165 then sees zeros and installs the
+    # defaults L, L/2, 3.  The golden pins exactly that: the records equal the default run's.
+    ("syn_passes1862", ["-passes", "18,6,2"], {}),
+    ("syn_e1em8", ["-e", "1e-8"], {"evalue": 1e-8}),
 ]
 
 

@@ -6,7 +6,7 @@ import sortmerna_amd as smr
 from . import golden, orc
 
 CASES = ["t0", "t9", "syn_default", "syn_all", "syn_best3", "syn_nobest2", "syn_F", "syn_R", "syn_full_search",
-         "syn_seeds3_edges10", "syn_multipart", "syn_seeds1", "syn_minlis3", "syn_minlis1", "syn_N0", "syn_gaps32", "real_default", "real_all", "two_db_default", "two_db_all"]
+         "syn_seeds3_edges10", "syn_multipart", "syn_seeds1", "syn_minlis3", "syn_minlis1", "syn_N0", "syn_gaps32", "syn_L14", "syn_score3463", "syn_passes1862", "syn_e1em8", "real_default", "real_all", "two_db_default", "two_db_all"]
 
 
 def build_case(case, tmpdir):
@@ -16,15 +16,16 @@ def build_case(case, tmpdir):
     if not isinstance(dbs, list):
         dbs = [dbs]
     max_mb = g["params"].get("max_mb", 3072.0)
+    lnwin, evalue = g["params"].get("lnwin", 18), g["params"].get("evalue", 1.0)
     out = []
     for k, db in enumerate(dbs):
-        parts = smr.Index.build(db, 18, max_mb, 10000, 0)
+        parts = smr.Index.build(db, lnwin, max_mb, 10000, 0)
         prefix = os.path.join(str(tmpdir), "idx%d" % k)
         smr.Index.write_files(parts, db, prefix)
         st = orc.load_stats(prefix)
         # read totals as the reference's Readfeed counted them (for the multi-line FASTA of t0 it mis-counts records,
         # SURVEY.md 0.3; everywhere else these equal len(seqs) / sum of lengths)
-        ms, _, _ = orc.minimal_score(g["log"]["lambda"][k], g["log"]["K"][k], st, g["readstats"]["all_reads_count"], g["readstats"]["all_reads_len"])
+        ms, _, _ = orc.minimal_score(g["log"]["lambda"][k], g["log"]["K"][k], st, g["readstats"]["all_reads_count"], g["readstats"]["all_reads_len"], evalue)
         assert ms == g["log"]["minimal_score"][k]                       # refstats.cpp:238-265 restated
         out.append(dict(db=db, parts=parts, prefix=prefix, stats=st, minimal_score=ms))
     if case != "t0":
@@ -35,7 +36,7 @@ def build_case(case, tmpdir):
 def oracle_run(case, tmpdir):
     g = golden.load()[case]
     idx, seqs = build_case(case, tmpdir)
-    params = {k: v for k, v in g["params"].items() if k != "max_mb"}
+    params = {k: v for k, v in g["params"].items() if k not in ("max_mb", "evalue")}
     run = orc.Run(seqs)
     for k, d in enumerate(idx):
         p = orc.default_params(minimal_score=d["minimal_score"], index_num=k, **params)
@@ -59,7 +60,7 @@ def gpu_run(engine, case, tmpdir, with_cigar=True):
     """The same case through libsmr_hip (C ABI): -> dict(records, num_aligned, num_short, per_db)"""
     g = golden.load()[case]
     idx, seqs = build_case(case, tmpdir)
-    params = {k: v for k, v in g["params"].items() if k != "max_mb"}
+    params = {k: v for k, v in g["params"].items() if k not in ("max_mb", "evalue", "lnwin")}        # (the seed length is the index's)
     reads = smr.Reads.from_seqs(seqs)
     plist = [smr.default_params(minimal_score=d["minimal_score"], **params) for d in idx]
     slots = 256 if plist[0].num_alignments == 0 else None          # -num_alignments 0 = all: a read may align to every reference

@@ -1,7 +1,7 @@
 """CPU: the oracle (oracle/smr_oracle.c, the plain-C restatement of the hot path) pinned against
   (1) the reference's own golden vectors: t2's BLAST row (scripts/test.jinja:265-266) and t9's SAM rows (:447-477),
   (2) per-read KVDB records (Read::toBinString bytes) the UNMODIFIED reference produced for the committed inputs
-      (tests/golden/*.records.bin, made by tests/golden/make_golden.py), for 10 option variants,
+      (tests/golden/*.records.bin, made by tests/golden/make_golden.py), for the option variants of helpers/cases.py CASES,
   (3) when oracle/_ref/sortmerna_ref and /root/reference are present: a live run on the bundled set4 reads x
       silva-arc-16s-id95 with the REFERENCE-built index files.
 The index consumed in (1)/(2) is built by our own host builder (smr_index_build, plain C++ in libsmr_hip.so, no GPU
