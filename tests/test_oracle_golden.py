@@ -30,6 +30,14 @@ def test_oracle_records_equal_reference_records(case, tmp_path):
     assert o["num_short"] == g["readstats"]["num_short"]
 
 
+def test_the_reference_ignores_its_passes_option():
+    """`-passes 18,6,2` never reaches the hot path of the reference (options.cpp:704-732 appends vector<uint32_t>(18) -- zeros -- and never parses
+    the last number; refstats.cpp:159-165 then installs L, L/2, 3): its records are the default run's, byte for byte.  The strides themselves
+    (smr_params.skiplengths) are compared with the oracle in tests/test_gpu_parity.py / tests/test_emu_kernels.py."""
+    assert golden.load()["syn_passes1862"]["options"] == ["-passes", "18,6,2"]
+    assert golden.records("syn_passes1862") == golden.records("syn_default")
+
+
 def test_t2_blast_row_of_the_reference_test_suite(tmp_path):
     """scripts/test.jinja:265-266 (expected row of test t2) re-derived from the oracle's record."""
     expected = ["AB271211", "Unc49508", "93.5", "1430", "64", "30", "58", "1487", "1", "1446", "0", "2069", "+",
