@@ -1185,7 +1185,7 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
   uint32_t c_next = 0, c_end = 0;                            // tasks claimed and not yet taken
   for (;;) {
     __syncthreads();
-    if (c_next >= c_end) {                                  // (eight rounds per claim: a returning atomic per round of four tasks made the counter a queue -- 200 000 per bench step at ~88 per microsecond)
+    if (c_next >= c_end) {                                  // (eight rounds per claim: a returning atomic per round of four tasks made the counter a queue -- 200 000 per bench step at 83 per microsecond)
       if (lane == 0) s_t0 = (uint32_t)atomicAdd(&ctr[C_BEGIN_NEXT], (unsigned long long)(8 * per));
       __syncthreads();
       c_next = s_t0; c_end = c_next + 8u * (uint32_t)per;

@@ -111,7 +111,7 @@ enum {
   // Work counters and the pool cursor are sharded 64 ways (by block id): one address would serialise ~10 ns per
   // atomic over ~10^6 waves.  Shard s keeps counter C_WINDOWS+k (k < 9) at C_SHARDS + 32*s + k and C_TUP_F+k at C_SHARDS + 32*s + 9 + k
   // (slots 16.. of a shard: the cycle counters of the -DSMR_*_PHASES debug builds); the host folds them.
-  C_NSHARD = 64, C_SHARD_W = 32, C_SHARD_X = 9, C_SHARD_NX = 6, C_SHARD_PH = 16, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + C_SHARD_W * C_NSHARD, C_PCUR_STRIDE = 16 /* a 128-byte line per cursor: returning atomics on one line queue up */, C_TOTAL = C_PCUR + C_NSHARD * C_PCUR_STRIDE
+  C_NSHARD = 64, C_SHARD_W = 32, C_SHARD_X = 9, C_SHARD_NX = 6, C_SHARD_PH = 16, C_SHARDS = C_COUNT, C_PCUR = C_SHARDS + C_SHARD_W * C_NSHARD, C_PCUR_STRIDE = 16 /* a 128-byte line per cursor: atomics on one line queue up */, C_TOTAL = C_PCUR + C_NSHARD * C_PCUR_STRIDE
 };
 __device__ __forceinline__ void ctr_add(unsigned long long* ctr, int idx, unsigned long long v) {
   atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * C_SHARD_W + (idx >= C_TUP_F ? C_SHARD_X + idx - C_TUP_F : idx - C_WINDOWS)], v);
@@ -145,7 +145,7 @@ __device__ __constant__ uint8_t c_lev[(16 + 8 + 4 + 2) * 14] = {
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // Append from a whole block with ONE returning atomic (blocks of up to 1024 threads; every thread must call it).  A counter that is hit by a
-// returning atomic from every wave of a launch is a queue: ~88 per microsecond on the MI355X whatever the CUs do -- 125 000 waves, 1.5 ms
+// returning atomic from every wave of a launch is a queue: 83 per microsecond and 128-byte line on the MI355X whatever the CUs do, returning or not (tools/microbench/atomics.hip) -- 125 000 waves, 1.5 ms
 // for a kernel that reads 200 MB (round 4: k_begins_collect, k_trace_collect, k_results_compact).  The compiler already folds a wave's lanes
 // into one atomic; this folds the block's waves.
 __device__ __forceinline__ uint32_t block_append(unsigned long long* counter, bool take) {
