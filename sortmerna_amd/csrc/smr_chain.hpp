@@ -568,7 +568,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                                               uint2* g_hits, uint32_t keys_cap, uint32_t pairs_cap, uint32_t hits_cap,
                                               uint32_t lds_ml, uint32_t lds_rf, uint32_t s_cap, uint32_t* g_stab, unsigned long long* g_tuples2,
                                               uint32_t lds_rq, int* g_bound, uint8_t* g_rdq, uint8_t* __restrict__ marks,
-                                              const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool) {
+                                              const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool,
+                                              const uint32_t* __restrict__ rlist, const unsigned long long* __restrict__ rlist_n) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_next;
   __shared__ uint32_t s_ncand;
@@ -639,6 +640,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
   bool q_hasn = false, need_flush = false, out_of_reads = false;
   uint32_t chunk_base = 0;                               // reads are claimed 64 at a time (one atomic per chunk: 31 k instead of 2 M same-address atomics per launch);
   unsigned long long chunk_todo = 0;                     // bit i: read chunk_base + i is still to be walked
+  uint32_t chunk_ri = 0;                                 // lane i: that read (chunk_base + i, or entry chunk_base + i of rlist)
   for (;;) {
     uint32_t r;
     int mode = 0, seed_slot = -1;                         // mode 1: immediate (sequential walk), possibly seeded with the parked task's result
@@ -685,20 +687,24 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         __syncthreads();
         // (a claim is 64 reads when the batch has many per wave -- one atomic per 64 reads instead of one per read --, fewer when it has few: a batch
         // of 50 000 long reads claimed 64 at a time kept 781 of the 3 072 waves busy)
-        const uint32_t claim = max(1u, min(64u, rd.n / (gridDim.x * 4u)));
+        // (rlist: the marked reads the split path of smr_walk.hpp left to this kernel, as a list -- a launch that follows it claims over that list, not over the batch)
+        const uint32_t n_claim = rlist ? (uint32_t)*rlist_n : rd.n;
+        const uint32_t claim = max(1u, min(64u, n_claim / (gridDim.x * 4u)));
         if (lane == 0) s_next = (uint32_t)atomicAdd(&ctr[C_WORK_NEXT], (unsigned long long)claim);
         __syncthreads();
         chunk_base = s_next;
-        if (chunk_base >= rd.n) { out_of_reads = true; continue; }
+        if (chunk_base >= n_claim) { out_of_reads = true; continue; }
         // (k_cand ended the pass of every read it did not mark; 2 = left to the EXT launch by the first one)
-        const uint32_t ri = chunk_base + (uint32_t)lane;
-        const uint32_t mk = ((uint32_t)lane < claim && ri < rd.n) ? marks[ri] : 0u;
+        const uint32_t li = chunk_base + (uint32_t)lane;
+        const bool in_claim = (uint32_t)lane < claim && li < n_claim;
+        chunk_ri = rlist ? (in_claim ? rlist[li] : 0u) : li;
+        const uint32_t mk = in_claim ? marks[chunk_ri] : 0u;
         const bool todo = EXT ? mk == 2u : mk == 1u;
         chunk_todo = __ballot(todo);
         if (chunk_todo == 0) continue;
       }
       __syncthreads();
-      r = chunk_base + (uint32_t)(__ffsll((long long)chunk_todo) - 1);
+      r = (uint32_t)__builtin_amdgcn_readlane((int)chunk_ri, __ffsll((long long)chunk_todo) - 1);
       chunk_todo &= chunk_todo - 1;
     }
     // (all four loads before the first use of any: one round trip, not two -- a marked read is always active.  Tried and dropped: the

@@ -35,8 +35,9 @@ struct EvMark { hipEvent_t e; int kind; };        // kind < 0: end of a run of i
 
 #define SMR_MAX_BATCHES 16
 // kernel families timed apart (one HIP event between them on the engine's stream)
-enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_COUNT };
-static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_chain", "k_begins", "k_trace"};
+enum { KP_KEYS = 0, KP_SPLIT, KP_BINS, KP_PG0, KP_PG1, KP_FINISH, KP_CAND, KP_CHAIN, KP_BEGINS, KP_TRACE, KP_WALK, KP_SW16, KP_WNEXT, KP_COUNT };
+static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_seed_bins", "k_seed_pg<0>", "k_seed_pg<1>", "k_seed_finish", "k_cand", "k_chain", "k_begins", "k_trace",
+                                              "k_walk", "k_sw16", "k_wnext"};
 
 // One resident read batch: packed reads + everything the reference keeps per read in the KVDB (read.cpp:429-539)
 // + its Readstats counter block + its CIGAR pool.  Several batches can be resident at once (the host uploads
@@ -98,6 +99,14 @@ struct smr_ctx {
   // k_cand -> k_chain hand-over (smr_chain.hpp): {offset, npos} per read, the records (SMR_HANDOVER=0 switches it off)
   int handover = getenv("SMR_HANDOVER") ? atoi(getenv("SMR_HANDOVER")) : 1;
   uint2* d_mrec = nullptr; uint32_t* d_mpool = nullptr; size_t mrec_cap = 0, mpool_words = 0;
+  // the candidate walk in rounds (smr_walk.hpp): walk kernel -> Smith-Waterman over a task list -> next list; SMR_WALK_SPLIT=0: k_chain walks every marked read
+  int walk_split = getenv("SMR_WALK_SPLIT") ? atoi(getenv("SMR_WALK_SPLIT")) : 1;
+  uint32_t walk_rounds = getenv("SMR_WALK_ROUNDS") ? (uint32_t)std::max(1, std::min(32, atoi(getenv("SMR_WALK_ROUNDS")))) : 6u;      // the last one scores in the kernel
+  uint32_t walk_k = getenv("SMR_WALK_K") ? (uint32_t)std::max(1, std::min((int)WK_MAX, atoi(getenv("SMR_WALK_K")))) : 4u;           // tasks a read leaves per round
+  uint32_t walk_assume = getenv("SMR_WALK_ASSUME") ? (uint32_t)atoi(getenv("SMR_WALK_ASSUME")) : 3u;                                 // round 0 predicts "aligns" from this many seeds of the best candidate
+  uint2* d_wlist[2] = {nullptr, nullptr}; WState* d_wstate[2] = {nullptr, nullptr}; WTask* d_wtask[2] = {nullptr, nullptr}; uint2* d_wres[2] = {nullptr, nullptr};
+  uint32_t* d_wtidx = nullptr; uint32_t* d_wslow = nullptr; unsigned long long* d_wctr = nullptr; size_t walk_cap = 0; uint32_t walk_kcap = 0, walk_rcap = 0;
+  size_t walk_lds_attr = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
@@ -395,13 +404,72 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
     if (c->mpool_words < want_w) { int rc = dev_alloc(c, &c->d_mpool, want_w); if (rc) return rc; c->mpool_words = want_w; }
   }
   uint2* const mrec = c->handover ? c->d_mrec : nullptr;
+  // the split path takes the marked reads with a record of k_cand whose Smith-Waterman problems fit the packed kernels
+  const uint32_t wmq = std::min<uint32_t>(c->b->max_len, WK_MAX_ROWS), wml = (wmq + 15) & ~15u;
+  const bool split = c->walk_split && mrec && P.sw_mode >= 1 && sw_pk_fits((int)wmq, (int)rq, P.match, P.mismatch, P.score_N, P.gap_open);
+  const uint32_t RM = c->walk_rounds, WK = c->walk_k;
+  if (split) {
+    const size_t n = c->b->n;
+    if (c->walk_cap < n || c->walk_kcap < WK) {
+      for (int q = 0; q < 2; q++) {
+        int rc;
+        if ((rc = dev_alloc(c, &c->d_wlist[q], n)) || (rc = dev_alloc(c, &c->d_wstate[q], n)) || (rc = dev_alloc(c, &c->d_wtask[q], n * WK)) || (rc = dev_alloc(c, &c->d_wres[q], n * WK))) return rc;
+      }
+      int rc;
+      if ((rc = dev_alloc(c, &c->d_wtidx, n * WK)) || (rc = dev_alloc(c, &c->d_wslow, n))) return rc;
+      c->walk_cap = n; c->walk_kcap = WK;
+    }
+    if (c->walk_rcap < RM) { int rc = dev_alloc(c, &c->d_wctr, (size_t)(RM + 2) * WC_STRIDE); if (rc) return rc; c->walk_rcap = RM; }
+    HIPCHK(c, hipMemsetAsync(c->d_wctr, 0, (size_t)(RM + 2) * WC_STRIDE * 8, c->stream));
+    const size_t lds_w = (size_t)wml + rq;
+    if (lds_w > 64 * 1024 && lds_w > c->walk_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); c->walk_lds_attr = lds_w; }
+  }
+  unsigned long long* const n_slow = split ? c->d_wctr + (size_t)(RM + 1) * WC_STRIDE : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
                      mrec, c->d_mpool, c->mpool_words);
+  if (split) {
+    // rounds of walk -> Smith-Waterman -> next list (smr_walk.hpp); the last round scores in the walk kernel, so every listed read ends its pass here
+    ev_mark(c, KP_WNEXT);
+    hipLaunchKernelGGL(k_wlist, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, dreads(c), c->b->d_marks, (const uint2*)mrec, (uint32_t)WK_MAX_ROWS, c->d_wlist[0], c->d_wslow, c->d_wctr, n_slow);
+    const int swr = wmq <= 104 ? 13 : wmq <= 152 ? 19 : 32;
+    const uint32_t walk_blocks = (uint32_t)c->n_cu * 4u * SMR_WALK_WAVES_PER_SIMD, sw_blocks = (uint32_t)c->n_cu * 4u * (uint32_t)SW16_WAVES(swr);
+    for (uint32_t rnd = 0; rnd < RM; rnd++) {
+      const int cur = (int)(rnd & 1u), prv = cur ^ 1;
+      unsigned long long* const wc = c->d_wctr + (size_t)rnd * WC_STRIDE;
+      const bool fin = rnd + 1 == RM;
+      ev_mark(c, KP_WALK);
+#define WALK_ARGS dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr, (const uint2*)mrec, (const uint32_t*)c->d_mpool, (const uint2*)c->d_wlist[cur], \
+                  (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, wc, WK, wml, rq, c->walk_assume
+      if (fin) hipLaunchKernelGGL(k_walk<true>, dim3(walk_blocks * 3u / SMR_WALK_WAVES_PER_SIMD), dim3(64), (size_t)wml + rq, c->stream, WALK_ARGS);
+      else {
+        hipLaunchKernelGGL(k_walk<false>, dim3(walk_blocks), dim3(64), 0, c->stream, WALK_ARGS);
+        ev_mark(c, KP_SW16);
+#define SW16_ARGS dreads(c), dindex(di), P, (const WTask*)c->d_wtask[cur], (const uint32_t*)c->d_wtidx, (const unsigned long long*)wc, c->d_wres[cur]
+        if (swr == 13) hipLaunchKernelGGL(k_sw16<13>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+        else if (swr == 19) hipLaunchKernelGGL(k_sw16<19>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+        else hipLaunchKernelGGL(k_sw16<32>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+#undef SW16_ARGS
+        ev_mark(c, KP_WNEXT);
+        hipLaunchKernelGGL(k_wnext, dim3((uint32_t)c->n_cu * 2u), dim3(1024), 0, c->stream, P, is_last_strand, c->b->d_work, c->b->d_rw, c->b->d_ctr, (const uint2*)c->d_wlist[cur], (const WState*)c->d_wstate[cur],
+                           (const uint2*)c->d_wres[cur], c->d_wlist[prv], (const unsigned long long*)wc, wc + WC_STRIDE, WK);
+      }
+#undef WALK_ARGS
+    }
+    if (getenv("SMR_WALK_DEBUG")) {                         // measurement aid: reads listed and tasks left per round, reads left to k_chain
+      std::vector<unsigned long long> h((size_t)(RM + 2) * WC_STRIDE);
+      HIPCHK(c, hipMemcpyAsync(h.data(), c->d_wctr, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      fprintf(stderr, "libsmr_hip: walk rounds (pass %d): slow %llu;", pass, h[(size_t)(RM + 1) * WC_STRIDE]);
+      for (uint32_t rnd = 0; rnd < RM; rnd++) fprintf(stderr, " %llu/%llu", h[(size_t)rnd * WC_STRIDE + WC_NLIST], h[(size_t)rnd * WC_STRIDE + WC_NTASK]);
+      fprintf(stderr, "\n");
+    }
+  }
   ev_mark(c, KP_CHAIN);
 #define CHAIN_ARGS(stab, t2) dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, \
-                             c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks, (const uint2*)mrec, (const uint32_t*)c->d_mpool
+                             c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks, (const uint2*)mrec, (const uint32_t*)c->d_mpool, \
+                             (const uint32_t*)(split ? c->d_wslow : nullptr), (const unsigned long long*)n_slow
   // (LONG: the batch has reads of more than one Smith-Waterman strip; the short-read instantiation carries none of their state)
   if (gb) hipLaunchKernelGGL((k_chain<false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
   else hipLaunchKernelGGL((k_chain<false, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
@@ -844,6 +912,8 @@ extern "C" void smr_destroy(smr_ctx* c) {
     dev_free(&B.d_cigar);
   }
   dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_mrec); dev_free(&c->d_mpool);
+  for (int q = 0; q < 2; q++) { dev_free(&c->d_wlist[q]); dev_free(&c->d_wstate[q]); dev_free(&c->d_wtask[q]); dev_free(&c->d_wres[q]); }
+  dev_free(&c->d_wtidx); dev_free(&c->d_wslow); dev_free(&c->d_wctr);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
   dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
   for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
@@ -1628,7 +1698,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
     for (int q = 0; q < C_COUNT; q++) h[q] += t[q];
   }
   o->seed_ms = c->kp_ms[KP_KEYS] + c->kp_ms[KP_SPLIT] + c->kp_ms[KP_BINS] + c->kp_ms[KP_PG0] + c->kp_ms[KP_PG1] + c->kp_ms[KP_FINISH]; o->seed_launches = c->kp_l[KP_KEYS];
-  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
+  o->chain_ms = c->kp_ms[KP_CAND] + c->kp_ms[KP_CHAIN] + c->kp_ms[KP_BEGINS] + c->kp_ms[KP_WALK] + c->kp_ms[KP_SW16] + c->kp_ms[KP_WNEXT]; o->chain_launches = c->kp_l[KP_CAND] + c->kp_l[KP_BEGINS];
   o->trace_ms = c->kp_ms[KP_TRACE]; o->trace_launches = c->kp_l[KP_TRACE];
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];

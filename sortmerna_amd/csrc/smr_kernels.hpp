@@ -248,4 +248,5 @@ __global__ void k_commit_part(uint32_t n, DParams P, RState* __restrict__ saved,
 #include "smr_seed.hpp"
 #include "smr_seed_pg.hpp"
 #include "smr_chain.hpp"
+#include "smr_walk.hpp"
 #include "smr_trace.hpp"

@@ -264,7 +264,7 @@ __device__ __forceinline__ SwRes sw_wave_pk_x4(const uint8_t* rdq, int m, int rd
 #ifndef SW_X4_INLINE
 #define SW_X4_INLINE __attribute__((noinline))
 #endif
-__device__ __forceinline__ bool sw_pk_fits(int m, int n, int match, int mismatch, int scoreN, int go) {
+__host__ __device__ __forceinline__ bool sw_pk_fits(int m, int n, int match, int mismatch, int scoreN, int go) {
   return (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255;
 }
 // max_m: the longest read span among the wave's problems (wave-uniform), hasn: some reference window holds an N (wave-uniform)

@@ -1,0 +1,604 @@
+// smr_walk.hpp -- part of the HIP kernels of libsmr_hip (included by smr_kernels.hpp after smr_chain.hpp).
+//
+// compute_lis_alignment (alignment.cpp:100-509) for the reads k_cand marks, taken apart into ROUNDS of three kernels instead of one persistent
+// kernel that walks and scores (k_chain, smr_chain.hpp: 168 VGPRs, 3 waves per SIMD, the walk's scalar control flow and the Smith-Waterman
+// systolic arrays in one register allocation).  The candidate walk is a resumable generator of Smith-Waterman tasks, so:
+//
+//   k_wlist   the marked reads whose positions k_cand left as a record (at most CAND_REC_MAX = 64 of them: 99 % of the marked reads) and that
+//             the packed SW kernel takes become the round-0 list; every other marked read stays with k_chain (the `slow` list)
+//   k_walk    one wave per listed read, no Smith-Waterman registers: candidate set, candidate order and every candidate's sorted pairs by ONE
+//             bitonic sort of the (reference, position, window) triples across the 64 lanes; the walk consumes the results of the tasks the
+//             read left in the previous round and, at the first task it has no result for, leaves up to K tasks (that one + the ones the walk
+//             reaches next under a prediction) and its Walk state
+//   k_sw16    nothing but Smith-Waterman over the dense task list: SIXTEEN problems per wave (a quad of lanes = 8 virtual lanes x R rows,
+//             hand-over by quad_perm DPP), no LDS, reference letters fetched one period of four columns ahead
+//   k_wnext   reads whose look-ahead ended inside their batch with nothing aligned end their pass here (what the sequential walk does with
+//             those results); the others form the next round's list
+//
+// The last round (k_walk<true>) scores what it still meets in the kernel itself (one problem per wave), so the number of rounds is fixed and no
+// host synchronisation sits between them.  Results equal the sequential walk's by construction -- a task's result is looked up by its geometry,
+// predictions only decide WHICH windows are scored ahead -- and by test (every parity test runs through this path; SMR_WALK_SPLIT=0 = k_chain only).
+#pragma once
+
+namespace smr {
+
+#define WK_MAX 8u                     // most tasks a read leaves per round
+#define WK_MAX_ROWS 256u              // longest read span k_sw16 takes (8 virtual lanes x 32 rows)
+// per-round counters (u64 words): every hot one on a 128-byte line of its own
+enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_STRIDE = 48 };
+
+struct WTask {                        // one Smith-Waterman task: read span x reference window (alignment.cpp:271-357)
+  uint32_t r, max_ref;
+  uint64_t rf_start;                  // where the window starts in ix.ref_seq
+  uint16_t aq, m, nref;               // align_que_start, read span, window length
+  uint16_t flags;                     // bit 0: the read is walked on its reverse-complement strand
+};
+struct WState {                       // where the walk of a read stood BEFORE the advance that met the first task without a result
+  uint32_t k, it, ms_lo, ms_hi, begin_ref, begin_read;
+  int32_t best, best_after;           // Walk::best at that point / after that advance (what the read ends with when nothing of the batch aligns)
+  uint32_t bits;                      // 0 is_aligned, 1 go_on, 2 started, 3 pending_pop, 4 search, 5 look-ahead ended under "nothing aligns", 6 last result aligned, 8..11 tasks left
+  uint32_t cells;                     // DP cells of the tasks left
+};
+#define WS_NK(bits) (((bits) >> 8) & 15u)
+
+// ------------------------------------------------------------------------------------------------
+// k_wlist: marks -> the round-0 list of the split path (marks cleared) and the list of the reads that stay with k_chain
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_wlist(DReads rd, uint8_t* __restrict__ marks, const uint2* __restrict__ mrec, uint32_t max_rows, uint2* __restrict__ list0,
+                                                uint32_t* __restrict__ slow, unsigned long long* __restrict__ wc0, unsigned long long* __restrict__ n_slow) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool mk = i < rd.n && marks[i] == 1;
+  const bool fast = mk && mrec && mrec[i].x != NONE && rd.len[i] <= max_rows;
+  const uint32_t o = block_append(&wc0[WC_NLIST], fast);
+  if (fast) { list0[o] = make_uint2(i, NONE); marks[i] = 0; }
+  const uint32_t o2 = block_append(n_slow, mk && !fast);
+  if (mk && !fast) slow[o2] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sixteen Smith-Waterman problems per wave.  A QUAD of lanes is one systolic array of 8 virtual lanes (low halves = virtual lanes 0..3, high
+// halves 4..7) with R consecutive read rows each: n + 7 steps for n columns instead of the n + 31 of the four-problem kernel, and the ~14
+// instructions of hand-over per step are shared by 8 R cells.  Recurrence, representation (Y = H - gap_open, one v_perm_b32 score lookup per
+// cell pair) and end-cell rule are those of sw_wave_pk_x4 (smr_sw_pk.hpp), whose results it must equal bit for bit.  No LDS: a lane builds the
+// score tables of its rows from the packed read record, and the reference letters enter at lane 0 of the quad from a register that holds the
+// four columns of the current period (quad_perm broadcast) while the next period's letters are on their way from memory.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpp_quad_ror1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x93 /* quad_perm:[3,0,1,2] */, 0xF, 0xF, false); }
+template <int U> __device__ __forceinline__ int dpp_quad_bcast(int v) { return __builtin_amdgcn_update_dpp(v, v, U * 0x55 /* quad_perm:[U,U,U,U] */, 0xF, 0xF, false); }
+__device__ __forceinline__ unsigned long long quad_max_u64(unsigned long long v) {
+  for (int d = 2; d > 0; d >>= 1) { const unsigned long long o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+  return v;
+}
+
+template <int R, bool HASN>
+__device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uint32_t len, uint32_t reversed, int m, int aq, const uint8_t* __restrict__ ref, int n,
+                                           int match, int mismatch, int scoreN, int go, int ge) {
+  const int gl = lane_id() & 3;
+  const pk16 GE = pk_splat(ge), GO = pk_splat(go), ZERO = pk_splat(0);
+  const uint32_t TN = (((uint32_t)(scoreN + go)) & 0xFFFFu) * 0x00010001u;
+  uint32_t tlo[R], thi[R];
+  pk16 Y[R], E[R];
+  uint32_t key[R];
+  const uint32_t t_mm = ((uint32_t)(mismatch + go) & 0xFFu) * 0x01010101u, t_x = ((uint32_t)(mismatch + go) ^ (uint32_t)(match + go)) & 0xFFu,
+                 t_n = ((uint32_t)(scoreN + go) & 0xFFu) * 0x01010101u;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    uint32_t t2[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+      const int row = (gl + 4 * hf) * R + j;
+      uint32_t t = 0;
+      if (row < m) {
+        const uint32_t c = read_nt(rec, len, (uint32_t)(aq + row), reversed, 4u);
+        t = c == 4u ? t_n : t_mm ^ (t_x << (8u * c));
+      }
+      t2[hf] = t;
+    }
+    tlo[j] = t2[0]; thi[j] = t2[1];
+    Y[j] = pk_splat(-go); E[j] = ZERO; key[j] = 0;
+  }
+  int steps = m > 0 ? n + (m + R - 1) / R - 1 : 0;
+  for (int d = 32; d > 0; d >>= 1) steps = max(steps, __shfl_xor(steps, d, 64));
+  uint32_t lastY = pk_bits(pk_splat(-go)), lastF = 0, selcur = PK_SEL_NONE * 0x00010001u;
+  pk16 diag0 = pk_splat(-go);
+  const uint32_t in_y = (uint32_t)(-go) & 0xFFFFu;
+  uint32_t xlo = ((uint32_t)(0x3FFF + gl) << 1) | 1u;
+  const bool first = gl == 0;
+  uint32_t wnext = gl < n ? pk_sel_of(ref[gl]) : PK_SEL_NONE;
+#define SW16_STEP(U)                                                                                                        \
+  {                                                                                                                         \
+    const uint32_t win = (uint32_t)dpp_quad_bcast<U>((int)wcur);                                                            \
+    const uint32_t rY = (uint32_t)dpp_quad_ror1((int)lastY), rF = (uint32_t)dpp_quad_ror1((int)lastF), rS = (uint32_t)dpp_quad_ror1((int)selcur); \
+    const pk16 upY = pk_from(first ? ((rY << 16) | in_y) : rY);                                                             \
+    const pk16 upF = pk_from(first ? (rF << 16) : rF);                                                                      \
+    selcur = first ? ((rS << 16) | win | 0x00040000u) : rS;                                                                 \
+    uint32_t nmask = 0;                                                                                                     \
+    if (HASN) nmask = ((selcur >> 8) & 0x00010001u) * 0xFFFFu;                                                              \
+    const uint32_t xhi = xlo + 7u;                                                                                          \
+    pk16 diag = diag0, uy = upY, uf = upF;                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < R; j++) {                                                                         \
+      uint32_t T = perm_b32(thi[j], tlo[j], selcur);                                                                        \
+      if (HASN) T = (T & ~nmask) | (TN & nmask);                                                                            \
+      const pk16 a = pk_add(diag, pk_from(T));                                                                              \
+      const pk16 e = pk_max(pk_sub(E[j], GE), Y[j]);                                                                        \
+      const pk16 f = pk_max(pk_sub(uf, GE), uy);                                                                            \
+      const pk16 h = pk_max(pk_max(a, e), pk_max(f, ZERO));                                                                 \
+      diag = Y[j];                                                                                                          \
+      const pk16 y = pk_sub(h, GO);                                                                                         \
+      Y[j] = y; E[j] = e;                                                                                                   \
+      const uint32_t hu = pk_bits(h);                                                                                       \
+      key[j] = max(key[j], max((hu << 16) | xlo, (hu & 0xFFFF0000u) | xhi));                                                \
+      uy = y; uf = f;                                                                                                       \
+    }                                                                                                                       \
+    diag0 = upY;                                                                                                            \
+    lastY = pk_bits(uy); lastF = pk_bits(uf);                                                                               \
+    xlo -= 2u;                                                                                                              \
+  }
+  // (steps beyond a problem's own n + lanes - 1, up to the wave's maximum rounded to a period, meet the selector NONE: values that never reach a maximum)
+  for (int t = 0; t < steps; t += 4) {
+    const uint32_t wcur = wnext;
+    const int cq = t + 4 + gl;
+    wnext = cq < n ? pk_sel_of(ref[cq]) : PK_SEL_NONE;
+    SW16_STEP(0) SW16_STEP(1) SW16_STEP(2) SW16_STEP(3)
+  }
+#undef SW16_STEP
+  int bestH = 0, bestcol = 0x1FFFFF, bestrow = 0x1FFFFF;
+#pragma unroll
+  for (int j = 0; j < R; j++) {
+    const int h = (int)(key[j] >> 16);
+    const int hf = (key[j] & 1u) ? 0 : 1;
+    const int col = 0x3FFF - (int)((key[j] >> 1) & 0x7FFFu);
+    const int row = (gl + 4 * hf) * R + j;
+    if (h > bestH || (h == bestH && h > 0 && (col < bestcol || (col == bestcol && row < bestrow)))) { bestH = h; bestcol = col; bestrow = row; }
+  }
+  unsigned long long k64 = bestH > 0 ? (((unsigned long long)bestH << 42) | ((unsigned long long)(0x1FFFFF - bestcol) << 21) |
+                                        (unsigned long long)(0x1FFFFF - bestrow)) : 0ull;
+  k64 = quad_max_u64(k64);
+  SwRes rr;
+  if (k64 == 0) { rr.score = 0; rr.end_ref = -1; rr.end_read = m - 1; return rr; }
+  rr.score = (int)(k64 >> 42);
+  rr.end_ref = 0x1FFFFF - (int)((k64 >> 21) & 0x1FFFFF);
+  rr.end_read = 0x1FFFFF - (int)(k64 & 0x1FFFFF);
+  return rr;
+}
+
+// a result: x = score, y = (end_ref + 1) << 16 | end_read
+__device__ __forceinline__ uint2 wres_pack(const SwRes& s) { return make_uint2((uint32_t)s.score, ((uint32_t)(s.end_ref + 1) << 16) | ((uint32_t)s.end_read & 0xFFFFu)); }
+__device__ __forceinline__ SwRes wres_unpack(const uint2 v) { SwRes s; s.score = (int)v.x; s.end_ref = (int)(v.y >> 16) - 1; s.end_read = (int)(v.y & 0xFFFFu); return s; }
+
+// R rows per virtual lane = read spans up to 8 R letters; the host picks the instantiation from the longest read of the batch (13: <= 104
+// letters, 19: <= 152, 32: <= 256).  Registers: five per row (two score tables, Y, E, the running-maximum key) + ~30
+#define SW16_WAVES(R) ((R) <= 13 ? 4 : (R) <= 19 ? 3 : 2)
+template <int R>
+__global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix, DParams P, const WTask* __restrict__ tk, const uint32_t* __restrict__ tidx,
+                                                           const unsigned long long* __restrict__ wc, uint2* __restrict__ res) {
+  const int lane = lane_id(), g = lane >> 2, gl = lane & 3;
+  const uint32_t nt = (uint32_t)wc[WC_NTASK];
+  const uint32_t npass = (nt + 15u) / 16u;
+  for (uint32_t p = blockIdx.x; p < npass; p += gridDim.x) {
+    const uint32_t ti = p * 16u + (uint32_t)g;
+    const bool have = ti < nt;
+    uint32_t slot = 0;
+    int m = 0, n = 0, aq = 0;
+    uint32_t len = 0, reversed = 0;
+    const uint32_t* rec = rd.words;
+    const uint8_t* ref = ix.ref_seq;
+    if (have) {
+      slot = tidx[ti];
+      const WTask t = tk[slot];
+      m = t.m; n = t.nref; aq = t.aq; reversed = t.flags & 1u;
+      len = rd.len[t.r]; rec = rd.words + rd.rec_off[t.r];
+      ref = ix.ref_seq + t.rf_start;
+    }
+    int nn = n;
+    for (int d = 32; d > 0; d >>= 1) nn = max(nn, __shfl_xor(nn, d, 64));
+    bool hn = false;
+    for (int q = gl; q < nn; q += 4) if (q < n) hn |= ref[q] == 4;
+    SwRes s;
+    if (__any(hn)) s = sw_quad16<R, true>(rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
+    else s = sw_quad16<R, false>(rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
+    if (have && gl == 0) res[slot] = wres_pack(s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_walk<FINAL>: one wave per listed read and round.
+// ------------------------------------------------------------------------------------------------
+#ifndef SMR_WALK_WAVES_PER_SIMD
+#define SMR_WALK_WAVES_PER_SIMD 5
+#endif
+template <bool FINAL>
+__global__ void __launch_bounds__(64, FINAL ? 3 : SMR_WALK_WAVES_PER_SIMD)
+k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
+       unsigned long long* __restrict__ ctr, const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool,
+       const uint2* __restrict__ list, const WState* __restrict__ ws_prev, const WTask* __restrict__ tk_prev, const uint2* __restrict__ res_prev,
+       WState* __restrict__ ws_cur, WTask* __restrict__ tk_cur, uint32_t* __restrict__ tidx, unsigned long long* __restrict__ wc,
+       uint32_t K, uint32_t lds_ml, uint32_t lds_rf, uint32_t assume_min) {
+  SMR_DYN_LDS(unsigned char, lds_raw);                  // FINAL: read letters (lds_ml) | reference window (lds_rf)
+  __shared__ unsigned long long l_pairs[64];            // (reference position << 32 | window position) of the sorted triples
+  __shared__ uint2 l_cand[64];                          // candidates in walk order: {reference, count | first triple << 8}
+  __shared__ WTask s_ctk[WK_MAX];                       // the tasks the read left in the previous round ...
+  __shared__ uint2 s_cres[WK_MAX];                      // ... and their results
+  __shared__ uint32_t s_tix[64 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx with one atomic per chunk)
+  __shared__ uint32_t s_next, s_tbase;
+  const int lane = lane_id();
+  const uint32_t nlist = (uint32_t)wc[WC_NLIST];
+  unsigned long long n_fwd = 0, n_cells = 0, n_spec = 0, n_spec_used = 0;
+  const uint32_t claim = max(1u, min(64u, nlist / (gridDim.x * 4u)));
+  for (;;) {
+    __syncthreads();
+    if (lane == 0) s_next = (uint32_t)atomicAdd(&wc[WC_CLAIM], (unsigned long long)claim);
+    __syncthreads();
+    const uint32_t chunk_base = s_next;
+    if (chunk_base >= nlist) break;
+    const uint32_t chunk_n = min(claim, nlist - chunk_base);
+    uint32_t ntix = 0;
+    for (uint32_t ci = 0; ci < chunk_n; ci++) {
+      const uint32_t e = chunk_base + ci;
+      const uint2 le = list[e];
+      const uint32_t r = le.x, prev = le.y;
+      RWork w = rw[r];
+      RState st = work[r];
+      const uint32_t len = rd.len[r];
+      const uint32_t* rec = rd.words + rd.rec_off[r];
+      const uint2 mr = mrec[r];
+      WState ps; ps.bits = 0;
+      if (prev != NONE) ps = ws_prev[prev];
+      uint32_t live_bits = 0;                             // what ws_cur[e].bits becomes: 0 = the read is finished
+      if (w.strand_active && w.search && w.pass_n == (uint32_t)pass && mr.x != NONE) {
+        // ---- the read's triples (reference, reference position, window position), sorted: equal references are runs, a run's pairs are in walk order ----
+        const uint32_t npos = mr.y;
+        const uint32_t* rp = mpool + mr.x;
+        uint32_t seq = 0xFFFFFFFFu, pos = 0xFFFFFFFFu, win = 0xFFFFFFFFu;
+        if ((uint32_t)lane < npos) { seq = rp[lane]; pos = rp[npos + lane]; win = rp[2u * npos + lane]; }
+        uint32_t np2 = 2; while (np2 < npos) np2 <<= 1;
+        for (uint32_t kk = 2; kk <= np2; kk <<= 1)
+          for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            const uint32_t oseq = (uint32_t)__shfl_xor((int)seq, (int)j, 64), opos = (uint32_t)__shfl_xor((int)pos, (int)j, 64), owin = (uint32_t)__shfl_xor((int)win, (int)j, 64);
+            const bool oless = oseq < seq || (oseq == seq && (opos < pos || (opos == pos && owin < win)));
+            const bool mless = seq < oseq || (seq == oseq && (pos < opos || (pos == opos && win < owin)));
+            const bool want_min = (((uint32_t)lane & j) == 0) == (((uint32_t)lane & kk) == 0);
+            if (want_min ? oless : mless) { seq = oseq; pos = opos; win = owin; }
+          }
+        const uint32_t pseq = (uint32_t)__shfl_up((int)seq, 1, 64);
+        const bool valid = (uint32_t)lane < npos;
+        const bool head = valid && (lane == 0 || seq != pseq);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long below = heads & ((2ull << lane) - 1ull);
+        const uint32_t start = below ? 63u - (uint32_t)__clzll((long long)below) : 0u;
+        const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
+        const uint32_t endp = above ? (uint32_t)lane + (uint32_t)__ffsll((long long)above) : npos;
+        const uint32_t count = endp - start;
+        const bool cand = head && (int)count >= P.num_seeds;
+        const unsigned long long candmask = __ballot(cand);
+        const uint32_t ncand = (uint32_t)__popcll(candmask);
+        // walk order: count descending, reference ascending (alignment.cpp:134-148)
+        const unsigned long long mykey = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | seq;
+        uint32_t rank = 0;
+        for (unsigned long long mq = candmask; mq; mq &= mq - 1) {
+          const int c = __ffsll((long long)mq) - 1;
+          const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)seq, c), kc = (uint32_t)__builtin_amdgcn_readlane((int)count, c);
+          const unsigned long long key_c = ((unsigned long long)(0xFFFFFFFFu - kc) << 32) | ks;
+          rank += key_c < mykey ? 1u : 0u;
+        }
+        __syncthreads();
+        if (valid) l_pairs[lane] = ((unsigned long long)pos << 32) | (win & 0xFFFFu);
+        if (cand) l_cand[rank] = make_uint2(seq, count | ((uint32_t)lane << 8));
+        // the tasks of the previous round and their results
+        const uint32_t n_prev = prev != NONE ? WS_NK(ps.bits) : 0u;
+        if ((uint32_t)lane < n_prev) { s_ctk[lane] = tk_prev[(size_t)prev * K + lane]; s_cres[lane] = res_prev[(size_t)prev * K + lane]; }
+        __syncthreads();
+
+        struct Walk {
+          uint32_t k, np, it, ms_lo, ms_hi, begin_ref, begin_read, start, max_ref;
+          uint64_t ref0, reflen;
+          int is_aligned, best, go_on, started, pending_pop;
+        };
+        const uint64_t rlen = len;
+        // candidate wk.k: termination rules (:156-169), its pairs = a run of l_pairs.  geometry_only: the walk is resumed inside this candidate
+        auto load_candidate = [&](Walk& wk, bool geometry_only) -> int {
+          if (wk.k >= ncand || !wk.go_on) return 0;
+          const uint2 ce = l_cand[wk.k];
+          const uint32_t max_ref = ce.x, max_occur = ce.y & 0xFFu;
+          if (max_occur < (uint32_t)P.num_seeds) return 0;
+          const uint64_t r0_ = ix.ref_off[max_ref], r1_ = ix.ref_off[max_ref + 1];
+          if (!geometry_only && wk.is_aligned && P.min_lis > 0 && wk.k > 0 && max_occur < (l_cand[wk.k - 1].y & 0xFFu)) {   // :165-169
+            --wk.best;
+            if (wk.best < 1) return 0;
+          }
+          wk.np = max_occur; wk.start = ce.y >> 8; wk.max_ref = max_ref;
+          wk.ref0 = r0_; wk.reflen = r1_ - r0_;
+          if (!geometry_only) {
+            const unsigned long long p0 = l_pairs[wk.start];
+            wk.it = 0; wk.ms_lo = 0; wk.ms_hi = 0;
+            wk.begin_ref = (uint32_t)(p0 >> 32); wk.begin_read = (uint32_t)p0;
+            wk.pending_pop = 0;
+          }
+          return 1;
+        };
+        // the sliding window of read length along candidate wk.k (:203-506), up to its next window that calls for ssw_align
+        auto next_task = [&](Walk& wk, SwTask& tk) -> bool {
+          const unsigned long long* pairs = l_pairs + wk.start;
+          const uint32_t np = wk.np;
+          while (wk.it != np && wk.go_on) {
+            if (!wk.pending_pop) {
+              wk.pending_pop = 1;
+              const uint64_t end_ref_max = (uint64_t)wk.begin_ref + len - wk.begin_read - P.lnwin + 1;
+              int push = 0;
+              {
+                const uint32_t pi = wk.it + (uint32_t)lane;
+                const bool okp = pi < np && (uint64_t)(uint32_t)(pairs[min(pi, np - 1)] >> 32) <= end_ref_max;
+                const unsigned long long pm = __ballot(okp);
+                const uint32_t pc = pm == ~0ull ? 64u : (uint32_t)__ffsll((long long)~pm) - 1u;
+                if (pc) { wk.it += pc; wk.ms_hi = wk.it; push = 1; }
+              }
+              int skip_to_pop = 0;
+              if (!push && wk.is_aligned) skip_to_pop = 1;        // heuristic 1 (:243-246)
+              else wk.is_aligned = 0;
+              if (!skip_to_pop && (wk.ms_hi - wk.ms_lo) >= (uint32_t)P.num_seeds) {
+                uint32_t lis0;
+                const uint32_t nw = wk.ms_hi - wk.ms_lo;
+                const uint32_t nl = wave_lis_first(pairs + wk.ms_lo, nw, lis0);
+                if (nl >= (uint32_t)P.min_lis) {
+                  const uint32_t lcs_ref_start = (uint32_t)(pairs[wk.ms_lo + lis0] >> 32);
+                  const uint32_t lcs_que_start = (uint32_t)pairs[wk.ms_lo + lis0];
+                  const uint64_t reflen = wk.reflen;
+                  uint64_t hd = 0, tail = 0, align_ref_start = 0, align_que_start = 0, align_length = 0;
+                  uint32_t edges;
+                  if (P.is_as_percent) edges = (uint32_t)((P.edges / 100.0) * (double)rlen);
+                  else edges = (uint32_t)P.edges;
+                  if (lcs_ref_start < lcs_que_start) {                         // :287-325
+                    align_ref_start = 0; align_que_start = lcs_que_start - lcs_ref_start; hd = 0;
+                    if (reflen < rlen) {
+                      tail = 0;
+                      if (align_que_start > (rlen - reflen)) align_length = reflen - (align_que_start - (rlen - reflen));
+                      else align_length = reflen;
+                    } else {
+                      tail = reflen - align_ref_start - rlen;
+                      if (tail > (uint64_t)(uint32_t)(edges - 1)) tail = edges;
+                      align_length = rlen + hd + tail - align_que_start;
+                    }
+                  } else {                                                     // :326-357
+                    align_ref_start = lcs_ref_start - lcs_que_start; align_que_start = 0;
+                    if (align_ref_start > (uint64_t)(uint32_t)(edges - 1)) hd = edges;
+                    if (align_ref_start + rlen > reflen) { tail = 0; align_length = reflen - align_ref_start - hd; }
+                    else {
+                      tail = reflen - align_ref_start - rlen;
+                      if (tail > (uint64_t)(uint32_t)(edges - 1)) tail = edges;
+                      align_length = rlen + hd + tail;
+                    }
+                  }
+                  tk.max_ref = wk.max_ref; tk.align_ref_start = align_ref_start; tk.head = hd; tk.align_que_start = align_que_start;
+                  tk.m = (int)(align_length - hd - tail); tk.nref = (int)align_length;
+                  tk.rf_start = wk.ref0 + align_ref_start - hd;
+                  return true;
+                }
+              }
+            }
+            // pop (:486-506)
+            wk.pending_pop = 0;
+            if (wk.ms_hi > wk.ms_lo) wk.ms_lo++;
+            if (wk.ms_hi == wk.ms_lo) {
+              if (wk.it != np) { wk.begin_ref = (uint32_t)(pairs[wk.it] >> 32); wk.begin_read = (uint32_t)pairs[wk.it]; }
+              else break;
+            } else { wk.begin_ref = (uint32_t)(pairs[wk.ms_lo] >> 32); wk.begin_read = (uint32_t)pairs[wk.ms_lo]; }
+          }
+          return false;
+        };
+        // 1 = the walk stands at a task, 0 = the walk is over
+        auto advance = [&](Walk& wk, SwTask& tk) -> int {
+          for (;;) {
+            if (!wk.started) {
+              if (load_candidate(wk, false) != 1) return 0;
+              wk.started = 1;
+            }
+            if (next_task(wk, tk)) return 1;
+            wk.k++; wk.started = 0;
+          }
+        };
+        auto put_task = [&](uint32_t j, const SwTask& t) {
+          if (lane == 0) {
+            WTask o; o.r = r; o.max_ref = t.max_ref; o.rf_start = t.rf_start; o.aq = (uint16_t)t.align_que_start;
+            o.m = (uint16_t)t.m; o.nref = (uint16_t)t.nref; o.flags = w.reversed ? 1 : 0;
+            tk_cur[(size_t)e * K + j] = o;
+          }
+        };
+        auto task_ok = [&](const SwTask& t) -> bool { return t.m > 0 && t.nref > 0 && (uint32_t)t.m <= lds_ml && (uint32_t)t.nref <= lds_rf && (uint32_t)t.nref <= 0xFFFFu; };
+
+        Walk R;
+        int search = 1, last_aligned = 0;
+        if (prev == NONE) {
+          R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0; R.start = 0; R.max_ref = 0;
+          R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.ref0 = 0; R.reflen = 0;
+        } else {
+          R.k = ps.k; R.it = ps.it; R.ms_lo = ps.ms_lo; R.ms_hi = ps.ms_hi; R.begin_ref = ps.begin_ref; R.begin_read = ps.begin_read; R.best = ps.best;
+          R.is_aligned = (int)(ps.bits & 1u); R.go_on = (int)((ps.bits >> 1) & 1u); R.started = (int)((ps.bits >> 2) & 1u); R.pending_pop = (int)((ps.bits >> 3) & 1u);
+          search = (int)((ps.bits >> 4) & 1u); last_aligned = (int)((ps.bits >> 6) & 1u);
+          R.np = 0; R.start = 0; R.max_ref = 0; R.ref0 = 0; R.reflen = 0;
+          if (R.started) load_candidate(R, true);
+        }
+        // what the look-ahead assumes of the tasks it runs past: in round 0 "aligns" for a read whose best candidate has many seeds (a read sampled
+        // from the DB meets a family of references, one accepted alignment each), "does not" otherwise (a spurious candidate of a background read);
+        // later what the read's last result was.  Only which windows get scored ahead depends on it, never a result.
+        const int assume = prev == NONE ? ((ncand > 0 && (l_cand[0].y & 0xFFu) >= assume_min) ? 1 : 0) : last_aligned;
+        const uint32_t max_SW_score = len * (uint32_t)P.match;
+        bool cap_err = false, live = false, rdq_staged = false;
+        for (;;) {
+          const Walk S = R;
+          SwTask tk;
+          if (advance(R, tk) != 1) break;
+          if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; }           // read.flip34() to the 0..4 alphabet before SSW (:360-361)
+          const int m = tk.m, nref = tk.nref;
+          const bool sw_ok = task_ok(tk);
+          if (!sw_ok && (m > 0 && nref > 0)) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
+          SwRes fw; fw.score = 0; fw.end_ref = -1; fw.end_read = m - 1;
+          if (sw_ok) {
+            int ce = -1;
+            for (uint32_t q = 0; q < n_prev; q++)
+              if (s_ctk[q].max_ref == tk.max_ref && s_ctk[q].rf_start == tk.rf_start && (uint32_t)s_ctk[q].aq == (uint32_t)tk.align_que_start && (int)s_ctk[q].m == m && (int)s_ctk[q].nref == nref) { ce = (int)q; break; }
+            if (ce >= 0) { fw = wres_unpack(s_cres[ce]); if (ce > 0) n_spec_used++; }
+            else if (!FINAL) {
+              // the walk needs a result it does not have: leave this task and the ones the walk reaches next under the prediction, and stop here
+              uint32_t nk = 1, cells = (uint32_t)m * (uint32_t)nref;
+              put_task(0, tk);
+              Walk L = R; L.is_aligned = assume;
+              bool ended = false;
+              while (nk < K) {
+                SwTask t2;
+                if (advance(L, t2) != 1) { ended = true; break; }
+                if (!task_ok(t2)) break;
+                put_task(nk, t2); nk++; cells += (uint32_t)t2.m * (uint32_t)t2.nref;
+                L.is_aligned = assume;
+              }
+              n_spec += nk - 1;
+              if (lane == 0) {
+                WState o; o.k = S.k; o.it = S.it; o.ms_lo = S.ms_lo; o.ms_hi = S.ms_hi; o.begin_ref = S.begin_ref; o.begin_read = S.begin_read; o.best = S.best; o.best_after = R.best;
+                o.bits = (uint32_t)(S.is_aligned & 1) | ((uint32_t)(S.go_on & 1) << 1) | ((uint32_t)(S.started & 1) << 2) | ((uint32_t)(S.pending_pop & 1) << 3) | ((uint32_t)(search & 1) << 4) |
+                         ((ended && !assume) ? 32u : 0u) | ((uint32_t)(last_aligned & 1) << 6) | (nk << 8);
+                o.cells = cells;
+                ws_cur[e] = o;
+              }
+              live_bits = nk << 8;
+              for (uint32_t q = lane; q < nk; q += 64) s_tix[ntix + q] = e * K + q;
+              ntix += nk;
+              live = true;
+              break;
+            } else {
+              // last round: score it here, one problem per wave
+              uint8_t* const rdq = lds_raw; uint8_t* const rfq = lds_raw + lds_ml;
+              __syncthreads();
+              if (!rdq_staged) { for (uint32_t q = lane; q < len; q += 64) rdq[q] = (uint8_t)read_nt(rec, len, q, w.reversed, 4u); rdq_staged = true; }
+              for (int q = lane; q < nref; q += 64) rfq[q] = ix.ref_seq[tk.rf_start + q];
+              __syncthreads();
+              fw = sw_wave(rdq, m, (int)tk.align_que_start, 1, rfq, nref, 0, 1, nullptr, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+              __syncthreads();
+            }
+            n_fwd++; n_cells += (unsigned long long)m * nref;
+          }
+          const uint64_t align_ref_start = tk.align_ref_start, hd = tk.head, align_que_start = tk.align_que_start;
+          const uint32_t max_ref = tk.max_ref;
+          const int score1 = fw.score > 65535 ? 65535 : fw.score;
+          const int ref_end1 = fw.end_ref, read_end1 = fw.end_read;
+          // (the begin cell is k_begins' business, as with k_chain: window start in ref_begin1 / read_begin1, has_cigar = 2)
+          R.is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
+          last_aligned = R.is_aligned;
+          if (R.is_aligned) {
+            if ((uint32_t)score1 == max_SW_score) ++st.max_SW_count;
+            AlignRec al;
+            al.ref_begin1 = (int32_t)(align_ref_start - hd);
+            al.ref_end1 = ref_end1 + (int32_t)(align_ref_start - hd);
+            al.read_begin1 = (int32_t)align_que_start;
+            al.read_end1 = read_end1 + (int32_t)align_que_start;
+            al.readlen = len; al.ref_num = max_ref;
+            al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
+            al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
+            al.has_cigar = 2; al.cigar_off = 0; al.cigar_len = 0;
+            AlignRec* slots = work_aln + (size_t)r * P.slots;
+            if (!st.is_hit) {                                              // :411-416
+              st.is_hit = 1;
+              if (lane == 0) { atomicAdd(&ctr[C_NUM_ALIGNED], 1ull); atomicAdd(&ctr[C_PER_DB + P.index_num], 1ull); }
+            }
+            if (P.num_alignments == 0 || !P.is_best || (P.is_best && st.n_align < P.num_alignments)) {
+              if (st.n_align < P.slots) { if (lane == 0) slots[st.n_align] = al; st.n_align++; w.is_new_hit = 1; }
+              else { if (lane == 0) atomicAdd(&ctr[C_ERR_SLOTS], 1ull); }
+            } else if (P.is_best && st.n_align == P.num_alignments) {
+              __syncthreads();
+              if (slots[st.min_index].score1 < (uint16_t)score1) {         // :425-459
+                if (P.num_alignments > 1 && st.max_index == 0 && st.min_index == 0) {
+                  uint32_t mn = 0, mx = 0;
+                  for (uint32_t q = 1; q < st.n_align; q++) { if (slots[q].score1 < slots[mn].score1) mn = q; if (slots[q].score1 > slots[mx].score1) mx = q; }
+                  st.min_index = mn; st.max_index = mx;
+                }
+                const uint32_t mn = st.min_index, mx = st.max_index;
+                const uint16_t mx_score = slots[mx].score1;
+                __syncthreads();
+                if (lane == 0) slots[mn] = al;
+                __threadfence_block();
+                __syncthreads();
+                w.is_new_hit = 1;
+                if ((uint16_t)score1 > (mn == mx ? (uint16_t)score1 : mx_score) && st.n_align > 1) {
+                  st.max_index = mn;
+                  uint32_t m2 = 0;
+                  for (uint32_t q = 1; q < st.n_align; q++) if (slots[q].score1 < slots[m2].score1) m2 = q;
+                  st.min_index = m2;
+                }
+              }
+            }
+            __syncthreads();
+            if (P.num_alignments > 0) {                                    // :462-469
+              if (P.is_best) { if (P.num_alignments == st.max_SW_count) R.go_on = 0; }
+              else if (P.num_alignments == st.n_align) R.go_on = 0;
+            }
+            search = 0;
+          }
+        }
+        (void)cap_err;
+        if (live) { if (lane == 0) { work[r] = st; rw[r] = w; } }
+        else { w.best = R.best; chain_finish_read(P, is_last_strand, r, st, w, search, lane == 0, work, rw); }
+      }
+      if (!live_bits && lane == 0) ws_cur[e].bits = 0;
+    }
+    // the chunk's tasks go to the dense list with one atomic
+    if (!FINAL && ntix) {
+      __syncthreads();
+      if (lane == 0) s_tbase = (uint32_t)atomicAdd(&wc[WC_NTASK], (unsigned long long)ntix);
+      __syncthreads();
+      const uint32_t tb = s_tbase;
+      for (uint32_t q = lane; q < ntix; q += 64) tidx[tb + q] = s_tix[q];
+    }
+  }
+  if (lane == 0) {
+    if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
+    if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
+    if (n_spec) atomicAdd(&ctr[C_SW_SPEC], n_spec);
+    if (n_spec_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_spec_used);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_wnext: after the round's tasks are scored.  A read whose look-ahead reached the end of its walk under "nothing aligns" and whose results
+// are all "no alignment" ends exactly as the sequential walk ends it: those ssw_align calls, nothing recorded, pass control.  Every other
+// read that left tasks goes on the next round's list, with the place of its state, tasks and results.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_wnext(DParams P, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw, unsigned long long* __restrict__ ctr,
+                                                const uint2* __restrict__ list, const WState* __restrict__ ws, const uint2* __restrict__ res, uint2* __restrict__ list_next,
+                                                const unsigned long long* __restrict__ wc, unsigned long long* __restrict__ wc_next, uint32_t K) {
+  const uint32_t n = (uint32_t)wc[WC_NLIST];
+  unsigned long long n_fwd = 0, n_cells = 0, n_used = 0;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const uint32_t e = base + threadIdx.x;
+    bool live = false;
+    uint32_t r = 0;
+    if (e < n) {
+      const WState s = ws[e];
+      const uint32_t nk = WS_NK(s.bits);
+      if (nk > 0) {
+        live = true;
+        r = list[e].x;
+        if (s.bits & 32u) {
+          bool any = false;
+          for (uint32_t j = 0; j < nk; j++) { const uint32_t sc = res[(size_t)e * K + j].x; any |= (sc > 65535u ? 65535u : sc) > P.minimal_score; }
+          if (!any) {
+            RWork w = rw[r];
+            RState st = work[r];
+            if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; }
+            w.best = s.best_after;
+            n_fwd += nk; n_cells += s.cells; n_used += nk - 1;
+            chain_finish_read(P, is_last_strand, r, st, w, (int)((s.bits >> 4) & 1u), true, work, rw);
+            live = false;
+          }
+        }
+      }
+    }
+    const uint32_t o = block_append(&wc_next[WC_NLIST], live);
+    if (live) list_next[o] = make_uint2(r, e);
+  }
+  for (int d = 32; d > 0; d >>= 1) { n_fwd += __shfl_xor(n_fwd, d, 64); n_cells += __shfl_xor(n_cells, d, 64); n_used += __shfl_xor(n_used, d, 64); }
+  if (lane_id() == 0) {
+    if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
+    if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
+    if (n_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_used);
+  }
+}
+
+}  // namespace smr

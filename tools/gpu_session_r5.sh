@@ -1,0 +1,61 @@
+#!/bin/bash
+# Round-5 GPU sessions (run through gpurun from the repo root):
+#     /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_session_r5.sh <tag> <stage> ...'
+# Everything lands in gpurun_out/<tag>/ ; what should be judged is copied into profiles/ afterwards.
+TAG=${1:-r5x}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ROOT=$PWD
+for W in "$@"; do case $W in
+tests)
+  timeout 1800 python -m pytest tests -m gpu -x -q -rs --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -15 $OUT/pytest_gpu.log ;;
+paritytests)
+  timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -m gpu -x -q -rs > $OUT/pytest_parity.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_parity.log
+  tail -8 $OUT/pytest_parity.log ;;
+mb=*)
+  # mb=NAME:ENV=v,ENV=v+NAME2:...   several library configurations in one process (tools/hw_minibench_r5.py)
+  CFGS=$(echo "${W#mb=}" | tr '+' ' ')
+  timeout 600 python tools/hw_minibench_r5.py $CFGS > $OUT/minibench.log 2>&1; grep -E "==|per step|FAILED|walk rounds" $OUT/minibench.log | cut -c1-1200 ;;
+mb2m=*)
+  CFGS=$(echo "${W#mb2m=}" | tr '+' ' ')
+  MB_BATCH=2000000 timeout 600 python tools/hw_minibench_r5.py $CFGS > $OUT/minibench2m.log 2>&1; grep -E "==|per step|FAILED|walk rounds" $OUT/minibench2m.log | cut -c1-1200 ;;
+bench20)
+  ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_steps20_warmup5.json 2> $OUT/bench_steps20_warmup5.err; tail -c 3000 $OUT/bench_steps20_warmup5.json; tail -4 $OUT/bench_steps20_warmup5.err ;;
+prof)
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python $ROOT/bench.py --steps 3 --warmup 1 --profile-run > $ROOT/$OUT/bench_prof.json 2> $ROOT/$OUT/bench_prof.err )
+  find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+  head -24 $OUT/kernel_stats.csv | cut -c1-60,150-260
+  rm -rf $OUT/prof ;;
+pmc)
+  for CTR in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 500 rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$CTR -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_$CTR.json 2> $ROOT/$OUT/pmc_$CTR.err )
+  done
+  F=$(find $OUT/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); W2=$(find $OUT/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  python tools/pmc_traffic.py $F $W2 8000000 150 140000000 $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt 2>&1; cat $OUT/hbm_traffic.txt | head -40
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
+sq)
+  FILES=""
+  for SET in "VALUBusy SALUBusy LDSBankConflict" "MemUnitStalled VALUUtilization"; do N=$(echo $SET | cut -c1-8)
+    ( cd /tmp && timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > /dev/null 2> $ROOT/$OUT/pmc_sq_$N.err )
+    FILES="$FILES $(find $OUT/pmc_sq_$N -name "*counter_collection.csv" | head -1)"
+  done
+  ( cd tools && python pmc_sq.py $ROOT/$OUT/sq_counters.json 8000000 150 140000000 $(for F in $FILES; do echo $ROOT/$F; done) ) > $OUT/sq_counters.txt 2>&1; cat $OUT/sq_counters.txt
+  rm -rf $OUT/pmc_sq_* ;;
+sqi)
+  ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sqi -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_sqi.json 2> $ROOT/$OUT/pmc_sqi.err )
+  find $OUT/pmc_sqi -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmc_sqi.txt 2>&1; head -24 $OUT/pmc_sqi.txt
+  rm -rf $OUT/pmc_sqi ;;
+refs8)
+  ( time timeout 900 python bench.py --workload refs8 --steps 5 --warmup 1 --resident-batches 2 ) > $OUT/bench_refs8.json 2> $OUT/bench_refs8.err; tail -c 2500 $OUT/bench_refs8.json; tail -4 $OUT/bench_refs8.err ;;
+pacbio)
+  ( time timeout 1200 python bench.py --workload pacbio5k --steps 3 --warmup 1 --resident-batches 2 ) > $OUT/bench_pacbio5k.json 2> $OUT/bench_pacbio5k.err; tail -c 2500 $OUT/bench_pacbio5k.json; tail -6 $OUT/bench_pacbio5k.err ;;
+config2)
+  ( time timeout 900 python bench.py --workload config2 --steps 5 --warmup 1 ) > $OUT/bench_config2.json 2> $OUT/bench_config2.err; tail -c 2500 $OUT/bench_config2.json; tail -6 $OUT/bench_config2.err ;;
+dropin)
+  timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
+e2e)
+  timeout 280 python tools/e2e_quick.py > $OUT/e2e_quick.log 2>&1; tail -12 $OUT/e2e_quick.log | cut -c1-700 ;;
+esac; done
+ls $OUT
