@@ -19,6 +19,9 @@ __device__ __forceinline__ uint32_t pk_bits(pk16 v) { return __builtin_bit_cast(
 __device__ __forceinline__ pk16 pk_add(pk16 a, pk16 b) { return a + b; }
 __device__ __forceinline__ pk16 pk_sub(pk16 a, pk16 b) { return a - b; }
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+// v_pk_sub_u16 ... clamp: per half max(a - b, 0) for non-negative a, b (the halves taken as unsigned)
+typedef unsigned short pku16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk_subs_u(pk16 a, pk16 b) { return __builtin_bit_cast(pk16, __builtin_elementwise_sub_sat(__builtin_bit_cast(pku16, a), __builtin_bit_cast(pku16, b))); }
 __device__ __forceinline__ uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 // A value that is the same in every lane of the wave, said so to the compiler (v_readfirstlane_b32): it then lives in a scalar register, costs
 // no vector register across a call and is worked on by the scalar unit.  The kernel emulator's version checks that the lanes do agree.

@@ -120,9 +120,9 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
       uint32_t T = perm_b32(thi[j], tlo[j], selcur);                                                                        \
       if (HASN) T = (T & ~nmask) | (TN & nmask);                                                                            \
       const pk16 a = pk_add(diag, pk_from(T));                                                                              \
-      const pk16 e = pk_max(pk_sub(E[j], GE), Y[j]);                                                                        \
+      const pk16 e = pk_max(pk_subs_u(E[j], GE), Y[j]);   /* E is kept clamped at 0 (saturating subtract): e >= 0, so */    \
       const pk16 f = pk_max(pk_sub(uf, GE), uy);                                                                            \
-      const pk16 h = pk_max(pk_max(a, e), pk_max(f, ZERO));                                                                 \
+      const pk16 h = pk_max(pk_max(a, e), f);             /* h = max(a, e, f, 0) without the fourth operand */               \
       diag = Y[j];                                                                                                          \
       const pk16 y = pk_sub(h, GO);                                                                                         \
       Y[j] = y; E[j] = e;                                                                                                   \

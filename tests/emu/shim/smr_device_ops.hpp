@@ -14,6 +14,8 @@ inline pk16 pk_from(uint32_t v) { pk16 r; r.lo = (int16_t)(v & 0xFFFF); r.hi = (
 inline uint32_t pk_bits(pk16 v) { return (uint32_t)(uint16_t)v.lo | ((uint32_t)(uint16_t)v.hi << 16); }
 inline pk16 pk_add(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo + b.lo); r.hi = (int16_t)(a.hi + b.hi); return r; }      // v_pk_add_i16 (wraps)
 inline pk16 pk_sub(pk16 a, pk16 b) { pk16 r; r.lo = (int16_t)(a.lo - b.lo); r.hi = (int16_t)(a.hi - b.hi); return r; }
+inline pk16 pk_subs_u(pk16 a, pk16 b) { pk16 r; const uint16_t al = (uint16_t)a.lo, bl = (uint16_t)b.lo, ah = (uint16_t)a.hi, bh = (uint16_t)b.hi;      // v_pk_sub_u16 clamp
+  r.lo = (int16_t)(al > bl ? al - bl : 0); r.hi = (int16_t)(ah > bh ? ah - bh : 0); return r; }
 inline pk16 pk_max(pk16 a, pk16 b) { pk16 r; r.lo = a.lo > b.lo ? a.lo : b.lo; r.hi = a.hi > b.hi ? a.hi : b.hi; return r; }
 inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {          // v_perm_b32: bytes 0-3 = s1, 4-7 = s0, 8-11 = sign of a 16-bit half, 12 = 0x00, >= 13 = 0xFF
   const unsigned long long src = ((unsigned long long)s0 << 32) | s1;

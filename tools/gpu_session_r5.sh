@@ -21,6 +21,14 @@ mb=*)
 mb2m=*)
   CFGS=$(echo "${W#mb2m=}" | tr '+' ' ')
   MB_BATCH=2000000 timeout 600 python tools/hw_minibench_r5.py $CFGS > $OUT/minibench2m.log 2>&1; grep -E "==|per step|FAILED|walk rounds" $OUT/minibench2m.log | cut -c1-1200 ;;
+pmcmb)
+  # issue-side counters of every kernel on the mini bench (one 8 M-read step per pass): instruction counts, then wave cycles / waits
+  for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT"; do N=$(echo $SET | cut -d' ' -f2)
+    ( cd /tmp && MB_STEPS=1 timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$N -o pmc -- python $ROOT/tools/hw_minibench_r5.py base > $ROOT/$OUT/pmcmb_$N.log 2> $ROOT/$OUT/pmcmb_$N.err )
+    find $OUT/pmc_$N -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmcmb_$N.txt 2>&1
+    grep -E "k_walk|k_sw16|k_wnext|k_wlist|k_cand|k_chain|k_begins|k_seed" $OUT/pmcmb_$N.txt | cut -c1-420
+    rm -rf $OUT/pmc_$N
+  done ;;
 bench20)
   ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_steps20_warmup5.json 2> $OUT/bench_steps20_warmup5.err; tail -c 3000 $OUT/bench_steps20_warmup5.json; tail -4 $OUT/bench_steps20_warmup5.err ;;
 prof)
