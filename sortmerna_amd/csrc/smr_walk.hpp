@@ -30,12 +30,13 @@ enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_STRIDE = 48 };
 struct WTask {                        // one Smith-Waterman task: read span x reference window (alignment.cpp:271-357)
   uint32_t r, max_ref;
   uint64_t rf_start;                  // where the window starts in ix.ref_seq
+  uint32_t ars, head;                 // align_ref_start, head (what the walk needs besides the window when it resumes at this task)
   uint16_t aq, m, nref;               // align_que_start, read span, window length
   uint16_t flags;                     // bit 0: the read is walked on its reverse-complement strand
 };
-struct WState {                       // where the walk of a read stood BEFORE the advance that met the first task without a result
+struct WState {                       // the walk of a read standing AT the first task it had no result for (= task 0 of the tasks it left)
   uint32_t k, it, ms_lo, ms_hi, begin_ref, begin_read;
-  int32_t best, best_after;           // Walk::best at that point / after that advance (what the read ends with when nothing of the batch aligns)
+  int32_t best;                       // Walk::best there (also what the read ends with when nothing of its tasks aligns)
   uint32_t bits;                      // 0 is_aligned, 1 go_on, 2 started, 3 pending_pop, 4 search, 5 look-ahead ended under "nothing aligns", 6 last result aligned, 8..11 tasks left
   uint32_t cells;                     // DP cells of the tasks left
 };
@@ -217,13 +218,22 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
   SMR_DYN_LDS(unsigned char, lds_raw);                  // FINAL: read letters (lds_ml) | reference window (lds_rf)
   __shared__ unsigned long long l_pairs[64];            // (reference position << 32 | window position) of the sorted triples
   __shared__ uint2 l_cand[64];                          // candidates in walk order: {reference, count | first triple << 8}
+  __shared__ unsigned long long l_cref[64], l_clen[64]; // ... where their reference sequences start, and their lengths
+  __shared__ uint32_t l_hkey[128], l_hcnt[128];         // the hash table that groups the triples by reference
+  __shared__ unsigned long long l_stage[64];
   __shared__ WTask s_ctk[WK_MAX];                       // the tasks the read left in the previous round ...
   __shared__ uint2 s_cres[WK_MAX];                      // ... and their results
   __shared__ uint32_t s_tix[64 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx with one atomic per chunk)
   __shared__ uint32_t s_next, s_tbase;
   const int lane = lane_id();
   const uint32_t nlist = (uint32_t)wc[WC_NLIST];
-  unsigned long long n_fwd = 0, n_cells = 0, n_spec = 0, n_spec_used = 0;
+  unsigned long long n_fwd = 0, n_cells = 0, n_spec = 0, n_spec_used = 0, n_newhit = 0;
+#ifdef SMR_WALK_PHASES                                    // where a wave's cycles go (build with -DSMR_WALK_PHASES, run with SMR_DEBUG_PHASES=1): claim + loads, sort + candidates, advance, results + bookkeeping, look-ahead + tasks, write-back, task list
+  unsigned long long wph[7] = {0, 0, 0, 0, 0, 0, 0}, wlast = clock64();
+#define WPH(i) { const unsigned long long tn_ = clock64(); wph[i] += tn_ - wlast; wlast = tn_; }
+#else
+#define WPH(i)
+#endif
   const uint32_t claim = max(1u, min(64u, nlist / (gridDim.x * 4u)));
   for (;;) {
     __syncthreads();
@@ -233,93 +243,117 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
     if (chunk_base >= nlist) break;
     const uint32_t chunk_n = min(claim, nlist - chunk_base);
     uint32_t ntix = 0;
+    // the chunk's entries at once: lane i asks for entry chunk_base + i and its read's record and length (one round trip per chunk, not two per read)
+    uint32_t c_r = 0, c_prev = NONE, c_len = 0;
+    uint2 c_mr = make_uint2(NONE, 0u);
+    if ((uint32_t)lane < chunk_n) { const uint2 le = list[chunk_base + lane]; c_r = le.x; c_prev = le.y; c_mr = mrec[c_r]; c_len = rd.len[c_r]; }
     for (uint32_t ci = 0; ci < chunk_n; ci++) {
       const uint32_t e = chunk_base + ci;
-      const uint2 le = list[e];
-      const uint32_t r = le.x, prev = le.y;
+      const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)c_r, (int)ci), prev = (uint32_t)__builtin_amdgcn_readlane((int)c_prev, (int)ci);
+      const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)c_len, (int)ci);
+      const uint2 mr = make_uint2((uint32_t)__builtin_amdgcn_readlane((int)c_mr.x, (int)ci), (uint32_t)__builtin_amdgcn_readlane((int)c_mr.y, (int)ci));
       RWork w = rw[r];
       RState st = work[r];
-      const uint32_t len = rd.len[r];
-      const uint32_t* rec = rd.words + rd.rec_off[r];
-      const uint2 mr = mrec[r];
+      const uint32_t* rec = FINAL ? rd.words + rd.rec_off[r] : nullptr;
       WState ps; ps.bits = 0;
       if (prev != NONE) ps = ws_prev[prev];
       uint32_t live_bits = 0;                             // what ws_cur[e].bits becomes: 0 = the read is finished
       if (w.strand_active && w.search && w.pass_n == (uint32_t)pass && mr.x != NONE) {
-        // ---- the read's triples (reference, reference position, window position), sorted: equal references are runs, a run's pairs are in walk order ----
+        WPH(0)
+        // ---- candidate references (alignment.cpp:117-148) and their (reference position, window position) pairs in walk order ----
+        // The read's triples (reference, reference position, window position), one per lane.  Equal references are found by an exact hash table
+        // in LDS (128 slots for at most 64 triples); the triples of the references with enough seeds are moved to the low lanes and sorted by
+        // (slot, reference position, window position) as ONE 64-bit key per lane: a candidate's pairs are a run of lanes, already in the order
+        // the walk wants them, and a read with one spurious candidate of two seeds sorts two lanes, not 64.
         const uint32_t npos = mr.y;
         const uint32_t* rp = mpool + mr.x;
-        uint32_t seq = 0xFFFFFFFFu, pos = 0xFFFFFFFFu, win = 0xFFFFFFFFu;
-        if ((uint32_t)lane < npos) { seq = rp[lane]; pos = rp[npos + lane]; win = rp[2u * npos + lane]; }
-        uint32_t np2 = 2; while (np2 < npos) np2 <<= 1;
-        for (uint32_t kk = 2; kk <= np2; kk <<= 1)
-          for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-            const uint32_t oseq = (uint32_t)__shfl_xor((int)seq, (int)j, 64), opos = (uint32_t)__shfl_xor((int)pos, (int)j, 64), owin = (uint32_t)__shfl_xor((int)win, (int)j, 64);
-            const bool oless = oseq < seq || (oseq == seq && (opos < pos || (opos == pos && owin < win)));
-            const bool mless = seq < oseq || (seq == oseq && (pos < opos || (pos == opos && win < owin)));
-            const bool want_min = (((uint32_t)lane & j) == 0) == (((uint32_t)lane & kk) == 0);
-            if (want_min ? oless : mless) { seq = oseq; pos = opos; win = owin; }
-          }
-        const uint32_t pseq = (uint32_t)__shfl_up((int)seq, 1, 64);
         const bool valid = (uint32_t)lane < npos;
-        const bool head = valid && (lane == 0 || seq != pseq);
+        uint32_t seq = 0, pos = 0, win = 0;
+        if (valid) { seq = rp[lane]; pos = rp[npos + lane]; win = rp[2u * npos + lane]; }
+        __syncthreads();
+        l_hkey[lane] = 0xFFFFFFFFu; l_hkey[lane + 64] = 0xFFFFFFFFu; l_hcnt[lane] = 0; l_hcnt[lane + 64] = 0;
+        __syncthreads();
+        uint32_t slot = 0;
+        if (valid) {
+          slot = (seq * 0x9E3779B1u) >> 25;
+          for (;;) { const uint32_t o = atomicCAS(&l_hkey[slot], 0xFFFFFFFFu, seq); if (o == 0xFFFFFFFFu || o == seq) break; slot = (slot + 1u) & 127u; }
+          atomicAdd(&l_hcnt[slot], 1u);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const bool member = valid && (int)l_hcnt[slot] >= P.num_seeds;
+        const unsigned long long mm = __ballot(member);
+        const uint32_t total = (uint32_t)__popcll(mm);
+        if (member) l_stage[__popcll(mm & ((1ull << lane) - 1ull))] = ((unsigned long long)slot << 48) | ((unsigned long long)pos << 16) | (unsigned long long)(win & 0xFFFFu);
+        __syncthreads();
+        unsigned long long key = (uint32_t)lane < total ? l_stage[lane] : ~0ull;
+        if (total > 1) {
+          uint32_t np2 = 2; while (np2 < total) np2 <<= 1;
+          for (uint32_t kk = 2; kk <= np2; kk <<= 1)
+            for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+              const unsigned long long o = __shfl_xor(key, (int)j, 64);
+              const bool want_min = (((uint32_t)lane & j) == 0) == (((uint32_t)lane & kk) == 0);
+              if (want_min ? o < key : key < o) key = o;
+            }
+        }
+        const bool inrun = (uint32_t)lane < total;
+        const uint32_t sl = (uint32_t)(key >> 48) & 127u;
+        const uint32_t psl = (uint32_t)__shfl_up((int)sl, 1, 64);
+        const bool head = inrun && (lane == 0 || sl != psl);
         const unsigned long long heads = __ballot(head);
-        const unsigned long long below = heads & ((2ull << lane) - 1ull);
-        const uint32_t start = below ? 63u - (uint32_t)__clzll((long long)below) : 0u;
         const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
-        const uint32_t endp = above ? (uint32_t)lane + (uint32_t)__ffsll((long long)above) : npos;
-        const uint32_t count = endp - start;
-        const bool cand = head && (int)count >= P.num_seeds;
-        const unsigned long long candmask = __ballot(cand);
-        const uint32_t ncand = (uint32_t)__popcll(candmask);
+        const uint32_t endp = above ? (uint32_t)lane + (uint32_t)__ffsll((long long)above) : total;
+        const uint32_t count = endp - (uint32_t)lane;                       // (of a head lane: the length of its run)
+        const uint32_t ncand = (uint32_t)__popcll(heads);
+        const uint32_t hseq = head ? l_hkey[sl] : 0u;
         // walk order: count descending, reference ascending (alignment.cpp:134-148)
-        const unsigned long long mykey = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | seq;
+        const unsigned long long mykey = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | hseq;
         uint32_t rank = 0;
-        for (unsigned long long mq = candmask; mq; mq &= mq - 1) {
+        for (unsigned long long mq = heads; mq; mq &= mq - 1) {
           const int c = __ffsll((long long)mq) - 1;
-          const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)seq, c), kc = (uint32_t)__builtin_amdgcn_readlane((int)count, c);
+          const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)hseq, c), kc = (uint32_t)__builtin_amdgcn_readlane((int)count, c);
           const unsigned long long key_c = ((unsigned long long)(0xFFFFFFFFu - kc) << 32) | ks;
           rank += key_c < mykey ? 1u : 0u;
         }
-        __syncthreads();
-        if (valid) l_pairs[lane] = ((unsigned long long)pos << 32) | (win & 0xFFFFu);
-        if (cand) l_cand[rank] = make_uint2(seq, count | ((uint32_t)lane << 8));
+        if (inrun) l_pairs[lane] = ((key >> 16) << 32) | (key & 0xFFFFull);
+        if (head) {
+          // (where the candidate's reference sequence lies: asked for by all candidates at once, not one round trip per candidate as the walk reaches it)
+          const uint64_t r0_ = ix.ref_off[hseq], r1_ = ix.ref_off[hseq + 1];
+          l_cand[rank] = make_uint2(hseq, count | ((uint32_t)lane << 8));
+          l_cref[rank] = r0_; l_clen[rank] = r1_ - r0_;
+        }
         // the tasks of the previous round and their results
         const uint32_t n_prev = prev != NONE ? WS_NK(ps.bits) : 0u;
         if ((uint32_t)lane < n_prev) { s_ctk[lane] = tk_prev[(size_t)prev * K + lane]; s_cres[lane] = res_prev[(size_t)prev * K + lane]; }
         __syncthreads();
+        WPH(1)
 
-        struct Walk {
-          uint32_t k, np, it, ms_lo, ms_hi, begin_ref, begin_read, start, max_ref;
-          uint64_t ref0, reflen;
-          int is_aligned, best, go_on, started, pending_pop;
-        };
+        // ONE walk state per read: the real walk consumes results until it meets a task without one; from there the same state runs on as
+        // the look-ahead (the read is suspended: what it resumes from is written first).  What a candidate's run of pairs, its reference and
+        // that reference's place are is read from LDS where it is needed, not carried along.
+        struct Walk { uint32_t k, it, ms_lo, ms_hi, begin_ref, begin_read; int is_aligned, best, go_on, started, pending_pop; };
         const uint64_t rlen = len;
-        // candidate wk.k: termination rules (:156-169), its pairs = a run of l_pairs.  geometry_only: the walk is resumed inside this candidate
-        auto load_candidate = [&](Walk& wk, bool geometry_only) -> int {
+        // candidate wk.k: termination rules (:156-169).  1 = loaded, 0 = the candidate loop ends here
+        auto load_candidate = [&](Walk& wk) -> int {
           if (wk.k >= ncand || !wk.go_on) return 0;
-          const uint2 ce = l_cand[wk.k];
-          const uint32_t max_ref = ce.x, max_occur = ce.y & 0xFFu;
+          const uint32_t cy = l_cand[wk.k].y;
+          const uint32_t max_occur = cy & 0xFFu;
           if (max_occur < (uint32_t)P.num_seeds) return 0;
-          const uint64_t r0_ = ix.ref_off[max_ref], r1_ = ix.ref_off[max_ref + 1];
-          if (!geometry_only && wk.is_aligned && P.min_lis > 0 && wk.k > 0 && max_occur < (l_cand[wk.k - 1].y & 0xFFu)) {   // :165-169
+          if (wk.is_aligned && P.min_lis > 0 && wk.k > 0 && max_occur < (l_cand[wk.k - 1].y & 0xFFu)) {   // :165-169
             --wk.best;
             if (wk.best < 1) return 0;
           }
-          wk.np = max_occur; wk.start = ce.y >> 8; wk.max_ref = max_ref;
-          wk.ref0 = r0_; wk.reflen = r1_ - r0_;
-          if (!geometry_only) {
-            const unsigned long long p0 = l_pairs[wk.start];
-            wk.it = 0; wk.ms_lo = 0; wk.ms_hi = 0;
-            wk.begin_ref = (uint32_t)(p0 >> 32); wk.begin_read = (uint32_t)p0;
-            wk.pending_pop = 0;
-          }
+          const unsigned long long p0 = l_pairs[cy >> 8];
+          wk.it = 0; wk.ms_lo = 0; wk.ms_hi = 0;
+          wk.begin_ref = (uint32_t)(p0 >> 32); wk.begin_read = (uint32_t)p0;
+          wk.pending_pop = 0;
           return 1;
         };
         // the sliding window of read length along candidate wk.k (:203-506), up to its next window that calls for ssw_align
         auto next_task = [&](Walk& wk, SwTask& tk) -> bool {
-          const unsigned long long* pairs = l_pairs + wk.start;
-          const uint32_t np = wk.np;
+          const uint2 ce = l_cand[wk.k];
+          const unsigned long long* pairs = l_pairs + (ce.y >> 8);
+          const uint32_t np = ce.y & 0xFFu;
           while (wk.it != np && wk.go_on) {
             if (!wk.pending_pop) {
               wk.pending_pop = 1;
@@ -340,9 +374,9 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
                 const uint32_t nw = wk.ms_hi - wk.ms_lo;
                 const uint32_t nl = wave_lis_first(pairs + wk.ms_lo, nw, lis0);
                 if (nl >= (uint32_t)P.min_lis) {
-                  const uint32_t lcs_ref_start = (uint32_t)(pairs[wk.ms_lo + lis0] >> 32);
-                  const uint32_t lcs_que_start = (uint32_t)pairs[wk.ms_lo + lis0];
-                  const uint64_t reflen = wk.reflen;
+                  const unsigned long long pl = pairs[wk.ms_lo + lis0];
+                  const uint32_t lcs_ref_start = (uint32_t)(pl >> 32), lcs_que_start = (uint32_t)pl;
+                  const uint64_t reflen = l_clen[wk.k];
                   uint64_t hd = 0, tail = 0, align_ref_start = 0, align_que_start = 0, align_length = 0;
                   uint32_t edges;
                   if (P.is_as_percent) edges = (uint32_t)((P.edges / 100.0) * (double)rlen);
@@ -368,9 +402,9 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
                       align_length = rlen + hd + tail;
                     }
                   }
-                  tk.max_ref = wk.max_ref; tk.align_ref_start = align_ref_start; tk.head = hd; tk.align_que_start = align_que_start;
+                  tk.max_ref = ce.x; tk.align_ref_start = align_ref_start; tk.head = hd; tk.align_que_start = align_que_start;
                   tk.m = (int)(align_length - hd - tail); tk.nref = (int)align_length;
-                  tk.rf_start = wk.ref0 + align_ref_start - hd;
+                  tk.rf_start = l_cref[wk.k] + align_ref_start - hd;
                   return true;
                 }
               }
@@ -379,9 +413,9 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
             wk.pending_pop = 0;
             if (wk.ms_hi > wk.ms_lo) wk.ms_lo++;
             if (wk.ms_hi == wk.ms_lo) {
-              if (wk.it != np) { wk.begin_ref = (uint32_t)(pairs[wk.it] >> 32); wk.begin_read = (uint32_t)pairs[wk.it]; }
+              if (wk.it != np) { const unsigned long long pn = pairs[wk.it]; wk.begin_ref = (uint32_t)(pn >> 32); wk.begin_read = (uint32_t)pn; }
               else break;
-            } else { wk.begin_ref = (uint32_t)(pairs[wk.ms_lo] >> 32); wk.begin_read = (uint32_t)pairs[wk.ms_lo]; }
+            } else { const unsigned long long pn = pairs[wk.ms_lo]; wk.begin_ref = (uint32_t)(pn >> 32); wk.begin_read = (uint32_t)pn; }
           }
           return false;
         };
@@ -389,7 +423,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
         auto advance = [&](Walk& wk, SwTask& tk) -> int {
           for (;;) {
             if (!wk.started) {
-              if (load_candidate(wk, false) != 1) return 0;
+              if (load_candidate(wk) != 1) return 0;
               wk.started = 1;
             }
             if (next_task(wk, tk)) return 1;
@@ -398,7 +432,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
         };
         auto put_task = [&](uint32_t j, const SwTask& t) {
           if (lane == 0) {
-            WTask o; o.r = r; o.max_ref = t.max_ref; o.rf_start = t.rf_start; o.aq = (uint16_t)t.align_que_start;
+            WTask o; o.r = r; o.max_ref = t.max_ref; o.rf_start = t.rf_start; o.ars = (uint32_t)t.align_ref_start; o.head = (uint32_t)t.head; o.aq = (uint16_t)t.align_que_start;
             o.m = (uint16_t)t.m; o.nref = (uint16_t)t.nref; o.flags = w.reversed ? 1 : 0;
             tk_cur[(size_t)e * K + j] = o;
           }
@@ -407,61 +441,65 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
 
         Walk R;
         int search = 1, last_aligned = 0;
+        SwTask tk;
+        bool have_tk = false;                               // a resumed read stands at the first task it left: no advance, the task is in the cache
         if (prev == NONE) {
-          R.k = 0; R.np = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0; R.start = 0; R.max_ref = 0;
-          R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0; R.ref0 = 0; R.reflen = 0;
+          R.k = 0; R.it = 0; R.ms_lo = 0; R.ms_hi = 0; R.begin_ref = 0; R.begin_read = 0;
+          R.is_aligned = 0; R.best = w.best; R.go_on = 1; R.started = 0; R.pending_pop = 0;
         } else {
           R.k = ps.k; R.it = ps.it; R.ms_lo = ps.ms_lo; R.ms_hi = ps.ms_hi; R.begin_ref = ps.begin_ref; R.begin_read = ps.begin_read; R.best = ps.best;
           R.is_aligned = (int)(ps.bits & 1u); R.go_on = (int)((ps.bits >> 1) & 1u); R.started = (int)((ps.bits >> 2) & 1u); R.pending_pop = (int)((ps.bits >> 3) & 1u);
           search = (int)((ps.bits >> 4) & 1u); last_aligned = (int)((ps.bits >> 6) & 1u);
-          R.np = 0; R.start = 0; R.max_ref = 0; R.ref0 = 0; R.reflen = 0;
-          if (R.started) load_candidate(R, true);
+          const WTask c0 = s_ctk[0];
+          tk.max_ref = c0.max_ref; tk.rf_start = c0.rf_start; tk.align_ref_start = c0.ars; tk.head = c0.head; tk.align_que_start = c0.aq; tk.m = c0.m; tk.nref = c0.nref;
+          have_tk = true;
         }
         // what the look-ahead assumes of the tasks it runs past: in round 0 "aligns" for a read whose best candidate has many seeds (a read sampled
         // from the DB meets a family of references, one accepted alignment each), "does not" otherwise (a spurious candidate of a background read);
         // later what the read's last result was.  Only which windows get scored ahead depends on it, never a result.
-        const int assume = prev == NONE ? ((ncand > 0 && (l_cand[0].y & 0xFFu) >= assume_min) ? 1 : 0) : last_aligned;
         const uint32_t max_SW_score = len * (uint32_t)P.match;
-        bool cap_err = false, live = false, rdq_staged = false;
+        bool live = false, rdq_staged = false, dirty = false;      // dirty: st / w changed by an accepted alignment (flip34 alone is redone where it matters)
         for (;;) {
-          const Walk S = R;
-          SwTask tk;
-          if (advance(R, tk) != 1) break;
+          WPH(3)
+          if (!have_tk) { if (advance(R, tk) != 1) break; }
+          WPH(2)
           if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; }           // read.flip34() to the 0..4 alphabet before SSW (:360-361)
           const int m = tk.m, nref = tk.nref;
           const bool sw_ok = task_ok(tk);
-          if (!sw_ok && (m > 0 && nref > 0)) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); cap_err = true; }
+          if (!sw_ok && (m > 0 && nref > 0)) { if (lane == 0) atomicAdd(&ctr[C_ERR_PAIRS], 1ull); }
           SwRes fw; fw.score = 0; fw.end_ref = -1; fw.end_read = m - 1;
           if (sw_ok) {
             int ce = -1;
-            for (uint32_t q = 0; q < n_prev; q++)
+            if (have_tk) ce = 0;
+            else for (uint32_t q = 0; q < n_prev; q++)
               if (s_ctk[q].max_ref == tk.max_ref && s_ctk[q].rf_start == tk.rf_start && (uint32_t)s_ctk[q].aq == (uint32_t)tk.align_que_start && (int)s_ctk[q].m == m && (int)s_ctk[q].nref == nref) { ce = (int)q; break; }
             if (ce >= 0) { fw = wres_unpack(s_cres[ce]); if (ce > 0) n_spec_used++; }
             else if (!FINAL) {
-              // the walk needs a result it does not have: leave this task and the ones the walk reaches next under the prediction, and stop here
+              // the walk needs a result it does not have: this task and the ones the walk reaches next under the prediction become the read's
+              // tasks of this round; the state the read resumes from (standing at this task) is written first, then the same walk runs on as the look-ahead
+              const int assume = prev == NONE ? ((ncand > 0 && (l_cand[0].y & 0xFFu) >= assume_min) ? 1 : 0) : last_aligned;
+              WState o; o.k = R.k; o.it = R.it; o.ms_lo = R.ms_lo; o.ms_hi = R.ms_hi; o.begin_ref = R.begin_ref; o.begin_read = R.begin_read; o.best = R.best;
+              const uint32_t bits0 = (uint32_t)(R.is_aligned & 1) | ((uint32_t)(R.go_on & 1) << 1) | ((uint32_t)(R.started & 1) << 2) | ((uint32_t)(R.pending_pop & 1) << 3) | ((uint32_t)(search & 1) << 4) |
+                                     ((uint32_t)(last_aligned & 1) << 6);
               uint32_t nk = 1, cells = (uint32_t)m * (uint32_t)nref;
               put_task(0, tk);
-              Walk L = R; L.is_aligned = assume;
+              R.is_aligned = assume;
               bool ended = false;
               while (nk < K) {
                 SwTask t2;
-                if (advance(L, t2) != 1) { ended = true; break; }
+                if (advance(R, t2) != 1) { ended = true; break; }
                 if (!task_ok(t2)) break;
                 put_task(nk, t2); nk++; cells += (uint32_t)t2.m * (uint32_t)t2.nref;
-                L.is_aligned = assume;
+                R.is_aligned = assume;
               }
               n_spec += nk - 1;
-              if (lane == 0) {
-                WState o; o.k = S.k; o.it = S.it; o.ms_lo = S.ms_lo; o.ms_hi = S.ms_hi; o.begin_ref = S.begin_ref; o.begin_read = S.begin_read; o.best = S.best; o.best_after = R.best;
-                o.bits = (uint32_t)(S.is_aligned & 1) | ((uint32_t)(S.go_on & 1) << 1) | ((uint32_t)(S.started & 1) << 2) | ((uint32_t)(S.pending_pop & 1) << 3) | ((uint32_t)(search & 1) << 4) |
-                         ((ended && !assume) ? 32u : 0u) | ((uint32_t)(last_aligned & 1) << 6) | (nk << 8);
-                o.cells = cells;
-                ws_cur[e] = o;
-              }
+              o.bits = bits0 | ((ended && !assume) ? 32u : 0u) | (nk << 8); o.cells = cells;
+              if (lane == 0) ws_cur[e] = o;
               live_bits = nk << 8;
               for (uint32_t q = lane; q < nk; q += 64) s_tix[ntix + q] = e * K + q;
               ntix += nk;
               live = true;
+              WPH(4)
               break;
             } else {
               // last round: score it here, one problem per wave
@@ -475,28 +513,27 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
             }
             n_fwd++; n_cells += (unsigned long long)m * nref;
           }
-          const uint64_t align_ref_start = tk.align_ref_start, hd = tk.head, align_que_start = tk.align_que_start;
-          const uint32_t max_ref = tk.max_ref;
+          have_tk = false;
           const int score1 = fw.score > 65535 ? 65535 : fw.score;
-          const int ref_end1 = fw.end_ref, read_end1 = fw.end_read;
           // (the begin cell is k_begins' business, as with k_chain: window start in ref_begin1 / read_begin1, has_cigar = 2)
           R.is_aligned = (sw_ok && (uint32_t)score1 > P.minimal_score);     // strict (:388)
           last_aligned = R.is_aligned;
           if (R.is_aligned) {
+            dirty = true;
             if ((uint32_t)score1 == max_SW_score) ++st.max_SW_count;
             AlignRec al;
-            al.ref_begin1 = (int32_t)(align_ref_start - hd);
-            al.ref_end1 = ref_end1 + (int32_t)(align_ref_start - hd);
-            al.read_begin1 = (int32_t)align_que_start;
-            al.read_end1 = read_end1 + (int32_t)align_que_start;
-            al.readlen = len; al.ref_num = max_ref;
+            al.ref_begin1 = (int32_t)(tk.align_ref_start - tk.head);
+            al.ref_end1 = fw.end_ref + (int32_t)(tk.align_ref_start - tk.head);
+            al.read_begin1 = (int32_t)tk.align_que_start;
+            al.read_end1 = fw.end_read + (int32_t)tk.align_que_start;
+            al.readlen = len; al.ref_num = tk.max_ref;
             al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
             al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
             al.has_cigar = 2; al.cigar_off = 0; al.cigar_len = 0;
             AlignRec* slots = work_aln + (size_t)r * P.slots;
             if (!st.is_hit) {                                              // :411-416
               st.is_hit = 1;
-              if (lane == 0) { atomicAdd(&ctr[C_NUM_ALIGNED], 1ull); atomicAdd(&ctr[C_PER_DB + P.index_num], 1ull); }
+              n_newhit++;                                                  // (counted per wave and added once: 400 000 reads become hits in one launch, and atomics on one line retire at 83 per microsecond)
             }
             if (P.num_alignments == 0 || !P.is_best || (P.is_best && st.n_align < P.num_alignments)) {
               if (st.n_align < P.slots) { if (lane == 0) slots[st.n_align] = al; st.n_align++; w.is_new_hit = 1; }
@@ -532,9 +569,9 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
             search = 0;
           }
         }
-        (void)cap_err;
-        if (live) { if (lane == 0) { work[r] = st; rw[r] = w; } }
+        if (live) { if (dirty && lane == 0) { work[r] = st; rw[r] = w; } }
         else { w.best = R.best; chain_finish_read(P, is_last_strand, r, st, w, search, lane == 0, work, rw); }
+        WPH(5)
       }
       if (!live_bits && lane == 0) ws_cur[e].bits = 0;
     }
@@ -546,13 +583,19 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
       const uint32_t tb = s_tbase;
       for (uint32_t q = lane; q < ntix; q += 64) tidx[tb + q] = s_tix[q];
     }
+    WPH(6)
   }
   if (lane == 0) {
     if (n_fwd) ctr_add(ctr, C_SW_FWD, n_fwd);
     if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
     if (n_spec) atomicAdd(&ctr[C_SW_SPEC], n_spec);
     if (n_spec_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_spec_used);
+    if (n_newhit) { atomicAdd(&ctr[C_NUM_ALIGNED], n_newhit); atomicAdd(&ctr[C_PER_DB + P.index_num], n_newhit); }
+#ifdef SMR_WALK_PHASES
+    for (int q = 0; q < 7; q++) if (wph[q]) atomicAdd(&ctr[C_SHARDS + (blockIdx.x & (C_NSHARD - 1)) * C_SHARD_W + C_SHARD_PH + q], wph[q]);
+#endif
   }
+#undef WPH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -582,7 +625,7 @@ __global__ void __launch_bounds__(1024) k_wnext(DParams P, int is_last_strand, R
             RWork w = rw[r];
             RState st = work[r];
             if (w.has_amb && !w.is04) { w.is04 = 1; w.aval = 4; }
-            w.best = s.best_after;
+            w.best = s.best;
             n_fwd += nk; n_cells += s.cells; n_used += nk - 1;
             chain_finish_read(P, is_last_strand, r, st, w, (int)((s.bits >> 4) & 1u), true, work, rw);
             live = false;

@@ -27,8 +27,15 @@ pmcmb)
     ( cd /tmp && MB_STEPS=1 timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$N -o pmc -- python $ROOT/tools/hw_minibench_r5.py base > $ROOT/$OUT/pmcmb_$N.log 2> $ROOT/$OUT/pmcmb_$N.err )
     find $OUT/pmc_$N -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmcmb_$N.txt 2>&1
     grep -E "k_walk|k_sw16|k_wnext|k_wlist|k_cand|k_chain|k_begins|k_seed" $OUT/pmcmb_$N.txt | cut -c1-420
+    find $OUT/pmc_$N -name "*counter_collection.csv" -exec python tools/pmc_dispatches.py {} k_walk \; > $OUT/pmcmb_${N}_k_walk_dispatches.txt 2>&1
     rm -rf $OUT/pmc_$N
   done ;;
+alt=*)
+  # alt=LIB[:ENV=v,...]  the mini bench on an alternative build sortmerna_amd/lib/LIB.so (made in the container), e.g. the -DSMR_WALK_PHASES one
+  A=${W#alt=}; LIBN=${A%%:*}; ENVS=""; [ "$A" != "$LIBN" ] && ENVS=${A#*:}
+  cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp sortmerna_amd/lib/$LIBN.so sortmerna_amd/lib/libsmr_hip.so
+  SMR_DEBUG_PHASES=1 MB_STEPS=2 timeout 400 python tools/hw_minibench_r5.py $LIBN:$ENVS > $OUT/minibench_$LIBN.log 2>&1; grep -E "==|per step|FAILED|phase cycles" $OUT/minibench_$LIBN.log | cut -c1-700 | tail -8
+  cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so ;;
 bench20)
   ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench_steps20_warmup5.json 2> $OUT/bench_steps20_warmup5.err; tail -c 3000 $OUT/bench_steps20_warmup5.json; tail -4 $OUT/bench_steps20_warmup5.err ;;
 prof)
