@@ -1166,7 +1166,7 @@ __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __res
   bool take = false;
   if (i < n * slots) {
     const uint32_t r = i / slots, k = i % slots;
-    take = rw[r].is_new_hit && k < work[r].n_align && work_aln[i].has_cigar == 2;
+    take = rw[r].is_new_hit && k < work[r].n_align && work_aln[i].has_cigar >= 2;
   }
   const uint32_t o = block_append(&ctr[C_BEGIN_N], take);
   if (take) tasks[o] = i;
@@ -1219,6 +1219,27 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
     bool hasn = false;
     __syncthreads();
     if (have && x4) { const int l0 = lane & 15; for (int q = l0; q < n; q += 16) hasn |= rfq[q] == 4; }
+    // has_cigar = 3 (smr_walk.hpp: an alignment of which only the score was asked): what is stored are the ENDS OF ITS WINDOW; the forward pass over
+    // the window finds the end cell (first column reaching the maximum, smallest row: ssw.c:305-336), then the reverse pass as for the others
+    const bool fwd = have && al.has_cigar == 3;
+    if (__any(fwd)) {
+      SwRes fw;
+      if (x4) {
+        int mf = fwd ? m : 0;
+        int mm = mf;
+        for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
+        fw = sw_wave_x4(rdq, mf, 0, 1, rfq, fwd ? n : 0, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
+      } else {
+        if (LONG) fw = sw_wave_any(rdq, m, 0, 1, rfq, n, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+        else fw = sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+      }
+      if (fwd) {
+        if ((fw.score > 65535 ? 65535 : fw.score) != (int)al.score1 && (x4 ? (lane & 15) == 0 : lane == 0)) atomicAdd(&ctr[C_ERR_TRACE], 1ull);     // (cannot happen: same cells, same recurrence)
+        al.ref_end1 = al.ref_begin1 + fw.end_ref; al.read_end1 = al.read_begin1 + fw.end_read;
+        m = fw.end_read + 1; n = fw.end_ref + 1;
+      }
+      __syncthreads();
+    }
     SwRes bw;
     if (x4) {
       int mm = m;

@@ -416,7 +416,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
         if ((rc = dev_alloc(c, &c->d_wlist[q], n)) || (rc = dev_alloc(c, &c->d_wstate[q], n)) || (rc = dev_alloc(c, &c->d_wtask[q], n * WK)) || (rc = dev_alloc(c, &c->d_wres[q], n * WK))) return rc;
       }
       int rc;
-      if ((rc = dev_alloc(c, &c->d_wtidx, n * WK)) || (rc = dev_alloc(c, &c->d_wslow, n))) return rc;
+      if ((rc = dev_alloc(c, &c->d_wtidx, 2 * n * WK)) || (rc = dev_alloc(c, &c->d_wslow, n))) return rc;
       c->walk_cap = n; c->walk_kcap = WK;
     }
     if (c->walk_rcap < RM) { int rc = dev_alloc(c, &c->d_wctr, (size_t)(RM + 2) * WC_STRIDE); if (rc) return rc; c->walk_rcap = RM; }
@@ -424,6 +424,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
     const size_t lds_w = (size_t)wml + rq;
     if (lds_w > 64 * 1024 && lds_w > c->walk_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); c->walk_lds_attr = lds_w; }
   }
+  const size_t n_tix = (size_t)c->walk_cap * c->walk_kcap;     // the second half of d_wtidx: the score-only tasks
   unsigned long long* const n_slow = split ? c->d_wctr + (size_t)(RM + 1) * WC_STRIDE : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
@@ -441,12 +442,12 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       const bool fin = rnd + 1 == RM;
       ev_mark(c, KP_WALK);
 #define WALK_ARGS dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr, (const uint2*)mrec, (const uint32_t*)c->d_mpool, (const uint2*)c->d_wlist[cur], \
-                  (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, wc, WK, wml, rq, c->walk_assume
+                  (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, c->d_wtidx + n_tix, wc, WK, wml, rq, c->walk_assume
       if (fin) hipLaunchKernelGGL(k_walk<true>, dim3(walk_blocks * 3u / SMR_WALK_WAVES_PER_SIMD), dim3(64), (size_t)wml + rq, c->stream, WALK_ARGS);
       else {
         hipLaunchKernelGGL(k_walk<false>, dim3(walk_blocks), dim3(64), 0, c->stream, WALK_ARGS);
         ev_mark(c, KP_SW16);
-#define SW16_ARGS dreads(c), dindex(di), P, (const WTask*)c->d_wtask[cur], (const uint32_t*)c->d_wtidx, (const unsigned long long*)wc, c->d_wres[cur]
+#define SW16_ARGS dreads(c), dindex(di), P, (const WTask*)c->d_wtask[cur], (const uint32_t*)c->d_wtidx, (const uint32_t*)(c->d_wtidx + n_tix), (const unsigned long long*)wc, c->d_wres[cur]
         if (swr == 13) hipLaunchKernelGGL(k_sw16<13>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
         else if (swr == 19) hipLaunchKernelGGL(k_sw16<19>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
         else hipLaunchKernelGGL(k_sw16<32>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
@@ -462,7 +463,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       HIPCHK(c, hipMemcpyAsync(h.data(), c->d_wctr, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
       fprintf(stderr, "libsmr_hip: walk rounds (pass %d): slow %llu;", pass, h[(size_t)(RM + 1) * WC_STRIDE]);
-      for (uint32_t rnd = 0; rnd < RM; rnd++) fprintf(stderr, " %llu/%llu", h[(size_t)rnd * WC_STRIDE + WC_NLIST], h[(size_t)rnd * WC_STRIDE + WC_NTASK]);
+      for (uint32_t rnd = 0; rnd < RM; rnd++) fprintf(stderr, " %llu/%llu+%llu", h[(size_t)rnd * WC_STRIDE + WC_NLIST], h[(size_t)rnd * WC_STRIDE + WC_NTASK], h[(size_t)rnd * WC_STRIDE + WC_NTASK2]);
       fprintf(stderr, "\n");
     }
   }

@@ -25,7 +25,7 @@ namespace smr {
 #define WK_MAX 8u                     // most tasks a read leaves per round
 #define WK_MAX_ROWS 256u              // longest read span k_sw16 takes (8 virtual lanes x 32 rows)
 // per-round counters (u64 words): every hot one on a 128-byte line of its own
-enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_STRIDE = 48 };
+enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_NTASK2 = 48, WC_STRIDE = 64 };
 
 struct WTask {                        // one Smith-Waterman task: read span x reference window (alignment.cpp:271-357)
   uint32_t r, max_ref;
@@ -71,7 +71,10 @@ __device__ __forceinline__ unsigned long long quad_max_u64(unsigned long long v)
   return v;
 }
 
-template <int R, bool HASN>
+// KEYS = false: the score only (no running-maximum key per row: ten instead of thirteen instructions per cell pair, R registers less) -- for
+// the tasks of reads that are not expected to align (their result is "score <= minimal_score", nothing else is asked of it; when one aligns
+// after all, its end cell is found by k_begins)
+template <int R, bool HASN, bool KEYS>
 __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uint32_t len, uint32_t reversed, int m, int aq, const uint8_t* __restrict__ ref, int n,
                                            int match, int mismatch, int scoreN, int go, int ge) {
   const int gl = lane_id() & 3;
@@ -79,7 +82,8 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
   const uint32_t TN = (((uint32_t)(scoreN + go)) & 0xFFFFu) * 0x00010001u;
   uint32_t tlo[R], thi[R];
   pk16 Y[R], E[R];
-  uint32_t key[R];
+  uint32_t key[KEYS ? R : 1];
+  pk16 hmax = ZERO;
   const uint32_t t_mm = ((uint32_t)(mismatch + go) & 0xFFu) * 0x01010101u, t_x = ((uint32_t)(mismatch + go) ^ (uint32_t)(match + go)) & 0xFFu,
                  t_n = ((uint32_t)(scoreN + go) & 0xFFu) * 0x01010101u;
 #pragma unroll
@@ -96,7 +100,7 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
       t2[hf] = t;
     }
     tlo[j] = t2[0]; thi[j] = t2[1];
-    Y[j] = pk_splat(-go); E[j] = ZERO; key[j] = 0;
+    Y[j] = pk_splat(-go); E[j] = ZERO; if (KEYS) key[j] = 0;
   }
   int steps = m > 0 ? n + (m + R - 1) / R - 1 : 0;
   for (int d = 32; d > 0; d >>= 1) steps = max(steps, __shfl_xor(steps, d, 64));
@@ -127,8 +131,8 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
       diag = Y[j];                                                                                                          \
       const pk16 y = pk_sub(h, GO);                                                                                         \
       Y[j] = y; E[j] = e;                                                                                                   \
-      const uint32_t hu = pk_bits(h);                                                                                       \
-      key[j] = max(key[j], max((hu << 16) | xlo, (hu & 0xFFFF0000u) | xhi));                                                \
+      if (KEYS) { const uint32_t hu = pk_bits(h); key[j] = max(key[j], max((hu << 16) | xlo, (hu & 0xFFFF0000u) | xhi)); }  \
+      else hmax = pk_max(hmax, h);                                                                                          \
       uy = y; uf = f;                                                                                                       \
     }                                                                                                                       \
     diag0 = upY;                                                                                                            \
@@ -143,6 +147,13 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
     SW16_STEP(0) SW16_STEP(1) SW16_STEP(2) SW16_STEP(3)
   }
 #undef SW16_STEP
+  if (!KEYS) {
+    const uint32_t hb = pk_bits(hmax);
+    int sc = max((int)(hb & 0xFFFFu), (int)(hb >> 16));
+    for (int d = 2; d > 0; d >>= 1) sc = max(sc, __shfl_xor(sc, d, 64));
+    SwRes rs; rs.score = sc; rs.end_ref = -2; rs.end_read = 0xFFFF;       // (end cell not computed: wres_pack makes y = 0xFFFFFFFF of it)
+    return rs;
+  }
   int bestH = 0, bestcol = 0x1FFFFF, bestrow = 0x1FFFFF;
 #pragma unroll
   for (int j = 0; j < R; j++) {
@@ -164,20 +175,29 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
 }
 
 // a result: x = score, y = (end_ref + 1) << 16 | end_read
-__device__ __forceinline__ uint2 wres_pack(const SwRes& s) { return make_uint2((uint32_t)s.score, ((uint32_t)(s.end_ref + 1) << 16) | ((uint32_t)s.end_read & 0xFFFFu)); }
-__device__ __forceinline__ SwRes wres_unpack(const uint2 v) { SwRes s; s.score = (int)v.x; s.end_ref = (int)(v.y >> 16) - 1; s.end_read = (int)(v.y & 0xFFFFu); return s; }
+__device__ __forceinline__ uint2 wres_pack(const SwRes& s) { return make_uint2((uint32_t)s.score, s.end_ref < -1 ? 0xFFFFFFFFu : ((uint32_t)(s.end_ref + 1) << 16) | ((uint32_t)s.end_read & 0xFFFFu)); }
+__device__ __forceinline__ SwRes wres_unpack(const uint2 v) {
+  SwRes s; s.score = (int)v.x;
+  if (v.y == 0xFFFFFFFFu) { s.end_ref = -2; s.end_read = 0; }
+  else { s.end_ref = (int)(v.y >> 16) - 1; s.end_read = (int)(v.y & 0xFFFFu); }
+  return s;
+}
 
 // R rows per virtual lane = read spans up to 8 R letters; the host picks the instantiation from the longest read of the batch (13: <= 104
 // letters, 19: <= 152, 32: <= 256).  Registers: five per row (two score tables, Y, E, the running-maximum key) + ~30
 #define SW16_WAVES(R) ((R) <= 13 ? 4 : (R) <= 19 ? 3 : 2)
 template <int R>
-__global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix, DParams P, const WTask* __restrict__ tk, const uint32_t* __restrict__ tidx,
-                                                           const unsigned long long* __restrict__ wc, uint2* __restrict__ res) {
+__global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix, DParams P, const WTask* __restrict__ tk, const uint32_t* __restrict__ tidx1,
+                                                           const uint32_t* __restrict__ tidx2, const unsigned long long* __restrict__ wc, uint2* __restrict__ res) {
   const int lane = lane_id(), g = lane >> 2, gl = lane & 3;
-  const uint32_t nt = (uint32_t)wc[WC_NTASK];
-  const uint32_t npass = (nt + 15u) / 16u;
+  // two lists: tidx[0, ntA) = tasks scored with their end cells, tidx2[0, ntB) = tasks of which only the score is asked
+  const uint32_t ntA = (uint32_t)wc[WC_NTASK], ntB = (uint32_t)wc[WC_NTASK2];
+  const uint32_t npassA = (ntA + 15u) / 16u, npass = npassA + (ntB + 15u) / 16u;
   for (uint32_t p = blockIdx.x; p < npass; p += gridDim.x) {
-    const uint32_t ti = p * 16u + (uint32_t)g;
+    const bool keys = p < npassA;
+    const uint32_t ti = (keys ? p : p - npassA) * 16u + (uint32_t)g;
+    const uint32_t nt = keys ? ntA : ntB;
+    const uint32_t* const tidx = keys ? tidx1 : tidx2;
     const bool have = ti < nt;
     uint32_t slot = 0;
     int m = 0, n = 0, aq = 0;
@@ -196,8 +216,11 @@ __global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix
     bool hn = false;
     for (int q = gl; q < nn; q += 4) if (q < n) hn |= ref[q] == 4;
     SwRes s;
-    if (__any(hn)) s = sw_quad16<R, true>(rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
-    else s = sw_quad16<R, false>(rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext);
+    const bool hasn = __any(hn);
+#define SW16_ARGS rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext
+    if (keys) { if (hasn) s = sw_quad16<R, true, true>(SW16_ARGS); else s = sw_quad16<R, false, true>(SW16_ARGS); }
+    else { if (hasn) s = sw_quad16<R, true, false>(SW16_ARGS); else s = sw_quad16<R, false, false>(SW16_ARGS); }
+#undef SW16_ARGS
     if (have && gl == 0) res[slot] = wres_pack(s);
   }
 }
@@ -213,7 +236,7 @@ __global__ void __launch_bounds__(64, FINAL ? 3 : SMR_WALK_WAVES_PER_SIMD)
 k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
        unsigned long long* __restrict__ ctr, const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool,
        const uint2* __restrict__ list, const WState* __restrict__ ws_prev, const WTask* __restrict__ tk_prev, const uint2* __restrict__ res_prev,
-       WState* __restrict__ ws_cur, WTask* __restrict__ tk_cur, uint32_t* __restrict__ tidx, unsigned long long* __restrict__ wc,
+       WState* __restrict__ ws_cur, WTask* __restrict__ tk_cur, uint32_t* __restrict__ tidx, uint32_t* __restrict__ tidx2, unsigned long long* __restrict__ wc,
        uint32_t K, uint32_t lds_ml, uint32_t lds_rf, uint32_t assume_min) {
   SMR_DYN_LDS(unsigned char, lds_raw);                  // FINAL: read letters (lds_ml) | reference window (lds_rf)
   __shared__ unsigned long long l_pairs[64];            // (reference position << 32 | window position) of the sorted triples
@@ -223,7 +246,8 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
   __shared__ unsigned long long l_stage[64];
   __shared__ WTask s_ctk[WK_MAX];                       // the tasks the read left in the previous round ...
   __shared__ uint2 s_cres[WK_MAX];                      // ... and their results
-  __shared__ uint32_t s_tix[64 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx with one atomic per chunk)
+  __shared__ uint32_t s_tix[64 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx / tidx2 with one atomic per chunk):
+                                                        // the tasks to be scored with their end cells from the front, the score-only ones from the back
   __shared__ uint32_t s_next, s_tbase;
   const int lane = lane_id();
   const uint32_t nlist = (uint32_t)wc[WC_NLIST];
@@ -242,7 +266,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
     const uint32_t chunk_base = s_next;
     if (chunk_base >= nlist) break;
     const uint32_t chunk_n = min(claim, nlist - chunk_base);
-    uint32_t ntix = 0;
+    uint32_t ntix = 0, ntix2 = 0;
     // the chunk's entries at once: lane i asks for entry chunk_base + i and its read's record and length (one round trip per chunk, not two per read)
     uint32_t c_r = 0, c_prev = NONE, c_len = 0;
     uint2 c_mr = make_uint2(NONE, 0u);
@@ -496,8 +520,9 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
               o.bits = bits0 | ((ended && !assume) ? 32u : 0u) | (nk << 8); o.cells = cells;
               if (lane == 0) ws_cur[e] = o;
               live_bits = nk << 8;
-              for (uint32_t q = lane; q < nk; q += 64) s_tix[ntix + q] = e * K + q;
-              ntix += nk;
+              // (a read that is expected to align gets its end cells with the scores; of the others only the score is asked)
+              if (assume) { for (uint32_t q = lane; q < nk; q += 64) s_tix[ntix + q] = e * K + q; ntix += nk; }
+              else { for (uint32_t q = lane; q < nk; q += 64) s_tix[64u * WK_MAX - 1u - (ntix2 + q)] = e * K + q; ntix2 += nk; }
               live = true;
               WPH(4)
               break;
@@ -523,13 +548,15 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
             if ((uint32_t)score1 == max_SW_score) ++st.max_SW_count;
             AlignRec al;
             al.ref_begin1 = (int32_t)(tk.align_ref_start - tk.head);
-            al.ref_end1 = fw.end_ref + (int32_t)(tk.align_ref_start - tk.head);
+            // (a task of which only the score was asked: the END of its window stands in for the end cell, has_cigar = 3, k_begins finds both cells)
+            const bool no_end = fw.end_ref < -1;
+            al.ref_end1 = (no_end ? nref - 1 : fw.end_ref) + (int32_t)(tk.align_ref_start - tk.head);
             al.read_begin1 = (int32_t)tk.align_que_start;
-            al.read_end1 = fw.end_read + (int32_t)tk.align_que_start;
+            al.read_end1 = (no_end ? m - 1 : fw.end_read) + (int32_t)tk.align_que_start;
             al.readlen = len; al.ref_num = tk.max_ref;
             al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
             al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
-            al.has_cigar = 2; al.cigar_off = 0; al.cigar_len = 0;
+            al.has_cigar = no_end ? 3 : 2; al.cigar_off = 0; al.cigar_len = 0;
             AlignRec* slots = work_aln + (size_t)r * P.slots;
             if (!st.is_hit) {                                              // :411-416
               st.is_hit = 1;
@@ -582,6 +609,13 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
       __syncthreads();
       const uint32_t tb = s_tbase;
       for (uint32_t q = lane; q < ntix; q += 64) tidx[tb + q] = s_tix[q];
+    }
+    if (!FINAL && ntix2) {
+      __syncthreads();
+      if (lane == 0) s_tbase = (uint32_t)atomicAdd(&wc[WC_NTASK2], (unsigned long long)ntix2);
+      __syncthreads();
+      const uint32_t tb = s_tbase;
+      for (uint32_t q = lane; q < ntix2; q += 64) tidx2[tb + q] = s_tix[64u * WK_MAX - 1u - q];
     }
     WPH(6)
   }
