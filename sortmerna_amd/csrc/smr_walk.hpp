@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix
     if (keys) { if (hasn) s = sw_quad16<R, true, true>(SW16_ARGS); else s = sw_quad16<R, false, true>(SW16_ARGS); }
     else { if (hasn) s = sw_quad16<R, true, false>(SW16_ARGS); else s = sw_quad16<R, false, false>(SW16_ARGS); }
 #undef SW16_ARGS
-    if (have && gl == 0) res[slot] = wres_pack(s);
+    // (the task's slot is asked for again rather than kept across the Smith-Waterman loop, whose rows take every register the occupancy allows)
+    if (have && gl == 0) res[tidx[ti]] = wres_pack(s);
   }
 }
 

@@ -32,6 +32,19 @@ else:
         _align_body(engine, wl, opts)
 
 
+from test_gpu_parity import test_candidate_walk_in_rounds_gives_the_oracle_records as _walk_body, WALK_VARIANTS  # noqa: E402
+
+# (the GPU suite runs every variant with five option sets; here every variant once and one variant with the other option sets, unless SMR_EMU_FULL=1)
+_WALK_CASES = [(e, o) for e in WALK_VARIANTS for o in ([{}, {"num_alignments": 0}, {"is_best": 0, "num_alignments": 2}, {"num_seeds": 1}, {"min_lis": 3, "num_alignments": 2}] if FULL else [{}])]
+if not FULL:
+    _WALK_CASES += [(WALK_VARIANTS[4], o) for o in ({"num_alignments": 0}, {"is_best": 0, "num_alignments": 2}, {"num_seeds": 1})]
+
+
+@pytest.mark.parametrize("env,opts", _WALK_CASES, ids=lambda v: ",".join("%s=%s" % (k.replace("SMR_WALK_", ""), x) for k, x in v.items()) or "default")
+def test_candidate_walk_in_rounds_gives_the_oracle_records(wl, monkeypatch, env, opts):
+    _walk_body(wl, monkeypatch, env, opts)
+
+
 @pytest.fixture(scope="module", autouse=True)
 def emulator():
     with emu.active() as lib:

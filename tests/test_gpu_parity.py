@@ -342,6 +342,35 @@ def test_optional_paths_of_the_candidate_stage_give_the_oracle_records(wl, monke
         e.close()
 
 
+WALK_VARIANTS = [{"SMR_WALK_SPLIT": "0"},                                   # k_chain walks every marked read (round 4's path)
+                 {"SMR_WALK_ROUNDS": "1"},                                  # the last round is the first: every task scored inside k_walk<true>
+                 {"SMR_WALK_ROUNDS": "2", "SMR_WALK_K": "1"},               # one task per read and round, the rest in the last round
+                 {"SMR_WALK_ROUNDS": "3", "SMR_WALK_K": "8", "SMR_WALK_ASSUME": "0"},     # every look-ahead predicts "aligns": all tasks scored with end cells
+                 {"SMR_WALK_ROUNDS": "12", "SMR_WALK_K": "2", "SMR_WALK_ASSUME": "100"}]  # round 0 predicts "does not align": accepted alignments stored end-pending (k_begins finds both cells)
+
+
+@pytest.mark.parametrize("env", WALK_VARIANTS, ids=lambda e: ",".join("%s=%s" % (k[9:], v) for k, v in e.items()))
+@pytest.mark.parametrize("opts", [{}, {"num_alignments": 0}, {"is_best": 0, "num_alignments": 2}, {"num_seeds": 1}, {"min_lis": 3, "num_alignments": 2}],
+                         ids=["default", "all", "nobest2", "seeds1", "min_lis3_best2"])
+def test_candidate_walk_in_rounds_gives_the_oracle_records(wl, monkeypatch, env, opts):
+    """smr_walk.hpp: the candidate walk as rounds of k_walk -> k_sw16 -> k_wnext.  How many rounds there are, how many tasks a read leaves per
+    round and what its look-ahead predicts decide which Smith-Waterman problems are scored when and by which kernel -- never a record, a
+    counter or the number of ssw_align calls of the sequential walk (the emulator runs the same cases: tests/test_emu_kernels.py)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = smr.Engine(0)
+    try:
+        recs_o, ctr_o = wl.oracle_records(**opts)
+        recs_g, ctr_g = wl.gpu_records(e, **opts)
+        _compare(recs_g, recs_o, "%s %s" % (env, opts))
+        assert ctr_g["num_aligned"] == ctr_o["num_aligned"] and ctr_g["reads_matched_per_db"][0] == ctr_o["per_db"]
+        assert e.prof().n_sw_fwd == ctr_o["n_sw_fwd"]
+        launched = {k: v["launches"] for k, v in e.prof_kernels().items()}
+        assert (launched.get("k_walk", 0) > 0) == (env.get("SMR_WALK_SPLIT") != "0")
+    finally:
+        e.close()
+
+
 def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
     """SMR_PG_CAND_CAP=8: most waves of k_seed_pg overflow their candidate pool and are searched again by the DFS kernel -- the records
     stay the oracle's -- and smr_align_part doubles the pool for the next part, so a second run over the same reads is redone less."""

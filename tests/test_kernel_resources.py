@@ -34,6 +34,29 @@ def _kernel_metadata():
     return out
 
 
+def _kernel_isa(*parts):
+    """disassembly lines of the kernel whose mangled name contains every part"""
+    bundler, objdump = os.path.join(LLVM, "clang-offload-bundler"), os.path.join(LLVM, "llvm-objdump")
+    if not (os.path.exists(bundler) and os.path.exists(objdump) and shutil.which("objcopy")):
+        pytest.skip("ROCm LLVM tools not installed")
+    lib = build.build_library()
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fatbin"), os.path.join(d, "gfx950.o")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([bundler, "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + co, "--unbundle"])
+        text = subprocess.check_output([objdump, "-d", co]).decode()
+    out, on = [], False
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            on = all(p in m.group(1) for p in parts)
+            continue
+        if on and line.strip():
+            out.append(line.split("//")[0].strip())
+    assert out, "kernel %s not in the code object" % (parts,)
+    return out
+
+
 def _find(md, *parts):
     hits = [k for k in md if all(p in k for p in parts)]
     assert hits, "kernel %s not in the code object" % (parts,)
@@ -63,3 +86,29 @@ def test_hot_kernels_use_no_scratch_and_stay_within_their_register_budget():
     for parts in [("k_ssw_batch",), ("k_beginsILb0",)]:
         for k in _find(md, *parts):
             assert k["vgpr"] <= 128 and k["spill"] <= 2, (parts, k)
+
+
+def test_the_round_kernels_of_the_candidate_walk():
+    """smr_walk.hpp.  k_walk: no Smith-Waterman registers (<= 102 VGPRs = 5 waves per SIMD), no vector spills; k_sw16<R>: the rows take every
+    register its occupancy allows, and what the compiler parks in scratch are loop-invariant values around the step loops -- no scratch access
+    may sit between the packed maxima of a step loop (that would be a spill per DP step; it happened with R = 19 under a 128-VGPR bound)."""
+    md = _kernel_metadata()
+    for k in _find(md, "k_walkILb0"):
+        assert k["vgpr"] <= 102 and k["spill"] <= 4 and k["scratch"] <= 64, k
+    for k in _find(md, "k_wnext") + _find(md, "k_wlist"):
+        assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, k
+    for parts, max_vgpr in [(("k_sw16ILi13",), 128), (("k_sw16ILi19",), 168), (("k_sw16ILi32",), 256)]:
+        for k in _find(md, *parts):
+            assert k["vgpr"] <= max_vgpr and k["spill"] <= 96, (parts, k)
+    isa = _kernel_isa("k_sw16ILi19")
+    # stretches of instructions without a scratch access; every packed maximum must lie in a long one (a step loop of 4 steps x 19 rows)
+    stretch, in_long, total = 0, 0, 0
+    runs = []
+    for ins in isa + ["scratch_end"]:
+        if ins.startswith("scratch_"):
+            runs.append(stretch); stretch = 0
+        elif ins.startswith("v_pk_max_i16"):
+            stretch += 1
+    total = sum(runs)
+    in_long = sum(r for r in runs if r >= 4 * 19 * 3)
+    assert total >= 4 * 4 * 19 * 3 and in_long == total, (total, in_long, [r for r in runs if r])
