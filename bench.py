@@ -188,7 +188,13 @@ WORKLOADS = {
               "options": "default options (--fastx, best 1), 8 --ref"},
     "pacbio5k": {"batch_reads": 50_000, "cpu_sample_reads": 4_000, "ref_opts": ["-fastx", "-sam", "-blast", "1"],
                  "options": "--sam --blast 1 (every alignment with its CIGAR), best 1"},
+    # BASELINE configs[1] on REAL data: the reference's bundled 100 000 amplicon reads (scripts/t3.jinja) against its bundled silva-arc-16s-id95
+    # (the id85 file the config names is not in the repository), the fixture of tests/golden/config2.  One pass over 100 000 reads is launch
+    # bound, so a batch is the read set 80 times over (8 M reads); the CPU-baseline sample is the read set itself, all 100 000 records compared
+    "config2": {"batch_reads": 8_000_000, "cpu_sample_reads": 100_000, "ref_opts": ["-fastx"],
+                "options": "default options (--fastx, best 1), classify-only"},
 }
+CONFIG2_DIR = os.path.join(HERE, "tests", "golden", "config2")
 # the 8-ref set: sizes (nt) and typical sequence lengths of sortmerna's rRNA_databases files; only silva-arc-16s-id95 is bundled with
 # this repository (tests/golden/config2, the reference's own file), the others are seeded synthetic families of the same size
 REFS8 = [("silva-bac-16s-like", 19_000_000, 1500, 400, 101), ("silva-arc-16s-id95", None, None, None, None), ("silva-euk-18s-like", 13_000_000, 1800, 400, 103),
@@ -203,6 +209,8 @@ def workload_dbs(args, synth, cache, rank):
         specs = [("synth_rrna_db_%d" % args.db_nt, args.db_nt, 1500, 400, 42)]
     elif args.workload == "pacbio5k":
         specs = [("synth_28s_like_%d" % args.db_nt, args.db_nt, 5500, 400, 77)]
+    elif args.workload == "config2":
+        specs = [("silva-arc-16s-id95", None, None, None, None)]
     else:
         sc = args.db_nt / 140_000_000.0                       # (--db-nt scales the synthetic members; the tests use tiny ones)
         specs = [(n, (int(nt * sc) if nt else None), ml, mn, sd) for n, nt, ml, mn, sd in REFS8]
@@ -213,7 +221,7 @@ def workload_dbs(args, synth, cache, rank):
                 import gzip
                 src = os.path.join(HERE, "tests", "golden", "config2", "silva-arc-16s-id95.fasta.gz")
                 with gzip.open(src, "rb") as f, open(path + ".tmp", "wb") as g:
-                    if args.db_nt >= 14_000_000:
+                    if args.db_nt >= 14_000_000 or args.workload == "config2":
                         shutil.copyfileobj(f, g)
                     else:
                         nseq = 0
@@ -266,9 +274,45 @@ def load_codes_iupac(path):
     return lut[np.frombuffer(b"".join(seqs), dtype=np.uint8)], offs
 
 
+_CONFIG2_READS = None
+
+
+def config2_reads():
+    """the bundled amplicon reads: (blob of ASCII letters, offsets uint64[n+1])"""
+    global _CONFIG2_READS
+    if _CONFIG2_READS is None:
+        import gzip
+        import numpy as np
+        seqs, cur = [], []
+        with gzip.open(os.path.join(CONFIG2_DIR, "set2_environmental_study_550_amplicon.fasta.gz"), "rb") as f:
+            for line in f:
+                if line.startswith(b">"):
+                    if cur:
+                        seqs.append(b"".join(cur))
+                    cur = []
+                else:
+                    cur.append(line.strip())
+        if cur:
+            seqs.append(b"".join(cur))
+        offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in seqs], dtype=np.uint64)
+        _CONFIG2_READS = (b"".join(seqs), offs)
+    return _CONFIG2_READS
+
+
 def make_batch(args, synth, codes, offs, n, seed):
     """-> (blob of ASCII letters, offsets uint64[n+1])"""
     import numpy as np
+    if args.workload == "config2":
+        # the read set over and over, whole copies first (read i of the batch = read i mod 100 000 of the file)
+        blob, o = config2_reads()
+        nr = len(o) - 1
+        reps, rest = divmod(n, nr)
+        lens = np.diff(o)
+        all_lens = np.concatenate([np.tile(lens, reps), lens[:rest]])
+        oo = np.zeros(n + 1, dtype=np.uint64)
+        oo[1:] = np.cumsum(all_lens, dtype=np.uint64)
+        return blob * reps + blob[:int(o[rest])], oo
     if args.workload == "pacbio5k":
         L = args.long_read_len
         return synth.make_long_reads(codes, offs, n, mean_len=L, sd_len=L // 10, min_len=L // 5, max_len=6 * L, seed=seed)
@@ -355,7 +399,7 @@ def main():
         args.batch_reads = (args.total_reads // units) * (units // world) + args.total_reads % units      # the last rank's shard (the largest); config.batch_reads reports it
         args.resident_batches = 1
     args.cpu_sample_reads = args.cpu_sample_reads or W["cpu_sample_reads"]
-    args.db_nt = args.db_nt or (14_000_000 if args.workload == "pacbio5k" else 140_000_000)
+    args.db_nt = args.db_nt or (14_000_000 if args.workload == "pacbio5k" else 3_770_000 if args.workload == "config2" else 140_000_000)
     if args.resident_batches <= 0:
         args.resident_batches = max(2, min(8, 16_000_000 // max(args.batch_reads, 1)))
 
@@ -464,7 +508,11 @@ def main():
 
     # C1: global read totals -> the same minimal_score (per DB) on every rank (refstats.cpp:247-265)
     g_reads, g_len, _, _ = shard.global_read_totals(tot_reads, tot_len, min_len, max_len, device=cdev)
-    mss = [smr.minimal_score(GUMBEL[0], GUMBEL[1], i, g_reads, g_len) for i in infos]
+    gumbel = GUMBEL
+    if args.workload == "config2":                           # the reference's own Gumbel parameters for this DB (its log: tests/golden/config2/config2.json)
+        g2 = json.load(open(os.path.join(CONFIG2_DIR, "config2.json")))["runs"]["default"]
+        gumbel = (g2["lambda"], g2["K"])
+    mss = [smr.minimal_score(gumbel[0], gumbel[1], i, g_reads, g_len) for i in infos]
     plist = [smr.default_params(minimal_score=m) for m in mss]
     ms = mss[0]
 
@@ -613,16 +661,24 @@ def main():
         r4 = 3 if m_sw <= 96 else (5 if m_sw <= 160 else 8)
         instr4 = (n_sw + (m_sw + r4 - 1) // r4 - 1) * (13 * r4 + 13)
         sw4_peak_gcups = 4 * m_sw * n_sw / (instr4 / 6.144e11) / 1e9 if m_sw <= 256 else None
+        # the sixteen-problem kernel of the split walk (k_sw16, smr_walk.hpp): 8 virtual lanes per problem, R = 13 / 19 / 32 rows each (by the longest
+        # read of the batch), n + 7 steps of 13 R + 33 instructions (end cells; 10 R + 28 where only the score is asked) for SIXTEEN problems
+        r16 = 13 if max_len <= 104 else (19 if max_len <= 152 else 32)
+        sw16_peak_gcups = 16 * m_sw * n_sw / ((n_sw + 7) * (13 * r16 + 33) / 6.144e11) / 1e9 if max_len <= 256 else None
         out = {
             "metric": {"illumina150": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "refs8": "reads/sec (150 bp vs the 8-ref rRNA set)",
-                       "pacbio5k": "reads/sec (5 kb PacBio-like reads vs a 28S-like DB, every alignment with its CIGAR)"}[args.workload], "value": reads_timed / dt, "unit": "reads/s",
+                       "pacbio5k": "reads/sec (5 kb PacBio-like reads vs a 28S-like DB, every alignment with its CIGAR)",
+                       "config2": "reads/sec (set2 amplicon reads vs silva-arc-16s-id95, classify-only)"}[args.workload], "value": reads_timed / dt, "unit": "reads/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/i32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/i32",
+            "data": "real (the reference's bundled fixture, the read set repeated to fill a batch)" if args.workload == "config2" else "synthetic",
             "config": {"workload": {
                 "illumina150": "BASELINE configs[2]: synthetic 150-nt Illumina-like reads (10%% from DB, 90%% background) vs seeded synthetic rRNA-like DB "
                                "of %d nt standing in for smr_v4.3_default_db.fasta (absent offline); " % args.db_nt,
                 "refs8": "BASELINE configs[3]: the same reads (10%% from the union of the DBs) vs EIGHT resident reference DBs: the bundled silva-arc-16s-id95 + 7 seeded synthetic "
                          "families sized like the rRNA_databases set (%s; the real files are absent offline); " % ", ".join("%s %.1f Mnt" % (n, int(i.full_len) / 1e6) for (n, _), i in zip(dbl, infos)),
+                "config2": "BASELINE configs[1] on real data: the reference's bundled set2_environmental_study_550_amplicon reads (100 000 reads of 50-200 nt; a batch = the set %d times over) "
+                           "vs its bundled silva-arc-16s-id95 (the id85 file of the config is not in the repository); " % max(1, args.batch_reads // 100_000),
                 "pacbio5k": "BASELINE configs[4]: synthetic PacBio-like reads ~N(%d, %d) nt," % (args.long_read_len, args.long_read_len // 10) + " 12%% errors (6%% ins, 4%% del, 2%% sub), all sampled from a seeded synthetic 28S-like DB "
                             "of %d nt (silva-euk-28s-id98 is absent offline); " % args.db_nt}[args.workload] + W["options"],
                        "name": args.workload, "batch_reads": args.batch_reads, "resident_batches": nb, "read_len": (args.read_len if args.workload != "pacbio5k" else mean_len), "db_nt": args.db_nt, "index_parts": len(parts),
@@ -631,7 +687,8 @@ def main():
                                        "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None)},
                        "total_reads": (args.total_reads if args.scaling == "strong" else None),
                        "cigar": not args.no_cigar, "index_build": index_built,
-                       "sw_kernel": "packed 16-bit (v_pk): candidate windows scored ahead four per wave, single problems on 128 virtual lanes" if eng.sw_mode() >= 1 else "32-bit"},
+                       "sw_kernel": ("packed 16-bit (v_pk): the candidate walk in rounds, its windows scored sixteen per wave by k_sw16 (reads <= 256 nt with a k_cand record); "
+                                     "four per wave / single problems on 128 virtual lanes inside k_chain for the others") if eng.sw_mode() >= 1 else "32-bit"},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1]), "reads_matched_per_db": [int(x) for x in ctr_t[2:2 + n_db]]},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,
@@ -642,6 +699,9 @@ def main():
                                     "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6,
                                     "valu_model_peak_gcups": sw_peak_gcups * args.gpus,
                                     "valu_model_x4_peak_gcups": sw4_peak_gcups * args.gpus if sw4_peak_gcups else None,
+                                    "valu_model_x16_peak_gcups": sw16_peak_gcups * args.gpus if sw16_peak_gcups else None,
+                                    "valu_model_frac_x16": (prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6 / (sw16_peak_gcups * args.gpus)) if sw16_peak_gcups else None,
+                                    "round_kernels_ms_per_step": {k: kp[k]["ms"] / args.gpus / args.steps for k in ("k_cand", "k_walk", "k_sw16", "k_wnext", "k_chain", "k_begins") if k in kp},
                                     # against the kernel that scores most windows: the four-problem kernel where reads fit it (<= 256 nt), else the single-problem strips
                                     "valu_model_frac": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6 / ((sw4_peak_gcups or sw_peak_gcups) * args.gpus),
                                     "valu_model_frac_single_problem_kernel": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6 / (sw_peak_gcups * args.gpus),

@@ -137,10 +137,16 @@ int smr_index_get_info(const smr_index*, smr_index_info* out);
  * (the compiled drop-in of INTEGRATION.md uses the reference's own Refstats object). */
 uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq,
                            uint64_t all_reads_count, uint64_t all_reads_len, double evalue);
+/* The same under -score_split (refstats.cpp:247: `full_read_scale = opts.is_score_split ? opts.num_proc_thread : 1`): the read totals are
+ * divided by the number of processing threads the reference was run with; full_read_scale = 1 is smr_minimal_score. */
+uint32_t smr_minimal_score_split(double lambda, double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq,
+                                 uint64_t all_reads_count, uint64_t all_reads_len, double evalue, uint32_t full_read_scale);
 
 /* The length-corrected database / read sizes of Refstats (refstats.cpp:238-257) that the e-value of the BLAST report uses. */
 void smr_refstats_corrected(double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
                             uint64_t* full_ref_corr, uint64_t* full_read_corr);
+void smr_refstats_corrected_split(double K, const double bg[4], uint64_t full_ref_len, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
+                                  uint32_t full_read_scale, uint64_t* full_ref_corr, uint64_t* full_read_corr);
 
 /* ------------------------------------------------------------------------------------------------
  * Reads (host side): 2-bit packed + ambiguity mask (Read::seqToIntStr: ACGT(U) -> 0..3, other -> 0

@@ -59,7 +59,7 @@ class Kprof(C.Structure):
 
 EXPORTS = [
     "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_save", "smr_index_load_flat", "smr_index_selfcheck", "smr_index_free",
-    "smr_index_get_info", "smr_minimal_score", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free", "smr_reads_slice",
+    "smr_index_get_info", "smr_minimal_score", "smr_minimal_score_split", "smr_refstats_corrected_split", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free", "smr_reads_slice",
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_device_count", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_check_device", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record", "smr_result_record_batch", "smr_counters_accumulate",
@@ -109,6 +109,8 @@ def bind(L):
     L.smr_index_get_info.argtypes = [vp, C.POINTER(IndexInfo)]
     L.smr_minimal_score.restype = u32
     L.smr_minimal_score.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), u64, u64, u64, u64, C.c_double]
+    L.smr_minimal_score_split.restype = u32
+    L.smr_minimal_score_split.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double), u64, u64, u64, u64, C.c_double, u32]
     L.smr_reads_pack.restype = i32
     L.smr_reads_pack.argtypes = [cp, vp, u32, C.POINTER(vp)]
     L.smr_reads_load_fastx.restype = i32

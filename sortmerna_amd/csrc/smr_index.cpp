@@ -546,26 +546,34 @@ extern "C" int smr_index_get_info(const smr_index* ix, smr_index_info* o) {
 }
 
 // refstats.cpp:238-257: expected HSP length, length-corrected sizes
-extern "C" void smr_refstats_corrected(double K, const double bg[4], uint64_t full_ref, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
-                                       uint64_t* full_ref_corr, uint64_t* full_read_corr) {
+// (full_read_scale: 1, or the number of processing threads under -score_split -- refstats.cpp:247: the reads are then scored per split)
+extern "C" void smr_refstats_corrected_split(double K, const double bg[4], uint64_t full_ref, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
+                                             uint32_t full_read_scale, uint64_t* full_ref_corr, uint64_t* full_read_corr) {
+  const int scale = full_read_scale ? (int)full_read_scale : 1;
   double H = -(bg[0] * std::log2(bg[0]) + bg[1] * std::log2(bg[1]) + bg[2] * std::log2(bg[2]) + bg[3] * std::log2(bg[3]));
   uint64_t full_read = all_reads_len;
-  uint64_t expect_L = static_cast<uint64_t>(std::log(K * full_ref * full_read / 1) / H);
+  uint64_t expect_L = static_cast<uint64_t>(std::log(K * full_ref * full_read / scale) / H);
   if (full_ref > expect_L * numseq) full_ref -= expect_L * numseq;
-  full_read -= expect_L * all_reads_count / 1;
+  full_read -= expect_L * all_reads_count / scale;
   if (full_ref_corr) *full_ref_corr = full_ref;
   if (full_read_corr) *full_read_corr = full_read;
 }
+extern "C" void smr_refstats_corrected(double K, const double bg[4], uint64_t full_ref, uint64_t numseq, uint64_t all_reads_count, uint64_t all_reads_len,
+                                       uint64_t* full_ref_corr, uint64_t* full_read_corr) {
+  smr_refstats_corrected_split(K, bg, full_ref, numseq, all_reads_count, all_reads_len, 1, full_ref_corr, full_read_corr);
+}
 
 // refstats.cpp:238-265
+extern "C" uint32_t smr_minimal_score_split(double lambda, double K, const double bg[4], uint64_t full_ref, uint64_t numseq,
+                                            uint64_t all_reads_count, uint64_t all_reads_len, double evalue, uint32_t full_read_scale) {
+  const int scale = full_read_scale ? (int)full_read_scale : 1;
+  uint64_t full_read = 0;
+  smr_refstats_corrected_split(K, bg, full_ref, numseq, all_reads_count, all_reads_len, (uint32_t)scale, &full_ref, &full_read);
+  return static_cast<uint32_t>(std::log(evalue / ((double)K * full_ref * full_read / scale)) / -lambda);
+}
 extern "C" uint32_t smr_minimal_score(double lambda, double K, const double bg[4], uint64_t full_ref, uint64_t numseq,
                                       uint64_t all_reads_count, uint64_t all_reads_len, double evalue) {
-  double H = -(bg[0] * std::log2(bg[0]) + bg[1] * std::log2(bg[1]) + bg[2] * std::log2(bg[2]) + bg[3] * std::log2(bg[3]));
-  uint64_t full_read = all_reads_len;
-  uint64_t expect_L = static_cast<uint64_t>(std::log(K * full_ref * full_read / 1) / H);
-  if (full_ref > expect_L * numseq) full_ref -= expect_L * numseq;
-  full_read -= expect_L * all_reads_count / 1;
-  return static_cast<uint32_t>(std::log(evalue / ((double)K * full_ref * full_read / 1)) / -lambda);
+  return smr_minimal_score_split(lambda, K, bg, full_ref, numseq, all_reads_count, all_reads_len, evalue, 1);
 }
 
 // =================================================================================================

@@ -185,7 +185,9 @@ __device__ __forceinline__ SwRes wres_unpack(const uint2 v) {
 
 // R rows per virtual lane = read spans up to 8 R letters; the host picks the instantiation from the longest read of the batch (13: <= 104
 // letters, 19: <= 152, 32: <= 256).  Registers: five per row (two score tables, Y, E, the running-maximum key) + ~30
+#ifndef SW16_WAVES
 #define SW16_WAVES(R) ((R) <= 13 ? 4 : (R) <= 19 ? 3 : 2)
+#endif
 template <int R>
 __global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix, DParams P, const WTask* __restrict__ tk, const uint32_t* __restrict__ tidx1,
                                                            const uint32_t* __restrict__ tidx2, const unsigned long long* __restrict__ wc, uint2* __restrict__ res) {

@@ -213,9 +213,10 @@ class Reads:
             self.h = None
 
 
-def minimal_score(lam, K, info, all_reads_count, all_reads_len, evalue=1.0):
-    """Refstats arithmetic (refstats.cpp:238-265) from Gumbel (lambda, K) + DB statistics + GLOBAL read totals."""
-    return capi.load().smr_minimal_score(lam, K, info.bg, info.full_len, info.numseq, all_reads_count, all_reads_len, evalue)
+def minimal_score(lam, K, info, all_reads_count, all_reads_len, evalue=1.0, full_read_scale=1):
+    """Refstats arithmetic (refstats.cpp:238-265) from Gumbel (lambda, K) + DB statistics + GLOBAL read totals; full_read_scale = the
+    reference's processing threads under -score_split (refstats.cpp:247), else 1."""
+    return capi.load().smr_minimal_score_split(lam, K, info.bg, info.full_len, info.numseq, all_reads_count, all_reads_len, evalue, full_read_scale)
 
 
 class Engine:

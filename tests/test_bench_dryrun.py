@@ -15,7 +15,7 @@ KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
         "config", "roofline", "cpu_baseline"]
 
 
-@pytest.mark.parametrize("steps,warmup,workload", [(2, 1, "illumina150"), (20, 5, "illumina150"), (1, 0, "refs8"), (2, 1, "pacbio5k")])          # (20, 5) = the driver's own command line of round 1, which aborted
+@pytest.mark.parametrize("steps,warmup,workload", [(2, 1, "illumina150"), (20, 5, "illumina150"), (1, 0, "refs8"), (2, 1, "pacbio5k"), (1, 1, "config2")])          # (20, 5) = the driver's own command line of round 1, which aborted
 def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup, workload):
     baseline = paths.have_ref_bin() and steps <= 2               # with the reference binary at hand the CPU-baseline leg runs too
     import torch
@@ -26,7 +26,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
     monkeypatch.setenv("SMR_BENCH_BACKEND", "gloo")          # the (world-size-1) reductions on CPU tensors
     import tempfile
     monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
-    nreads = 60 if workload == "pacbio5k" else (300 if steps > 2 else 1500)
+    nreads = 60 if workload == "pacbio5k" else (300 if steps > 2 else 1500)      # (config2: the first 1500 reads of the bundled read set vs the whole bundled DB)
     argv = ["bench.py", "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup), "--batch-reads", str(nreads), "--db-nt", "1000000" if workload == "refs8" else "150000",
             "--cpu-sample-reads", str(nreads), "--cpu-threads", "2", "--workload", workload, "--long-read-len", "600"]
     if not baseline:
@@ -48,6 +48,7 @@ def test_bench_control_flow_on_the_emulator(monkeypatch, tmp_path, steps, warmup
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert out["counters"]["reads"] == steps * nreads and out["config"]["name"] == workload
+    assert out["data"].startswith("real" if workload == "config2" else "synthetic")
     if workload == "refs8":
         assert out["config"]["n_dbs"] == 8 and len(out["counters"]["reads_matched_per_db"]) == 8 and sum(out["counters"]["reads_matched_per_db"]) == out["counters"]["num_aligned"] > 0
     assert out["config"]["resident_batches"] == min(steps + warmup, 8)       # (tiny batches: the automatic choice is 8)

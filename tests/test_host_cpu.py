@@ -154,6 +154,21 @@ def test_minimal_score_equals_reference_log():
     assert ms == g["log"]["minimal_score"][0]
 
 
+def test_minimal_score_under_score_split_equals_reference_log():
+    """-score_split (refstats.cpp:247-265): the read totals are divided by the reference's number of processing threads.  tests/golden/score_split.json
+    holds what the unmodified binary logged for 1, 2, 4 and 7 threads (make_golden_score_split.py): 33, 32, 31, 30 on the synthetic inputs."""
+    import json
+    g = json.load(open(os.path.join(paths.GOLDEN, "score_split.json")))
+    db, _, seqs = golden.inputs("syn_default")
+    info = smr.Index.build(db, 18, 3072.0, 10000, 0)[0].info()
+    seen = set()
+    for r in g["runs"]:
+        scale = r["threads"] if r["score_split"] else 1
+        assert smr.minimal_score(r["lambda"], r["K"], info, len(seqs), sum(map(len, seqs)), full_read_scale=scale) == r["minimal_score"], r
+        seen.add(r["minimal_score"])
+    assert len(seen) >= 3                                   # the option does change the threshold on these inputs
+
+
 def test_builder_part_split_matches_reference():
     db, _, _ = golden.inputs("syn_multipart")
     parts = smr.Index.build(db, 18, 0.15, 10000, 0)
