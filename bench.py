@@ -383,6 +383,7 @@ def main():
                     help="distinct read batches kept resident in HBM (1..%d); step i runs on batch i %% this; 0 = as many as hold 16 M reads, between 2 and 8" % MAX_RESIDENT)
     args = ap.parse_args()
 
+    t_process = time.time()                                  # set-up (DBs, index replica, resident batches) is timed per rank and reported: config.setup_s
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -521,6 +522,10 @@ def main():
         eng.reset_state()
         smr.align_resident(eng, idx_slots, plist, with_cigar=not args.no_cigar)
 
+    setup_s = time.time() - t_process                       # this rank: process start -> everything resident, before the first step
+    setup_max = shard.time_max(setup_s, device=cdev)
+    setup_min = -shard.time_max(-setup_s, device=cdev)
+    log("set-up of this rank %.1f s (ranks: %.1f .. %.1f s)" % (setup_s, setup_min, setup_max))
     for i in range(args.warmup):
         step(i % nb)
     timed = [i % nb for i in range(args.warmup, n_total)]        # the resident batch of every timed step
@@ -686,6 +691,8 @@ def main():
                        "collectives": {"backend": (backend if dist is not None else None), "what": "all-reduce of the read totals before, of the Readstats counters after; none on the data path",
                                        "rccl_version": (".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None)},
                        "total_reads": (args.total_reads if args.scaling == "strong" else None),
+                       "setup_s": {"slowest_rank": setup_max, "fastest_rank": setup_min,
+                                   "what": "process start -> DB files, index replica built on the rank's GPU and resident batches generated + uploaded, all ranks concurrently on the shared host"},
                        "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": ("packed 16-bit (v_pk): the candidate walk in rounds, its windows scored sixteen per wave by k_sw16 (reads <= 256 nt with a k_cand record); "
                                      "four per wave / single problems on 128 virtual lanes inside k_chain for the others") if eng.sw_mode() >= 1 else "32-bit"},

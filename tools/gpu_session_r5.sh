@@ -68,6 +68,15 @@ pacbio)
   ( time timeout 1200 python bench.py --workload pacbio5k --steps 3 --warmup 1 --resident-batches 2 ) > $OUT/bench_pacbio5k.json 2> $OUT/bench_pacbio5k.err; tail -c 2500 $OUT/bench_pacbio5k.json; tail -6 $OUT/bench_pacbio5k.err ;;
 config2)
   ( time timeout 900 python bench.py --workload config2 --steps 5 --warmup 1 ) > $OUT/bench_config2.json 2> $OUT/bench_config2.err; tail -c 2500 $OUT/bench_config2.json; tail -6 $OUT/bench_config2.err ;;
+ranks8)
+  # `python bench.py --gpus 8` as typed, its 8 ranks on the one GPU of this box (the two tiny collectives on gloo): what an 8-GPU node will run, set-up time per rank included
+  ( time SMR_BENCH_BACKEND=gloo SMR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --steps 3 --warmup 1 ) > $OUT/bench_8ranks_on_one_gpu.json 2> $OUT/bench_8ranks_on_one_gpu.err
+  grep -E "set-up|real" $OUT/bench_8ranks_on_one_gpu.err | tail -4; python -c "
+import json,sys
+o=json.loads([l for l in open('$OUT/bench_8ranks_on_one_gpu.json') if l.startswith('{')][-1])
+print('value %.3g reads/s, nranks %s, n_gpus %d, setup %s' % (o['value'], o['config'].get('nranks'), o['n_gpus'], o['config']['setup_s']))" ;;
+c2dbg)
+  SMR_WALK_DEBUG=1 timeout 300 python bench.py --workload config2 --steps 1 --warmup 0 --no-cpu-baseline --resident-batches 1 > $OUT/bench_config2_dbg.json 2> $OUT/bench_config2_dbg.err; grep "walk rounds" $OUT/bench_config2_dbg.err | head -8 | cut -c1-300 ;;
 dropin)
   timeout 900 python -m pytest tests/test_dropin.py tests/test_cpp_driver.py -m gpu -x -q -rs > $OUT/pytest_dropin_mgpu.log 2>&1; tail -6 $OUT/pytest_dropin_mgpu.log ;;
 e2e)
