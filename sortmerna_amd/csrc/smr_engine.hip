@@ -101,8 +101,8 @@ struct smr_ctx {
   uint2* d_mrec = nullptr; uint32_t* d_mpool = nullptr; size_t mrec_cap = 0, mpool_words = 0;
   // the candidate walk in rounds (smr_walk.hpp): walk kernel -> Smith-Waterman over a task list -> next list; SMR_WALK_SPLIT=0: k_chain walks every marked read
   int walk_split = getenv("SMR_WALK_SPLIT") ? atoi(getenv("SMR_WALK_SPLIT")) : 1;
-  uint32_t walk_rounds = getenv("SMR_WALK_ROUNDS") ? (uint32_t)std::max(1, std::min(32, atoi(getenv("SMR_WALK_ROUNDS")))) : 6u;      // the last one scores in the kernel
-  uint32_t walk_k = getenv("SMR_WALK_K") ? (uint32_t)std::max(1, std::min((int)WK_MAX, atoi(getenv("SMR_WALK_K")))) : 4u;           // tasks a read leaves per round
+  uint32_t walk_rounds = getenv("SMR_WALK_ROUNDS") ? (uint32_t)std::max(1, std::min(32, atoi(getenv("SMR_WALK_ROUNDS")))) : 8u;      // the last one scores in the kernel
+  uint32_t walk_k = getenv("SMR_WALK_K") ? (uint32_t)std::max(1, std::min((int)WK_MAX, atoi(getenv("SMR_WALK_K")))) : 4u;           // tasks a read leaves per round, at least (smr_walk.hpp walk_tasks_per_read)
   uint32_t walk_assume = getenv("SMR_WALK_ASSUME") ? (uint32_t)atoi(getenv("SMR_WALK_ASSUME")) : 3u;                                 // round 0 predicts "aligns" from this many seeds of the best candidate
   uint2* d_wlist[2] = {nullptr, nullptr}; WState* d_wstate[2] = {nullptr, nullptr}; WTask* d_wtask[2] = {nullptr, nullptr}; uint2* d_wres[2] = {nullptr, nullptr};
   uint32_t* d_wtidx = nullptr; uint32_t* d_wslow = nullptr; unsigned long long* d_wctr = nullptr; size_t walk_cap = 0; uint32_t walk_kcap = 0, walk_rcap = 0;
@@ -434,7 +434,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
     // rounds of walk -> Smith-Waterman -> next list (smr_walk.hpp); the last round scores in the walk kernel, so every listed read ends its pass here
     ev_mark(c, KP_WNEXT);
     hipLaunchKernelGGL(k_wlist, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, dreads(c), c->b->d_marks, (const uint2*)mrec, (uint32_t)WK_MAX_ROWS, c->d_wlist[0], c->d_wslow, c->d_wctr, n_slow);
-    const int swr = wmq <= 104 ? 13 : wmq <= 152 ? 19 : 32;
+    const int swr = wmq <= 104 ? 13 : wmq <= 152 ? 19 : wmq <= 208 ? 26 : 32;
     const uint32_t walk_blocks = (uint32_t)c->n_cu * 4u * SMR_WALK_WAVES_PER_SIMD, sw_blocks = (uint32_t)c->n_cu * 4u * (uint32_t)SW16_WAVES(swr);
     for (uint32_t rnd = 0; rnd < RM; rnd++) {
       const int cur = (int)(rnd & 1u), prv = cur ^ 1;
@@ -442,7 +442,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       const bool fin = rnd + 1 == RM;
       ev_mark(c, KP_WALK);
 #define WALK_ARGS dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr, (const uint2*)mrec, (const uint32_t*)c->d_mpool, (const uint2*)c->d_wlist[cur], \
-                  (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, c->d_wtidx + n_tix, wc, WK, wml, rq, c->walk_assume
+                  (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, c->d_wtidx + n_tix, wc, WK, (unsigned long long)n_tix, (int)rnd, wml, rq, c->walk_assume
       if (fin) hipLaunchKernelGGL(k_walk<true>, dim3(walk_blocks * 3u / SMR_WALK_WAVES_PER_SIMD), dim3(64), (size_t)wml + rq, c->stream, WALK_ARGS);
       else {
         hipLaunchKernelGGL(k_walk<false>, dim3(walk_blocks), dim3(64), 0, c->stream, WALK_ARGS);
@@ -450,11 +450,12 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
 #define SW16_ARGS dreads(c), dindex(di), P, (const WTask*)c->d_wtask[cur], (const uint32_t*)c->d_wtidx, (const uint32_t*)(c->d_wtidx + n_tix), (const unsigned long long*)wc, c->d_wres[cur]
         if (swr == 13) hipLaunchKernelGGL(k_sw16<13>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
         else if (swr == 19) hipLaunchKernelGGL(k_sw16<19>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+        else if (swr == 26) hipLaunchKernelGGL(k_sw16<26>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
         else hipLaunchKernelGGL(k_sw16<32>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
 #undef SW16_ARGS
         ev_mark(c, KP_WNEXT);
         hipLaunchKernelGGL(k_wnext, dim3((uint32_t)c->n_cu * 2u), dim3(1024), 0, c->stream, P, is_last_strand, c->b->d_work, c->b->d_rw, c->b->d_ctr, (const uint2*)c->d_wlist[cur], (const WState*)c->d_wstate[cur],
-                           (const uint2*)c->d_wres[cur], c->d_wlist[prv], (const unsigned long long*)wc, wc + WC_STRIDE, WK);
+                           (const uint2*)c->d_wres[cur], c->d_wlist[prv], (const unsigned long long*)wc, wc + WC_STRIDE, WK, (unsigned long long)n_tix, (int)rnd);
       }
 #undef WALK_ARGS
     }

@@ -22,7 +22,16 @@
 
 namespace smr {
 
-#define WK_MAX 8u                     // most tasks a read leaves per round
+#define WK_MAX 15u                    // most tasks a read leaves per round
+// The task arrays of a round hold `cap` tasks (K0 per read of the batch).  A round with few listed reads lets each of them leave more tasks: a
+// read that meets a family of a hundred references (real 16S data) gets through its candidates in a handful of rounds, and round 0, where
+// most listed reads have one spurious candidate, stays at K0.  Every kernel of a round derives the same number from the round's list length
+// (round 0: K0 whatever the list length).
+__host__ __device__ __forceinline__ uint32_t walk_tasks_per_read(uint32_t nlist, unsigned long long cap, uint32_t k0, int round) {
+  if (round == 0) return k0;
+  const unsigned long long q = nlist ? cap / nlist : (unsigned long long)WK_MAX;
+  return (uint32_t)(q < k0 ? k0 : (q > WK_MAX ? WK_MAX : q));
+}
 #define WK_MAX_ROWS 256u              // longest read span k_sw16 takes (8 virtual lanes x 32 rows)
 // per-round counters (u64 words): every hot one on a 128-byte line of its own
 enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_NTASK2 = 48, WC_STRIDE = 64 };
@@ -184,7 +193,7 @@ __device__ __forceinline__ SwRes wres_unpack(const uint2 v) {
 }
 
 // R rows per virtual lane = read spans up to 8 R letters; the host picks the instantiation from the longest read of the batch (13: <= 104
-// letters, 19: <= 152, 32: <= 256).  Registers: five per row (two score tables, Y, E, the running-maximum key) + ~30
+// letters, 19: <= 152, 26: <= 208, 32: <= 256).  Registers: five per row (two score tables, Y, E, the running-maximum key) + ~30
 #ifndef SW16_WAVES
 #define SW16_WAVES(R) ((R) <= 13 ? 4 : (R) <= 19 ? 3 : 2)
 #endif
@@ -240,7 +249,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
        unsigned long long* __restrict__ ctr, const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool,
        const uint2* __restrict__ list, const WState* __restrict__ ws_prev, const WTask* __restrict__ tk_prev, const uint2* __restrict__ res_prev,
        WState* __restrict__ ws_cur, WTask* __restrict__ tk_cur, uint32_t* __restrict__ tidx, uint32_t* __restrict__ tidx2, unsigned long long* __restrict__ wc,
-       uint32_t K, uint32_t lds_ml, uint32_t lds_rf, uint32_t assume_min) {
+       uint32_t K0, unsigned long long task_cap, int round, uint32_t lds_ml, uint32_t lds_rf, uint32_t assume_min) {
   SMR_DYN_LDS(unsigned char, lds_raw);                  // FINAL: read letters (lds_ml) | reference window (lds_rf)
   __shared__ unsigned long long l_pairs[64];            // (reference position << 32 | window position) of the sorted triples
   __shared__ uint2 l_cand[64];                          // candidates in walk order: {reference, count | first triple << 8}
@@ -249,11 +258,13 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
   __shared__ unsigned long long l_stage[64];
   __shared__ WTask s_ctk[WK_MAX];                       // the tasks the read left in the previous round ...
   __shared__ uint2 s_cres[WK_MAX];                      // ... and their results
-  __shared__ uint32_t s_tix[64 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx / tidx2 with one atomic per chunk):
+  __shared__ uint32_t s_tix[32 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx / tidx2 with one atomic per chunk):
                                                         // the tasks to be scored with their end cells from the front, the score-only ones from the back
   __shared__ uint32_t s_next, s_tbase;
   const int lane = lane_id();
   const uint32_t nlist = (uint32_t)wc[WC_NLIST];
+  const uint32_t K = walk_tasks_per_read(nlist, task_cap, K0, round);                                                // tasks per read of this round ...
+  const uint32_t Kp = round > 0 ? walk_tasks_per_read((uint32_t)(wc - WC_STRIDE)[WC_NLIST], task_cap, K0, round - 1) : K0;      // ... and of the previous one (where this round's reads left theirs)
   unsigned long long n_fwd = 0, n_cells = 0, n_spec = 0, n_spec_used = 0, n_newhit = 0;
 #ifdef SMR_WALK_PHASES                                    // where a wave's cycles go (build with -DSMR_WALK_PHASES, run with SMR_DEBUG_PHASES=1): claim + loads, sort + candidates, advance, results + bookkeeping, look-ahead + tasks, write-back, task list
   unsigned long long wph[7] = {0, 0, 0, 0, 0, 0, 0}, wlast = clock64();
@@ -261,7 +272,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
 #else
 #define WPH(i)
 #endif
-  const uint32_t claim = max(1u, min(64u, nlist / (gridDim.x * 4u)));
+  const uint32_t claim = max(1u, min(32u, nlist / (gridDim.x * 4u)));
   for (;;) {
     __syncthreads();
     if (lane == 0) s_next = (uint32_t)atomicAdd(&wc[WC_CLAIM], (unsigned long long)claim);
@@ -351,7 +362,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
         }
         // the tasks of the previous round and their results
         const uint32_t n_prev = prev != NONE ? WS_NK(ps.bits) : 0u;
-        if ((uint32_t)lane < n_prev) { s_ctk[lane] = tk_prev[(size_t)prev * K + lane]; s_cres[lane] = res_prev[(size_t)prev * K + lane]; }
+        if ((uint32_t)lane < n_prev) { s_ctk[lane] = tk_prev[(size_t)prev * Kp + lane]; s_cres[lane] = res_prev[(size_t)prev * Kp + lane]; }
         __syncthreads();
         WPH(1)
 
@@ -525,7 +536,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
               live_bits = nk << 8;
               // (a read that is expected to align gets its end cells with the scores; of the others only the score is asked)
               if (assume) { for (uint32_t q = lane; q < nk; q += 64) s_tix[ntix + q] = e * K + q; ntix += nk; }
-              else { for (uint32_t q = lane; q < nk; q += 64) s_tix[64u * WK_MAX - 1u - (ntix2 + q)] = e * K + q; ntix2 += nk; }
+              else { for (uint32_t q = lane; q < nk; q += 64) s_tix[32u * WK_MAX - 1u - (ntix2 + q)] = e * K + q; ntix2 += nk; }
               live = true;
               WPH(4)
               break;
@@ -618,7 +629,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
       if (lane == 0) s_tbase = (uint32_t)atomicAdd(&wc[WC_NTASK2], (unsigned long long)ntix2);
       __syncthreads();
       const uint32_t tb = s_tbase;
-      for (uint32_t q = lane; q < ntix2; q += 64) tidx2[tb + q] = s_tix[64u * WK_MAX - 1u - q];
+      for (uint32_t q = lane; q < ntix2; q += 64) tidx2[tb + q] = s_tix[32u * WK_MAX - 1u - q];
     }
     WPH(6)
   }
@@ -642,8 +653,9 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_wnext(DParams P, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw, unsigned long long* __restrict__ ctr,
                                                 const uint2* __restrict__ list, const WState* __restrict__ ws, const uint2* __restrict__ res, uint2* __restrict__ list_next,
-                                                const unsigned long long* __restrict__ wc, unsigned long long* __restrict__ wc_next, uint32_t K) {
+                                                const unsigned long long* __restrict__ wc, unsigned long long* __restrict__ wc_next, uint32_t K0, unsigned long long task_cap, int round) {
   const uint32_t n = (uint32_t)wc[WC_NLIST];
+  const uint32_t K = walk_tasks_per_read(n, task_cap, K0, round);
   unsigned long long n_fwd = 0, n_cells = 0, n_used = 0;
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
     const uint32_t e = base + threadIdx.x;

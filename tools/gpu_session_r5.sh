@@ -69,8 +69,8 @@ pacbio)
 config2)
   ( time timeout 900 python bench.py --workload config2 --steps 5 --warmup 1 ) > $OUT/bench_config2.json 2> $OUT/bench_config2.err; tail -c 2500 $OUT/bench_config2.json; tail -6 $OUT/bench_config2.err ;;
 ranks8)
-  # `python bench.py --gpus 8` as typed, its 8 ranks on the one GPU of this box (the two tiny collectives on gloo): what an 8-GPU node will run, set-up time per rank included
-  ( time SMR_BENCH_BACKEND=gloo SMR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --steps 3 --warmup 1 ) > $OUT/bench_8ranks_on_one_gpu.json 2> $OUT/bench_8ranks_on_one_gpu.err
+  # `python bench.py --gpus 8`, its 8 ranks on the one GPU (2 M-read batches: 8 ranks with 8 M-read batches need 8 x 36 GB of the one GPU's HBM) of this box (the two tiny collectives on gloo): what an 8-GPU node will run, set-up time per rank included
+  ( time SMR_BENCH_BACKEND=gloo SMR_BENCH_DEVICE=0 timeout 1200 python bench.py --gpus 8 --steps 3 --warmup 1 --batch-reads ${RANKS8_BATCH:-2000000} ) > $OUT/bench_8ranks_on_one_gpu.json 2> $OUT/bench_8ranks_on_one_gpu.err
   grep -E "set-up|real" $OUT/bench_8ranks_on_one_gpu.err | tail -4; python -c "
 import json,sys
 o=json.loads([l for l in open('$OUT/bench_8ranks_on_one_gpu.json') if l.startswith('{')][-1])
