@@ -419,7 +419,8 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
       if (g0 + 32u < npos) { mpool[off + g0 + 32u] = kp2.y; mpool[off + npos + g0 + 32u] = kp2.x; mpool[off + 2u * npos + g0 + 32u] = wn_[kh2]; }
       if (g0 + 48u < npos) { mpool[off + g0 + 48u] = kp3.y; mpool[off + npos + g0 + 48u] = kp3.x; mpool[off + 2u * npos + g0 + 48u] = wn_[kh3]; }
     }
-    if (r < rd.n && gl == 0) mrec[r] = (want && off != NONE) ? make_uint2(off, npos) : make_uint2(NONE, 0u);
+    // (a marked read without a record: .y says why -- its number of positions, ~0 when its hits outgrew the group (k_wlist's census, SMR_WALK_DEBUG))
+    if (r < rd.n && gl == 0) mrec[r] = (want && off != NONE) ? make_uint2(off, npos) : make_uint2(NONE, scan ? npos : 0xFFFFFFFFu);
   }
 }
 

@@ -103,6 +103,7 @@ struct smr_ctx {
   int walk_split = getenv("SMR_WALK_SPLIT") ? atoi(getenv("SMR_WALK_SPLIT")) : 1;
   uint32_t walk_rounds = getenv("SMR_WALK_ROUNDS") ? (uint32_t)std::max(1, std::min(32, atoi(getenv("SMR_WALK_ROUNDS")))) : 8u;      // the last one scores in the kernel
   uint32_t walk_k = getenv("SMR_WALK_K") ? (uint32_t)std::max(1, std::min((int)WK_MAX, atoi(getenv("SMR_WALK_K")))) : 4u;           // tasks a read leaves per round, at least (smr_walk.hpp walk_tasks_per_read)
+  int walk_gather = getenv("SMR_WALK_GATHER") ? atoi(getenv("SMR_WALK_GATHER")) : 1;     // 0: only reads with a record of k_cand go through the rounds (at most 64 positions)
   uint32_t walk_assume = getenv("SMR_WALK_ASSUME") ? (uint32_t)atoi(getenv("SMR_WALK_ASSUME")) : 3u;                                 // round 0 predicts "aligns" from this many seeds of the best candidate
   uint2* d_wlist[2] = {nullptr, nullptr}; WState* d_wstate[2] = {nullptr, nullptr}; WTask* d_wtask[2] = {nullptr, nullptr}; uint2* d_wres[2] = {nullptr, nullptr};
   uint32_t* d_wtidx = nullptr; uint32_t* d_wslow = nullptr; unsigned long long* d_wctr = nullptr; size_t walk_cap = 0; uint32_t walk_kcap = 0, walk_rcap = 0;
@@ -433,7 +434,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   if (split) {
     // rounds of walk -> Smith-Waterman -> next list (smr_walk.hpp); the last round scores in the walk kernel, so every listed read ends its pass here
     ev_mark(c, KP_WNEXT);
-    hipLaunchKernelGGL(k_wlist, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, dreads(c), c->b->d_marks, (const uint2*)mrec, (uint32_t)WK_MAX_ROWS, c->d_wlist[0], c->d_wslow, c->d_wctr, n_slow);
+    hipLaunchKernelGGL(k_wlist, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, dreads(c), c->b->d_marks, (const uint2*)mrec, (uint32_t)WK_MAX_ROWS, c->d_wlist[0], c->d_wslow, c->d_wctr, n_slow, getenv("SMR_WALK_DEBUG") ? n_slow + 8 : (unsigned long long*)nullptr, (P.num_seeds >= 2 && c->walk_gather) ? 1 : 0);
     const int swr = wmq <= 104 ? 13 : wmq <= 152 ? 19 : wmq <= 208 ? 26 : 32;
     const uint32_t walk_blocks = (uint32_t)c->n_cu * 4u * SMR_WALK_WAVES_PER_SIMD, sw_blocks = (uint32_t)c->n_cu * 4u * (uint32_t)SW16_WAVES(swr);
     for (uint32_t rnd = 0; rnd < RM; rnd++) {
@@ -441,7 +442,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       unsigned long long* const wc = c->d_wctr + (size_t)rnd * WC_STRIDE;
       const bool fin = rnd + 1 == RM;
       ev_mark(c, KP_WALK);
-#define WALK_ARGS dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr, (const uint2*)mrec, (const uint32_t*)c->d_mpool, (const uint2*)c->d_wlist[cur], \
+#define WALK_ARGS dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr, (const uint2*)mrec, (const uint32_t*)c->d_mpool, (const uint32_t*)c->d_pool, (const uint2*)c->d_wlist[cur], \
                   (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, c->d_wtidx + n_tix, wc, WK, (unsigned long long)n_tix, (int)rnd, wml, rq, c->walk_assume
       if (fin) hipLaunchKernelGGL(k_walk<true>, dim3(walk_blocks * 3u / SMR_WALK_WAVES_PER_SIMD), dim3(64), (size_t)wml + rq, c->stream, WALK_ARGS);
       else {
@@ -463,7 +464,8 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       std::vector<unsigned long long> h((size_t)(RM + 2) * WC_STRIDE);
       HIPCHK(c, hipMemcpyAsync(h.data(), c->d_wctr, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      fprintf(stderr, "libsmr_hip: walk rounds (pass %d): slow %llu;", pass, h[(size_t)(RM + 1) * WC_STRIDE]);
+      { const unsigned long long* q = &h[(size_t)(RM + 1) * WC_STRIDE];
+        fprintf(stderr, "libsmr_hip: walk rounds (pass %d): slow %llu (positions <= 64 / 128 / 256 / 512 / more / > 64 hits: %llu %llu %llu %llu %llu %llu);", pass, q[0], q[8], q[9], q[10], q[11], q[12], q[13]); }
       for (uint32_t rnd = 0; rnd < RM; rnd++) fprintf(stderr, " %llu/%llu+%llu", h[(size_t)rnd * WC_STRIDE + WC_NLIST], h[(size_t)rnd * WC_STRIDE + WC_NTASK], h[(size_t)rnd * WC_STRIDE + WC_NTASK2]);
       fprintf(stderr, "\n");
     }

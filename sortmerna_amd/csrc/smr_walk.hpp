@@ -33,6 +33,7 @@ __host__ __device__ __forceinline__ uint32_t walk_tasks_per_read(uint32_t nlist,
   return (uint32_t)(q < k0 ? k0 : (q > WK_MAX ? WK_MAX : q));
 }
 #define WK_MAX_ROWS 256u              // longest read span k_sw16 takes (8 virtual lanes x 32 rows)
+#define WK_MAX_POS 128u               // most positions (seed hits x their occurrences) of a read the round kernels take: two per lane
 // per-round counters (u64 words): every hot one on a 128-byte line of its own
 enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_NTASK2 = 48, WC_STRIDE = 64 };
 
@@ -55,14 +56,21 @@ struct WState {                       // the walk of a read standing AT the firs
 // k_wlist: marks -> the round-0 list of the split path (marks cleared) and the list of the reads that stay with k_chain
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_wlist(DReads rd, uint8_t* __restrict__ marks, const uint2* __restrict__ mrec, uint32_t max_rows, uint2* __restrict__ list0,
-                                                uint32_t* __restrict__ slow, unsigned long long* __restrict__ wc0, unsigned long long* __restrict__ n_slow) {
+                                                uint32_t* __restrict__ slow, unsigned long long* __restrict__ wc0, unsigned long long* __restrict__ n_slow, unsigned long long* census, int gather) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool mk = i < rd.n && marks[i] == 1;
-  const bool fast = mk && mrec && mrec[i].x != NONE && rd.len[i] <= max_rows;
+  // (with a record of k_cand, or with few enough positions for k_walk to gather them itself; num_seeds < 2 makes every reference a candidate: records only)
+  const bool fast = mk && mrec && (mrec[i].x != NONE || (mrec[i].y - 1u < WK_MAX_POS && gather)) && rd.len[i] <= max_rows;
   const uint32_t o = block_append(&wc0[WC_NLIST], fast);
   if (fast) { list0[o] = make_uint2(i, NONE); marks[i] = 0; }
   const uint32_t o2 = block_append(n_slow, mk && !fast);
   if (mk && !fast) slow[o2] = i;
+  if (census) {                                            // (measurement aid: why the reads left to k_chain have no record -- positions <= 64 but no room in the block's slice, <= 128, <= 256, <= 512, more, too many hits)
+    const uint32_t np = (mk && !fast && mrec) ? mrec[i].y : 0u;
+    const bool s = mk && !fast;
+    const int cls = !s ? -1 : np == 0xFFFFFFFFu ? 5 : np <= 64u ? 0 : np <= 128u ? 1 : np <= 256u ? 2 : np <= 512u ? 3 : 4;
+    for (int q = 0; q < 6; q++) { const unsigned long long m = __ballot(cls == q); if (m && (threadIdx.x & 63u) == 0) atomicAdd(&census[q], (unsigned long long)__popcll(m)); }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,16 +254,16 @@ __global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix
 template <bool FINAL>
 __global__ void __launch_bounds__(64, FINAL ? 3 : SMR_WALK_WAVES_PER_SIMD)
 k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
-       unsigned long long* __restrict__ ctr, const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool,
+       unsigned long long* __restrict__ ctr, const uint2* __restrict__ mrec, const uint32_t* __restrict__ mpool, const uint32_t* __restrict__ pool,
        const uint2* __restrict__ list, const WState* __restrict__ ws_prev, const WTask* __restrict__ tk_prev, const uint2* __restrict__ res_prev,
        WState* __restrict__ ws_cur, WTask* __restrict__ tk_cur, uint32_t* __restrict__ tidx, uint32_t* __restrict__ tidx2, unsigned long long* __restrict__ wc,
        uint32_t K0, unsigned long long task_cap, int round, uint32_t lds_ml, uint32_t lds_rf, uint32_t assume_min) {
   SMR_DYN_LDS(unsigned char, lds_raw);                  // FINAL: read letters (lds_ml) | reference window (lds_rf)
-  __shared__ unsigned long long l_pairs[64];            // (reference position << 32 | window position) of the sorted triples
+  __shared__ unsigned long long l_pairs[WK_MAX_POS];    // (reference position << 32 | window position) of the sorted triples of the candidates
   __shared__ uint2 l_cand[64];                          // candidates in walk order: {reference, count | first triple << 8}
   __shared__ unsigned long long l_cref[64], l_clen[64]; // ... where their reference sequences start, and their lengths
-  __shared__ uint32_t l_hkey[128], l_hcnt[128];         // the hash table that groups the triples by reference
-  __shared__ unsigned long long l_stage[64];
+  __shared__ uint32_t l_hkey[256], l_hcnt[256];         // the hash table that groups the triples by reference
+  __shared__ unsigned long long l_stage[WK_MAX_POS];    // the member triples as sort keys (before that: the hits of a read that gathers its positions itself; after: LIS arrays)
   __shared__ WTask s_ctk[WK_MAX];                       // the tasks the read left in the previous round ...
   __shared__ uint2 s_cres[WK_MAX];                      // ... and their results
   __shared__ uint32_t s_tix[32 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx / tidx2 with one atomic per chunk):
@@ -296,36 +304,71 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
       WState ps; ps.bits = 0;
       if (prev != NONE) ps = ws_prev[prev];
       uint32_t live_bits = 0;                             // what ws_cur[e].bits becomes: 0 = the read is finished
-      if (w.strand_active && w.search && w.pass_n == (uint32_t)pass && mr.x != NONE) {
+      if (w.strand_active && w.search && w.pass_n == (uint32_t)pass && mr.y - 1u < WK_MAX_POS) {
         WPH(0)
         // ---- candidate references (alignment.cpp:117-148) and their (reference position, window position) pairs in walk order ----
-        // The read's triples (reference, reference position, window position), one per lane.  Equal references are found by an exact hash table
-        // in LDS (128 slots for at most 64 triples); the triples of the references with enough seeds are moved to the low lanes and sorted by
-        // (slot, reference position, window position) as ONE 64-bit key per lane: a candidate's pairs are a run of lanes, already in the order
-        // the walk wants them, and a read with one spurious candidate of two seeds sorts two lanes, not 64.
+        // The read's triples (reference, reference position, window position), up to two per lane: from k_cand's record, or -- a read whose
+        // record found no room, or that has 65..128 positions -- gathered here through hits -> list bounds -> positions.  Equal references are
+        // found by an exact hash table in LDS; the triples of the references with enough seeds are moved to the front and sorted by (slot,
+        // reference position, window position) as ONE 64-bit key each: a candidate's pairs are a run, already in the order the walk wants
+        // them, and a read with one spurious candidate of two seeds sorts two lanes, not all of them.
         const uint32_t npos = mr.y;
-        const uint32_t* rp = mpool + mr.x;
-        const bool valid = (uint32_t)lane < npos;
-        uint32_t seq = 0, pos = 0, win = 0;
-        if (valid) { seq = rp[lane]; pos = rp[npos + lane]; win = rp[2u * npos + lane]; }
+        uint32_t seq[2] = {0, 0}, pos[2] = {0, 0}, win[2] = {0, 0};
+        const bool valid[2] = {(uint32_t)lane < npos, (uint32_t)lane + 64u < npos};
         __syncthreads();
-        l_hkey[lane] = 0xFFFFFFFFu; l_hkey[lane + 64] = 0xFFFFFFFFu; l_hcnt[lane] = 0; l_hcnt[lane + 64] = 0;
+        if (mr.x != NONE) {
+          const uint32_t* rp = mpool + mr.x;
+          if (valid[0]) { seq[0] = rp[lane]; pos[0] = rp[npos + lane]; win[0] = rp[2u * npos + lane]; }      // (a record has at most 64 positions)
+        } else {
+          uint32_t* const g_hp = (uint32_t*)l_stage;            // [65] first position of every hit | [64] its list start | [64] its window position
+          uint32_t* const g_lo = g_hp + 65, * const g_wn = g_lo + 64;
+          const uint32_t nh = w.hit_total;                      // (<= CAND_HITS = 64: k_cand only scans such reads)
+          uint32_t lo = 0, ln = 0;
+          if ((uint32_t)lane < nh) {
+            const uint32_t h = (uint32_t)lane, c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
+            const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
+            const uint32_t id = pool[at];
+            g_wn[lane] = pool[at + 1];
+            lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
+          }
+          uint32_t tot;
+          const uint32_t ex = wave_excl_scan_u32(ln, tot);
+          if ((uint32_t)lane < nh) { g_hp[lane] = ex; g_lo[lane] = lo; }
+          if (lane == 0) g_hp[nh] = tot;
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < 2; q++) if (valid[q]) {
+            const uint32_t p = (uint32_t)lane + 64u * q;
+            uint32_t h = 0;
+            for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && g_hp[t] <= p) h = t; }
+            const uint2 pa = ix.pos_arr[g_lo[h] + (p - g_hp[h])];
+            seq[q] = pa.y; pos[q] = pa.x; win[q] = g_wn[h];
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { l_hkey[lane + 64 * q] = 0xFFFFFFFFu; l_hcnt[lane + 64 * q] = 0; }
         __syncthreads();
-        uint32_t slot = 0;
-        if (valid) {
-          slot = (seq * 0x9E3779B1u) >> 25;
-          for (;;) { const uint32_t o = atomicCAS(&l_hkey[slot], 0xFFFFFFFFu, seq); if (o == 0xFFFFFFFFu || o == seq) break; slot = (slot + 1u) & 127u; }
-          atomicAdd(&l_hcnt[slot], 1u);
+        uint32_t slot[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; q++) if (valid[q]) {
+          uint32_t sl = (seq[q] * 0x9E3779B1u) >> 24;
+          for (;;) { const uint32_t o = atomicCAS(&l_hkey[sl], 0xFFFFFFFFu, seq[q]); if (o == 0xFFFFFFFFu || o == seq[q]) break; sl = (sl + 1u) & 255u; }
+          atomicAdd(&l_hcnt[sl], 1u);
+          slot[q] = sl;
         }
         __threadfence_block();
         __syncthreads();
-        const bool member = valid && (int)l_hcnt[slot] >= P.num_seeds;
-        const unsigned long long mm = __ballot(member);
-        const uint32_t total = (uint32_t)__popcll(mm);
-        if (member) l_stage[__popcll(mm & ((1ull << lane) - 1ull))] = ((unsigned long long)slot << 48) | ((unsigned long long)pos << 16) | (unsigned long long)(win & 0xFFFFu);
+        const bool mem0 = valid[0] && (int)l_hcnt[slot[0]] >= P.num_seeds, mem1 = valid[1] && (int)l_hcnt[slot[1]] >= P.num_seeds;
+        const unsigned long long mm0 = __ballot(mem0), mm1 = __ballot(mem1);
+        const uint32_t tot0 = (uint32_t)__popcll(mm0), total = tot0 + (uint32_t)__popcll(mm1);
+        const unsigned long long ltm = (1ull << lane) - 1ull;
+        if (mem0) l_stage[__popcll(mm0 & ltm)] = ((unsigned long long)slot[0] << 48) | ((unsigned long long)pos[0] << 16) | (unsigned long long)(win[0] & 0xFFFFu);
+        if (mem1) l_stage[tot0 + (uint32_t)__popcll(mm1 & ltm)] = ((unsigned long long)slot[1] << 48) | ((unsigned long long)pos[1] << 16) | (unsigned long long)(win[1] & 0xFFFFu);
         __syncthreads();
-        unsigned long long key = (uint32_t)lane < total ? l_stage[lane] : ~0ull;
-        if (total > 1) {
+        if (total > 64) wave_sort_u64(l_stage, total);          // (in LDS; rare: more than 64 triples belong to candidates)
+        else if (total > 1) {
+          unsigned long long key = (uint32_t)lane < total ? l_stage[lane] : ~0ull;
           uint32_t np2 = 2; while (np2 < total) np2 <<= 1;
           for (uint32_t kk = 2; kk <= np2; kk <<= 1)
             for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
@@ -333,32 +376,53 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
               const bool want_min = (((uint32_t)lane & j) == 0) == (((uint32_t)lane & kk) == 0);
               if (want_min ? o < key : key < o) key = o;
             }
+          if ((uint32_t)lane < total) l_stage[lane] = key;
         }
-        const bool inrun = (uint32_t)lane < total;
-        const uint32_t sl = (uint32_t)(key >> 48) & 127u;
-        const uint32_t psl = (uint32_t)__shfl_up((int)sl, 1, 64);
-        const bool head = inrun && (lane == 0 || sl != psl);
-        const unsigned long long heads = __ballot(head);
-        const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
-        const uint32_t endp = above ? (uint32_t)lane + (uint32_t)__ffsll((long long)above) : total;
-        const uint32_t count = endp - (uint32_t)lane;                       // (of a head lane: the length of its run)
-        const uint32_t ncand = (uint32_t)__popcll(heads);
-        const uint32_t hseq = head ? l_hkey[sl] : 0u;
+        __syncthreads();
+        // runs of equal slots in the sorted keys = the candidates; element i of the sorted array is looked at by lane i & 63 (two per lane)
+        unsigned long long key2[2]; bool head[2]; uint32_t sl2[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const uint32_t i = (uint32_t)lane + 64u * q;
+          key2[q] = i < total ? l_stage[i] : ~0ull;
+          sl2[q] = (uint32_t)(key2[q] >> 48) & 255u;
+          head[q] = i < total && (i == 0 || sl2[q] != ((uint32_t)(l_stage[i - (i ? 1u : 0u)] >> 48) & 255u));
+        }
+        const unsigned long long h0 = __ballot(head[0]), h1 = __ballot(head[1]);
+        const uint32_t ncand = (uint32_t)__popcll(h0) + (uint32_t)__popcll(h1);
+        uint32_t count[2], hseq[2];
+        {
+          const unsigned long long ab0 = lane < 63 ? h0 >> (lane + 1) : 0ull, ab1 = lane < 63 ? h1 >> (lane + 1) : 0ull;
+          const uint32_t e0 = ab0 ? (uint32_t)lane + (uint32_t)__ffsll((long long)ab0) : h1 ? 63u + (uint32_t)__ffsll((long long)h1) : total;
+          const uint32_t e1 = ab1 ? 64u + (uint32_t)lane + (uint32_t)__ffsll((long long)ab1) : total;
+          count[0] = e0 - (uint32_t)lane; count[1] = e1 - (64u + (uint32_t)lane);      // (of a head: the length of its run)
+          hseq[0] = head[0] ? l_hkey[sl2[0]] : 0u; hseq[1] = head[1] ? l_hkey[sl2[1]] : 0u;
+        }
         // walk order: count descending, reference ascending (alignment.cpp:134-148)
-        const unsigned long long mykey = ((unsigned long long)(0xFFFFFFFFu - count) << 32) | hseq;
-        uint32_t rank = 0;
-        for (unsigned long long mq = heads; mq; mq &= mq - 1) {
+        const unsigned long long my0 = ((unsigned long long)(0xFFFFFFFFu - count[0]) << 32) | hseq[0], my1 = ((unsigned long long)(0xFFFFFFFFu - count[1]) << 32) | hseq[1];
+        uint32_t rank0 = 0, rank1 = 0;
+        for (unsigned long long mq = h0; mq; mq &= mq - 1) {
           const int c = __ffsll((long long)mq) - 1;
-          const uint32_t ks = (uint32_t)__builtin_amdgcn_readlane((int)hseq, c), kc = (uint32_t)__builtin_amdgcn_readlane((int)count, c);
-          const unsigned long long key_c = ((unsigned long long)(0xFFFFFFFFu - kc) << 32) | ks;
-          rank += key_c < mykey ? 1u : 0u;
+          const unsigned long long key_c = ((unsigned long long)(0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)count[0], c)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)hseq[0], c);
+          rank0 += key_c < my0 ? 1u : 0u; rank1 += key_c < my1 ? 1u : 0u;
         }
-        if (inrun) l_pairs[lane] = ((key >> 16) << 32) | (key & 0xFFFFull);
-        if (head) {
-          // (where the candidate's reference sequence lies: asked for by all candidates at once, not one round trip per candidate as the walk reaches it)
-          const uint64_t r0_ = ix.ref_off[hseq], r1_ = ix.ref_off[hseq + 1];
-          l_cand[rank] = make_uint2(hseq, count | ((uint32_t)lane << 8));
-          l_cref[rank] = r0_; l_clen[rank] = r1_ - r0_;
+        for (unsigned long long mq = h1; mq; mq &= mq - 1) {
+          const int c = __ffsll((long long)mq) - 1;
+          const unsigned long long key_c = ((unsigned long long)(0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)count[1], c)) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)hseq[1], c);
+          rank0 += key_c < my0 ? 1u : 0u; rank1 += key_c < my1 ? 1u : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const uint32_t i = (uint32_t)lane + 64u * q;
+          if (i < total) l_pairs[i] = ((key2[q] >> 16) << 32) | (key2[q] & 0xFFFFull);
+          if (head[q]) {
+            // (where the candidate's reference sequence lies: asked for by all candidates at once, not one round trip per candidate as the walk reaches it)
+            const uint32_t rk = q ? rank1 : rank0;
+            const uint64_t r0_ = ix.ref_off[hseq[q]], r1_ = ix.ref_off[hseq[q] + 1];
+            l_cand[rk] = make_uint2(hseq[q], count[q] | (i << 8));
+            l_cref[rk] = r0_; l_clen[rk] = r1_ - r0_;
+          }
         }
         // the tasks of the previous round and their results
         const uint32_t n_prev = prev != NONE ? WS_NK(ps.bits) : 0u;
@@ -397,12 +461,13 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
               wk.pending_pop = 1;
               const uint64_t end_ref_max = (uint64_t)wk.begin_ref + len - wk.begin_read - P.lnwin + 1;
               int push = 0;
-              {
+              for (;;) {                                            // (the pairs are sorted by reference position: the ones to push are a prefix of what is left)
                 const uint32_t pi = wk.it + (uint32_t)lane;
                 const bool okp = pi < np && (uint64_t)(uint32_t)(pairs[min(pi, np - 1)] >> 32) <= end_ref_max;
                 const unsigned long long pm = __ballot(okp);
                 const uint32_t pc = pm == ~0ull ? 64u : (uint32_t)__ffsll((long long)~pm) - 1u;
                 if (pc) { wk.it += pc; wk.ms_hi = wk.it; push = 1; }
+                if (pc < 64u) break;
               }
               int skip_to_pop = 0;
               if (!push && wk.is_aligned) skip_to_pop = 1;        // heuristic 1 (:243-246)
@@ -410,7 +475,8 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
               if (!skip_to_pop && (wk.ms_hi - wk.ms_lo) >= (uint32_t)P.num_seeds) {
                 uint32_t lis0;
                 const uint32_t nw = wk.ms_hi - wk.ms_lo;
-                const uint32_t nl = wave_lis_first(pairs + wk.ms_lo, nw, lis0);
+                uint32_t* const lisb = (uint32_t*)l_stage;           // (free once the candidates are laid out: 2 x WK_MAX_POS words)
+                const uint32_t nl = nw <= 64 ? wave_lis_first(pairs + wk.ms_lo, nw, lis0) : serial_lis_first(pairs + wk.ms_lo, nw, lisb, lisb + WK_MAX_POS, lis0);
                 if (nl >= (uint32_t)P.min_lis) {
                   const unsigned long long pl = pairs[wk.ms_lo + lis0];
                   const uint32_t lcs_ref_start = (uint32_t)(pl >> 32), lcs_que_start = (uint32_t)pl;
