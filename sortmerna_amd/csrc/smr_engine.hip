@@ -1251,7 +1251,26 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
         ev_mark(c, KP_BEGINS);
         hipLaunchKernelGGL(k_begins_collect, dim3((uint32_t)((ntot + 1023) / 1024)), dim3(1024), 0, c->stream, c->b->n, c->b->slots, (const RState*)c->b->d_work, (const RWork*)c->b->d_rw,
                            (const AlignRec*)c->b->d_work_aln, c->d_tasks, c->b->d_ctr);
-        if (c->b->max_len > SW_X4_MAX_ROWS)
+        const size_t task_cap = (size_t)c->walk_cap * c->walk_kcap;
+        if (x4 && c->walk_split && c->d_wtask[0] && c->d_wctr && ntot <= task_cap && !getenv("SMR_BEGINS_X4")) {
+          // sixteen per wave through k_sw16 (smr_walk.hpp): stage 0 = the end cells of the alignments stored end-pending, stage 1 = the begin cells of all
+          const uint32_t wmq = std::min<uint32_t>(c->b->max_len, WK_MAX_ROWS);
+          const int swr = wmq <= 104 ? 13 : wmq <= 152 ? 19 : wmq <= 208 ? 26 : 32;
+          const uint32_t sw_blocks = (uint32_t)c->n_cu * 4u * (uint32_t)SW16_WAVES(swr);
+          for (int stage = 0; stage < 2; stage++) {
+            HIPCHK(c, hipMemsetAsync(c->d_wctr, 0, (size_t)WC_STRIDE * 8, c->stream));
+            hipLaunchKernelGGL(k_begins_prep, dim3((uint32_t)c->n_cu * 2u), dim3(1024), 0, c->stream, dindex(di), c->b->slots, (const uint32_t*)c->d_tasks, (const unsigned long long*)&c->b->d_ctr[C_BEGIN_N],
+                               (const AlignRec*)c->b->d_work_aln, stage, c->d_wtask[0], c->d_wtidx, c->d_wctr);
+#define SW16_ARGS dreads(c), dindex(di), P, (const WTask*)c->d_wtask[0], (const uint32_t*)c->d_wtidx, (const uint32_t*)(c->d_wtidx + task_cap), (const unsigned long long*)c->d_wctr, c->d_wres[0]
+            if (swr == 13) hipLaunchKernelGGL(k_sw16<13>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+            else if (swr == 19) hipLaunchKernelGGL(k_sw16<19>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+            else if (swr == 26) hipLaunchKernelGGL(k_sw16<26>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+            else hipLaunchKernelGGL(k_sw16<32>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
+#undef SW16_ARGS
+            hipLaunchKernelGGL(k_begins_apply, dim3((uint32_t)c->n_cu * 4u), dim3(256), 0, c->stream, (const uint32_t*)c->d_tasks, (const unsigned long long*)&c->b->d_ctr[C_BEGIN_N], c->b->d_work_aln, stage,
+                               (const WTask*)c->d_wtask[0], (const uint2*)c->d_wres[0], c->b->d_ctr);
+          }
+        } else if (c->b->max_len > SW_X4_MAX_ROWS)
           hipLaunchKernelGGL(k_begins<true>, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, c->d_bound, c->d_rdq);
         else
           hipLaunchKernelGGL(k_begins<false>, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, (int*)nullptr, (uint8_t*)nullptr);

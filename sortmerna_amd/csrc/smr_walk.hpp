@@ -42,7 +42,7 @@ struct WTask {                        // one Smith-Waterman task: read span x re
   uint64_t rf_start;                  // where the window starts in ix.ref_seq
   uint32_t ars, head;                 // align_ref_start, head (what the walk needs besides the window when it resumes at this task)
   uint16_t aq, m, nref;               // align_que_start, read span, window length
-  uint16_t flags;                     // bit 0: the read is walked on its reverse-complement strand
+  uint16_t flags;                     // bit 0: the read is walked on its reverse-complement strand; bit 1: rows and columns run backwards from aq / rf_start (a begin-cell task)
 };
 struct WState {                       // the walk of a read standing AT the first task it had no result for (= task 0 of the tasks it left)
   uint32_t k, it, ms_lo, ms_hi, begin_ref, begin_read;
@@ -93,7 +93,7 @@ __device__ __forceinline__ unsigned long long quad_max_u64(unsigned long long v)
 // after all, its end cell is found by k_begins)
 template <int R, bool HASN, bool KEYS>
 __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uint32_t len, uint32_t reversed, int m, int aq, const uint8_t* __restrict__ ref, int n,
-                                           int match, int mismatch, int scoreN, int go, int ge) {
+                                           int match, int mismatch, int scoreN, int go, int ge, int dir) {      // dir = 1, or -1: rows and columns run backwards from aq / ref (ssw_align's reverse pass)
   const int gl = lane_id() & 3;
   const pk16 GE = pk_splat(ge), GO = pk_splat(go), ZERO = pk_splat(0);
   const uint32_t TN = (((uint32_t)(scoreN + go)) & 0xFFFFu) * 0x00010001u;
@@ -111,7 +111,7 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
       const int row = (gl + 4 * hf) * R + j;
       uint32_t t = 0;
       if (row < m) {
-        const uint32_t c = read_nt(rec, len, (uint32_t)(aq + row), reversed, 4u);
+        const uint32_t c = read_nt(rec, len, (uint32_t)(aq + dir * row), reversed, 4u);
         t = c == 4u ? t_n : t_mm ^ (t_x << (8u * c));
       }
       t2[hf] = t;
@@ -126,7 +126,7 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
   const uint32_t in_y = (uint32_t)(-go) & 0xFFFFu;
   uint32_t xlo = ((uint32_t)(0x3FFF + gl) << 1) | 1u;
   const bool first = gl == 0;
-  uint32_t wnext = gl < n ? pk_sel_of(ref[gl]) : PK_SEL_NONE;
+  uint32_t wnext = gl < n ? pk_sel_of(ref[dir * gl]) : PK_SEL_NONE;
 #define SW16_STEP(U)                                                                                                        \
   {                                                                                                                         \
     const uint32_t win = (uint32_t)dpp_quad_bcast<U>((int)wcur);                                                            \
@@ -160,7 +160,7 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
   for (int t = 0; t < steps; t += 4) {
     const uint32_t wcur = wnext;
     const int cq = t + 4 + gl;
-    wnext = cq < n ? pk_sel_of(ref[cq]) : PK_SEL_NONE;
+    wnext = cq < n ? pk_sel_of(ref[dir * cq]) : PK_SEL_NONE;
     SW16_STEP(0) SW16_STEP(1) SW16_STEP(2) SW16_STEP(3)
   }
 #undef SW16_STEP
@@ -219,24 +219,24 @@ __global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix
     const uint32_t* const tidx = keys ? tidx1 : tidx2;
     const bool have = ti < nt;
     uint32_t slot = 0;
-    int m = 0, n = 0, aq = 0;
+    int m = 0, n = 0, aq = 0, dir = 1;
     uint32_t len = 0, reversed = 0;
     const uint32_t* rec = rd.words;
     const uint8_t* ref = ix.ref_seq;
     if (have) {
       slot = tidx[ti];
       const WTask t = tk[slot];
-      m = t.m; n = t.nref; aq = t.aq; reversed = t.flags & 1u;
+      m = t.m; n = t.nref; aq = t.aq; reversed = t.flags & 1u; dir = (t.flags & 2u) ? -1 : 1;
       len = rd.len[t.r]; rec = rd.words + rd.rec_off[t.r];
       ref = ix.ref_seq + t.rf_start;
     }
     int nn = n;
     for (int d = 32; d > 0; d >>= 1) nn = max(nn, __shfl_xor(nn, d, 64));
     bool hn = false;
-    for (int q = gl; q < nn; q += 4) if (q < n) hn |= ref[q] == 4;
+    for (int q = gl; q < nn; q += 4) if (q < n) hn |= ref[dir * q] == 4;
     SwRes s;
     const bool hasn = __any(hn);
-#define SW16_ARGS rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext
+#define SW16_ARGS rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, dir
     if (keys) { if (hasn) s = sw_quad16<R, true, true>(SW16_ARGS); else s = sw_quad16<R, false, true>(SW16_ARGS); }
     else { if (hasn) s = sw_quad16<R, true, false>(SW16_ARGS); else s = sw_quad16<R, false, false>(SW16_ARGS); }
 #undef SW16_ARGS
@@ -757,6 +757,50 @@ __global__ void __launch_bounds__(1024) k_wnext(DParams P, int is_last_strand, R
     if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells);
     if (n_used) atomicAdd(&ctr[C_SW_SPEC_USED], n_used);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The begin cells of the alignments that are still stored when the part is done (ssw_align's reverse pass, ssw.c:900-918; see k_begins in
+// smr_chain.hpp), sixteen per wave: k_begins_prep turns the pending alignments k_begins_collect listed into tasks of k_sw16 -- stage 0: the
+// forward pass over the window of an alignment stored end-pending (has_cigar = 3), stage 1: the reverse pass from the end cell of every
+// pending alignment --, k_begins_apply puts the cells into the records.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_begins_prep(DIndex ix, uint32_t slots, const uint32_t* __restrict__ tasks, const unsigned long long* __restrict__ n_tasks_p, const AlignRec* __restrict__ work_aln,
+                                                      int stage, WTask* __restrict__ tk, uint32_t* __restrict__ tidx, unsigned long long* __restrict__ wc) {
+  const uint32_t n_tasks = (uint32_t)*n_tasks_p;
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n_tasks; base += gridDim.x * blockDim.x) {
+    const uint32_t t = base + threadIdx.x;
+    bool take = false;
+    if (t < n_tasks) {
+      const AlignRec al = work_aln[tasks[t]];
+      take = stage == 0 ? al.has_cigar == 3 : al.has_cigar >= 2;
+      if (take) {
+        WTask o;
+        o.r = tasks[t] / slots; o.max_ref = al.ref_num; o.ars = 0; o.head = 0;
+        o.m = (uint16_t)(al.read_end1 - al.read_begin1 + 1); o.nref = (uint16_t)(al.ref_end1 - al.ref_begin1 + 1);
+        if (stage == 0) { o.aq = (uint16_t)al.read_begin1; o.rf_start = ix.ref_off[al.ref_num] + (uint64_t)al.ref_begin1; o.flags = al.strand ? 0 : 1; }
+        else { o.aq = (uint16_t)al.read_end1; o.rf_start = ix.ref_off[al.ref_num] + (uint64_t)al.ref_end1; o.flags = (al.strand ? 0 : 1) | 2; }
+        tk[t] = o;
+      }
+    }
+    const uint32_t p = block_append(&wc[WC_NTASK], take);
+    if (take) tidx[p] = t;
+  }
+}
+__global__ void __launch_bounds__(256) k_begins_apply(const uint32_t* __restrict__ tasks, const unsigned long long* __restrict__ n_tasks_p, AlignRec* __restrict__ work_aln, int stage,
+                                                      const WTask* __restrict__ tk, const uint2* __restrict__ res, unsigned long long* __restrict__ ctr) {
+  const uint32_t n_tasks = (uint32_t)*n_tasks_p;
+  unsigned long long n_rev = 0, n_cells = 0;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tasks; t += gridDim.x * blockDim.x) {
+    AlignRec* const al = work_aln + tasks[t];
+    const uint32_t hc = al->has_cigar;
+    if (stage == 0 ? hc != 3 : hc < 2) continue;
+    const SwRes s = wres_unpack(res[t]);
+    if (stage == 0) { al->ref_end1 = al->ref_begin1 + s.end_ref; al->read_end1 = al->read_begin1 + s.end_read; al->has_cigar = 2; }
+    else { al->ref_begin1 = al->ref_end1 - s.end_ref; al->read_begin1 = al->read_end1 - s.end_read; al->has_cigar = 0; n_rev++; n_cells += (unsigned long long)tk[t].m * tk[t].nref; }
+  }
+  for (int d = 32; d > 0; d >>= 1) { n_rev += __shfl_xor(n_rev, d, 64); n_cells += __shfl_xor(n_cells, d, 64); }
+  if (lane_id() == 0) { if (n_rev) ctr_add(ctr, C_SW_REV, n_rev); if (n_cells) ctr_add(ctr, C_SW_CELLS, n_cells); }
 }
 
 }  // namespace smr
