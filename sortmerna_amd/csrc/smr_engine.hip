@@ -89,7 +89,7 @@ struct smr_ctx {
   uint32_t keys_need = 0;
   bool chain_ext = false;                                              // a read's candidate set has outgrown the LDS table once: global tables are on
   uint32_t* d_stab = nullptr; unsigned long long* d_tuples2 = nullptr; // per block: CH_EXT_CAP-slot table (4 arrays), tuples grouped by member
-  size_t chain_lds_attr = 0, begins_lds_attr = 0, split_lds_attr = 0;
+  size_t chain_lds_attr = 0, begins_lds_attr = 0, split_lds_attr = 0, bins_lds_attr = 0;
   uint32_t* d_fidx = nullptr; RState* d_fstate = nullptr; AlignRec* d_faln = nullptr; size_t fetch_cap_r = 0, fetch_cap_a = 0;   // staging of smr_results_fetch
   int sw_mode = getenv("SMR_SW_PACKED") ? atoi(getenv("SMR_SW_PACKED")) : 2;   // 1 / 2: packed 16-bit Smith-Waterman kernels (smr_sw_pk.hpp; 2 = lane hand-over by wave_ror, measured faster) where they apply
   unsigned long long* d_keys = nullptr; uint32_t keys_cap = 0;
@@ -306,7 +306,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
   const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
-  if (lds_bins > 60 * 1024) { static size_t bins_lds_attr = 0; if (lds_bins > bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); bins_lds_attr = lds_bins; } }
+  if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
   if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     c->split_lds_attr = lds_split;
@@ -1382,7 +1382,12 @@ static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
       const uint64_t per_block = flags_cap + (rows_lds ? 0 : (uint64_t)wcap * 8);
       // (measured on 5 kb reads, k_trace per 50 000-read step: 8 blocks per CU 762 ms; 16: 496; 32: 459: the kernel lives on waves in flight, profiles/r4s10_*)
       static const int tw_bpc = getenv("SMR_TRACE_BPC") ? atoi(getenv("SMR_TRACE_BPC")) : 32;
-      uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((16ull << 30) / per_block, 1), (uint64_t)c->n_cu * tw_bpc);
+      // (the tiles take at most 16 GiB and at most a quarter of what is free on the device now: with many resident batches and index parts, or on a
+      // smaller device, fewer blocks run instead of the allocation failing)
+      size_t mem_free = 0, mem_total = 0;
+      if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = (size_t)16 << 30;
+      const uint64_t budget = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(c->trflags_bytes, (uint64_t)mem_free / 4));
+      uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(budget / per_block, 1), (uint64_t)c->n_cu * tw_bpc);
       blocks = std::min(blocks, n_tasks);
       const size_t lds_tw = (size_t)TR_CIG_STAGE * 4 + (rows_lds ? (size_t)wcap * 8 : 0);
       if (c->trflags_bytes < (uint64_t)blocks * flags_cap) { if ((rc = dev_alloc(c, &c->d_trflags, (size_t)blocks * flags_cap))) return rc; c->trflags_bytes = (uint64_t)blocks * flags_cap; }

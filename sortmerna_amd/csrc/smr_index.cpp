@@ -1136,6 +1136,17 @@ void par_copy(void* dst, const void* src, size_t n, uint32_t threads) {
     th.emplace_back([&] { for (size_t c; (c = next.fetch_add(1)) < nch;) memcpy((char*)dst + c * CH, (const char*)src + c * CH, std::min(CH, n - c * CH)); });
   for (auto& x : th) x.join();
 }
+// f(first, last) over [0, n) in chunks, by `threads` threads
+template <class F> void par_for(size_t n, uint32_t threads, F f) {
+  const size_t CH = (size_t)1 << 20;
+  const size_t nch = (n + CH - 1) / CH;
+  if (nch <= 1) { if (n) f((size_t)0, n); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (uint32_t t = 0; t < std::min<size_t>(threads, nch); t++)
+    th.emplace_back([&] { for (size_t c; (c = next.fetch_add(1)) < nch;) f(c * CH, std::min(n, (c + 1) * CH)); });
+  for (auto& x : th) x.join();
+}
 }  // namespace
 
 extern "C" int smr_index_save(const smr_index* ix, const char* path, uint64_t stamp, char* err, size_t errcap) {
@@ -1154,10 +1165,12 @@ extern "C" int smr_index_save(const smr_index* ix, const char* path, uint64_t st
   uint64_t o = FLAT_ALIGN;
   for (int q = 0; q < 9; q++) { H.off[q] = o; o = (o + bytes[q] + FLAT_ALIGN - 1) & ~(FLAT_ALIGN - 1); }
   H.total_bytes = o;
-  const std::string tmp = std::string(path) + ".tmp";
+  // (a name of this process's own: two processes saving the same part must not write into each other's file; the blocks are allocated before
+  // the mapping is written -- a full disk is an error return here, not a SIGBUS in par_copy)
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
   int fd = open(tmp.c_str(), O_CREAT | O_TRUNC | O_RDWR, 0644);
   if (fd < 0) { set_err(err, errcap, "smr_index_save: cannot create " + tmp); return SMR_ERR_IO; }
-  bool ok = ftruncate(fd, (off_t)o) == 0;
+  bool ok = posix_fallocate(fd, 0, (off_t)o) == 0;
   void* m = ok ? mmap(nullptr, o, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
   ok = ok && m != MAP_FAILED;
   if (ok) {
@@ -1187,7 +1200,14 @@ extern "C" int smr_index_load_flat(const char* path, uint64_t stamp, smr_index**
   FlatHeader H; memcpy(&H, m, sizeof H);
   const uint64_t bytes[9] = {H.n_lookup * sizeof(Lookup), H.n_trie * 4, H.n_pos_off * 4, H.n_pos_arr * 4, H.n_ref_seq, H.n_ref_off * 8, H.n_lkc * 4, H.n_parts_stats * sizeof(PartStats), H.n_sq_bytes};
   bool ok = memcmp(H.magic, "SMRFLAT1", 8) == 0 && H.version == 1 && H.total_bytes == n && H.lnwin >= 8 && H.lnwin <= 20 && H.n_lookup == (1ull << H.lnwin);
+  {
+    // (element counts first: a count like 2^62 + k wraps to a small byte count, passes the bounds test below and throws in resize)
+    const uint64_t cnt[9] = {H.n_lookup, H.n_trie, H.n_pos_off, H.n_pos_arr, H.n_ref_seq, H.n_ref_off, H.n_lkc, H.n_parts_stats, H.n_sq_bytes};
+    const uint64_t esz[9] = {sizeof(Lookup), 4, 4, 4, 1, 8, 4, sizeof(PartStats), 1};
+    for (int q = 0; q < 9 && ok; q++) ok = cnt[q] <= n / esz[q];
+  }
   for (int q = 0; q < 9 && ok; q++) ok = H.off[q] % FLAT_ALIGN == 0 && H.off[q] <= n && bytes[q] <= n - H.off[q];
+  ok = ok && H.n_lkc == H.n_lookup && H.n_pos_off >= 1 && H.n_ref_off >= 1;
   if (!ok) { set_err(err, errcap, std::string(path) + ": damaged or foreign flat index"); return SMR_ERR_IO; }
   if (H.stamp != stamp) { set_err(err, errcap, std::string(path) + ": the flat index was written for other reference files (stamp)"); return SMR_ERR_STATE; }
   (void)madvise(m, n, MADV_WILLNEED);
@@ -1198,12 +1218,17 @@ extern "C" int smr_index_load_flat(const char* path, uint64_t stamp, smr_index**
   const char* base = (const char*)m;
   try {
     // the arrays are sized side by side (a vector zero-fills what it is resized to: one thread per array, 2 MB pages), then filled by all cores
+    // (an exception thrown inside a thread would end the process: every lambda reports through `failed` instead)
     std::vector<std::thread> th;
-    th.emplace_back([&] { reserve_huge(ix->trie, H.n_trie); ix->trie.resize(H.n_trie); });
-    th.emplace_back([&] { reserve_huge(ix->pos_arr, H.n_pos_arr); ix->pos_arr.resize(H.n_pos_arr); });
-    th.emplace_back([&] { reserve_huge(ix->pos_off, H.n_pos_off); ix->pos_off.resize(H.n_pos_off); });
-    th.emplace_back([&] { reserve_huge(ix->ref_seq, H.n_ref_seq); ix->ref_seq.resize(H.n_ref_seq); ix->ref_off.resize(H.n_ref_off); ix->lookup.resize(H.n_lookup); ix->lkc.resize(H.n_lkc); ix->parts.resize(H.n_parts_stats); });
+    std::atomic<bool> failed{false};
+#define SIZED(...) [&] { try { __VA_ARGS__ } catch (...) { failed = true; } }
+    th.emplace_back(SIZED(reserve_huge(ix->trie, H.n_trie); ix->trie.resize(H.n_trie);));
+    th.emplace_back(SIZED(reserve_huge(ix->pos_arr, H.n_pos_arr); ix->pos_arr.resize(H.n_pos_arr);));
+    th.emplace_back(SIZED(reserve_huge(ix->pos_off, H.n_pos_off); ix->pos_off.resize(H.n_pos_off);));
+    th.emplace_back(SIZED(reserve_huge(ix->ref_seq, H.n_ref_seq); ix->ref_seq.resize(H.n_ref_seq); ix->ref_off.resize(H.n_ref_off); ix->lookup.resize(H.n_lookup); ix->lkc.resize(H.n_lkc); ix->parts.resize(H.n_parts_stats);));
+#undef SIZED
     for (auto& x : th) x.join();
+    if (failed) { set_err(err, errcap, std::string(path) + ": the arrays of the flat index could not be sized (out of memory?)"); return SMR_ERR_IO; }
   } catch (const std::exception& e) { set_err(err, errcap, std::string("smr_index_load_flat: ") + e.what()); return SMR_ERR_IO; }
   tm.lap("load flat: arrays sized");
   const uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
@@ -1220,6 +1245,17 @@ extern "C" int smr_index_load_flat(const char* path, uint64_t stamp, smr_index**
   // what the other loaders guarantee, checked here too: offsets inside the arrays
   if (ix->pos_off.empty() || ix->pos_off.back() * 2ull != ix->pos_arr.size() || ix->ref_off.empty() || ix->ref_off.back() != ix->ref_seq.size()) {
     set_err(err, errcap, std::string(path) + ": inconsistent flat index"); return SMR_ERR_IO;
+  }
+  {
+    // (no checksum in the file: the offsets the kernels follow are range-checked instead -- monotone position and reference offsets, every
+    // mini-trie inside the arena; a damaged file with a valid header must not reach the device)
+    std::atomic<bool> bad{false};
+    const uint64_t ntrie = ix->trie.size();
+    par_for(ix->pos_off.size() - 1, threads, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) if (ix->pos_off[i] > ix->pos_off[i + 1]) { bad = true; return; } });
+    par_for(ix->ref_off.size() - 1, threads, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) if (ix->ref_off[i] > ix->ref_off[i + 1]) { bad = true; return; } });
+    par_for(ix->lookup.size(), threads, [&](size_t a, size_t b) {
+      for (size_t i = a; i < b; i++) { const Lookup& l = ix->lookup[i]; if ((l.wordsF && (uint64_t)l.rootF + l.wordsF > ntrie) || (l.wordsR && (uint64_t)l.rootR + l.wordsR > ntrie)) { bad = true; return; } } });
+    if (bad) { set_err(err, errcap, std::string(path) + ": offsets of the flat index point outside its arrays"); return SMR_ERR_IO; }
   }
   tm.lap("load flat: arrays copied");
   *out = ix.release();
