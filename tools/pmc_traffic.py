@@ -26,7 +26,7 @@ SEED_SOURCES = ["smr_seed.hpp", "smr_seed_pg.hpp", "smr_ibuild.hpp", "smr_trie_l
 FAMILY = [("k_seed_keys", "k_seed_keys"), ("k_seed_emap", "k_seed_keys"), ("k_seed_wbin", "k_seed_split"), ("k_seed_cscan", "k_seed_split"), ("k_seed_colscan", "k_seed_split"), ("k_seed_split", "k_seed_split"),
           ("k_seed_bins", "k_seed_bins"), ("k_seed_pg<0>", "k_seed_pg<0>"), ("k_seed_search<0>", "k_seed_pg<0>"), ("k_seed_pg<1>", "k_seed_pg<1>"),
           ("k_seed_search<1>", "k_seed_pg<1>"), ("k_seed_finish", "k_seed_finish"), ("k_cand", "k_cand"), ("k_chain", "k_chain"), ("k_begins", "k_begins"),
-          ("k_trace", "k_trace")]
+          ("k_trace", "k_trace"), ("k_walk", "k_walk"), ("k_sw16", "k_sw16"), ("k_wnext", "k_wnext"), ("k_wlist", "k_wnext")]      # (round 5: the candidate walk in rounds, smr_walk.hpp)
 
 
 def kernel_src_sha():
