@@ -191,6 +191,11 @@ int smr_index_upload(smr_ctx*, const smr_index*, int slot);
  * it replaces a host pass over every mini-trie, indexdb.cpp's in-memory tries being what both start from) against the host transform of the
  * same index, word for word.  SMR_PG_HOST=1 makes smr_index_upload use the host transform instead. */
 int smr_index_check_device(smr_ctx*, int slot, smr_index*);
+/* Test seams of the roofline numerator's audit (tests/test_gpu_parity.py::test_pigeonhole_search_bytes_equal_a_host_recount): the pigeonhole
+ * layout of a host index as the host transform builds it, and the sorted tuples of the context's last seed-stage launch with what decodes them
+ * (meta = {tuples, forward tuples, coarse bins, fine key bits, char bits, forward keys, candidate records per wave, waves handed to the DFS kernel}). */
+int smr_index_pigeonhole(smr_index*, const uint32_t** pg, uint64_t* pg_words, const uint32_t** root3, uint64_t* root3_words, char* err, size_t errcap);
+int smr_seed_tuples_fetch(smr_ctx*, uint64_t* tuples, uint64_t cap_tuples, uint32_t* cbase, uint32_t cap_cbase, uint32_t meta[8]);
 int smr_index_unload(smr_ctx*, int slot);
 
 /* Several read batches (0..15) can be resident at once, so the host can upload batch k+1 while batch k is being

@@ -4,4 +4,4 @@ The product is libsmr_hip.so (hand-written HIP kernels behind the C ABI of inclu
 its thin host-side mirror of the reference driver (processor.cpp:align()).  There is no CPU fallback: importing
 the engine without hipcc-built code or without a GPU raises.
 """
-from .engine import Engine, Index, Reads, SmrError, align, align_resident, default_params, minimal_score  # noqa: F401
+from .engine import Engine, Index, Reads, SmrError, align, align_resident, default_params, minimal_score, pigeonhole_layout  # noqa: F401

@@ -61,7 +61,7 @@ EXPORTS = [
     "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_save", "smr_index_load_flat", "smr_index_selfcheck", "smr_index_free",
     "smr_index_get_info", "smr_minimal_score", "smr_minimal_score_split", "smr_refstats_corrected_split", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free", "smr_reads_slice",
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_device_count", "smr_destroy",
-    "smr_last_error", "smr_index_upload", "smr_index_check_device", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
+    "smr_last_error", "smr_index_upload", "smr_index_check_device", "smr_index_pigeonhole", "smr_seed_tuples_fetch", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record", "smr_result_record_batch", "smr_counters_accumulate",
     "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_sw_selfcheck", "smr_sw_mode", "smr_ssw_batch", "smr_cigar_batch", "smr_prof_reset", "smr_prof_get", "smr_prof_kernels", "smr_refstats_corrected", "smr_report_open",
     "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_add_pair", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
@@ -140,6 +140,10 @@ def bind(L):
     L.smr_index_upload.argtypes = [vp, vp, i32]
     L.smr_index_check_device.restype = i32
     L.smr_index_check_device.argtypes = [vp, i32, vp]
+    L.smr_index_pigeonhole.restype = i32
+    L.smr_index_pigeonhole.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(u64), cp, C.c_size_t]
+    L.smr_seed_tuples_fetch.restype = i32
+    L.smr_seed_tuples_fetch.argtypes = [vp, vp, u64, vp, u32, C.POINTER(u32)]
     L.smr_index_unload.restype = i32
     L.smr_index_unload.argtypes = [vp, i32]
     L.smr_batch_select.restype = i32

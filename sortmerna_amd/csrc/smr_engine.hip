@@ -1670,6 +1670,22 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
   return SMR_ERR_CAPACITY;
 }
 
+// Test seam (the roofline numerator's audit, tests/test_gpu_parity.py): the sorted tuples of the LAST seed-stage launch of this context -- what
+// k_seed_pg searched -- and what it takes to decode them: meta = {tuples, forward tuples, coarse bins nc, fine bits fb, char bits cb, nkh,
+// candidate records per wave}, cbase[nc + 1].
+extern "C" int smr_seed_tuples_fetch(smr_ctx* c, uint64_t* tuples, uint64_t cap_tuples, uint32_t* cbase, uint32_t cap_cbase, uint32_t meta[8]) {
+  if (!c || !meta) return SMR_ERR_ARG;
+  if (!c->sb.srt || !c->sb.sn) { set_err(c, "no seed stage has run"); return SMR_ERR_STATE; }
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t sn[SN_COUNT];
+  HIPCHK(c, hipMemcpy(sn, c->sb.sn, sizeof sn, hipMemcpyDeviceToHost));
+  const uint32_t nt = (uint32_t)std::min<uint64_t>(sn[SN_TUPLES], 2 * c->sb_slots);      // (cap_tuples is a per-launch field of launch_seed's copy; the arrays hold 2 x sb_slots)
+  meta[0] = nt; meta[1] = std::min(sn[SN_FWD], nt); meta[2] = c->sb.nc; meta[3] = c->sb.fb; meta[4] = c->sb.cb; meta[5] = c->sb.nkh; meta[6] = c->ccap; meta[7] = sn[SN_REDO];
+  if (tuples) { if (cap_tuples < nt) return SMR_ERR_CAPACITY; if (nt) HIPCHK(c, hipMemcpy(tuples, c->sb.srt, (size_t)nt * sizeof(SeedTup), hipMemcpyDeviceToHost)); }
+  if (cbase) { if (cap_cbase < c->sb.nc + 1u) return SMR_ERR_CAPACITY; HIPCHK(c, hipMemcpy(cbase, c->sb.cbase, (size_t)(c->sb.nc + 1u) * 4, hipMemcpyDeviceToHost)); }
+  return SMR_OK;
+}
+
 extern "C" int smr_seed_hits_fetch(smr_ctx* c, uint32_t* triples, uint64_t cap_triples, uint64_t* n_out) {
   if (!c || !n_out) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));

@@ -576,6 +576,16 @@ extern "C" uint32_t smr_minimal_score(double lambda, double K, const double bg[4
   return smr_minimal_score_split(lambda, K, bg, full_ref, numseq, all_reads_count, all_reads_len, evalue, 1);
 }
 
+// Test seam: the pigeonhole layout of a host index as the HOST transform builds it (smr_build_pigeonhole; built on first use) -- the arena
+// and the block table k_seed_pg reads (smr_host.hpp).  The pointers stay valid as long as the index.
+extern "C" int smr_index_pigeonhole(smr_index* ix, const uint32_t** pg, uint64_t* pg_words, const uint32_t** root3, uint64_t* root3_words, char* err, size_t errcap) {
+  if (!ix || !pg || !pg_words || !root3 || !root3_words) { set_err(err, errcap, "smr_index_pigeonhole: null argument"); return SMR_ERR_ARG; }
+  std::string why;
+  if (!smr_build_pigeonhole(*ix, 0, why)) { set_err(err, errcap, why); return SMR_ERR_CAPACITY; }
+  *pg = ix->pg.data(); *pg_words = ix->pg.size(); *root3 = ix->root3.data(); *root3_words = ix->root3.size();
+  return SMR_OK;
+}
+
 // =================================================================================================
 // Our own builder.
 // =================================================================================================

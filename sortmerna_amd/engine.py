@@ -219,6 +219,18 @@ def minimal_score(lam, K, info, all_reads_count, all_reads_len, evalue=1.0, full
     return capi.load().smr_minimal_score_split(lam, K, info.bg, info.full_len, info.numseq, all_reads_count, all_reads_len, evalue, full_read_scale)
 
 
+def pigeonhole_layout(index):
+    """(pg uint32[], root3 uint32[]) of a host index as the host transform builds it (smr_index_pigeonhole: a test seam; views into the index)"""
+    L = capi.load()
+    pg, r3 = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)()
+    npg, nr3 = C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(512)
+    rc = L.smr_index_pigeonhole(index.h, C.byref(pg), C.byref(npg), C.byref(r3), C.byref(nr3), err, 512)
+    if rc != 0:
+        raise SmrError("smr_index_pigeonhole: %s (rc=%d)" % (err.value.decode(), rc))
+    return np.ctypeslib.as_array(pg, shape=(npg.value,)), np.ctypeslib.as_array(r3, shape=(nr3.value,))
+
+
 class Engine:
     """One GPU.  Fails loudly when no HIP device / library is available (no CPU fallback)."""
 
@@ -363,6 +375,15 @@ class Engine:
         arr = np.zeros((max(n.value, 1), 3), dtype=np.uint32)
         self._chk(self.L.smr_seed_hits_fetch(self.h, arr.ctypes.data, n.value, C.byref(n)), "smr_seed_hits_fetch")
         return arr[: n.value]
+
+    def seed_tuples(self):
+        """(sorted tuples uint64[n], cbase uint32[nc + 1], meta dict) of the last seed-stage launch (smr_seed_tuples_fetch: a test seam)"""
+        meta = (C.c_uint32 * 8)()
+        self._chk(self.L.smr_seed_tuples_fetch(self.h, None, 0, None, 0, meta), "smr_seed_tuples_fetch")
+        tup = np.zeros(max(meta[0], 1), dtype=np.uint64)
+        cbase = np.zeros(meta[2] + 1, dtype=np.uint32)
+        self._chk(self.L.smr_seed_tuples_fetch(self.h, tup.ctypes.data, len(tup), cbase.ctypes.data, len(cbase), meta), "smr_seed_tuples_fetch")
+        return tup[: meta[0]], cbase, dict(n=meta[0], n_fwd=meta[1], nc=meta[2], fb=meta[3], cb=meta[4], nkh=meta[5], ccap=meta[6], redo=meta[7])
 
     def prof_reset(self):
         self._chk(self.L.smr_prof_reset(self.h), "smr_prof_reset")

@@ -434,6 +434,137 @@ def test_seed_work_counters_match_oracle(wl):
         e.close()
 
 
+def _closed_form_lev1(P, T, pw):
+    """smr_seed.hpp::lev1_entry on Python ints -> (accepted, zero-error); proven equal to the reference's tables in tests/test_lev_closed_form.py"""
+    eq0 = [((P >> (2 * i)) & 3) == ((T >> (2 * i)) & 3) for i in range(pw)]
+    eq1 = [((P >> (2 * i)) & 3) == ((T >> (2 * (i + 1))) & 3) for i in range(pw)]
+    eq2 = [((P >> (2 * (i + 1))) & 3) == ((T >> (2 * i)) & 3) for i in range(pw - 1)]
+
+    def lead(v):
+        n = 0
+        while n < len(v) and v[n]:
+            n += 1
+        return n
+
+    a, s0, s1, s2 = lead(eq0), lead(eq0[::-1]), lead(eq1[::-1]), lead(eq2[::-1])
+    return (a + s2 >= pw - 1) or (a + s0 >= pw - 1) or (a + s1 >= pw), a >= pw
+
+
+def _pg_key(T, frm, cnt):
+    k = 0
+    for q in range(cnt):
+        k = (k << 2) | ((T >> (2 * (frm + q))) & 3)
+    return k
+
+
+def _host_recount_of_the_search(pg, root3, tuples, cbase, meta, direction, zero_slots, pw, full=False):
+    """What k_seed_pg<direction> counts as its algorithmic HBM bytes (smr_seed_pg.hpp, C_B_PG0 / C_B_PG1), recomputed on the host from the
+    pigeonhole layout of the HOST transform and the launch's sorted tuples: per tuple 8 B + its block-table entry 8 B (+ 1 B: the window's
+    group bit, reverse); per search with directories 8 directory words; 4 B per string inside its four exact-key ranges; 8 B per accepted
+    {rank, id}; the segment written (4 B per word) + 4 B for the window slot pointing to it; 2 B per wave chunk (its coarse bin).
+    -> (bytes, slots whose forward search ended with a 0-error match)"""
+    h = pw // 2
+    n_fwd, n_all, fb, cb, nkh = meta["n_fwd"], meta["n"], meta["fb"], meta["cb"], meta["nkh"]
+    lo, hi = (0, n_fwd) if direction == 0 else (n_fwd, n_all)
+    chunks = ((hi + 63) >> 6) - (lo >> 6) if hi > lo or direction == 0 else 0
+    if direction == 0:
+        chunks = (n_fwd + 63) >> 6
+    else:
+        chunks = ((n_all + 63) >> 6) - (n_fwd >> 6)
+    total = 2 * chunks + (hi - lo) * (8 + 8 + direction)
+    zeros = set()
+    import bisect
+    cb_list = [int(x) for x in cbase]
+    for i in range(lo, hi):
+        t = int(tuples[i])
+        slot, chars = t & 0xFFFFFFFF, (t >> 32) & ((1 << cb) - 1)
+        c = bisect.bisect_right(cb_list, i) - 1                     # the coarse bin tuple i lies in (empty bins begin where the next one does)
+        key = (c << fb) | (t >> (32 + cb))
+        if direction == 1 and slot in zero_slots:
+            continue                                               # no reverse search after a 0-error forward match (paralleltraversal.cpp:188)
+        e = 2 * (2 * (key - (nkh if direction else 0)) + direction)
+        off4, metaw = int(root3[e]), int(root3[e + 1])
+        if off4 == 0xFFFFFFFF:
+            continue
+        n, cA, cB = metaw & 0xFFFFFF, (metaw >> 24) & 15, metaw >> 28
+        blk = off4 * 4
+        P = chars
+        ranges = []                                                # (which key, first string in TA / TB numbering, count)
+        if cA == 0:
+            strings = blk
+            ranges.append((0, 0, n))
+        else:
+            total += 32
+            nA, nB = (1 << (2 * cA)) + 1, (1 << (2 * cB)) + 1
+            dirA, dirB = blk, blk + nA
+            strings = blk + nA + nB
+            kA, kb0, kb1 = _pg_key(P, 0, cA), _pg_key(P, h, cB), _pg_key(P, h - 1, cB)
+            if cB == pw - h:
+                lo2 = 4 * _pg_key(P, h + 1, cB - 1); hi2 = lo2 + 4
+            else:
+                lo2 = _pg_key(P, h + 1, cB); hi2 = lo2 + 1
+            ranges.append((0, int(pg[dirA + kA]), int(pg[dirA + kA + 1]) - int(pg[dirA + kA])))
+            ranges.append((1, n + int(pg[dirB + kb0]), int(pg[dirB + kb0 + 1]) - int(pg[dirB + kb0])))
+            if kb1 != kb0:
+                ranges.append((2, n + int(pg[dirB + kb1]), int(pg[dirB + kb1 + 1]) - int(pg[dirB + kb1])))
+            ranges.append((3, n + int(pg[dirB + lo2]), int(pg[dirB + hi2]) - int(pg[dirB + lo2])))
+        mA, mB = (1 << (2 * cA)) - 1, (1 << (2 * cB)) - 1
+        cands = []
+        for w, u0, cnt in ranges:
+            total += 4 * cnt
+            for u in range(u0, u0 + cnt):
+                T = int(pg[strings + u])
+                tb = (T >> (2 * h)) & mB
+                dup = (w != 0 and ((T ^ P) & mA) == 0) or (w == 3 and (tb == ((P >> (2 * h)) & mB) or tb == ((P >> (2 * h - 2)) & mB)))
+                if dup:
+                    continue
+                acc, zero = _closed_form_lev1(P, T, pw)
+                if acc:
+                    ri = strings + (2 if cA else 1) * n + 2 * u
+                    cands.append((int(pg[ri]), int(pg[ri + 1]), zero and not full))
+        total += 8 * len(cands)
+        hl, zero_end = [], False
+        for rank, idc, cond in sorted(cands):
+            present = idc in hl
+            if direction == 0 and cond and not present:
+                hl, zero_end = [idc], True
+                break
+            if not present:
+                hl.append(idc)
+        if hl:
+            total += 4 * (1 + len(hl)) + 4
+        if zero_end:
+            zeros.add(slot)
+    return total, zeros
+
+
+@pytest.mark.parametrize("strand,pass_", [(0, 0), (1, 2)])
+def test_pigeonhole_search_bytes_equal_a_host_recount(wl, strand, pass_):
+    """The roofline numerator of the dominant seed kernel is counted by the kernel itself (C_B_PG0 / C_B_PG1).  Here the same quantity is
+    recomputed on the HOST -- from the pigeonhole layout the host transform builds (smr_build_pigeonhole) and the launch's sorted tuples, walking
+    the four exact-key ranges of every search, the closed-form automaton, the duplicate rule and the reference's list rules in Python -- and
+    must equal the device's counters exactly, for the forward and for the reverse launch."""
+    e = smr.Engine(0)
+    try:
+        e.upload_reads(wl.reads, 1)
+        e.upload_index(wl.parts[0], 0)
+        p = smr.default_params(minimal_score=wl.minimal_score)
+        pg, root3 = smr.pigeonhole_layout(wl.parts[0])
+        e.reset_state()
+        e.prof_reset()
+        e.seed_scan(0, p, strand, pass_)
+        tuples, cbase, meta = e.seed_tuples()
+        assert meta["redo"] == 0 and meta["n"] > 1000 and 0 < meta["n_fwd"] < meta["n"]
+        kp = e.prof_kernels()
+        exp0, zeros = _host_recount_of_the_search(pg, root3, tuples, cbase, meta, 0, set(), 9)
+        exp1, _ = _host_recount_of_the_search(pg, root3, tuples, cbase, meta, 1, zeros, 9)
+        assert len(zeros) > 10                                    # the workload has exact seed matches: the reverse launch really skips searches
+        assert int(kp["k_seed_pg<0>"]["bytes"]) == exp0, (int(kp["k_seed_pg<0>"]["bytes"]), exp0)
+        assert int(kp["k_seed_pg<1>"]["bytes"]) == exp1, (int(kp["k_seed_pg<1>"]["bytes"]), exp1)
+    finally:
+        e.close()
+
+
 def test_very_long_reads(engine, tmp_path):
     """8-12.5 kb reads (BASELINE config 5 is 5 kb PacBio; this is beyond it): k_chain needs more than 64 KB of dynamic LDS per
     workgroup (hipFuncSetAttribute), the packed SW kernel runs 512-row strips up to ~8 kb and the 32-bit kernel beyond, the
