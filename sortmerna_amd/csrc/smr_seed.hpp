@@ -805,41 +805,8 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
   if (threadIdx.x < 5) s_st[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
-  bool act = false;                                        // the read is searched in this pass; p_*: what its first phase (windows with segments, their lengths) found
-  uint32_t p_upper = 0, p_seeds = 0, p_numwin = 0, p_stride = 0, p_slot0 = 0;
-  RWork w;
-  // the windows' bits, 32 at a time: a read's windows are consecutive bits of fbits[0] / fbits[1]
-  auto bits32 = [&](int d, uint32_t b0) -> uint32_t {
-    const uint32_t i = b0 >> 5, s = b0 & 31u;
-    const uint32_t lo = sb.fbits[d][i], hi = sb.fbits[d][i + 1];
-    return s ? (lo >> s) | (hi << (32u - s)) : lo;
-  };
-  // the merged list of window k (segments sf / sr, NONE = none) appended at pool[o...] as (id, win_pos) pairs when o != NONE; returns its length
-  auto merge = [&](uint32_t sf, uint32_t sr, uint32_t win_pos, uint32_t o) -> uint32_t {
-    uint32_t n = 0;
-    const bool fzero = sf != NONE && (sf & SEED_ZERO_BIT);
-    const uint32_t of = sf & ~SEED_ZERO_BIT, orv = sr & ~SEED_ZERO_BIT;
-    const uint32_t hr = sr != NONE ? pool[orv] : 0u;
-    const uint32_t nf = sf != NONE ? (pool[of] & 0xFFFFu) : 0u, nr = hr & 0xFFFFu;
-    if (sr != NONE && (hr & SEED_SEG_MERGED) && !fzero) {
-      for (uint32_t q = 0; q < nr; q++) { if (o != NONE) { pool[o + 2 * n] = pool[orv + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
-      return n;
-    }
-    for (uint32_t q = 0; q < nf; q++) { if (o != NONE) { pool[o + 2 * n] = pool[of + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
-    if (fzero || sr == NONE) return n;
-    for (uint32_t q = 0; q < nr; q++) {
-      const uint32_t c = pool[orv + 1 + q], id = c & ~SEED_CAND_COND;
-      bool present = false;
-      for (uint32_t f = 0; f < nf; f++) if (pool[of + 1 + f] == id) { present = true; break; }
-      if (present) continue;
-      if (c & SEED_CAND_COND) { if (o != NONE) { pool[o] = id; pool[o + 1] = win_pos; } return 1u; }
-      if (o != NONE) { pool[o + 2 * n] = id; pool[o + 2 * n + 1] = win_pos; }
-      n++;
-    }
-    return n;
-  };
   if (r < rd.n) {
-    w = rw[r];
+    RWork w = rw[r];
     const uint32_t len = rd.len[r];                        // (asked for with the state, not after it)
     moved = sizeof(RWork);
     kin = sizeof(RWork) + 12u;                             // k_seed_keys looks at every read's state, length and record offset ...
@@ -849,6 +816,36 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       const uint32_t slot0 = r * sb.maxwin;
       uint32_t seeds = 0, upper = 0, rlook = 0, nsearched = 0;
       uint32_t rem0 = 0, rem1 = 0;                           // (k * stride) % skip[0], % skip[1], kept by addition
+      // the windows' bits, 32 at a time: a read's windows are consecutive bits of fbits[0] / fbits[1]
+      auto bits32 = [&](int d, uint32_t b0) -> uint32_t {
+        const uint32_t i = b0 >> 5, s = b0 & 31u;
+        const uint32_t lo = sb.fbits[d][i], hi = sb.fbits[d][i + 1];
+        return s ? (lo >> s) | (hi << (32u - s)) : lo;
+      };
+      // the merged list of window k (segments sf / sr, NONE = none) appended at pool[o...] as (id, win_pos) pairs when o != NONE; returns its length
+      auto merge = [&](uint32_t sf, uint32_t sr, uint32_t win_pos, uint32_t o) -> uint32_t {
+        uint32_t n = 0;
+        const bool fzero = sf != NONE && (sf & SEED_ZERO_BIT);
+        const uint32_t of = sf & ~SEED_ZERO_BIT, orv = sr & ~SEED_ZERO_BIT;
+        const uint32_t hr = sr != NONE ? pool[orv] : 0u;
+        const uint32_t nf = sf != NONE ? (pool[of] & 0xFFFFu) : 0u, nr = hr & 0xFFFFu;
+        if (sr != NONE && (hr & SEED_SEG_MERGED) && !fzero) {
+          for (uint32_t q = 0; q < nr; q++) { if (o != NONE) { pool[o + 2 * n] = pool[orv + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
+          return n;
+        }
+        for (uint32_t q = 0; q < nf; q++) { if (o != NONE) { pool[o + 2 * n] = pool[of + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
+        if (fzero || sr == NONE) return n;
+        for (uint32_t q = 0; q < nr; q++) {
+          const uint32_t c = pool[orv + 1 + q], id = c & ~SEED_CAND_COND;
+          bool present = false;
+          for (uint32_t f = 0; f < nf; f++) if (pool[of + 1 + f] == id) { present = true; break; }
+          if (present) continue;
+          if (c & SEED_CAND_COND) { if (o != NONE) { pool[o] = id; pool[o + 1] = win_pos; } return 1u; }
+          if (o != NONE) { pool[o + 2 * n] = id; pool[o + 2 * n + 1] = win_pos; }
+          n++;
+        }
+        return n;
+      };
       for (uint32_t kb = 0; kb < numwin; kb += 32) {
         const uint32_t nk = min(32u, numwin - kb);
         const uint32_t vm = nk < 32 ? (1u << nk) - 1u : 0xFFFFFFFFu;
@@ -873,40 +870,13 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       }
       looks = rlook;
       kin += 4u * (((len + 15) >> 4) + ((len + 31) >> 5));      // ... and of an active read its packed record
-      p_upper = upper; p_seeds = seeds; p_numwin = numwin; p_stride = stride; p_slot0 = slot0; act = true;
-    }
-  }
-  // Room in the pool for the longest the merged lists of the block's reads can be (blk_cnt is what they are): ONE returning atomic per block.
-  // (Round 4 had one per read with hits: five million per launch on the 64 cursor lines, and atomics on a line retire at 83 per microsecond --
-  // 0.9 of the kernel's 1.27 ms were that queue.)
-  uint32_t base = 0;
-  {
-    __shared__ uint32_t s_wtot[4];
-    __shared__ unsigned long long s_bbase;
-    const uint32_t amt = act ? 2u * p_upper : 0u;
-    uint32_t inc = amt;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, d, 64); if (lane_id() >= d) inc += t; }
-    if (lane_id() == 63) s_wtot[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    const uint32_t wv = threadIdx.x >> 6;
-    uint32_t before = 0, btot = 0;
-    for (uint32_t q = 0; q < 4; q++) { if (q < wv) before += s_wtot[q]; btot += s_wtot[q]; }
-    const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
-    if (threadIdx.x == 0) {
-      unsigned long long old = 0;
-      if (btot) { old = atomicAdd(&ctr[C_PCUR + shard * C_PCUR_STRIDE], (unsigned long long)btot); if (old + btot > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); old = ~0ull; } }
-      s_bbase = old;
-    }
-    __syncthreads();
-    if (s_bbase == ~0ull) { p_upper = 0; p_seeds = 0; }
-    else base = shard * region + (uint32_t)s_bbase + before + inc - amt;
-  }
-  if (r < rd.n) {
-    if (act) {
-      const uint32_t len = rd.len[r];
-      uint32_t upper = p_upper, seeds = p_seeds;
-      const uint32_t numwin = p_numwin, stride = p_stride, slot0 = p_slot0;
-      uint32_t total = 0;
+      uint32_t base = 0, total = 0;
+      if (upper) {                                           // room for the longest the merged lists can be; blk_cnt is what they are
+        const uint32_t shard = blockIdx.x & (C_NSHARD - 1), region = pool_words / C_NSHARD;
+        const unsigned long long old = atomicAdd(&ctr[C_PCUR + shard * C_PCUR_STRIDE], 2ull * upper);
+        if (old + 2ull * upper > region) { atomicAdd(&ctr[C_ERR_POOL], 1ull); upper = 0; seeds = 0; }
+        else base = shard * region + (uint32_t)old;
+      }
       unsigned long long segw = 0;                           // segment words read
       if (upper && seeds <= FIN_KEEP) {
         for (uint32_t i = 0; i < seeds; i++) {

@@ -74,7 +74,7 @@ def test_hot_kernels_use_no_scratch_and_stay_within_their_register_budget():
             assert k["vgpr"] <= max_vgpr, (parts, k)
     # static LDS: only what the source declares.  (A per-read struct indexed with a run-time value is moved to LDS by the compiler -- 48 bytes per
     # thread, 12 KB per block of k_cand and k_seed_finish in round 2 -- and nothing but this number tells.)
-    for parts, max_lds in [(("k_candE",), 64), (("k_seed_keys",), 64), (("k_seed_pgILi",), 64), (("k_seed_finish",), 3 * 8 * 256 * 4 + 64 + 1344)]:      # (+ the block-level pool reservation of round 5 and 5 bytes per thread the compiler keeps there across it)
+    for parts, max_lds in [(("k_candE",), 64), (("k_seed_keys",), 64), (("k_seed_pgILi",), 64), (("k_seed_finish",), 3 * 8 * 256 * 4 + 64)]:
         for k in _find(md, *parts):
             assert k["lds"] <= max_lds, (parts, k)
     # k_chain is built for 3 waves per SIMD (168 VGPRs) and is allowed the spills DESIGN.md 3.2 accounts for
