@@ -75,6 +75,17 @@ ranks8)
 import json,sys
 o=json.loads([l for l in open('$OUT/bench_8ranks_on_one_gpu.json') if l.startswith('{')][-1])
 print('value %.3g reads/s, nranks %s, n_gpus %d, setup %s' % (o['value'], o['config'].get('nranks'), o['n_gpus'], o['config']['setup_s']))" ;;
+counters)
+  ( cd /tmp && timeout 120 rocprofv3 -L > $ROOT/$OUT/counters_list.txt 2>&1 ); grep -iE "^\s*(Name|Counter)|TCC_EA.*(WR|STALL)|TCP_.*STALL|SQ_WAIT_INST|SQ_INSTS_LDS|SQ_INST_CYCLES|LDS_IDX|BARRIER|TCC_.*BUBBLE|WRREQ" $OUT/counters_list.txt | head -80 | cut -c1-200 ;;
+pmcx=*)
+  # pmcx=COUNTER+COUNTER+...  one PMC pass of the given counters on the mini bench, per kernel
+  SET=$(echo "${W#pmcx=}" | tr '+' ' ')
+  ( cd /tmp && MB_STEPS=1 timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmcx -o pmc -- python $ROOT/tools/hw_minibench_r5.py base > $ROOT/$OUT/pmcx.log 2> $ROOT/$OUT/pmcx.err )
+  find $OUT/pmcx -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmcx_$(echo $SET | cut -d' ' -f1).txt 2>&1
+  grep -E "k_walk|k_sw16|k_cand|k_seed" $OUT/pmcx_$(echo $SET | cut -d' ' -f1).txt | cut -c1-420
+  rm -rf $OUT/pmcx ;;
+r8dbg)
+  SMR_WALK_DEBUG=1 timeout 400 python bench.py --workload refs8 --steps 1 --warmup 0 --no-cpu-baseline --resident-batches 1 > $OUT/bench_refs8_dbg.json 2> $OUT/bench_refs8_dbg.err; grep "walk rounds" $OUT/bench_refs8_dbg.err | awk '{print $1,$2,$3,$4,$5,$6,$7,$8,$9,$10,$11,$12,$13,$14,$15,$16,$17,$18,$19,$20,$21,$22,$23,$24}' | head -60 ;;
 c2dbg)
   SMR_WALK_DEBUG=1 timeout 300 python bench.py --workload config2 --steps 1 --warmup 0 --no-cpu-baseline --resident-batches 1 > $OUT/bench_config2_dbg.json 2> $OUT/bench_config2_dbg.err; grep "walk rounds" $OUT/bench_config2_dbg.err | head -8 | cut -c1-300 ;;
 dropin)
