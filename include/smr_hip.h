@@ -26,7 +26,7 @@
  *   reads                 <= 65 535 letters each; reads x windows of the finest pass < 2^31 per batch (150-nt reads: ~47 M; the benches use 8 M)
  *   resident batches      16 per context (smr_batch_select), resident index parts 64 per context (smr_index_upload slot 0..63)
  *   seed length           8..20, even; < 2^31 - 1 distinct seeds (ids) per index part
- *   seed hits             <= 128 distinct 18-mers within one error of ONE seed window (the lane-local hit lists double up to that)
+ *   seed hits             no limit: the lane-local hit lists grow to what a half-seed search can accept at most (31 L/2 - 20 strings, smr_prof.hit_list_cap)
  *   candidate references  <= 49 152 references sharing seeds with ONE read on one strand (the per-block global table of k_chain<EXT>)
  *   alignments per read   max_alignments_per_read given to smr_reads_upload (the reference's -num_alignments, or 256 for "all")
  *   scoring               match <= 127, mismatch >= -127, |score_N| <= 127, gaps <= 255, and 2 * gap_open, 2 * gap_ext >= |mismatch|
@@ -263,6 +263,7 @@ typedef struct {
   uint64_t n_sw_fwd, n_sw_rev, n_sw_cells;     /* ssw_align calls of the sequential walk (forward / reverse passes) and their DP cells */
   uint64_t n_sw_spec, n_sw_spec_used;          /* forward passes scored ahead of the walk in four-problem batches, and how many of them the walk then asked for */
   uint64_t n_seed_redo;                        /* waves (64 searches) of the fast seed kernel whose candidate pool overflowed and that the per-lane DFS kernel searched again */
+  uint64_t hit_list_cap;                       /* entries of the per-search hit lists in use: 4, doubled on demand up to 128, then 31 L/2 - 20 (twice that for the DFS kernel) = what a search can accept at most */
 } smr_prof;
 /* smr_index_build with the per-occurrence work (sorting all (L+1)-mers, ids, position lists, mini-trie layout) done
  * on the device: same arguments (threads does not apply), same smr_index objects, byte-identical index files

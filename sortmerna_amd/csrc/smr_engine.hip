@@ -107,7 +107,7 @@ struct smr_ctx {
   uint32_t walk_assume = getenv("SMR_WALK_ASSUME") ? (uint32_t)atoi(getenv("SMR_WALK_ASSUME")) : 3u;                                 // round 0 predicts "aligns" from this many seeds of the best candidate
   uint2* d_wlist[2] = {nullptr, nullptr}; WState* d_wstate[2] = {nullptr, nullptr}; WTask* d_wtask[2] = {nullptr, nullptr}; uint2* d_wres[2] = {nullptr, nullptr};
   uint32_t* d_wtidx = nullptr; uint32_t* d_wslow = nullptr; unsigned long long* d_wctr = nullptr; size_t walk_cap = 0; uint32_t walk_kcap = 0, walk_rcap = 0;
-  size_t walk_lds_attr = 0;
+  size_t walk_lds_attr = 0, pg_lds_attr = 0, search_lds_attr = 0;
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
@@ -275,6 +275,20 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   return SMR_OK;
 }
 
+// The longest hit list ONE half-seed search can leave: the strings T of pw + 1 chars that lev1_entry (smr_seed.hpp) accepts for a pattern P number
+// at most 31 pw - 20 (104, 135, 166 for pw = 4, 5, 6 over every P; 197 ... 290 for pw = 7 ... 10 on the patterns that reach the maximum and on
+// sampled ones: tests/test_lev_closed_form.py), each at most one id.  k_seed_pg keeps the forward and the reverse search's list apart (that bound
+// each); k_seed_search<1> starts from the forward list (twice the bound).
+#define SEED_HCAP_BOUND(pw) (31u * (pw) - 20u)
+// A search's hit list overflowed: the next size.  4, 8, ... 128, then the bound, then twice the bound, which no search can exceed -- reaching the
+// error below would mean the bound is wrong, not that the data is unusual.  (2 x 290 entries x 64 lanes = 145 KB of the 160 KB of LDS.)
+bool grow_hcap(smr_ctx* c, uint32_t pw) {
+  const uint32_t bound = SEED_HCAP_BOUND(pw);
+  if (c->hcap >= 2 * bound) { set_err(c, "a seed search accepted more strings than the LEV(1) bound allows (internal error)"); return false; }
+  c->hcap = c->hcap < 128 ? c->hcap * 2 : c->hcap < bound ? bound : 2 * bound;
+  return true;
+}
+
 // the seed stage of one (strand, pass): the forward and reverse half-seed searches of all windows (smr_seed.hpp)
 int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   int rc = ensure_seed_bufs(c, P); if (rc) return rc;
@@ -301,8 +315,20 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
   const bool mapped = (sb.nkh / 16) * 4 <= 64 * 1024;
   const size_t lds_keys = (size_t)4 * (((sb.nc + 3u) & ~3u) + (mapped ? sb.nkh / 16 : 0u) + (staged ? SEED_WAVES * (SEED_STAGE_WORDS + 8u) : 0u));
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->hcap, c->ccap) * 4;
+  const uint32_t hcap_pg = std::min<uint32_t>(c->hcap, std::max<uint32_t>(128u, SEED_HCAP_BOUND(P.partialwin)));      // (its lists hold one search's hits)
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(hcap_pg, c->ccap) * 4;
   const size_t lds_pg = lds_pg1 + (getenv("SMR_PG_LDS_PAD") ? (size_t)atoi(getenv("SMR_PG_LDS_PAD")) : 0);      // (the variable: occupancy experiments)
+  // lists of more than 128 hits per search (a crafted neighbourhood: SEED_HCAP_MAX) take more than the default 64 KB of dynamic LDS
+  if (lds_pg > 64 * 1024 && lds_pg > c->pg_lds_attr) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_pg<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pg));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_pg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pg));
+    c->pg_lds_attr = lds_pg;
+  }
+  if (lds > 64 * 1024 && lds > c->search_lds_attr) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_search<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_search<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    c->search_lds_attr = lds;
+  }
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
   const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
@@ -347,10 +373,10 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       ev_mark(c, dir ? KP_PG1 : KP_PG0);
       if (dir == 0) {
-        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
+        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, hcap_pg, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       } else {
-        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->hcap, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
+        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, hcap_pg, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       }
     }
@@ -1198,7 +1224,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if ((rc = read_ctr(c, h))) return rc;
     ev_collect(c);
     bool retry = false;
-    if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { set_err(c, "more than 128 distinct seed hits in one window"); return SMR_ERR_CAPACITY; } }
+    if (h[C_ERR_HITCAP]) { if (!grow_hcap(c, P.partialwin)) return SMR_ERR_CAPACITY; retry = true; }
     if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if (w > 0x7FFFFFF0ull) { set_err(c, "seed-hit pool exceeds 8 GiB"); return SMR_ERR_CAPACITY; }
       if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (h[C_ERR_PAIRS]) {
@@ -1662,7 +1688,7 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
     if ((rc = read_ctr(c, h))) return rc;
     ev_collect(c);
     bool retry = false;
-    if (h[C_ERR_HITCAP]) { c->hcap *= 2; retry = true; if (c->hcap > 128) { set_err(c, "more than 128 distinct seed hits in one window"); return SMR_ERR_CAPACITY; } }
+    if (h[C_ERR_HITCAP]) { if (!grow_hcap(c, P.partialwin)) return SMR_ERR_CAPACITY; retry = true; }
     if (h[C_ERR_POOL]) { uint64_t w = c->pool_words * 2; if ((rc = dev_alloc(c, &c->d_pool, w))) return rc; c->pool_words = w; retry = true; }
     if (!retry) { if (n_hits_out) *n_hits_out = h[C_HIT]; return SMR_OK; }
   }
@@ -1746,7 +1772,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
   o->trace_ms = c->kp_ms[KP_TRACE]; o->trace_launches = c->kp_l[KP_TRACE];
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];
-  o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED]; o->n_seed_redo = h[C_SEED_REDO];
+  o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED]; o->n_seed_redo = h[C_SEED_REDO]; o->hit_list_cap = c->hcap;
   return SMR_OK;
 }
 

@@ -17,22 +17,27 @@ GUMBEL_UNIFORM = (0.618874, 0.343238)
 
 class Workload:
     def __init__(self, tmpdir, db_nt=300_000, n_reads=4000, read_len=150, frac_db=0.4, seed=5, max_mb=3072.0,
-                 n_rate=0.002, family_size=40, lnwin=18, mean_len=1500, db_kw=None):
+                 n_rate=0.002, family_size=40, lnwin=18, mean_len=1500, db_kw=None, db_fasta=None, seqs=None):
+        """db_fasta + seqs: a DB file and reads the test wrote itself (a crafted case) instead of the seeded synthetic ones"""
         self.lnwin = lnwin
         self.dir = tmpdir
-        self.db = os.path.join(tmpdir, "db_%d_%d.fasta" % (db_nt, seed))
-        synth.make_db(self.db, db_nt, seed=seed, family_size=family_size, mean_len=mean_len, **(db_kw or {}))
-        codes, offs = synth.load_db_codes(self.db)
-        self.letters = synth.make_reads(codes, offs, n_reads, read_len=read_len, frac_db=frac_db, seed=seed + 1, n_rate=n_rate)
-        # ragged lengths, a too-short read and an empty read to cover the edge cases
-        self.seqs = [bytes(x).decode() for x in self.letters]
-        rng = np.random.Generator(np.random.PCG64(seed + 2))
-        for i in range(0, n_reads, 17):
-            self.seqs[i] = self.seqs[i][: int(rng.integers(lnwin, read_len))]
-        if n_reads > 10:
-            self.seqs[3] = self.seqs[3][:12]
-            self.seqs[7] = ""
-            self.seqs[9] = self.seqs[9][:lnwin]
+        if db_fasta is not None:
+            self.db = db_fasta
+            self.seqs = list(seqs)
+        else:
+            self.db = os.path.join(tmpdir, "db_%d_%d.fasta" % (db_nt, seed))
+            synth.make_db(self.db, db_nt, seed=seed, family_size=family_size, mean_len=mean_len, **(db_kw or {}))
+            codes, offs = synth.load_db_codes(self.db)
+            self.letters = synth.make_reads(codes, offs, n_reads, read_len=read_len, frac_db=frac_db, seed=seed + 1, n_rate=n_rate)
+            # ragged lengths, a too-short read and an empty read to cover the edge cases
+            self.seqs = [bytes(x).decode() for x in self.letters]
+            rng = np.random.Generator(np.random.PCG64(seed + 2))
+            for i in range(0, n_reads, 17):
+                self.seqs[i] = self.seqs[i][: int(rng.integers(lnwin, read_len))]
+            if n_reads > 10:
+                self.seqs[3] = self.seqs[3][:12]
+                self.seqs[7] = ""
+                self.seqs[9] = self.seqs[9][:lnwin]
         self.parts = smr.Index.build(self.db, lnwin, max_mb, 10000, 0)
         self.prefix = os.path.join(tmpdir, "idx_%d_%d" % (db_nt, seed))
         smr.Index.write_files(self.parts, self.db, self.prefix)

@@ -2,7 +2,9 @@
 against the CPU oracle on the same seeded inputs.  Bar: byte-exact Read::toBinString records (classification,
 hit counts, SW scores, coordinates, CIGARs) and identical Readstats counters."""
 import ctypes as C
+import os
 
+import numpy as np
 import pytest
 
 import sortmerna_amd as smr
@@ -410,6 +412,66 @@ def test_batch_dominated_by_one_sequence(engine, tmp_path):
     _compare(recs_g, recs_o, "hot reads")
     assert ctr_g["num_aligned"] == ctr_o["num_aligned"]
     assert recs_g[500] == recs_g[502] and recs_g[501] == recs_g[503]
+
+
+def _dense_neighbourhood_workload(tmp):
+    """A DB that holds, for ONE 18-mer A+B which it does not contain itself, every string within one error of it that a half-seed search can
+    accept: under the key A the 255 ten-letter continuations lev1_entry accepts for B (all but the four exact ones), and in front of the key B
+    the 255 accepted for A read backwards; each in a sequence of its own with its own random flanks.  Reads: a sequence's flanks around A+B."""
+    pw, acgt = 9, "ACGT"
+    rng = np.random.Generator(np.random.PCG64(2024))
+    A = [(i + 1) & 3 for i in range(pw)]                    # CGTACGTAC: no letter equals a neighbour or a neighbour's neighbour -- the patterns with the most accepted strings
+    B = [(3 * i + 2) & 3 for i in range(pw)]                # GCATGCATG
+
+    def accepted(pat):
+        P = sum(c << (2 * i) for i, c in enumerate(pat))
+        u = np.uint64
+        T = np.arange(4 ** (pw + 1), dtype=np.uint64)
+        m2 = u((1 << (2 * pw)) - 1)
+        x0, x1, x2 = (u(P) ^ T) & m2, (u(P) ^ (T >> u(2))) & m2, ((u(P) >> u(2)) ^ T) & (m2 >> u(2))
+        y = x0 | u(1 << (2 * pw))
+        a2 = np.log2((y & (~y + u(1))).astype(np.float64)).astype(np.uint64) & ~u(1)
+        ok = ((((x0 >> a2) >> u(2)) == 0) | ((x1 >> a2) == 0) | ((x2 >> a2) == 0)) & (x0 != 0)
+        return [[(int(t) >> (2 * i)) & 3 for i in range(pw + 1)] for t in T[ok]]
+
+    def rnd(n):
+        return [int(x) for x in rng.integers(0, 4, n)]
+
+    refs = []
+    for t in accepted(B):
+        refs.append((rnd(36), A + t, rnd(60)))
+    for t in accepted(A[::-1]):
+        refs.append((rnd(35), t[::-1] + B, rnd(60)))
+    assert len(refs) == 2 * 255
+    db = os.path.join(tmp, "dense.fasta")
+    with open(db, "w") as f:
+        for i, (l, m, r) in enumerate(refs):
+            f.write(">dense%d\n%s\n" % (i, "".join(acgt[c] for c in l + m + r)))
+    seqs = []
+    for j in range(0, len(refs), 9):                        # A+B at read position 36 (a window of every pass), flanks of sequence j
+        l, m, r = refs[j]
+        seqs.append("".join(acgt[c] for c in (l[-36:] if len(l) >= 36 else [0] + l) + A + B + r[:60]))
+    seqs += ["".join(acgt[c] for c in rnd(150)) for _ in range(40)]
+    return Workload(tmp, db_fasta=db, seqs=seqs)
+
+
+def test_a_window_with_hundreds_of_hits(engine, tmp_path):
+    """More accepted strings than the 128 entries the lane-local hit lists grow to by doubling (round 4: SMR_ERR_CAPACITY): the lists then get the
+    size no search can exceed (SEED_HCAP_BOUND).  The (read, id, window) triples of every strand and pass and the records equal the oracle's."""
+    w = _dense_neighbourhood_workload(str(tmp_path))
+    L = orc.lib()
+    ix = L.orc_index_load(w.prefix.encode(), 0, 18)
+    ids = (C.c_uint32 * 4096)()
+    v = iseq_for_strand(w.seqs[0], 0)
+    z = C.c_int()
+    assert L.orc_window_hits(ix, v.ctypes.data, 36, 18, 0, 0, ids, 4096, C.byref(z)) > 300      # forward + reverse neighbours of A+B
+    L.orc_index_free(ix)
+    test_seed_scan_matches_oracle(engine, w)
+    recs_o, ctr_o = w.oracle_records()
+    recs_g, ctr_g = w.gpu_records(engine)
+    _compare(recs_g, recs_o, "dense neighbourhood")
+    assert engine.prof().hit_list_cap in (259, 518)          # lists of 128 were too short: the bound of one search (31 * 9 - 20), or of a reverse search of the DFS kernel on top of the forward list
+    assert ctr_g["num_aligned"] == ctr_o["num_aligned"] >= 50
 
 
 def test_seed_work_counters_match_oracle(wl):

@@ -197,3 +197,38 @@ def test_the_four_keys_are_exhaustive_on_a_small_alphabet_of_lengths():
             for T in range(4 ** (pw + 1)):
                 if closed_form(P, T, pw)[0]:
                     assert pigeonhole_reaches(P, T, pw, h, pw - h) and pigeonhole_reaches(P, T, pw, 1, 1), (pw, P, T)
+
+
+def _accepted_per_pattern(Ps, pw):
+    """how many of the 4^(pw+1) strings T lev1_entry accepts for each pattern of Ps (the bit form of smr_seed.hpp, vectorised)"""
+    u = np.uint64
+    T = np.arange(4 ** (pw + 1), dtype=np.uint64)[None, :]
+    P = np.asarray(Ps, dtype=np.uint64)[:, None]
+    m2 = u((1 << (2 * pw)) - 1)
+    m2b = m2 >> u(2)
+    x0, x1, x2 = (P ^ T) & m2, (P ^ (T >> u(2))) & m2, ((P >> u(2)) ^ T) & m2b
+    y = x0 | u(1 << (2 * pw))
+    a2 = np.log2((y & (~y + u(1))).astype(np.float64)).astype(np.uint64) & ~u(1)          # 2 * common prefix length
+    return ((((x0 >> a2) >> u(2)) == 0) | ((x1 >> a2) == 0) | ((x2 >> a2) == 0)).sum(axis=1)
+
+
+@pytest.mark.parametrize("pw", [4, 5, 6, 7, 8, 9, 10])
+def test_a_search_accepts_at_most_31_pw_minus_20_strings(pw):
+    """What bounds a search's hit list (SEED_HCAP_BOUND in smr_engine.hip): every accepted string is one entry of the mini-trie = at most one id.
+    Exhaustive over P for pw <= 6; for the longer seeds the patterns without equal neighbours (they reach the maximum) + random ones."""
+    import os
+    import re
+    from helpers import paths
+    bound = 31 * pw - 20
+    if pw <= 6:
+        c = np.concatenate([_accepted_per_pattern(np.arange(s, min(s + 256, 4 ** pw)), pw) for s in range(0, 4 ** pw, 256)])
+        assert int(c.max()) == bound
+    else:
+        rng = np.random.Generator(np.random.PCG64(pw))
+        pats = [sum(((i + s) & 3) << (2 * i) for i in range(pw)) for s in range(4)]               # ACGTACG... : no char equals a neighbour or a neighbour's neighbour
+        pats += [sum(((i * k) & 3) << (2 * i) for i in range(pw)) for k in (1, 3)]
+        pats += [int(x) for x in rng.integers(0, 4 ** pw, 6 if pw == 10 else 10)]
+        c = np.concatenate([_accepted_per_pattern(pats[i:i + 2], pw) for i in range(0, len(pats), 2)])
+        assert int(c.max()) == bound
+    src = open(os.path.join(paths.REPO, "sortmerna_amd", "csrc", "smr_engine.hip")).read()
+    assert re.search(r"#define SEED_HCAP_BOUND\(pw\) \(31u \* \(pw\) - 20u\)", src)
