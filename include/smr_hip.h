@@ -277,6 +277,10 @@ int smr_index_build_gpu(smr_ctx*, const char* ref_fasta, uint32_t lnwin, double 
  * SMR_SW_PACKED=2 selects its wave_ror variant (the kernel checked is the selected one). */
 int smr_sw_selfcheck(smr_ctx*, uint32_t n_cases, uint32_t seed, uint32_t max_len, uint64_t* n_bad);
 int smr_sw_mode(smr_ctx*, int set_to);
+/* The candidate walk (alignment.cpp:150-508) runs in rounds of walk kernel -> Smith-Waterman over a task list -> next list; the last round scores inside
+ * the walk kernel, so the records never depend on the number.  out[pass] = rounds the next smr_align_part runs for that pass: at most 8 (SMR_WALK_ROUNDS=<n>
+ * fixes it), lowered part by part towards what the previous part needed (an empty round still costs three launches). */
+int smr_walk_rounds(const smr_ctx*, uint32_t out[3]);
 /* The SW kernels at the ssw.h seam: for n independent pairs (read / reference window in the 0..4 alphabet, pair i = bytes [off[i], off[i+1])),
  * what ssw_align(prof, ref, refLen, gapO, gapE, flag = 2, filters, 0, 0) returns without the CIGAR (ssw.h:118-140, ssw.c:834-941):
  * out[5 i ..] = {score1, ref_begin1, ref_end1, read_begin1, read_end1}, begins = -1 when score1 < filters.  mode 0 / 1 / 2 = 32-bit / packed / packed wave_ror kernel. */

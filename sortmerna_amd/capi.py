@@ -63,7 +63,7 @@ EXPORTS = [
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_device_count", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_check_device", "smr_index_pigeonhole", "smr_seed_tuples_fetch", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
     "smr_traceback", "smr_counters", "smr_counters_device", "smr_results_fetch", "smr_result_record", "smr_result_record_batch", "smr_counters_accumulate",
-    "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_sw_selfcheck", "smr_sw_mode", "smr_ssw_batch", "smr_cigar_batch", "smr_prof_reset", "smr_prof_get", "smr_prof_kernels", "smr_refstats_corrected", "smr_report_open",
+    "smr_result_is_hit", "smr_seed_scan", "smr_seed_hits_fetch", "smr_sw_selfcheck", "smr_sw_mode", "smr_walk_rounds", "smr_ssw_batch", "smr_cigar_batch", "smr_prof_reset", "smr_prof_get", "smr_prof_kernels", "smr_refstats_corrected", "smr_report_open",
     "smr_report_set_db", "smr_report_set_part", "smr_report_add", "smr_report_add_pair", "smr_report_set_cmdline", "smr_report_close", "smr_report_last_error",
     "smr_summary_write", "smr_readstats_record", "smr_readstats_key",
 ]
@@ -192,6 +192,8 @@ def bind(L):
     L.smr_cigar_batch.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, u64, vp]
     L.smr_sw_mode.restype = i32
     L.smr_sw_mode.argtypes = [vp, i32]
+    L.smr_walk_rounds.restype = i32
+    L.smr_walk_rounds.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.smr_prof_reset.restype = i32
     L.smr_prof_reset.argtypes = [vp]
     L.smr_prof_get.restype = i32

@@ -108,6 +108,11 @@ struct smr_ctx {
   uint2* d_wlist[2] = {nullptr, nullptr}; WState* d_wstate[2] = {nullptr, nullptr}; WTask* d_wtask[2] = {nullptr, nullptr}; uint2* d_wres[2] = {nullptr, nullptr};
   uint32_t* d_wtidx = nullptr; uint32_t* d_wslow = nullptr; unsigned long long* d_wctr = nullptr; size_t walk_cap = 0; uint32_t walk_kcap = 0, walk_rcap = 0;
   size_t walk_lds_attr = 0, pg_lds_attr = 0, search_lds_attr = 0;
+  // rounds per (strand, pass): without SMR_WALK_ROUNDS the number adapts to what the previous part needed (the last round with more than a few
+  // reads listed + the closing one: an empty round still costs three launches, ~70 us of stream time; 8 -> 4 rounds = 3 % of the bench step)
+  bool walk_rounds_fixed = getenv("SMR_WALK_ROUNDS") != nullptr;
+  uint32_t walk_need[3] = {0, 0, 0};
+  unsigned long long* d_wstat = nullptr; uint32_t wstat_n = 0; int wstat_pass[8] = {}; uint32_t wstat_rm[8] = {};
   int* d_bound = nullptr; size_t bound_cap = 0;                        // strip-boundary rows of the SW kernels (reads of more than one strip), per block
   uint32_t* d_tasks = nullptr; uint64_t tasks_cap = 0;
   uint8_t* d_trflags = nullptr; uint64_t trflags_bytes = 0;            // direction flags of k_trace_wide (one tile per block)
@@ -409,6 +414,32 @@ int ensure_bound(smr_ctx* c, uint32_t blocks, uint32_t rf) {
   return SMR_OK;
 }
 
+__global__ void k_wstat(const unsigned long long* __restrict__ wctr, unsigned long long* __restrict__ out, uint32_t rounds) {
+  if (threadIdx.x < 32) out[threadIdx.x] = threadIdx.x < rounds ? wctr[(size_t)threadIdx.x * WC_STRIDE + WC_NLIST] : 0ull;
+}
+// After a part (the stream is idle): how many rounds its (strand, pass) launches needed -- the last round that listed more reads than the
+// closing round takes in its stride, + that closing round; when the closing round itself was that full, two more next time.  Whatever the
+// number, the closing round ends every listed read's pass: the records do not depend on it (WALK_VARIANTS of the parity tests).
+int adapt_walk_rounds(smr_ctx* c) {
+  if (c->walk_rounds_fixed || !c->wstat_n || !c->d_wstat) return SMR_OK;
+  unsigned long long h[8 * 32];
+  HIPCHK(c, hipMemcpy(h, c->d_wstat, (size_t)c->wstat_n * 32 * 8, hipMemcpyDeviceToHost));
+  const unsigned long long few = (unsigned long long)c->n_cu * 8ull;
+  uint32_t need[3] = {0, 0, 0};
+  for (uint32_t e = 0; e < c->wstat_n; e++) {
+    uint32_t want = 2;
+    for (uint32_t r = 0; r < c->wstat_rm[e]; r++) if (h[e * 32 + r] > few) want = r + 2 + (r + 1 == c->wstat_rm[e] ? 2u : 0u);
+    need[c->wstat_pass[e]] = std::max(need[c->wstat_pass[e]], want);
+  }
+  // more rounds at once; fewer by half the difference per part (parts of one run differ: eight databases, batches of a mixed sample)
+  for (int p = 0; p < 3; p++) if (need[p]) {
+    const uint32_t prev = c->walk_need[p] ? c->walk_need[p] : c->walk_rounds;
+    c->walk_need[p] = std::min(c->walk_rounds, need[p] >= prev ? need[p] : prev - std::max(1u, (prev - need[p]) / 2u));
+  }
+  c->wstat_n = 0;
+  return SMR_OK;
+}
+
 int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int is_last_strand) {
   uint32_t ml, rf, rq; size_t lds;
   chain_lds(c, P, ml, rf, rq, lds);
@@ -434,7 +465,8 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   // the split path takes the marked reads with a record of k_cand whose Smith-Waterman problems fit the packed kernels
   const uint32_t wmq = std::min<uint32_t>(c->b->max_len, WK_MAX_ROWS), wml = (wmq + 15) & ~15u;
   const bool split = c->walk_split && mrec && P.sw_mode >= 1 && sw_pk_fits((int)wmq, (int)rq, P.match, P.mismatch, P.score_N, P.gap_open);
-  const uint32_t RM = c->walk_rounds, WK = c->walk_k;
+  const uint32_t RMX = c->walk_rounds, WK = c->walk_k;         // RMX: what d_wctr is laid out for; RM: the rounds of this launch
+  const uint32_t RM = (!c->walk_rounds_fixed && c->walk_need[pass]) ? std::min(RMX, c->walk_need[pass]) : RMX;
   if (split) {
     const size_t n = c->b->n;
     if (c->walk_cap < n || c->walk_kcap < WK) {
@@ -446,13 +478,13 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       if ((rc = dev_alloc(c, &c->d_wtidx, 2 * n * WK)) || (rc = dev_alloc(c, &c->d_wslow, n))) return rc;
       c->walk_cap = n; c->walk_kcap = WK;
     }
-    if (c->walk_rcap < RM) { int rc = dev_alloc(c, &c->d_wctr, (size_t)(RM + 2) * WC_STRIDE); if (rc) return rc; c->walk_rcap = RM; }
-    HIPCHK(c, hipMemsetAsync(c->d_wctr, 0, (size_t)(RM + 2) * WC_STRIDE * 8, c->stream));
+    if (c->walk_rcap < RMX) { int rc = dev_alloc(c, &c->d_wctr, (size_t)(RMX + 2) * WC_STRIDE); if (rc) return rc; if ((rc = dev_alloc(c, &c->d_wstat, (size_t)8 * 32))) return rc; c->walk_rcap = RMX; }
+    HIPCHK(c, hipMemsetAsync(c->d_wctr, 0, (size_t)(RMX + 2) * WC_STRIDE * 8, c->stream));
     const size_t lds_w = (size_t)wml + rq;
     if (lds_w > 64 * 1024 && lds_w > c->walk_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); c->walk_lds_attr = lds_w; }
   }
   const size_t n_tix = (size_t)c->walk_cap * c->walk_kcap;     // the second half of d_wtidx: the score-only tasks
-  unsigned long long* const n_slow = split ? c->d_wctr + (size_t)(RM + 1) * WC_STRIDE : nullptr;
+  unsigned long long* const n_slow = split ? c->d_wctr + (size_t)(RMX + 1) * WC_STRIDE : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
   hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
@@ -486,11 +518,15 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
       }
 #undef WALK_ARGS
     }
+    if (!c->walk_rounds_fixed && c->wstat_n < 8) {         // the reads listed per round, kept for adapt_walk_rounds
+      hipLaunchKernelGGL(k_wstat, dim3(1), dim3(32), 0, c->stream, (const unsigned long long*)c->d_wctr, c->d_wstat + (size_t)c->wstat_n * 32, RM);
+      c->wstat_pass[c->wstat_n] = pass; c->wstat_rm[c->wstat_n] = RM; c->wstat_n++;
+    }
     if (getenv("SMR_WALK_DEBUG")) {                         // measurement aid: reads listed and tasks left per round, reads left to k_chain
-      std::vector<unsigned long long> h((size_t)(RM + 2) * WC_STRIDE);
+      std::vector<unsigned long long> h((size_t)(RMX + 2) * WC_STRIDE);
       HIPCHK(c, hipMemcpyAsync(h.data(), c->d_wctr, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
-      { const unsigned long long* q = &h[(size_t)(RM + 1) * WC_STRIDE];
+      { const unsigned long long* q = &h[(size_t)(RMX + 1) * WC_STRIDE];
         fprintf(stderr, "libsmr_hip: walk rounds (pass %d): slow %llu (positions <= 64 / 128 / 256 / 512 / more / > 64 hits: %llu %llu %llu %llu %llu %llu);", pass, q[0], q[8], q[9], q[10], q[11], q[12], q[13]); }
       for (uint32_t rnd = 0; rnd < RM; rnd++) fprintf(stderr, " %llu/%llu+%llu", h[(size_t)rnd * WC_STRIDE + WC_NLIST], h[(size_t)rnd * WC_STRIDE + WC_NTASK], h[(size_t)rnd * WC_STRIDE + WC_NTASK2]);
       fprintf(stderr, "\n");
@@ -886,6 +922,13 @@ extern "C" int smr_sw_mode(smr_ctx* c, int set_to) {      // set_to: 0 / 1 = sel
   return c->sw_mode;
 }
 
+// rounds the candidate walk of the next part runs per pass (smr_walk.hpp; adapts to what the previous part needed unless SMR_WALK_ROUNDS fixes it)
+extern "C" int smr_walk_rounds(const smr_ctx* c, uint32_t out[3]) {
+  if (!c || !out) return SMR_ERR_ARG;
+  for (int p = 0; p < 3; p++) out[p] = (!c->walk_rounds_fixed && c->walk_need[p]) ? std::min(c->walk_rounds, c->walk_need[p]) : c->walk_rounds;
+  return SMR_OK;
+}
+
 // =================================================================================================
 extern "C" int smr_device_count(void) {
   int n = 0;
@@ -1208,6 +1251,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   for (int attempt = 0; attempt < 8; attempt++) {
     if ((rc = ensure_chain_scratch(c, di))) return rc;
     const KpSave kp0 = kp_save(c);
+    c->wstat_n = 0;
     // restore counters (retry) and clear the per-part ones (processor.cpp:230 resets num_short per part)
     hipLaunchKernelGGL(k_ctr_begin, dim3(1), dim3(256), 0, c->stream, c->b->d_ctr, (const unsigned long long*)c->d_ctr_snap);
     hipLaunchKernelGGL(k_begin_part, dim3(nb), dim3(tb), 0, c->stream, dreads(c), P, c->b->d_saved, c->b->d_saved_aln, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr);
@@ -1256,6 +1300,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
     if (h[C_ERR_SLOTS]) { set_err(c, "a read produced more alignments than max_alignments_per_read (smr_reads_upload)"); return SMR_ERR_CAPACITY; }
     if (retry) kp_restore(c, kp0);   // timings of a discarded attempt
     if (!retry) {
+      if ((rc = adapt_walk_rounds(c))) return rc;
       // the begin cells of the alignments that are still stored (k_chain records the accepted ones "begin pending"): four reverse passes per wave
       {
         const uint64_t ntot = (uint64_t)c->b->n * c->b->slots;

@@ -273,6 +273,12 @@ class Engine:
         """Smith-Waterman kernel in use: 1 = packed 16-bit (default when the device self-check passes), 0 = 32-bit; set_to 0/1 selects"""
         return self.L.smr_sw_mode(self.h, set_to)
 
+    def walk_rounds(self):
+        """rounds of the candidate walk the next align_part runs, per pass (smr_walk_rounds)"""
+        out = (C.c_uint32 * 3)()
+        self._chk(self.L.smr_walk_rounds(self.h, out), "smr_walk_rounds")
+        return list(out)
+
     def sw_selfcheck(self, n_cases=256, seed=1, max_len=700):
         """packed vs 32-bit Smith-Waterman kernel on n_cases random pairs x 2 scoring schemes, on the device; returns the number of differing cases"""
         bad = C.c_uint64()

@@ -373,6 +373,25 @@ def test_candidate_walk_in_rounds_gives_the_oracle_records(wl, monkeypatch, env,
         e.close()
 
 
+def test_rounds_adapt_from_part_to_part_without_changing_a_record(wl, monkeypatch):
+    """Without SMR_WALK_ROUNDS a context starts with eight rounds per (strand, pass) and lowers the number part by part towards what the previous
+    part needed (its last round with more than a few reads + the closing round): every run over the same reads gives the oracle's records."""
+    monkeypatch.delenv("SMR_WALK_ROUNDS", raising=False)
+    e = smr.Engine(0)
+    try:
+        assert e.walk_rounds() == [8, 8, 8]
+        recs_o, ctr_o = wl.oracle_records()
+        seen = [e.walk_rounds()]
+        for _ in range(5):
+            recs_g, ctr_g = wl.gpu_records(e)
+            _compare(recs_g, recs_o, "rounds %s" % seen[-1])
+            assert ctr_g["num_aligned"] == ctr_o["num_aligned"]
+            seen.append(e.walk_rounds())
+        assert all(a >= b for x, y in zip(seen, seen[1:]) for a, b in zip(x, y)) and max(seen[-1]) <= 4 and min(seen[-1]) >= 2, seen
+    finally:
+        e.close()
+
+
 def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
     """SMR_PG_CAND_CAP=8: most waves of k_seed_pg overflow their candidate pool and are searched again by the DFS kernel -- the records
     stay the oracle's -- and smr_align_part doubles the pool for the next part, so a second run over the same reads is redone less."""

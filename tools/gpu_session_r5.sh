@@ -11,6 +11,10 @@ for W in "$@"; do case $W in
 tests)
   timeout 1800 python -m pytest tests -m gpu -x -q -rs --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
   tail -15 $OUT/pytest_gpu.log ;;
+one=*)
+  # one=<pytest -k expression>   selected GPU tests
+  timeout 900 python -m pytest tests -m gpu -x -q -rs -k "${W#one=}" > $OUT/pytest_one.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_one.log
+  tail -8 $OUT/pytest_one.log ;;
 paritytests)
   timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_golden.py -m gpu -x -q -rs > $OUT/pytest_parity.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_parity.log
   tail -8 $OUT/pytest_parity.log ;;
