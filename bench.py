@@ -696,7 +696,7 @@ def main():
                        "cigar": not args.no_cigar, "index_build": index_built,
                        "sw_kernel": ("packed 16-bit (v_pk): the candidate walk in rounds, its windows scored sixteen per wave by k_sw16 (reads <= 256 nt with a k_cand record); "
                                      "four per wave / single problems on 128 virtual lanes inside k_chain for the others") if eng.sw_mode() >= 1 else "32-bit",
-                       "walk_rounds_per_pass": eng.walk_rounds()},
+                       "walk_rounds_per_pass": eng.walk_rounds(), "hit_list_entries_per_search": int(eng.prof().hit_list_cap)},
             "pcie_inclusive_reads_per_s_per_gpu": pcie_rate,
             "counters": {"reads": reads_timed, "num_aligned": int(ctr_t[0]), "num_short": int(ctr_t[1]), "reads_matched_per_db": [int(x) for x in ctr_t[2:2 + n_db]]},
             "work_per_read": {"windows": prof[6] / reads_timed, "lookups": n_lookup / reads_timed, "nodes": n_node / reads_timed,

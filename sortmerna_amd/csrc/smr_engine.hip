@@ -72,7 +72,7 @@ struct smr_ctx {
   Batch* b = &bt[0];
   // pools / scratch (shared by all batches: one batch is aligned at a time)
   uint32_t* d_pool = nullptr; uint64_t pool_words = 0;
-  uint32_t hcap = 4;                      // lane-local hit list capacity; doubles (and the part is redone) on overflow
+  uint32_t hcap = 4;                      // lane-local hit list capacity of k_seed_search; doubles (and the part is redone) on overflow
   int seed_exact = 0;                     // 1: k_seed_search for every wave (exact work counters); 0: k_seed_pg (+ redo of the waves whose pool overflowed)
   // Bloom words per read in k_cand (a power of two, 64..512): fewer = more blocks of k_cand per CU, but more reads marked for k_chain by a false
   // collision.  Measured per 2 M-read launch (profiles/r3s18_*): 512 words k_cand 1.07 ms + k_chain 6.01 ms, 256: 0.59 + 6.06, 128: 0.48 + 6.07
@@ -282,10 +282,11 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
 
 // The longest hit list ONE half-seed search can leave: the strings T of pw + 1 chars that lev1_entry (smr_seed.hpp) accepts for a pattern P number
 // at most 31 pw - 20 (104, 135, 166 for pw = 4, 5, 6 over every P; 197 ... 290 for pw = 7 ... 10 on the patterns that reach the maximum and on
-// sampled ones: tests/test_lev_closed_form.py), each at most one id.  k_seed_pg keeps the forward and the reverse search's list apart (that bound
-// each); k_seed_search<1> starts from the forward list (twice the bound).
+// sampled ones: tests/test_lev_closed_form.py), each at most one id.  k_seed_pg needs no capacity per search (its lists lie back to back in the
+// wave's candidate budget); k_seed_search -- the DFS kernel: overflow redo, exact-counter mode -- has lane-local lists of hcap entries, and its
+// reverse search starts from the forward list (twice the bound).
 #define SEED_HCAP_BOUND(pw) (31u * (pw) - 20u)
-// A search's hit list overflowed: the next size.  4, 8, ... 128, then the bound, then twice the bound, which no search can exceed -- reaching the
+// A list of k_seed_search overflowed: the next size.  4, 8, ... 128, then the bound, then twice the bound, which no search can exceed -- reaching the
 // error below would mean the bound is wrong, not that the data is unusual.  (2 x 290 entries x 64 lanes = 145 KB of the 160 KB of LDS.)
 bool grow_hcap(smr_ctx* c, uint32_t pw) {
   const uint32_t bound = SEED_HCAP_BOUND(pw);
@@ -320,8 +321,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
   const bool mapped = (sb.nkh / 16) * 4 <= 64 * 1024;
   const size_t lds_keys = (size_t)4 * (((sb.nc + 3u) & ~3u) + (mapped ? sb.nkh / 16 : 0u) + (staged ? SEED_WAVES * (SEED_STAGE_WORDS + 8u) : 0u));
-  const uint32_t hcap_pg = std::min<uint32_t>(c->hcap, std::max<uint32_t>(128u, SEED_HCAP_BOUND(P.partialwin)));      // (its lists hold one search's hits)
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(hcap_pg, c->ccap) * 4;
+  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->ccap) * 4;
   const size_t lds_pg = lds_pg1 + (getenv("SMR_PG_LDS_PAD") ? (size_t)atoi(getenv("SMR_PG_LDS_PAD")) : 0);      // (the variable: occupancy experiments)
   // lists of more than 128 hits per search (a crafted neighbourhood: SEED_HCAP_MAX) take more than the default 64 KB of dynamic LDS
   if (lds_pg > 64 * 1024 && lds_pg > c->pg_lds_attr) {
@@ -378,10 +378,10 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       ev_mark(c, dir ? KP_PG1 : KP_PG0);
       if (dir == 0) {
-        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, hcap_pg, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
+        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       } else {
-        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, hcap_pg, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
+        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
       }
     }

@@ -33,8 +33,11 @@ namespace smr {
 #ifndef PG_TRIP
 #define PG_TRIP 4
 #endif
-// dynamic LDS words: hit lists, candidates (rank, id, next | kind << 16), chain heads of the 64 searches, the searches that start in a row of 64 strings
-#define PG_LDS_WORDS(hcap, ccap) (64u * (hcap) + 3u * (ccap) + 128u)
+// dynamic LDS words: candidates (rank, id, next | kind << 16), the hit lists (in all as many entries as there are candidates: a search's list is
+// as long as its chain at most, so the lists lie back to back at offsets taken from the chain lengths -- no capacity per search, and 4.6 KB per wave
+// whatever the longest list of the batch: with 64 x hcap words per wave the bench batch, whose longest list has 16 entries, ran 5 waves per SIMD
+// instead of the 7 the registers allow, 16 % slower than at 7: profiles/r5s30_*), chain heads of the 64 searches, a row's owners / the chain lengths
+#define PG_LDS_WORDS(ccap) (4u * (ccap) + 128u)
 
 // inclusive prefix sum / maximum over the 64 lanes in six DPP steps: row_shr:1/2/4/8 inside the rows of 16, then row_bcast:15 into rows 1 and 3 and
 // row_bcast:31 into rows 2 and 3 (a lane without a source adds / compares 0)
@@ -134,7 +137,7 @@ __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32
 
 // The {DFS rank, id} of every accepted string of the wave, 64 records per trip: record p holds its string's number in the block and its
 // search; the search's lane has the block ({offset, n | cA << 24 | cB << 28}).
-__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo, uint32_t bhi, uint32_t rty, uint32_t* cdk, uint32_t* cdv) {
+__device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo, uint32_t bhi, uint32_t rty, uint32_t* cdk, uint32_t* cdv, uint32_t* cnt) {
   for (uint32_t p0 = 0; p0 < nrec; p0 += 64) {
     const uint32_t p = p0 + (uint32_t)lane;
     const uint32_t rec = p < nrec ? cdk[p] : 0u;
@@ -144,6 +147,7 @@ __device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo
       const uint32_t u = rec & 0x1FFFFFFu, on = om & 0xFFFFFFu, ocA = (om >> 24) & 15u;
       SMR_GLOBAL_U32* ri = pg_ptr(olo, ohi) + (ocA ? 2 : 1) * (size_t)on + 2 * (size_t)u;      // (two neighbouring words: one 8-byte load)
       cdk[p] = ri[0]; cdv[p] = ri[1];
+      atomicAdd(&cnt[s], 1u);                              // the length of the search's chain (one LDS instruction per 64 records)
     }
   }
 }
@@ -158,18 +162,18 @@ __device__ __forceinline__ void pg_resolve(uint32_t nrec, int lane, uint32_t blo
 // `swz`: wave it works on chunk (it % 8) * ceil(chunks / 8) + it / 8 -- blocks run on XCD b % 8, so every XCD's L2 sees one contiguous
 // eighth of the key range.
 template <int DIR>
-__global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t hcap, uint32_t ccap,
+__global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DIndex ix, DParams P, int pass, SeedBufs sb, uint32_t ccap,
                                                 uint32_t* __restrict__ pool, uint32_t pool_words, unsigned long long* __restrict__ ctr, int swz) {
   const uint32_t n_tup = min(sb.sn[SN_TUPLES], sb.cap_tuples), n_fwd = min(sb.sn[SN_FWD], n_tup);
   // this launch's wave chunks of 64 tuples: [c0, c0 + nw) (the chunk that holds the last forward and the first reverse tuple belongs to both)
   const uint32_t c0 = DIR ? n_fwd >> 6 : 0u, nw = (DIR ? (n_tup + 63u) >> 6 : (n_fwd + 63u) >> 6) - c0, per = (nw + 7u) >> 3;
   SMR_DYN_LDS(uint32_t, lds_dyn);
-  uint32_t* hl = lds_dyn + (threadIdx.x >> 6) * PG_LDS_WORDS(hcap, ccap);
-  uint32_t* cdk = hl + 64 * hcap;                          // rank in the reference's traversal order
+  uint32_t* cdk = lds_dyn + (threadIdx.x >> 6) * PG_LDS_WORDS(ccap);    // rank in the reference's traversal order
   uint32_t* cdv = cdk + ccap;                              // id
   uint32_t* cdn = cdv + ccap;                              // next record of the same search | kind << 16
-  uint32_t* hd = cdn + ccap;                               // [64] newest record of each search
-  uint32_t* own = hd + 64;                                 // [64] 1 + the search whose strings start at string g0 + i of the wave (0: none does)
+  uint32_t* hp = cdn + ccap;                               // the hit lists of the 64 searches, back to back
+  uint32_t* hd = hp + ccap;                                // [64] newest record of each search
+  uint32_t* own = hd + 64;                                 // [64] 1 + the search whose strings start at string g0 + i of the wave (0: none does); after the rows: the chain lengths
   __shared__ uint32_t s_ncand_[PG_WAVES];
   uint32_t& s_ncand = s_ncand_[threadIdx.x >> 6];
   const int lane = lane_id();
@@ -211,7 +215,6 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   const bool counted = mine;
   uint32_t nh = 0, P9 = 0, slot = 0;
   uint2 rt = make_uint2(NONE, 0);
-  bool hl_over = false;
   {
     const bool hit = pf && pf_vb == vb;
     const SeedTup t = hit ? pf_t : (pos < n_tup ? sb.srt[pos] : 0ull);
@@ -314,8 +317,11 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
     }
     continue;
   }
-  pg_resolve(s_ncand, lane, O.blo, O.bhi, rt.y, cdk, cdv);
+  own[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  pg_resolve(s_ncand, lane, O.blo, O.bhi, rt.y, cdk, cdv, own);
   __syncthreads();
+  const uint32_t hb = pg_scan_add(own[lane]) - own[lane];   // where this search's hit list begins: it has at most one entry per candidate
   GPH(6)
   // ---------- every search takes its candidates in DFS order (selection by increasing rank).  Forward: applied to its list -- the window's
   // list so far -- with the reference's rules.  Reverse: collected without repeats, the kind of the first occurrence kept (a later occurrence
@@ -334,9 +340,9 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
       if (!more || best == 0xFFFFFFFFu) { more = false; continue; }
       const uint32_t idc = cdv[bi], kc = cdn[bi] >> 16;
       bool present = false;
-      for (uint32_t f = 0; f < nh; f++) if ((hl[f * 64 + lane] & ~SEED_CAND_COND) == idc) { present = true; break; }
-      if (DIR == 0 && kc == CK_COND && !present) { hl[lane] = idc; nh = 1; zero = true; more = false; }
-      else if (!present) { if (nh < hcap) { hl[nh * 64 + lane] = idc | ((DIR && kc == CK_COND) ? SEED_CAND_COND : 0u); nh++; } else hl_over = true; }
+      for (uint32_t f = 0; f < nh; f++) if ((hp[hb + f] & ~SEED_CAND_COND) == idc) { present = true; break; }
+      if (DIR == 0 && kc == CK_COND && !present) { hp[hb] = idc; nh = 1; zero = true; more = false; }
+      else if (!present) { hp[hb + nh] = idc | ((DIR && kc == CK_COND) ? SEED_CAND_COND : 0u); nh++; }
       last = best + 1;
     }
   }
@@ -359,10 +365,9 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   if (wr && base != NONE) {
     const uint32_t o = base + incl - need;
     pool[o] = nh;
-    for (uint32_t q = 0; q < nh; q++) pool[o + 1 + q] = hl[q * 64 + lane];
+    for (uint32_t q = 0; q < nh; q++) pool[o + 1 + q] = hp[hb + q];
     wseg_put(sb, DIR, slot, o | (zero ? SEED_ZERO_BIT : 0u), zero);
   }
-  if (__any(hl_over) && lane == 0) atomicAdd(&ctr[C_ERR_HITCAP], 1ull);
   // algorithmic bytes of this wave (C_B_PG0/1): per tuple 8 B + its block-table entry (8 B); a search with directories reads 8 directory
   // words; 4 B per string looked at; {rank, id} = 8 B per accepted string; the segment written (4 B per word) and the window slot pointing
   // to it; the chunk's coarse bin; DIR 1: the window's group bit (what does not come out of the scans above is summed per lane: < 2^32 per wave)

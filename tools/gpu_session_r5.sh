@@ -21,7 +21,7 @@ paritytests)
 mb=*)
   # mb=NAME:ENV=v,ENV=v+NAME2:...   several library configurations in one process (tools/hw_minibench_r5.py)
   CFGS=$(echo "${W#mb=}" | tr '+' ' ')
-  timeout 600 python tools/hw_minibench_r5.py $CFGS > $OUT/minibench.log 2>&1; grep -E "==|per step|FAILED|walk rounds" $OUT/minibench.log | cut -c1-1200 ;;
+  timeout 600 python tools/hw_minibench_r5.py $CFGS > $OUT/minibench.log 2>&1; grep -E "==|per step|hit lists|FAILED|walk rounds" $OUT/minibench.log | cut -c1-1200 ;;
 mb2m=*)
   CFGS=$(echo "${W#mb2m=}" | tr '+' ' ')
   MB_BATCH=2000000 timeout 600 python tools/hw_minibench_r5.py $CFGS > $OUT/minibench2m.log 2>&1; grep -E "==|per step|FAILED|walk rounds" $OUT/minibench2m.log | cut -c1-1200 ;;

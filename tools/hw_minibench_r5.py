@@ -82,6 +82,7 @@ for cfg in sys.argv[1:] or ["base"]:
         say("== %s %s: %.2f M reads/s (%.1f ms per %d-read step); seed %.2f ms/launch, chain family %.1f ms/step, trace %.2f ms/step; sw_fwd %d spec %d used %d; aligned %d" % (
             name, env, STEPS * BATCH / dt / 1e6, dt / STEPS * 1e3, BATCH, p.seed_ms / max(p.seed_launches, 1), p.chain_ms / STEPS, p.trace_ms / STEPS,
             p.n_sw_fwd // STEPS, p.n_sw_spec // STEPS, p.n_sw_spec_used // STEPS, al))
+        say("   hit lists of %d entries per search, candidate walk rounds per pass %s" % (p.hit_list_cap, eng.walk_rounds()))
         say("   per step: " + "  ".join("%s %.2f ms (x%d)" % (k, v["ms"] / STEPS, v["launches"] // STEPS) for k, v in eng.prof_kernels().items() if v["launches"]))
         eng.close()
     except Exception as x:  # noqa: BLE001
