@@ -795,12 +795,13 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 // the forward search ended with a 0-error match (:188); else the reverse search's candidates in its DFS order -- one already present is
 // skipped, a 0-error candidate (SEED_CAND_COND) that is not present REPLACES the list and ends the window, any other is appended.  A reverse
 // segment marked SEED_SEG_MERGED (k_seed_search<1>) is that final list already.
-#define FIN_KEEP 8u                                       // segments per read and pass whose place k_seed_finish remembers (24 KB of LDS per block; a read from the DB has one per window of the first pass)
+#define FIN_KEEP 8u                                       // segments per read and pass whose place k_seed_finish remembers (20 KB of LDS per block; a read from the DB has one per window of the first pass)
 __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
                                                      unsigned long long* __restrict__ ctr) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  __shared__ uint32_t s_sf[FIN_KEEP][256], s_sr[FIN_KEEP][256], s_k[FIN_KEEP][256];     // the first windows with segments a thread met: forward / reverse segment (NONE: none), window
+  __shared__ uint32_t s_sf[FIN_KEEP][256], s_sr[FIN_KEEP][256];     // the first windows with segments a thread met: forward / reverse segment (NONE: none),
+  __shared__ uint16_t s_k[FIN_KEEP][256];                           // ... window (reads <= 65 535 letters; 16 bits: 20.5 KB per block = 7 blocks per CU, with 32 bits 24.6 KB = 6)
   __shared__ unsigned long long s_st[5];
   if (threadIdx.x < 5) s_st[threadIdx.x] = 0;
   __syncthreads();
@@ -864,7 +865,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
           const uint32_t sf = ((mf >> j) & 1u) ? sb.wseg[0][slot0 + k] : NONE, sr = ((mr >> j) & 1u) ? sb.wseg[1][slot0 + k] : NONE;
           if (sf != NONE && ((srch >> j) & 1u) && !(sf & SEED_ZERO_BIT)) rlook++;        // ... unless the forward search hit exactly
           const uint32_t cf = sf != NONE ? (pool[sf & ~SEED_ZERO_BIT] & 0xFFFFu) : 0u, cr = sr != NONE ? (pool[sr & ~SEED_ZERO_BIT] & 0xFFFFu) : 0u;
-          if (seeds < FIN_KEEP) { s_sf[seeds][threadIdx.x] = sf; s_sr[seeds][threadIdx.x] = sr; s_k[seeds][threadIdx.x] = k; }
+          if (seeds < FIN_KEEP) { s_sf[seeds][threadIdx.x] = sf; s_sr[seeds][threadIdx.x] = sr; s_k[seeds][threadIdx.x] = (uint16_t)k; }
           seeds++; upper += cf + cr;
         }
       }
@@ -881,7 +882,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       if (upper && seeds <= FIN_KEEP) {
         for (uint32_t i = 0; i < seeds; i++) {
           const uint32_t sf = s_sf[i][threadIdx.x], sr = s_sr[i][threadIdx.x];
-          total += merge(sf, sr, s_k[i][threadIdx.x] * stride, base + 2 * total);
+          total += merge(sf, sr, (uint32_t)s_k[i][threadIdx.x] * stride, base + 2 * total);
         }
       } else if (upper) for (uint32_t kb = 0; kb < numwin; kb += 32) {
         const uint32_t nk = min(32u, numwin - kb);

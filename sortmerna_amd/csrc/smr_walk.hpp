@@ -34,6 +34,7 @@ __host__ __device__ __forceinline__ uint32_t walk_tasks_per_read(uint32_t nlist,
 }
 #define WK_MAX_ROWS 256u              // longest read span k_sw16 takes (8 virtual lanes x 32 rows)
 #define WK_MAX_POS 128u               // most positions (seed hits x their occurrences) of a read the round kernels take: two per lane
+#define WK_CLAIM 24u                                      // list entries a wave claims at a time, at most (24 x WK_MAX task slots: with 32 the kernel's LDS was 8 160 bytes, 19 waves per CU where its registers allow 20)
 // per-round counters (u64 words): every hot one on a 128-byte line of its own
 enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_NTASK2 = 48, WC_STRIDE = 64 };
 
@@ -261,12 +262,13 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
   SMR_DYN_LDS(unsigned char, lds_raw);                  // FINAL: read letters (lds_ml) | reference window (lds_rf)
   __shared__ unsigned long long l_pairs[WK_MAX_POS];    // (reference position << 32 | window position) of the sorted triples of the candidates
   __shared__ uint2 l_cand[64];                          // candidates in walk order: {reference, count | first triple << 8}
-  __shared__ unsigned long long l_cref[64], l_clen[64]; // ... where their reference sequences start, and their lengths
+  __shared__ unsigned long long l_cref[64];             // ... where their reference sequences start,
+  __shared__ uint32_t l_clen[64];                       // ... and their lengths
   __shared__ uint32_t l_hkey[256], l_hcnt[256];         // the hash table that groups the triples by reference
   __shared__ unsigned long long l_stage[WK_MAX_POS];    // the member triples as sort keys (before that: the hits of a read that gathers its positions itself; after: LIS arrays)
   __shared__ WTask s_ctk[WK_MAX];                       // the tasks the read left in the previous round ...
   __shared__ uint2 s_cres[WK_MAX];                      // ... and their results
-  __shared__ uint32_t s_tix[32 * WK_MAX];               // task slots of the chunk being worked on (appended to tidx / tidx2 with one atomic per chunk):
+  __shared__ uint32_t s_tix[WK_CLAIM * WK_MAX];         // task slots of the chunk being worked on (appended to tidx / tidx2 with one atomic per chunk):
                                                         // the tasks to be scored with their end cells from the front, the score-only ones from the back
   __shared__ uint32_t s_next, s_tbase;
   const int lane = lane_id();
@@ -280,7 +282,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
 #else
 #define WPH(i)
 #endif
-  const uint32_t claim = max(1u, min(32u, nlist / (gridDim.x * 4u)));
+  const uint32_t claim = max(1u, min(WK_CLAIM, nlist / (gridDim.x * 4u)));
   for (;;) {
     __syncthreads();
     if (lane == 0) s_next = (uint32_t)atomicAdd(&wc[WC_CLAIM], (unsigned long long)claim);
@@ -421,7 +423,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
             const uint32_t rk = q ? rank1 : rank0;
             const uint64_t r0_ = ix.ref_off[hseq[q]], r1_ = ix.ref_off[hseq[q] + 1];
             l_cand[rk] = make_uint2(hseq[q], count[q] | (i << 8));
-            l_cref[rk] = r0_; l_clen[rk] = r1_ - r0_;
+            l_cref[rk] = r0_; l_clen[rk] = (uint32_t)(r1_ - r0_);
           }
         }
         // the tasks of the previous round and their results
@@ -602,7 +604,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
               live_bits = nk << 8;
               // (a read that is expected to align gets its end cells with the scores; of the others only the score is asked)
               if (assume) { for (uint32_t q = lane; q < nk; q += 64) s_tix[ntix + q] = e * K + q; ntix += nk; }
-              else { for (uint32_t q = lane; q < nk; q += 64) s_tix[32u * WK_MAX - 1u - (ntix2 + q)] = e * K + q; ntix2 += nk; }
+              else { for (uint32_t q = lane; q < nk; q += 64) s_tix[WK_CLAIM * WK_MAX - 1u - (ntix2 + q)] = e * K + q; ntix2 += nk; }
               live = true;
               WPH(4)
               break;
@@ -695,7 +697,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
       if (lane == 0) s_tbase = (uint32_t)atomicAdd(&wc[WC_NTASK2], (unsigned long long)ntix2);
       __syncthreads();
       const uint32_t tb = s_tbase;
-      for (uint32_t q = lane; q < ntix2; q += 64) tidx2[tb + q] = s_tix[32u * WK_MAX - 1u - q];
+      for (uint32_t q = lane; q < ntix2; q += 64) tidx2[tb + q] = s_tix[WK_CLAIM * WK_MAX - 1u - q];
     }
     WPH(6)
   }
