@@ -112,3 +112,19 @@ def test_the_round_kernels_of_the_candidate_walk():
     total = sum(runs)
     in_long = sum(r for r in runs if r >= 4 * 19 * 3)
     assert total >= 4 * 4 * 19 * 3 and in_long == total, (total, in_long, [r for r in runs if r])
+
+
+def test_lds_leaves_room_for_the_waves_the_registers_allow():
+    """Round 5's lesson: `k_seed_pg` ran at 5 waves per SIMD with a 7-wave register budget because its LDS was sized for the batch's
+    longest hit list.  160 KB of LDS per CU, four SIMDs; a kernel's LDS per wave must let as many waves in as its registers do."""
+    md = _kernel_metadata()
+    lds_cu = 160 * 1024
+    src = open(os.path.join(build.CSRC, "smr_seed_pg.hpp")).read()
+    assert re.search(r"#define PG_LDS_WORDS\(ccap\) \(4u \* \(ccap\) \+ 128u\)", src) and re.search(r"#define PG_CAND_CAP0 256u", src) and re.search(r"#define PG_OCC 7\b", src)
+    for k in _find(md, "k_seed_pgILi"):
+        per_wave = 4 * (4 * 256 + 128) + k["lds"]                        # dynamic (PG_LDS_WORDS at the initial candidate budget) + static
+        assert per_wave * 7 * 4 <= lds_cu and k["vgpr"] <= 72, k          # 7 waves per SIMD: 512 / 7 = 73 registers
+    for k in _find(md, "k_walkILb0"):
+        assert k["lds"] <= 7680 and k["lds"] * 5 * 4 <= lds_cu and k["vgpr"] <= 96, k        # 5 waves per SIMD; 8 160 bytes measured 6 % slower than 7 424 (profiles/r5s33_*)
+    for k in _find(md, "k_seed_finish"):
+        assert k["lds"] * 7 <= lds_cu and k["vgpr"] <= 72, k              # 7 blocks of four waves
