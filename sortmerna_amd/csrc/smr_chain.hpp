@@ -314,15 +314,17 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 // ------------------------------------------------------------------------------------------------
 #define CAND_HITS 64u                 // seed hits per read handled here
 #define CAND_BLOOM_WORDS 512u         // most Bloom words per read: 16 384 bits
-// dynamic LDS bytes of a block (16 reads): Bloom words | prefix of the list lengths | list starts
-#define CAND_LDS_BYTES(bw, handover) (16u * ((bw) + CAND_HITS + 1u + ((handover) ? 2u : 1u) * CAND_HITS) * 4u)
+// dynamic LDS bytes of a block (16 reads): Bloom words | prefix of the list lengths | list starts | window positions (16 bits each: reads <= 65 535 letters).
+// 18.5 KB with the default 128 Bloom words = 8 blocks per CU, the 8 waves per SIMD the kernel is compiled for (round 5; 20.5 KB = 7 blocks before)
+#define CAND_LDS_BYTES(bw, handover) (16u * (((bw) + 2u * CAND_HITS + 1u) * 4u + ((handover) ? 2u * CAND_HITS : 0u)))
 #define CAND_REC_MAX 64u              // positions of a marked read that k_cand hands over to k_chain as a record (99 % of the marked reads have no more)
 #define CAND_REC_WORDS 32u            // words of mpool per read of the batch (a block of 16 reads shares 512: room for its two or three marked reads)
 // The hand-over (mrec != nullptr): k_cand has walked hit -> list bounds -> positions of every read it marks; k_chain would repeat those three
 // dependent gathers one read per wave.  So a marked read with at most CAND_REC_MAX positions leaves a RECORD in mpool -- npos reference
 // numbers | npos reference positions | npos window positions, in the order of the walk -- and {offset, npos} in mrec[r] ({NONE, 0}: none);
 // k_chain builds the read's candidate set from it with coalesced loads.
-__global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
+struct __attribute__((aligned(4))) CandPair { uint32_t x, y; };          // two neighbouring words of the pool (4-byte aligned: global_load_dwordx2 takes that)
+__global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __restrict__ work, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, uint8_t* __restrict__ marks, uint32_t bloom_words,
                                               uint2* __restrict__ mrec, uint32_t* __restrict__ mpool, size_t mpool_words) {
   SMR_DYN_LDS(uint32_t, cand_lds);
@@ -330,7 +332,7 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   uint32_t* const bloom = cand_lds + (size_t)g * bloom_words;                                  // this read's 32 * bloom_words bits
   uint32_t* const hp_ = cand_lds + 16u * bloom_words + (size_t)g * (CAND_HITS + 1u);
   uint32_t* const lo_ = cand_lds + 16u * (bloom_words + CAND_HITS + 1u) + (size_t)g * CAND_HITS;
-  uint32_t* const wn_ = cand_lds + 16u * (bloom_words + 2u * CAND_HITS + 1u) + (size_t)g * CAND_HITS;   // window position of every hit
+  uint16_t* const wn_ = reinterpret_cast<uint16_t*>(cand_lds + 16u * (bloom_words + 2u * CAND_HITS + 1u)) + (size_t)g * CAND_HITS;   // window position of every hit
   __shared__ uint32_t s_rec_cur;                            // words of the block's slice of mpool already given out
   if (threadIdx.x == 0) s_rec_cur = 0;
   const uint32_t bshift = 32u - (5u + (uint32_t)__ffs((int)bloom_words) - 1u);
@@ -353,25 +355,38 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   // the group's hits: list start and length of each, prefix over the lengths (row-wise, 16 hits per round)
   uint32_t npos = 0;
   if (scan) { for (uint32_t q = gl; q < bloom_words; q += 16) bloom[q] = 0; }
-  for (uint32_t h0 = 0; h0 < CAND_HITS; h0 += 16) {
-    const uint32_t h = h0 + (uint32_t)gl;
-    uint32_t lo = 0, ln = 0;
+  // (all four rows' hit words are asked for, then all list bounds, before anything waits: two round trips per read, not eight)
+  uint32_t hid[CAND_HITS / 16], hlo[CAND_HITS / 16], hln[CAND_HITS / 16];
+#pragma unroll
+  for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
+    const uint32_t h = 16u * k + (uint32_t)gl;
+    hid[k] = NONE;
     if (scan && h < nh) {
       // the hit blocks of the passes run so far on this strand, concatenated (no loop over the three: an index that the compiler cannot
       // resolve sends the read's state to 12 KB of LDS per block)
       const uint32_t c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
       const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
-      const uint32_t id = pool[at];
-      if (mrec) wn_[h] = pool[at + 1];
-      lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
+      const CandPair hw = *reinterpret_cast<const CandPair*>(pool + at);      // (id, win_pos) with one 8-byte load
+      hid[k] = hw.x;
+      if (mrec) wn_[h] = (uint16_t)hw.y;
     }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
+    hlo[k] = 0; hln[k] = 0;
+    if (hid[k] != NONE) { hlo[k] = ix.pos_off[hid[k]]; hln[k] = ix.pos_off[hid[k] + 1] - hlo[k]; }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
+    const uint32_t h = 16u * k + (uint32_t)gl;
+    const uint32_t lo = hlo[k], ln = hln[k];
     uint32_t inc = ln;                                     // inclusive prefix inside the row of 16 lanes (row_shr:1/2/4/8)
     uint32_t v;
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xF, 0xF, false); inc += v;
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xF, 0xF, false); inc += v;
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xF, 0xF, false); inc += v;
     v = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xF, 0xF, false); inc += v;
-    if (scan && h < nh) { hp_[h] = npos + inc - ln; lo_[h] = lo; }
+    if (hid[k] != NONE) { hp_[h] = npos + inc - ln; lo_[h] = lo; }
     npos += (uint32_t)__shfl((int)inc, 15, 16);
   }
   if (scan && gl == 0) hp_[nh] = npos;
@@ -382,17 +397,34 @@ __global__ void __launch_bounds__(256) k_cand(DReads rd, DIndex ix, DParams P, i
   // (the first 64 positions of a read -- four rounds -- stay in registers with their hits: if the read is marked they become its record)
   uint2 kp0 = make_uint2(0, 0), kp1 = kp0, kp2 = kp0, kp3 = kp0;
   uint32_t kh0 = 0, kh1 = 0, kh2 = 0, kh3 = 0;
-  for (uint32_t it = 0; it < rounds; it++) {
+  // (the same for the positions: the loads of the first four rounds are under way together before the first Bloom bit is set)
+  auto hit_of = [&](uint32_t p) -> uint32_t {
+    uint32_t h = 0;
+    for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp_[t] <= p) h = t; }
+    return h;
+  };
+  auto bloom_set = [&](uint32_t seq) {
+    const uint32_t hb = (seq * 2654435761u) >> bshift;                // 14 bits for 512 words
+    const uint32_t old = atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
+    hit |= ((old >> (hb & 31u)) & 1u) != 0;
+  };
+  if (rounds) {
+    const uint32_t p0 = (uint32_t)gl, p1 = p0 + 16u, p2 = p0 + 32u, p3 = p0 + 48u;
+    const bool a0 = scan && p0 < npos, a1 = scan && p1 < npos, a2 = scan && p2 < npos, a3 = scan && p3 < npos;
+    if (a0) { kh0 = hit_of(p0); kp0 = ix.pos_arr[lo_[kh0] + (p0 - hp_[kh0])]; }
+    if (a1) { kh1 = hit_of(p1); kp1 = ix.pos_arr[lo_[kh1] + (p1 - hp_[kh1])]; }
+    if (a2) { kh2 = hit_of(p2); kp2 = ix.pos_arr[lo_[kh2] + (p2 - hp_[kh2])]; }
+    if (a3) { kh3 = hit_of(p3); kp3 = ix.pos_arr[lo_[kh3] + (p3 - hp_[kh3])]; }
+    if (a0) bloom_set(kp0.y);
+    if (a1) bloom_set(kp1.y);
+    if (a2) bloom_set(kp2.y);
+    if (a3) bloom_set(kp3.y);
+  }
+  for (uint32_t it = 4; it < rounds; it++) {
     const uint32_t p = it * 16u + (uint32_t)gl;
     if (scan && p < npos) {
-      uint32_t h = 0;
-      for (uint32_t step = 32; step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && hp_[t] <= p) h = t; }
-      const uint2 pa = ix.pos_arr[lo_[h] + (p - hp_[h])];
-      if (it == 0) { kp0 = pa; kh0 = h; } else if (it == 1) { kp1 = pa; kh1 = h; } else if (it == 2) { kp2 = pa; kh2 = h; } else if (it == 3) { kp3 = pa; kh3 = h; }
-      const uint32_t seq = pa.y;
-      const uint32_t hb = (seq * 2654435761u) >> bshift;                // 14 bits for 512 words
-      const uint32_t old = atomicOr(&bloom[hb >> 5], 1u << (hb & 31u));
-      hit |= ((old >> (hb & 31u)) & 1u) != 0;
+      const uint32_t h = hit_of(p);
+      bloom_set(ix.pos_arr[lo_[h] + (p - hp_[h])].y);
     }
   }
   const unsigned long long hm = __ballot(hit);
