@@ -423,7 +423,8 @@ __global__ void k_wstat(const unsigned long long* __restrict__ wctr, unsigned lo
 int adapt_walk_rounds(smr_ctx* c) {
   if (c->walk_rounds_fixed || !c->wstat_n || !c->d_wstat) return SMR_OK;
   unsigned long long h[8 * 32];
-  HIPCHK(c, hipMemcpy(h, c->d_wstat, (size_t)c->wstat_n * 32 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpyAsync(h, c->d_wstat, (size_t)c->wstat_n * 32 * 8, hipMemcpyDeviceToHost, c->stream));       // (on the context's stream, like read_ctr: no other stream is waited for)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   const unsigned long long few = (unsigned long long)c->n_cu * 8ull;
   uint32_t need[3] = {0, 0, 0};
   for (uint32_t e = 0; e < c->wstat_n; e++) {

@@ -4,6 +4,7 @@ binding through it.  It exists so that the kernel source itself can be checked a
 fallback of the product (nothing in sortmerna_amd/ knows about it) and `-m gpu` tests never use it."""
 import contextlib
 import ctypes
+import fcntl
 import os
 import subprocess
 
@@ -24,16 +25,25 @@ def _sources():
     return src
 
 
+def _fresh():
+    return os.path.isfile(LIB) and all(os.path.getmtime(s) <= os.path.getmtime(LIB) for s in _sources())
+
+
 def build(force=False):
-    if not force and os.path.isfile(LIB) and all(os.path.getmtime(s) <= os.path.getmtime(LIB) for s in _sources()):
+    if not force and _fresh():
         return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(EMU, "shim"), "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           os.path.join(EMU, "emu_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "smr_engine.hip"), "-x", "none", "-D__host__=", "-D__device__=",
-           os.path.join(CSRC, "smr_index.cpp"), os.path.join(CSRC, "smr_reads.cpp"), os.path.join(CSRC, "smr_report.cpp"),
-           "-o", LIB + ".tmp", "-lpthread", "-lz", "-ldl"] + os.environ.get("SMR_EMU_EXTRA_FLAGS", "").split()
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)            # new inode: a process that has the old library mapped keeps running
+    # several test processes (pytest -n) may find the library stale at once: one builds, the others wait and find it fresh
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not _fresh():
+            tmp = "%s.%d.tmp" % (LIB, os.getpid())
+            cmd = ["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-I", os.path.join(EMU, "shim"), "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                   os.path.join(EMU, "emu_runtime.cpp"), "-x", "c++", os.path.join(CSRC, "smr_engine.hip"), "-x", "none", "-D__host__=", "-D__device__=",
+                   os.path.join(CSRC, "smr_index.cpp"), os.path.join(CSRC, "smr_reads.cpp"), os.path.join(CSRC, "smr_report.cpp"),
+                   "-o", tmp, "-lpthread", "-lz", "-ldl"] + os.environ.get("SMR_EMU_EXTRA_FLAGS", "").split()
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)             # new inode: a process that has the old library mapped keeps running
     return LIB
 
 
