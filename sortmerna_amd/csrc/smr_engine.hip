@@ -168,18 +168,29 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
   return P;
 }
 
-int check_params(smr_ctx* c, const smr_params* p) {
+// nullptr when the Smith-Waterman kernels here (the affine recurrence H = max(0, diag + s, E, F)) give ssw.c's results under the scheme, else why not.
+// (1) The reference's striped kernels store E before the lazy-F loop has raised H (ssw.c:267,496): a gap in one sequence directly after a gap in
+// the other is missed when the second crosses a SIMD stripe.  Under 2 * gap_open >= |mismatch| and 2 * gap_ext >= |mismatch| such paths are never
+// optimal.  (2) Its 16-bit kernel leaves the lazy-F loop as soon as no lane has F - gap_ext > H - gap_open (ssw.c:496-507); with gap_open <= gap_ext
+// that is already true one cell behind a stripe boundary, so a longer gap across a boundary is lost whenever the score needs the 16-bit kernel
+// (>= 255 - bias: a 150-nt read's good alignments).  Measured against ssw.c itself on seeded pairs: 2 / -3 / 3 / 3 and 2 / -3 / 2 / 3 differ in
+// 1 - 5 % of the high-scoring pairs, every scheme with gap_open > gap_ext in none (tests/test_oracle_golden.py).
+const char* scheme_unsupported(int mismatch, int score_N, int gap_open, int gap_ext) {
+  const int mm = std::max(-mismatch, -std::min(score_N, 0));
+  if (2 * gap_open < mm || 2 * gap_ext < mm) return "scoring scheme outside the supported range (2*gap_open and 2*gap_ext must be >= |mismatch|)";
+  if (gap_open <= gap_ext) return "scoring scheme outside the supported range (gap_open must be greater than gap_ext: the reference's 16-bit kernel ends its lazy-F loop early otherwise, ssw.c:496-507)";
+  return nullptr;
+}
+
+// sw: the call scores with the Smith-Waterman kernels (the banded traceback alone is exact under every scheme: smr_cigar_batch)
+int check_params(smr_ctx* c, const smr_params* p, bool sw = true) {
   if (!p) { set_err(c, "null params"); return SMR_ERR_ARG; }
   if (p->index_num >= 64) { set_err(c, "index_num must be < 64"); return SMR_ERR_ARG; }
   if ((uint64_t)p->minoccur >= 0x3FFFFFFFull) { set_err(c, "minoccur must be < 2^30 - 1"); return SMR_ERR_ARG; }
   if (p->num_seeds < 1 || p->gap_open < 0 || p->gap_ext < 0 || p->match <= 0 || p->mismatch > 0) { set_err(c, "bad scoring/seed options"); return SMR_ERR_ARG; }
   // the reference's scoring matrix is int8_t (ssw_init, ssw.h:88); the SW kernel keeps a row's scores as 4 signed bytes
   if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { set_err(c, "scores must fit int8 / gaps uint8 like the reference's"); return SMR_ERR_ARG; }
-  // The reference's striped kernels never open a gap in one sequence directly after a gap in the other when the
-  // second gap would cross a SIMD stripe (ssw.c:267,496).  Under 2*gap_open >= |mismatch| and 2*gap_ext >= |mismatch|
-  // such paths are never optimal and the standard affine recurrence computed here is cell-for-cell identical.
-  int mm = std::max(-p->mismatch, -std::min(p->score_N, 0));
-  if (2 * p->gap_open < mm || 2 * p->gap_ext < mm) { set_err(c, "scoring scheme outside the supported range (2*gap_open and 2*gap_ext must be >= |mismatch|)"); return SMR_ERR_ARG; }
+  if (sw) if (const char* why = scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
   if (p->num_alignments > 0 && p->num_alignments > c->b->slots) { set_err(c, "num_alignments exceeds max_alignments_per_read given to smr_reads_upload"); return SMR_ERR_ARG; }
   return SMR_OK;
 }
@@ -885,6 +896,7 @@ __global__ void __launch_bounds__(64) k_ssw_batch_x4(uint32_t n_pairs, const uin
 extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                              int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out) {
   if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 3) return SMR_ERR_ARG;
+  if (const char* why = scheme_unsupported(mismatch, score_N, gap_open, gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
   if (n_pairs == 0) return SMR_OK;
   (void)hipSetDevice(c->device);
   uint64_t mx_m = 1, mx_n = 1;
@@ -1549,7 +1561,7 @@ extern "C" int smr_cigar_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* read
     HIPCHK(c, hipMemcpyAsync(di.ref_seq, refs, (size_t)ref_off[n_pairs], hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(di.ref_off, ref_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     di.n_refs = n_pairs; di.lnwin = 18; di.used = true;
-    if ((r2 = check_params(c, &p))) return r2;
+    if ((r2 = check_params(c, &p, false))) return r2;
     if ((r2 = traceback_core(c, di, &p))) return r2;
     std::vector<unsigned long long> h;
     if ((r2 = read_ctr(c, h))) return r2;

@@ -392,6 +392,23 @@ def test_rounds_adapt_from_part_to_part_without_changing_a_record(wl, monkeypatc
         e.close()
 
 
+@pytest.mark.parametrize("scoring", [{"gap_open": 3, "gap_ext": 3}, {"gap_open": 2, "gap_ext": 3}, {"mismatch": -5, "gap_open": 2, "gap_ext": 1}],
+                         ids=["open_equals_ext", "open_below_ext", "gaps_below_half_a_mismatch"])
+def test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_are_refused(engine, wl, scoring):
+    """An explicit error, never a silent difference: with gap_open <= gap_ext the reference's 16-bit kernel loses gaps across stripe boundaries
+    (tests/test_oracle_golden.py shows it on ssw.c itself), with gaps cheaper than half a mismatch both kernels miss adjacent gaps -- the scores
+    then depend on the SIMD stripe geometry, which the kernels here do not emulate.  smr_align_part and smr_ssw_batch say so."""
+    with pytest.raises(smr.SmrError, match="supported range"):
+        wl.gpu_records(engine, **scoring)
+    sc = dict(match=2, mismatch=-3, score_N=-3, gap_open=5, gap_ext=2)
+    sc.update(scoring)
+    with pytest.raises(smr.SmrError, match="supported range"):
+        engine.ssw_batch([b"\x00\x01\x02\x03"], [b"\x00\x01\x02\x03\x00"], filters=0, mode=0, **sc)
+    recs_o, _ = wl.oracle_records(gap_open=3, gap_ext=2)           # (the context is as usable as before)
+    recs_g, _ = wl.gpu_records(engine, gap_open=3, gap_ext=2)
+    _compare(recs_g, recs_o, "after a refused scheme")
+
+
 def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
     """SMR_PG_CAND_CAP=8: most waves of k_seed_pg overflow their candidate pool and are searched again by the DFS kernel -- the records
     stay the oracle's -- and smr_align_part doubles the pool for the next part, so a second run over the same reads is redone less."""

@@ -100,3 +100,68 @@ def test_oracle_vs_live_reference_on_bundled_data(tmp_path, extra, params):
     assert not bad, "%d differ, first %d" % (len(bad), bad[0])
     assert run.counters.num_aligned == res.log["num_aligned"] > 300
     run.close()
+
+
+def _affine_score(read, ref, match, mismatch, go, ge):
+    """best local score of the affine recurrence H = max(0, diag + s, E, F) (first gap base costs go, further ones ge; go >= ge), column by column
+    in numpy: F(i) = max over k < i of Hpre(k) - go - (i - 1 - k) ge with Hpre = max(0, diag + s, E) -- a gap opened from a cell that F itself
+    raised never wins while go >= ge -- i.e. a prefix maximum of Hpre(k) + k ge."""
+    import numpy as np
+    m = len(read)
+    H = np.zeros(m + 1, dtype=np.int64)
+    E = np.zeros(m + 1, dtype=np.int64)
+    idx = np.arange(m + 1, dtype=np.int64)
+    best = 0
+    for c in ref:
+        E = np.maximum(E - ge, H - go)
+        s = np.where(read == c, match, mismatch)
+        hp = np.zeros(m + 1, dtype=np.int64)
+        hp[1:] = np.maximum(np.maximum(H[:-1] + s, E[1:]), 0)
+        pm = np.maximum.accumulate(hp[1:] + idx[1:] * ge)                   # over rows 1..i
+        F = np.full(m + 1, -10**9, dtype=np.int64)
+        F[2:] = pm[:-1] - go - (idx[2:] - 1) * ge
+        H = np.maximum(hp, F)
+        H[0] = 0
+        best = max(best, int(H.max()))
+    return best
+
+
+def test_only_schemes_with_gap_open_above_gap_ext_follow_the_affine_recurrence():
+    """Why libsmr_hip refuses gap_open <= gap_ext (smr_engine.hip scheme_unsupported): the reference's 16-bit striped kernel leaves its lazy-F loop as soon
+    as no lane has F - gap_ext > H - gap_open (ssw.c:496-507), which with gap_open == gap_ext is the case one cell behind a stripe boundary -- a longer gap
+    across a boundary is lost.  Seeded pairs whose scores need the 16-bit kernel (> 255): the reference's result (the oracle's port of the striped kernels,
+    pinned to ssw.c elsewhere; the compiled ssw.c itself when it is here) against the plain recurrence."""
+    import ctypes as C
+    import numpy as np
+    L = orc.lib()
+    real = None
+    if os.path.isfile(os.path.join(paths.ORACLE_DIR, "_ref", "libssw_ref.so")):
+        import sys
+        sys.path.insert(0, os.path.join(paths.GOLDEN))
+        import make_golden_ssw as G
+        real = (G, G.ref_lib())
+    differing = {}
+    for match, mismatch, go, ge in [(2, -3, 3, 3), (2, -3, 5, 2), (2, -3, 4, 3)]:
+        rng = np.random.Generator(np.random.PCG64(21))
+        mat = np.array([(match if a == b else mismatch) if a < 4 and b < 4 else mismatch for a in range(5) for b in range(5)], dtype=np.int8)
+        bad = 0
+        for _ in range(400 if go == ge else 120):
+            m = int(rng.integers(200, 260))
+            ref = rng.integers(0, 4, m + 40, dtype=np.int8)
+            a = list(ref[10:10 + m])
+            for _k in range(int(rng.integers(1, 4))):
+                p, ln = int(rng.integers(5, len(a) - 5)), int(rng.integers(1, 7))
+                if rng.random() < 0.5:
+                    del a[p:p + ln]
+                else:
+                    a[p:p] = list(rng.integers(0, 4, ln, dtype=np.int8))
+            read = np.array(a, dtype=np.int8)
+            r = orc.SswResult()
+            assert L.orc_ssw(read.ctypes.data, len(read), ref.ctypes.data, len(ref), mat.ctypes.data, go, ge, 0, C.byref(r))
+            if real:
+                assert real[0].ssw_reference(real[1], read.tobytes(), ref.tobytes(), match, mismatch, mismatch, go, ge, 0)[0] == r.score1
+            plain = _affine_score(read, ref, match, mismatch, go, ge)
+            assert r.score1 <= plain and plain > 255
+            bad += r.score1 != plain
+        differing[(go, ge)] = bad
+    assert differing[(3, 3)] >= 3 and differing[(5, 2)] == 0 and differing[(4, 3)] == 0, differing
