@@ -32,6 +32,7 @@
  *   scoring               match <= 127, mismatch >= -127, |score_N| <= 127, gaps <= 255, 2 * gap_open, 2 * gap_ext >= |mismatch| and gap_open > gap_ext
  *                         (under these conditions the affine recurrence here equals the reference's striped kernels cell for cell; outside them ssw.c's
  *                         scores depend on its SIMD stripe geometry: ssw.c:267,496 and its 16-bit lazy-F loop :496-507)
+ *   edges                 1..10 letters or percent like the reference's --edges; a percentage must not round to 0 letters for any searchable read of the batch
  *   pools                 seed-hit pool <= 8 GiB, CIGAR pool < 2^32 words, pigeonhole arena < 2^34 words per part (all grown on demand)
  */
 #ifndef SMR_HIP_H

@@ -18,12 +18,12 @@
 /* ------------------------------------------------------------------------------------------ */
 static void* xcalloc(size_t n, size_t sz) {
   void* p = calloc(n ? n : 1, sz ? sz : 1);
-  if (!p) { fprintf(stderr, "smr_oracle: out of memory\n"); exit(1); }
+  if (!p) { fprintf(stderr, "smr_oracle: out of memory (calloc of %zu x %zu bytes)\n", n, sz); exit(1); }
   return p;
 }
 static void* xrealloc(void* q, size_t sz) {
   void* p = realloc(q, sz ? sz : 1);
-  if (!p) { fprintf(stderr, "smr_oracle: out of memory\n"); exit(1); }
+  if (!p) { fprintf(stderr, "smr_oracle: out of memory (realloc to %zu bytes)\n", sz); exit(1); }
   return p;
 }
 
@@ -1091,9 +1091,14 @@ static void compute_lis_alignment(wread* read, const orc_params* o, const orc_in
           }
           if (read->is03) flip34(read);                                                     /* :360-361 */
           ssw_res res;
-          int ok = ssw_run((const int8_t*)read->iseq + align_que_start, (int32_t)(align_length - head - tail),
-                           (const int8_t*)refs->seq[max_ref] + align_ref_start - head, (int32_t)align_length,
-                           read->mat, 5, (uint8_t)o->gap_open, (uint8_t)o->gap_ext, (uint16_t)o->minimal_score, &res, ctr);
+          /* With large -edges a read that hangs off the end of its reference can leave align_length - head - tail (size_t in the reference,
+           * :341-343) at or below zero: the reference then hands ssw_align a wrapped length -- undefined, it crashes or reads out of bounds.
+           * The oracle defines the case the way libsmr_hip does (smr_walk.hpp task_ok): no Smith-Waterman call, the candidate does not align. */
+          int ok = 0;
+          if ((int64_t)align_length - (int64_t)head - (int64_t)tail > 0 && (int64_t)align_length > 0)
+            ok = ssw_run((const int8_t*)read->iseq + align_que_start, (int32_t)(align_length - head - tail),
+                         (const int8_t*)refs->seq[max_ref] + align_ref_start - head, (int32_t)align_length,
+                         read->mat, 5, (uint8_t)o->gap_open, (uint8_t)o->gap_ext, (uint16_t)o->minimal_score, &res, ctr);
           is_aligned = (ok && res.score1 > o->minimal_score);                               /* :388 */
           if (is_aligned) {
             if (res.score1 == max_SW_score) ++read->st.max_SW_count;

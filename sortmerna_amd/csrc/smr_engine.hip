@@ -45,6 +45,7 @@ static const char* const KP_NAME[KP_COUNT] = {"k_seed_keys", "k_seed_split", "k_
 struct Batch {
   bool used = false;
   uint32_t n = 0, max_len = 0, slots = 1;
+  uint32_t min_ge[7] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};     // the shortest read of at least 8, 10, ... 20 letters (~0: none): what `--edges N%` is smallest for
   uint32_t* d_words = nullptr; uint64_t* d_rec_off = nullptr; uint32_t* d_len = nullptr;
   RState* d_saved = nullptr; RState* d_work = nullptr; RWork* d_rw = nullptr;
   uint8_t* d_marks = nullptr;              // per read: k_chain has to walk it in this (strand, pass) (k_cand)
@@ -191,6 +192,9 @@ int check_params(smr_ctx* c, const smr_params* p, bool sw = true) {
   // the reference's scoring matrix is int8_t (ssw_init, ssw.h:88); the SW kernel keeps a row's scores as 4 signed bytes
   if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { set_err(c, "scores must fit int8 / gaps uint8 like the reference's"); return SMR_ERR_ARG; }
   if (sw) if (const char* why = scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
+  // --edges: the reference's parser takes 1..10, nucleotides or percent (options.cpp:676); its geometry is not defined outside (0: `tail > edges - 1` is an
+  // unsigned compare, alignment.cpp:320,345 -- the whole rest of the reference becomes the window; larger values: more reads whose window length wraps)
+  if (sw && (p->edges < 1 || p->edges > 10)) { set_err(c, "edges must be 1..10 (nucleotides or percent), like the reference's --edges"); return SMR_ERR_ARG; }
   if (p->num_alignments > 0 && p->num_alignments > c->b->slots) { set_err(c, "num_alignments exceeds max_alignments_per_read given to smr_reads_upload"); return SMR_ERR_ARG; }
   return SMR_OK;
 }
@@ -1190,6 +1194,9 @@ int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipS
     B.cap_aln = na;
   }
   B.n = r->n; B.max_len = r->max_len; B.slots = max_aln; B.used = true;
+  for (int k = 0; k < 7; k++) B.min_ge[k] = ~0u;
+  if (r->n && r->min_len >= 100) { for (int k = 0; k < 7; k++) B.min_ge[k] = r->min_len; }      // (1 % of 100 letters is a margin already: nothing to look for)
+  else for (uint32_t i = 0; i < r->n; i++) { const uint32_t l = r->len[i]; for (int k = 0; k < 7; k++) if (l >= 8u + 2u * (uint32_t)k && l < B.min_ge[k]) B.min_ge[k] = l; }
   HIPCHK(c, hipMemcpyAsync(B.d_words, r->words.data(), r->words.size() * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(B.d_rec_off, r->rec_off.data(), r->rec_off.size() * 8, hipMemcpyHostToDevice, st));
   if (r->n) HIPCHK(c, hipMemcpyAsync(B.d_len, r->len.data(), r->len.size() * 4, hipMemcpyHostToDevice, st));
@@ -1248,6 +1255,16 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   const DevIndex& di = c->idx[slot];
   if (di.lnwin < 8 || di.lnwin > 20) { set_err(c, "unsupported seed length"); return SMR_ERR_ARG; }
   DParams P = make_dparams(c, di, p);
+  // --edges N% of a read of fewer than 100 / N letters is 0, and 0 is not "no margin" in the reference: `tail > edges - 1` is an unsigned compare
+  // (alignment.cpp:320,345), so such a read is aligned against the whole rest of its reference sequence.  Not built here (the windows of the
+  // Smith-Waterman kernels are sized read + 2 x edges): said before anything runs, not as a capacity error of some kernel.
+  if (p->is_as_percent) {
+    const uint32_t lmin = c->b->min_ge[(std::min<uint32_t>(std::max<uint32_t>(di.lnwin, 8u), 20u) - 8u) / 2u];
+    if (lmin != ~0u && (uint32_t)((p->edges / 100.0) * (double)lmin) == 0) {
+      set_err(c, "edges as a percentage: the batch has a searchable read so short that the percentage rounds to 0 letters; the reference then aligns it against the whole rest of the reference sequence (alignment.cpp:320,345), which is not supported -- use an absolute --edges");
+      return SMR_ERR_ARG;
+    }
+  }
   uint32_t ml, rf; size_t lds; chain_lds(c, P, ml, rf, lds);
   if (lds > 150 * 1024) { set_err(c, "reads too long for this build of the SW kernel (LDS)"); return SMR_ERR_CAPACITY; }
   c->b->last_num_alignments = p->num_alignments;

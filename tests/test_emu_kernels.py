@@ -19,7 +19,7 @@ from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_inde
                              test_percent_edges_on_kilobase_reads, test_mixed_read_lengths, test_reads_sharing_seeds_with_thousands_of_references,
                              test_optional_paths_of_the_candidate_stage_give_the_oracle_records, test_pigeonhole_search_bytes_equal_a_host_recount,
                              test_a_window_with_hundreds_of_hits, test_rounds_adapt_from_part_to_part_without_changing_a_record,
-                             test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_are_refused)
+                             test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_are_refused, test_edges_outside_what_the_reference_defines_are_refused)
 from test_gpu_parity import test_align_records_match_oracle as _align_body
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 

@@ -409,6 +409,19 @@ def test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_are_refused(engi
     _compare(recs_g, recs_o, "after a refused scheme")
 
 
+@pytest.mark.parametrize("opts,msg", [({"edges": 0}, "edges must be 1..10"), ({"edges": 11}, "edges must be 1..10"), ({"edges": 1, "is_as_percent": 1}, "rounds to 0 letters")],
+                         ids=["edges0", "edges11", "one_percent_of_a_short_read"])
+def test_edges_outside_what_the_reference_defines_are_refused(engine, wl, opts, msg):
+    """--edges: the reference's parser takes 1..10 (options.cpp:676).  With 0 -- also what N % of a read of fewer than 100 / N letters rounds to -- its
+    `tail > edges - 1` is an unsigned compare (alignment.cpp:320,345) and the read is aligned against the whole rest of the reference sequence; larger
+    margins make window lengths wrap (found by tools/fuzz_emu.py).  Said before anything runs."""
+    with pytest.raises(smr.SmrError, match=msg):
+        wl.gpu_records(engine, **opts)
+    recs_o, _ = wl.oracle_records(edges=10, is_as_percent=1)        # 10 % of the shortest searchable read (18 letters) is a letter: fine
+    recs_g, _ = wl.gpu_records(engine, edges=10, is_as_percent=1)
+    _compare(recs_g, recs_o, "edges 10 %")
+
+
 def test_small_candidate_pool_is_redone_and_grows(wl, monkeypatch):
     """SMR_PG_CAND_CAP=8: most waves of k_seed_pg overflow their candidate pool and are searched again by the DFS kernel -- the records
     stay the oracle's -- and smr_align_part doubles the pool for the next part, so a second run over the same reads is redone less."""

@@ -1,0 +1,96 @@
+"""Differential fuzzing of the kernel sources against the CPU oracle, without a GPU: seeded random workloads (DB shape, read lengths, error and N rates,
+seed length) x random points of the option space of the path (scoring scheme, num_seeds, min_lis, edges, best / num_alignments, strands, full search,
+minoccur, strides, minimal score), each run through the oracle and through the kernels compiled for the host against the wave64 emulator (tests/emu);
+records (Read::toBinString bytes) and counters must be equal.  TEST INFRASTRUCTURE (uses oracle/ and tests/helpers); the GPU parity tests cover a
+fixed list of option sets -- this looks for the combinations nobody wrote down.
+
+    python tools/fuzz_emu.py [first_seed [n_cases]]        # prints one line per case, the differing ones with everything needed to repeat them
+"""
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+import sortmerna_amd as smr  # noqa: E402
+from helpers import emu  # noqa: E402
+from helpers.workload import Workload  # noqa: E402
+
+SCHEMES = [(2, -3, 5, 2), (2, -3, 5, 2), (2, -3, 3, 2), (3, -4, 6, 3), (5, -4, 5, 2), (1, -2, 3, 1), (2, -3, 4, 3), (4, -5, 7, 3), (2, -3, 10, 2), (1, -1, 2, 1)]
+
+
+def case(seed, tmp):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
+    lnwin = pick([18, 18, 18, 18, 16, 14, 12, 12])       # (10 with 300-letter reads: every read meets most references -- minutes per case on the emulator)
+    wk = dict(db_nt=int(pick([40_000, 80_000, 150_000, 300_000])), n_reads=int(pick([200, 400, 700])), read_len=int(pick([40, 75, 100, 150, 150, 220, 301])),
+              frac_db=float(pick([0.2, 0.5, 0.8])), seed=seed, n_rate=float(pick([0.0, 0.002, 0.02])), family_size=int(pick([1, 4, 40, 40, 200])),
+              lnwin=lnwin, mean_len=int(pick([300, 1500])), db_kw=dict(sub_lo=float(pick([0.0, 0.01, 0.03])), sub_hi=float(pick([0.02, 0.06, 0.10])), indel=float(pick([0.0, 0.005, 0.02]))))
+    if wk["db_kw"]["sub_hi"] < wk["db_kw"]["sub_lo"]:
+        wk["db_kw"]["sub_hi"] = wk["db_kw"]["sub_lo"] + 0.01
+    wk["db_kw"]["min_len"] = min(400, wk["mean_len"])
+    match, mismatch, go, ge = pick(SCHEMES)
+    score_n = pick([mismatch, mismatch, 0, -1, -min(2 * go, 2 * ge, 127), 1])
+    opts = dict(match=match, mismatch=mismatch, gap_open=go, gap_ext=ge, score_N=int(score_n),
+                num_seeds=int(pick([1, 2, 2, 2, 3])), min_lis=int(pick([1, 2, 2, 3])), is_best=int(pick([1, 1, 0])), num_alignments=int(pick([0, 1, 1, 2, 3, 5])),
+                is_full_search=int(pick([0, 0, 1])), minoccur=int(pick([0, 0, 0, 1, 3])))
+    if pick([0, 0, 1]):
+        opts["edges"], opts["is_as_percent"] = int(pick([6, 8, 10, 10])), 1
+    else:
+        opts["edges"] = int(pick([1, 2, 4, 4, 10]))
+    fr = pick([(1, 1), (1, 1), (1, 0), (0, 1)])
+    opts["is_forward"], opts["is_reverse"] = fr
+    half = lnwin // 2
+    opts["skiplengths"] = pick([[lnwin, half, 3], [lnwin, half, 3], [lnwin, lnwin, 3], [lnwin, 6, 2], [half, half, half], [lnwin, half, 1]])
+    delta = int(pick([0, 0, 0, -20, 15, 60]))
+    w = Workload(tmp, **wk)
+    ms = max(1, int(w.minimal_score) + delta)
+    return w, wk, opts, ms
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    bad = 0
+    with emu.active():
+        e = smr.Engine(0)
+        for seed in range(first, first + n):
+            t = time.time()
+            with tempfile.TemporaryDirectory(prefix="smr_fuzz_") as tmp:
+                try:
+                    w, wk, opts, ms = case(seed, tmp)
+                    o_opts = dict(opts)
+                    o_opts["lnwin"] = wk["lnwin"]
+                    recs_o, ctr_o = w.oracle_records(minimal_score=ms, **o_opts)
+                    e.set_seed_mode(seed & 1 if seed % 5 == 0 else 0)
+                    try:
+                        p = smr.default_params(minimal_score=ms, **opts)
+                        smr.align(e, w.reads, [w.parts], [p], max_alignments_per_read=(256 if opts["num_alignments"] == 0 else None))
+                        recs_g, ctr_g = e.records(), e.counters(1)
+                    except smr.SmrError as x:
+                        if "rounds to 0 letters" in str(x) or "max_alignments_per_read" in str(x):      # documented limits, said explicitly
+                            print("seed %d refused: %s" % (seed, str(x)[:110]), flush=True)
+                            continue
+                        raise
+                    diff = [i for i, (a, b) in enumerate(zip(recs_g, recs_o)) if a != b]
+                    same_ctr = ctr_g["num_aligned"] == ctr_o["num_aligned"] and ctr_g["reads_matched_per_db"][0] == ctr_o["per_db"] and ctr_g["num_short"] == ctr_o["num_short"]
+                    ok = not diff and same_ctr
+                    print("seed %d %s: %d reads, %d aligned, %.1f s%s" % (seed, "ok" if ok else "DIFFERS", len(recs_o), ctr_o["num_aligned"], time.time() - t,
+                                                                        "" if ok else "  records differing %d (first read %s), counters gpu %s oracle %s\n    workload %s\n    options %s minimal_score %d" % (
+                                                                            len(diff), diff[:1], {k: ctr_g[k] for k in ("num_aligned", "num_short")}, {k: ctr_o[k] for k in ("num_aligned", "num_short")}, wk, opts, ms)), flush=True)
+                    bad += not ok
+                except Exception as x:  # noqa: BLE001
+                    print("seed %d ERROR %s: %s" % (seed, type(x).__name__, x), flush=True)
+                    bad += 1
+        e.close()
+    print("%d case(s), %d differing or failing" % (n, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
