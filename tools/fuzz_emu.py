@@ -48,6 +48,8 @@ def case(seed, tmp):
     half = lnwin // 2
     opts["skiplengths"] = pick([[lnwin, half, 3], [lnwin, half, 3], [lnwin, lnwin, 3], [lnwin, 6, 2], [half, half, half], [lnwin, half, 1]])
     delta = int(pick([0, 0, 0, -20, 15, 60]))
+    if pick([0, 0, 0, 1]):
+        wk["max_mb"] = float(pick([0.4, 0.8, 1.5]))          # several index parts
     w = Workload(tmp, **wk)
     ms = max(1, int(w.minimal_score) + delta)
     return w, wk, opts, ms
@@ -58,9 +60,19 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     bad = 0
     with emu.active():
-        e = smr.Engine(0)
         for seed in range(first, first + n):
             t = time.time()
+            # the library's own switches (each one a different route to the same records), drawn per case: a context reads them when it is created
+            rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+            env = {}
+            for name, vals in (("SMR_WALK_ROUNDS", [None, None, "1", "2", "3"]), ("SMR_WALK_K", [None, None, "1", "2", "8"]), ("SMR_WALK_ASSUME", [None, None, "0", "100"]),
+                               ("SMR_WALK_SPLIT", [None, None, None, "0"]), ("SMR_HANDOVER", [None, None, None, "0"]), ("SMR_CAND_BLOOM", [None, None, None, "64"]),
+                               ("SMR_PG_CAND_CAP", [None, None, None, "8"]), ("SMR_WALK_GATHER", [None, None, None, "0"])):
+                v = vals[int(rng.integers(0, len(vals)))]
+                os.environ.pop(name, None)
+                if v is not None:
+                    os.environ[name] = env[name] = v
+            e = smr.Engine(0)
             with tempfile.TemporaryDirectory(prefix="smr_fuzz_") as tmp:
                 try:
                     w, wk, opts, ms = case(seed, tmp)
@@ -75,19 +87,20 @@ def main():
                     except smr.SmrError as x:
                         if "rounds to 0 letters" in str(x) or "max_alignments_per_read" in str(x):      # documented limits, said explicitly
                             print("seed %d refused: %s" % (seed, str(x)[:110]), flush=True)
+                            e.close()
                             continue
                         raise
                     diff = [i for i, (a, b) in enumerate(zip(recs_g, recs_o)) if a != b]
                     same_ctr = ctr_g["num_aligned"] == ctr_o["num_aligned"] and ctr_g["reads_matched_per_db"][0] == ctr_o["per_db"] and ctr_g["num_short"] == ctr_o["num_short"]
                     ok = not diff and same_ctr
                     print("seed %d %s: %d reads, %d aligned, %.1f s%s" % (seed, "ok" if ok else "DIFFERS", len(recs_o), ctr_o["num_aligned"], time.time() - t,
-                                                                        "" if ok else "  records differing %d (first read %s), counters gpu %s oracle %s\n    workload %s\n    options %s minimal_score %d" % (
-                                                                            len(diff), diff[:1], {k: ctr_g[k] for k in ("num_aligned", "num_short")}, {k: ctr_o[k] for k in ("num_aligned", "num_short")}, wk, opts, ms)), flush=True)
+                                                                        "" if ok else "  records differing %d (first read %s), counters gpu %s oracle %s\n    workload %s\n    options %s minimal_score %d\n    switches %s" % (
+                                                                            len(diff), diff[:1], {k: ctr_g[k] for k in ("num_aligned", "num_short")}, {k: ctr_o[k] for k in ("num_aligned", "num_short")}, wk, opts, ms, env)), flush=True)
                     bad += not ok
                 except Exception as x:  # noqa: BLE001
-                    print("seed %d ERROR %s: %s" % (seed, type(x).__name__, x), flush=True)
+                    print("seed %d ERROR %s: %s  (switches %s)" % (seed, type(x).__name__, x, env), flush=True)
                     bad += 1
-        e.close()
+            e.close()
     print("%d case(s), %d differing or failing" % (n, bad))
     return 1 if bad else 0
 
