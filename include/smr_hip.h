@@ -29,7 +29,7 @@
  *   seed hits             no limit: the lane-local hit lists grow to what a half-seed search can accept at most (31 L/2 - 20 strings, smr_prof.hit_list_cap)
  *   candidate references  <= 49 152 references sharing seeds with ONE read on one strand (the per-block global table of k_chain<EXT>)
  *   alignments per read   max_alignments_per_read given to smr_reads_upload (the reference's -num_alignments, or 256 for "all")
- *   scoring               match <= 127, mismatch >= -127, |score_N| <= 127, gaps <= 255, 2 * gap_open, 2 * gap_ext >= |mismatch| and gap_open > gap_ext
+ *   scoring               match <= 127, mismatch >= -127, -127 <= score_N <= 0, gaps <= 255, 2 * gap_open, 2 * gap_ext >= |mismatch| and gap_open > gap_ext
  *                         (under these conditions the affine recurrence here equals the reference's striped kernels cell for cell; outside them ssw.c's
  *                         scores depend on its SIMD stripe geometry: ssw.c:267,496 and its 16-bit lazy-F loop :496-507)
  *   edges                 1..10 letters or percent like the reference's --edges; a percentage must not round to 0 letters for any searchable read of the batch

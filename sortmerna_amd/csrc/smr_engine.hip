@@ -179,6 +179,9 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
 const char* scheme_unsupported(int mismatch, int score_N, int gap_open, int gap_ext) {
   const int mm = std::max(-mismatch, -std::min(score_N, 0));
   if (2 * gap_open < mm || 2 * gap_ext < mm) return "scoring scheme outside the supported range (2*gap_open and 2*gap_ext must be >= |mismatch|)";
+  // (3) rows and columns beyond the end of a sequence are scored as N by the packed kernels, which is harmless as long as N never adds to a score
+  // (found by tools/fuzz_emu.py: with score_N = +1 and ambiguous letters in the reference a reverse pass ran one row past the start of a read)
+  if (score_N > 0) return "scoring scheme outside the supported range (score_N must be <= 0: the kernels pad sequences with N)";
   if (gap_open <= gap_ext) return "scoring scheme outside the supported range (gap_open must be greater than gap_ext: the reference's 16-bit kernel ends its lazy-F loop early otherwise, ssw.c:496-507)";
   return nullptr;
 }

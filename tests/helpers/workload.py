@@ -17,7 +17,7 @@ GUMBEL_UNIFORM = (0.618874, 0.343238)
 
 class Workload:
     def __init__(self, tmpdir, db_nt=300_000, n_reads=4000, read_len=150, frac_db=0.4, seed=5, max_mb=3072.0,
-                 n_rate=0.002, family_size=40, lnwin=18, mean_len=1500, db_kw=None, db_fasta=None, seqs=None):
+                 n_rate=0.002, family_size=40, lnwin=18, mean_len=1500, db_kw=None, db_fasta=None, seqs=None, read_kw=None, db_ambiguous=0.0):
         """db_fasta + seqs: a DB file and reads the test wrote itself (a crafted case) instead of the seeded synthetic ones"""
         self.lnwin = lnwin
         self.dir = tmpdir
@@ -28,7 +28,20 @@ class Workload:
             self.db = os.path.join(tmpdir, "db_%d_%d.fasta" % (db_nt, seed))
             synth.make_db(self.db, db_nt, seed=seed, family_size=family_size, mean_len=mean_len, **(db_kw or {}))
             codes, offs = synth.load_db_codes(self.db)
-            self.letters = synth.make_reads(codes, offs, n_reads, read_len=read_len, frac_db=frac_db, seed=seed + 1, n_rate=n_rate)
+            if db_ambiguous > 0:                 # a fraction of the reference letters become IUPAC ambiguity codes / lower case (the reads are sampled from the clean text)
+                arng = np.random.Generator(np.random.PCG64(seed + 3))
+                out = []
+                for line in open(self.db, "rb"):
+                    if not line.startswith(b">"):
+                        a = np.frombuffer(line.rstrip(b"\r\n"), dtype=np.uint8).copy()
+                        m = arng.random(len(a)) < db_ambiguous
+                        a[m] = np.frombuffer(b"NNNRYKMSWn", dtype=np.uint8)[arng.integers(0, 10, int(m.sum()))]
+                        lo = arng.random(len(a)) < db_ambiguous
+                        a[lo] = np.frombuffer(bytes(a[lo]).lower(), dtype=np.uint8)
+                        line = a.tobytes() + b"\n"
+                    out.append(line)
+                open(self.db, "wb").write(b"".join(out))
+            self.letters = synth.make_reads(codes, offs, n_reads, read_len=read_len, frac_db=frac_db, seed=seed + 1, n_rate=n_rate, **(read_kw or {}))
             # ragged lengths, a too-short read and an empty read to cover the edge cases
             self.seqs = [bytes(x).decode() for x in self.letters]
             rng = np.random.Generator(np.random.PCG64(seed + 2))

@@ -392,12 +392,13 @@ def test_rounds_adapt_from_part_to_part_without_changing_a_record(wl, monkeypatc
         e.close()
 
 
-@pytest.mark.parametrize("scoring", [{"gap_open": 3, "gap_ext": 3}, {"gap_open": 2, "gap_ext": 3}, {"mismatch": -5, "gap_open": 2, "gap_ext": 1}],
-                         ids=["open_equals_ext", "open_below_ext", "gaps_below_half_a_mismatch"])
+@pytest.mark.parametrize("scoring", [{"gap_open": 3, "gap_ext": 3}, {"gap_open": 2, "gap_ext": 3}, {"mismatch": -5, "gap_open": 2, "gap_ext": 1}, {"score_N": 1}],
+                         ids=["open_equals_ext", "open_below_ext", "gaps_below_half_a_mismatch", "positive_N"])
 def test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_are_refused(engine, wl, scoring):
     """An explicit error, never a silent difference: with gap_open <= gap_ext the reference's 16-bit kernel loses gaps across stripe boundaries
     (tests/test_oracle_golden.py shows it on ssw.c itself), with gaps cheaper than half a mismatch both kernels miss adjacent gaps -- the scores
-    then depend on the SIMD stripe geometry, which the kernels here do not emulate.  smr_align_part and smr_ssw_batch say so."""
+    then depend on the SIMD stripe geometry, which the kernels here do not emulate; a positive score for N would make the N the kernels pad
+    sequences with part of alignments (tools/fuzz_emu.py found a begin cell in front of a read).  smr_align_part and smr_ssw_batch say so."""
     with pytest.raises(smr.SmrError, match="supported range"):
         wl.gpu_records(engine, **scoring)
     sc = dict(match=2, mismatch=-3, score_N=-3, gap_open=5, gap_ext=2)

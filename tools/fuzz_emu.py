@@ -28,16 +28,19 @@ def case(seed, tmp):
     rng = np.random.Generator(np.random.PCG64(seed))
     pick = lambda xs: xs[int(rng.integers(0, len(xs)))]  # noqa: E731
     lnwin = pick([18, 18, 18, 18, 16, 14, 12, 12])       # (10 with 300-letter reads: every read meets most references -- minutes per case on the emulator)
-    wk = dict(db_nt=int(pick([40_000, 80_000, 150_000, 300_000])), n_reads=int(pick([200, 400, 700])), read_len=int(pick([40, 75, 100, 150, 150, 220, 301])),
-              frac_db=float(pick([0.2, 0.5, 0.8])), seed=seed, n_rate=float(pick([0.0, 0.002, 0.02])), family_size=int(pick([1, 4, 40, 40, 200])),
+    wk = dict(db_nt=int(pick([40_000, 80_000, 150_000, 300_000])), n_reads=int(pick([200, 400, 700, 33, 12])), read_len=int(pick([40, 75, 100, 150, 150, 220, 301, 301, 600, 1100])),
+              frac_db=float(pick([0.2, 0.5, 0.8])), seed=seed, n_rate=float(pick([0.0, 0.002, 0.02, 0.06])), family_size=int(pick([1, 4, 40, 40, 200])),
               lnwin=lnwin, mean_len=int(pick([300, 1500])), db_kw=dict(sub_lo=float(pick([0.0, 0.01, 0.03])), sub_hi=float(pick([0.02, 0.06, 0.10])), indel=float(pick([0.0, 0.005, 0.02]))))
+    if wk["read_len"] >= 600:
+        wk["n_reads"] = min(wk["n_reads"], 60)
+        wk["mean_len"] = 1500
     if wk["db_kw"]["sub_hi"] < wk["db_kw"]["sub_lo"]:
         wk["db_kw"]["sub_hi"] = wk["db_kw"]["sub_lo"] + 0.01
     wk["db_kw"]["min_len"] = min(400, wk["mean_len"])
     match, mismatch, go, ge = pick(SCHEMES)
-    score_n = pick([mismatch, mismatch, 0, -1, -min(2 * go, 2 * ge, 127), 1])
+    score_n = pick([mismatch, mismatch, 0, -1, -min(2 * go, 2 * ge, 127)])
     opts = dict(match=match, mismatch=mismatch, gap_open=go, gap_ext=ge, score_N=int(score_n),
-                num_seeds=int(pick([1, 2, 2, 2, 3])), min_lis=int(pick([1, 2, 2, 3])), is_best=int(pick([1, 1, 0])), num_alignments=int(pick([0, 1, 1, 2, 3, 5])),
+                num_seeds=int(pick([1, 2, 2, 2, 3, 4])), min_lis=int(pick([1, 2, 2, 3, 4])), is_best=int(pick([1, 1, 0])), num_alignments=int(pick([0, 1, 1, 2, 3, 5, 8])),
                 is_full_search=int(pick([0, 0, 1])), minoccur=int(pick([0, 0, 0, 1, 3])))
     if pick([0, 0, 1]):
         opts["edges"], opts["is_as_percent"] = int(pick([6, 8, 10, 10])), 1
@@ -48,6 +51,9 @@ def case(seed, tmp):
     half = lnwin // 2
     opts["skiplengths"] = pick([[lnwin, half, 3], [lnwin, half, 3], [lnwin, lnwin, 3], [lnwin, 6, 2], [half, half, half], [lnwin, half, 1]])
     delta = int(pick([0, 0, 0, -20, 15, 60]))
+    wk["read_kw"] = dict(sub=float(pick([0.0, 0.005, 0.005, 0.03, 0.08])), indel=float(pick([0.0, 0.0001, 0.002, 0.01])))
+    if pick([0, 0, 1]):
+        wk["db_ambiguous"] = float(pick([0.0005, 0.003]))
     if pick([0, 0, 0, 1]):
         wk["max_mb"] = float(pick([0.4, 0.8, 1.5]))          # several index parts
     w = Workload(tmp, **wk)
