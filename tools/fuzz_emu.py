@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 import sortmerna_amd as smr  # noqa: E402
-from helpers import emu  # noqa: E402
+from helpers import emu, orc  # noqa: E402
 from helpers.workload import Workload  # noqa: E402
 
 SCHEMES = [(2, -3, 5, 2), (2, -3, 5, 2), (2, -3, 3, 2), (3, -4, 6, 3), (5, -4, 5, 2), (1, -2, 3, 1), (2, -3, 4, 3), (4, -5, 7, 3), (2, -3, 10, 2), (1, -1, 2, 1)]
@@ -61,6 +61,27 @@ def case(seed, tmp):
     return w, wk, opts, ms
 
 
+def second_db(w, wk, tmp, seed):
+    """a second reference DB for the same reads: the first one's sequences with 3 % of their letters changed and a fifth of them dropped -- reads align to
+    both with different scores (best-N replacement across DBs, the per-DB counters moving with it: alignment.cpp:420-459)"""
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0xDB2))
+    out, keep = [], True
+    for line in open(w.db, "rb"):
+        if line.startswith(b">"):
+            keep = rng.random() < 0.8
+            if keep:
+                out.append(line)
+        elif keep:
+            a = np.frombuffer(line.rstrip(b"\r\n"), dtype=np.uint8).copy()
+            m = rng.random(len(a)) < 0.03
+            a[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+            out.append(a.tobytes() + b"\n")
+    os.makedirs(os.path.join(tmp, "db2"), exist_ok=True)
+    db2 = os.path.join(tmp, "db2", "second.fasta")
+    open(db2, "wb").write(b"".join(out))
+    return Workload(os.path.join(tmp, "db2"), db_fasta=db2, seqs=w.seqs, lnwin=wk["lnwin"], max_mb=wk.get("max_mb", 3072.0))
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -84,12 +105,26 @@ def main():
                     w, wk, opts, ms = case(seed, tmp)
                     o_opts = dict(opts)
                     o_opts["lnwin"] = wk["lnwin"]
-                    recs_o, ctr_o = w.oracle_records(minimal_score=ms, **o_opts)
+                    ws = [w]
+                    if seed % 4 == 3:
+                        ws.append(second_db(w, wk, tmp, seed))
+                        if seed % 8 == 7:
+                            ws.reverse()                    # the mutated DB first: the second one then replaces alignments with better ones
+                    mss = [max(1, int(x.minimal_score) + (ms - int(w.minimal_score))) for x in ws]
+                    run = orc.Run(w.seqs)
+                    for k, x in enumerate(ws):
+                        for part in range(x.stats.nparts):
+                            po = orc.default_params(minimal_score=mss[k], **o_opts)
+                            po.index_num, po.part, po.is_last_index_part = k, part, int(k == len(ws) - 1 and part == x.stats.nparts - 1)
+                            run.align_part(x.prefix, x.db, x.stats, part, po)
+                    recs_o = run.records()
+                    ctr_o = dict(num_aligned=run.counters.num_aligned, num_short=run.counters.num_short, per_db=[int(run.counters.reads_matched_per_db[k]) for k in range(len(ws))])
+                    run.close()
                     e.set_seed_mode(seed & 1 if seed % 5 == 0 else 0)
                     try:
-                        p = smr.default_params(minimal_score=ms, **opts)
-                        smr.align(e, w.reads, [w.parts], [p], max_alignments_per_read=(256 if opts["num_alignments"] == 0 else None))
-                        recs_g, ctr_g = e.records(), e.counters(1)
+                        ps = [smr.default_params(minimal_score=m, **opts) for m in mss]
+                        smr.align(e, w.reads, [x.parts for x in ws], ps, max_alignments_per_read=(256 if opts["num_alignments"] == 0 else None))
+                        recs_g, ctr_g = e.records(), e.counters(len(ws))
                     except smr.SmrError as x:
                         if "rounds to 0 letters" in str(x) or "max_alignments_per_read" in str(x):      # documented limits, said explicitly
                             print("seed %d refused: %s" % (seed, str(x)[:110]), flush=True)
@@ -97,9 +132,9 @@ def main():
                             continue
                         raise
                     diff = [i for i, (a, b) in enumerate(zip(recs_g, recs_o)) if a != b]
-                    same_ctr = ctr_g["num_aligned"] == ctr_o["num_aligned"] and ctr_g["reads_matched_per_db"][0] == ctr_o["per_db"] and ctr_g["num_short"] == ctr_o["num_short"]
+                    same_ctr = ctr_g["num_aligned"] == ctr_o["num_aligned"] and list(ctr_g["reads_matched_per_db"][:len(ws)]) == ctr_o["per_db"] and ctr_g["num_short"] == ctr_o["num_short"]
                     ok = not diff and same_ctr
-                    print("seed %d %s: %d reads, %d aligned, %.1f s%s" % (seed, "ok" if ok else "DIFFERS", len(recs_o), ctr_o["num_aligned"], time.time() - t,
+                    print("seed %d %s: %d reads, %d aligned%s, %.1f s%s" % (seed, "ok" if ok else "DIFFERS", len(recs_o), ctr_o["num_aligned"], " (two DBs: %s)" % ctr_o["per_db"] if len(ws) > 1 else "", time.time() - t,
                                                                         "" if ok else "  records differing %d (first read %s), counters gpu %s oracle %s\n    workload %s\n    options %s minimal_score %d\n    switches %s" % (
                                                                             len(diff), diff[:1], {k: ctr_g[k] for k in ("num_aligned", "num_short")}, {k: ctr_o[k] for k in ("num_aligned", "num_short")}, wk, opts, ms, env)), flush=True)
                     bad += not ok
