@@ -120,7 +120,7 @@ def main():
                     recs_o = run.records()
                     ctr_o = dict(num_aligned=run.counters.num_aligned, num_short=run.counters.num_short, per_db=[int(run.counters.reads_matched_per_db[k]) for k in range(len(ws))])
                     run.close()
-                    e.set_seed_mode(seed & 1 if seed % 5 == 0 else 0)
+                    e.set_seed_mode(int(os.environ["FUZZ_SEED_MODE"]) if "FUZZ_SEED_MODE" in os.environ else (seed & 1 if seed % 5 == 0 else 0))      # 1: the DFS seed kernel
                     try:
                         ps = [smr.default_params(minimal_score=m, **opts) for m in mss]
                         smr.align(e, w.reads, [x.parts for x in ws], ps, max_alignments_per_read=(256 if opts["num_alignments"] == 0 else None))
