@@ -79,6 +79,8 @@ struct smr_ctx {
   // collision.  Measured per 2 M-read launch (profiles/r3s18_*): 512 words k_cand 1.07 ms + k_chain 6.01 ms, 256: 0.59 + 6.06, 128: 0.48 + 6.07
   // (16 KB of LDS per block: the 8 blocks per CU that the wave slots allow)
   uint32_t cand_bloom = 128;
+  // repeated seeds (k_seed_dedup): keys with at least this many tuples in a launch (and four times the average) are searched once per different seed; 0: off
+  uint32_t hot_min = getenv("SMR_SEED_DEDUP") ? (uint32_t)std::max(0, atoi(getenv("SMR_SEED_DEDUP"))) : 1024u;
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
   // k_seed_pg: waves of the launch (0: one per wave chunk the batch can have; else a wave walks chunks it, it + grid, ...), XCD-aware chunk order
   uint32_t pg_grid = getenv("SMR_PG_GRID") ? (uint32_t)atoi(getenv("SMR_PG_GRID")) : 262144u;
@@ -271,6 +273,7 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
   if (c->sb_nk < nk) {
     if ((rc = dev_alloc(c, &c->sb.chist, (size_t)4096 + 1))) return rc;
     if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.hpre, (size_t)4096 + 2))) return rc;
     if (!c->sb.rows && (rc = dev_alloc(c, &c->sb.rows, (size_t)SEED_KEY_BLOCKS * 4096))) return rc;
     if (!c->sb.bcnt && (rc = dev_alloc(c, &c->sb.bcnt, (size_t)SEED_KEY_BLOCKS))) return rc;
     if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
@@ -290,8 +293,16 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
     if ((rc = dev_alloc(c, &c->sb.wbin, 2 * slots / 64 + 2))) return rc;
     if ((rc = dev_alloc(c, &c->sb.zbits, slots / 32 + 2))) return rc;
     if ((rc = dev_alloc(c, &c->sb.gflag, slots / 2048 + 2))) return rc;
+    // skewed batches: a coarse bin of at least SEED_HOT_BIN_MIN tuples in sub-ranges of SEED_HOT_SUB (their fine histograms); the pieces of hot keys (>= 1024 tuples each)
+    c->sb.hbin_min = getenv("SMR_SEED_HOT_BIN") ? (uint32_t)std::max(1, atoi(getenv("SMR_SEED_HOT_BIN"))) : SEED_HOT_BIN_MIN;
+    c->sb.hsub = getenv("SMR_SEED_HOT_SUB") ? (uint32_t)std::max(1, atoi(getenv("SMR_SEED_HOT_SUB"))) : SEED_HOT_SUB;
+    c->sb.cap_hent = (uint32_t)(2 * slots / c->sb.hsub + 2 * slots / c->sb.hbin_min + 2);
+    if ((rc = dev_alloc(c, &c->sb.hh, (size_t)c->sb.cap_hent * 512))) return rc;
+    c->sb.cap_pieces = (uint32_t)std::min<uint64_t>(2 * slots / std::max(c->hot_min, 64u) + 2 * slots / SEED_DD_PIECE + 16, 1u << 26);
+    if ((rc = dev_alloc(c, &c->sb.pieces, (size_t)c->sb.cap_pieces))) return rc;
     c->sb_slots = slots;
   }
+  c->sb.hot_min = c->hot_min;
   c->sb.nk = nk; c->sb.nkh = nk / 2;
   c->sb.fb = std::min<uint32_t>(9, P.lnwin); c->sb.nc = nk >> c->sb.fb;       // L <= 20: at most 4096 coarse bins
   c->sb.cb = 2 * P.partialwin; c->sb.kbits = P.lnwin + 1;
@@ -355,7 +366,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
   const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
-  if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
+  if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_hbins_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
   if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
     HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     c->split_lds_attr = lds_split;
@@ -382,6 +393,14 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
   ev_mark(c, KP_BINS);
   hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
+  // the coarse bins that are far larger than the others, several blocks each (none on evenly spread keys: three empty launches)
+  const uint32_t gh = std::min<uint32_t>(sb.cap_hent, (uint32_t)c->n_cu * 8u);
+  hipLaunchKernelGGL(k_seed_hbins_hist, dim3(gh), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_hbins_scan, dim3(sb.nc), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_hbins_move, dim3(gh), dim3(1024), lds_bins, c->stream, sb);
+  if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
+  const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 16u);
+  if (sb.hot_min) hipLaunchKernelGGL(k_seed_dedup, dim3(gd), dim3(256), 0, c->stream, sb);
   const uint32_t* no_redo = nullptr;
   if (c->seed_exact) {
     ev_mark(c, KP_PG0);
@@ -398,11 +417,20 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
       if (dir == 0) {
         hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
+        if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<0>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
       } else {
         hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
         hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
+        if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<1>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
       }
     }
+  }
+  if (getenv("SMR_SEED_DEBUG")) {                            // (debug aid: synchronises)
+    uint32_t sn[SN_COUNT], hent = 0;
+    HIPCHK(c, hipMemcpyAsync(sn, sb.sn, sizeof sn, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&hent, sb.hpre + sb.nc, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fprintf(stderr, "libsmr_hip: seed stage pass %d: %u tuples (%u forward), %u sub-ranges of large coarse bins, %u pieces of hot keys (from %u tuples per key), %u redo waves\n", pass, sn[SN_TUPLES], sn[SN_FWD], hent, sn[SN_PIECES], sb.hot_min, sn[SN_REDO]);
   }
   ev_mark(c, KP_FINISH);
   hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, pool_words, c->b->d_ctr);
@@ -1008,7 +1036,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   for (int q = 0; q < 2; q++) { dev_free(&c->d_wlist[q]); dev_free(&c->d_wstate[q]); dev_free(&c->d_wtask[q]); dev_free(&c->d_wres[q]); }
   dev_free(&c->d_wtidx); dev_free(&c->d_wslow); dev_free(&c->d_wctr);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
-  dev_free(&c->sb.srt); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
+  dev_free(&c->sb.srt); dev_free(&c->sb.hpre); dev_free(&c->sb.hh); dev_free(&c->sb.pieces); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
   for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);

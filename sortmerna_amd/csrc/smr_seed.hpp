@@ -134,7 +134,7 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 #define SEED_ZERO_BIT 0x80000000u
 
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
-enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples
+enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_PIECES = 3, SN_COUNT = 4 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples, pieces of hot keys
 
 // The tuples of the seed stage are 8 bytes (round 3: 12).  A tuple = one half-seed search of one window: its 9-mer key (direction in the top
 // bit: forward keys [0, nkh), reverse keys [nkh, 2 nkh)), the pw chars that feed the automaton, and the window's SLOT = read * maxwin +
@@ -143,8 +143,12 @@ enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_COUNT = 4 };      // device co
 // to the block's first slot, and from the first sort pass on the coarse key bits are implied by where the tuple lies:
 //   tmp        key (kbits = L + 1) | chars (cb = L) << kbits | block-relative slot << (kbits + cb)
 //   mid, srt   slot (32) | chars << 32 | fine key bits (fb) << (32 + cb)            coarse bin of srt[i]: wbin[i / 64], then cbase
+//   srt, a tuple that k_seed_dedup found to repeat another one of its key:   slot (32) | slot of that REPRESENTATIVE << 32 | 1 << 63
+//   (slots are < 2^31, chars | fine bits < 2^29: bit 63 tells the two apart).  Such a tuple is not searched: its window gets the
+//   representative's hit segment (k_seed_prop).
 typedef unsigned long long SeedTup;
-struct SeedKey { uint32_t slot, chars, key; };          // a decoded tuple of srt
+#define SEED_TUP_DUP (1ull << 63)
+struct SeedKey { uint32_t slot, chars, key; bool dup; };          // a decoded tuple of srt
 
 #define SEED_KEY_BLOCKS 2048u                             // most blocks of k_seed_keys / k_seed_split (rows of the histogram matrix)
 #define SEED_WAVES 16u                                    // waves per block of k_seed_keys
@@ -176,6 +180,13 @@ struct SeedBufs {
   uint32_t kb, rpb;          // blocks of k_seed_keys / k_seed_split, reads per block
   uint32_t cb, kbits;        // bits of the automaton chars (2 pw = L) and of the key (L + 1)
   uint32_t g_shift;          // k_seed_keys: log2 of the lanes per read (0: a lane walks all windows of its read; 6: one read per wave)
+  // skewed batches (amplicons, a sample dominated by one organism's rRNA: thousands of windows share a key, and most of them the whole seed)
+  uint32_t* hpre;            // [nc + 1] coarse bins far larger than the average are sorted by several blocks: exclusive prefix of their numbers of sub-ranges (0 for the others)
+  uint32_t* hh;              // [cap_hent][2^fb] per sub-range of a large coarse bin: its histogram of the fine bits, then where its first tuple of every fine bin goes
+  uint2* pieces;             // {first tuple, tuples <= SEED_DD_PIECE} of the keys with at least hot_min tuples (and four times the average): where k_seed_dedup looks for repeated seeds
+  uint32_t cap_hent, cap_pieces;
+  uint32_t hot_min;          // 0: no search for repeated seeds
+  uint32_t hbin_min, hsub;   // a coarse bin is "large" from 4 x the average size and at least hbin_min tuples (SEED_HOT_BIN_MIN); tuples per sub-range (SEED_HOT_SUB)
 };
 __device__ __forceinline__ bool wseg_has(const SeedBufs& sb, int d, uint32_t slot) { return (sb.fbits[d][slot >> 5] >> (slot & 31u)) & 1u; }
 __device__ __forceinline__ void wseg_put(const SeedBufs& sb, int d, uint32_t slot, uint32_t v, bool zero) {
@@ -189,7 +200,8 @@ __device__ __forceinline__ SeedKey seed_decode(const SeedBufs& sb, uint32_t i) {
   uint32_t nx = sb.cbase[c + 1];
   while (i >= nx) { c++; nx = sb.cbase[c + 1]; }           // (i < cbase[nc]: ends; a chunk of 64 tuples rarely spans more than two bins)
   SeedKey k;
-  k.slot = (uint32_t)t; k.chars = (uint32_t)(t >> 32) & ((1u << sb.cb) - 1u); k.key = (c << sb.fb) | (uint32_t)(t >> (32u + sb.cb));
+  k.slot = (uint32_t)t; k.chars = (uint32_t)(t >> 32) & ((1u << sb.cb) - 1u); k.key = (c << sb.fb) | ((uint32_t)(t >> (32u + sb.cb)) & ((1u << sb.fb) - 1u));
+  k.dup = (t & SEED_TUP_DUP) != 0;                          // (chars and key of such a tuple mean nothing)
   return k;
 }
 
@@ -366,8 +378,15 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
 //   k_seed_bins     one block per coarse bin: histogram of the fine key bits (<= 512 bins), then the same staged move to the final places
 // History per 60 M tuples on the MI355X: one counting sort with a returning global atomic per tuple 2.4 + 1.9 ms; two-level with LDS
 // atomics and per-lane stores 1.3 + 0.9 + 1.0 ms (HBM writes 3.0 x and 2.7 x the tuple bytes, profiles/r03a_sort_variants_*).
+// + which coarse bins are far larger than the average (a key that thousands of windows share): k_seed_bins leaves those to the k_seed_hbins_*
+// kernels, which sort one bin with several blocks -- hpre[c] = the sub-ranges of SEED_HOT_SUB tuples of the large bins in front of c
+#define SEED_HOT_SUB 65536u                               // tuples of a large coarse bin that one block of k_seed_hbins_* takes   (SeedBufs::hsub; SMR_SEED_HOT_SUB: the tests' small batches)
+#define SEED_HOT_BIN_MIN 262144u                          // a coarse bin is "large" from 4 x the average size and at least this many tuples   (SeedBufs::hbin_min; SMR_SEED_HOT_BIN)
+#define SEED_DD_PIECE 16384u                              // tuples of one key that a block of k_seed_dedup looks at together
+#define SEED_DD_TAB 4096u                                 // ... slots of its hash table in LDS (8 bytes each)
+__device__ __forceinline__ uint32_t seed_hot_bin(const SeedBufs& sb, uint32_t n_tup) { return max(sb.hbin_min, 4u * (n_tup / sb.nc)); }
 __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long long* __restrict__ ctr) {
-  __shared__ uint32_t s_part[16];
+  __shared__ uint32_t s_part[16], s_part2[16];
   // <= 4096 bins: 4 consecutive bins per thread
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
   uint32_t v[4], sum = 0;
@@ -376,13 +395,26 @@ __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long 
   for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += x; }
   if (lane == 63) s_part[wv] = incl;
   __syncthreads();
-  uint32_t pre = incl - sum;
-  for (uint32_t q = 0; q < wv; q++) pre += s_part[q];
+  uint32_t pre = incl - sum, n_all = 0;
+  for (uint32_t q = 0; q < 16; q++) { if (q < wv) pre += s_part[q]; n_all += s_part[q]; }
+  // the sub-ranges of the large bins
+  const uint32_t big = seed_hot_bin(sb, n_all);
+  uint32_t ns[4], nsum = 0;
+  for (int q = 0; q < 4; q++) { ns[q] = v[q] >= big ? (v[q] + sb.hsub - 1u) / sb.hsub : 0u; nsum += ns[q]; }
+  uint32_t nincl = nsum;
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(nincl, d, 64); if ((int)lane >= d) nincl += x; }
+  if (lane == 63) s_part2[wv] = nincl;
+  __syncthreads();
+  uint32_t npre = nincl - nsum;
+  for (uint32_t q = 0; q < wv; q++) npre += s_part2[q];
   for (int q = 0; q < 4; q++) {
     const uint32_t c = 4 * t + q;
-    if (c < sb.nc) { sb.cbase[c] = pre; if (c == (sb.nkh >> sb.fb)) { sb.sn[SN_FWD] = pre; if (pre) ctr_add(ctr, C_TUP_F, pre); } }   // the forward tuples lie in front of coarse bin nkh >> fb
-    pre += v[q];
-    if (c + 1 == sb.nc) { sb.cbase[sb.nc] = pre; sb.sn[SN_TUPLES] = pre; if (pre) ctr_add(ctr, C_TUP_ALL, pre); }
+    if (c < sb.nc) {
+      sb.cbase[c] = pre; sb.hpre[c] = npre;
+      if (c == (sb.nkh >> sb.fb)) { sb.sn[SN_FWD] = pre; if (pre) ctr_add(ctr, C_TUP_F, pre); }   // the forward tuples lie in front of coarse bin nkh >> fb
+    }
+    pre += v[q]; npre += ns[q];
+    if (c + 1 == sb.nc) { sb.cbase[sb.nc] = pre; sb.hpre[sb.nc] = npre; sb.sn[SN_TUPLES] = pre; if (pre) ctr_add(ctr, C_TUP_ALL, pre); }
   }
 }
 
@@ -490,21 +522,143 @@ __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
               });
 }
 
+// The keys of a batch that many windows share -- at least sb.hot_min tuples and four times the average per key -- are where k_seed_dedup looks
+// for repeated seeds: their tuples as pieces of at most SEED_DD_PIECE
+__device__ __forceinline__ uint32_t seed_hot_key(const SeedBufs& sb) { return max(sb.hot_min, min(sb.sn[SN_TUPLES], sb.cap_tuples) >> (sb.kbits - 2u)); }
+__device__ __forceinline__ void seed_push_pieces(const SeedBufs& sb, uint32_t start, uint32_t cnt) {
+  const uint32_t np = (cnt + SEED_DD_PIECE - 1u) / SEED_DD_PIECE;
+  const uint32_t b = atomicAdd(&sb.sn[SN_PIECES], np);
+  for (uint32_t q = 0; q < np && b + q < sb.cap_pieces; q++) sb.pieces[b + q] = make_uint2(start + q * SEED_DD_PIECE, min(SEED_DD_PIECE, cnt - q * SEED_DD_PIECE));
+}
+
 __global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
   __shared__ uint32_t cur[512], pc0[512], pst[512], s_part[16];
   SMR_DYN_LDS(uint32_t, lds);
   SeedTup* stage = reinterpret_cast<SeedTup*>(lds);
   const uint32_t c = blockIdx.x, lo = sb.cbase[c], hi = sb.cbase[c + 1];
-  if (lo == hi) return;
+  if (lo == hi || sb.hpre[c + 1] != sb.hpre[c]) return;     // (a large bin: k_seed_hbins_*)
   const uint32_t t = threadIdx.x, nf = 1u << sb.fb, sh = 32u + sb.cb;
   if (t < 512) pst[t] = 0;
   __syncthreads();
   for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&pst[(uint32_t)(sb.mid[i] >> sh)], 1u);
   __syncthreads();
   block_excl_scan(pst, cur, nf, s_part);
-  if (t < nf) cur[t] += lo;                               // the next free place of every fine bin
+  if (t < nf) {
+    cur[t] += lo;                                         // the next free place of every fine bin
+    if (sb.hot_min && pst[t] >= seed_hot_key(sb)) seed_push_pieces(sb, cur[t], pst[t]);
+  }
   __syncthreads();
   staged_move(sb.mid, lo, hi, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
+}
+
+// A coarse bin far larger than the others (cscan: hpre) would keep ONE block of k_seed_bins busy long after the rest of the launch is over --
+// on the reference's amplicon fixture a handful of keys hold most of the batch's windows: 8.7 ms for a pass that takes 1.6 ms on evenly spread keys
+// (profiles/r5s37_bench_config2.json).  Such a bin is cut into sub-ranges of SEED_HOT_SUB tuples: k_seed_hbins_hist counts the fine bits of each,
+// k_seed_hbins_scan turns the counts into the places of every sub-range's tuples (per fine bin in sub-range order: the sort stays stable), and
+// k_seed_hbins_move is the staged move of k_seed_bins, one block per sub-range.
+__device__ __forceinline__ bool seed_hot_entry(const SeedBufs& sb, uint32_t e, uint32_t& c, uint32_t& i0, uint32_t& i1) {
+  uint32_t lo = 0, hi = sb.nc;                            // hpre[0] = 0 <= e < hpre[nc]: the last bin whose prefix is <= e
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sb.hpre[mid] <= e) lo = mid; else hi = mid; }
+  c = lo;
+  const uint32_t s = e - sb.hpre[c], b0 = sb.cbase[c], b1 = sb.cbase[c + 1];
+  i0 = b0 + s * sb.hsub; i1 = min(b1, i0 + sb.hsub);
+  return i0 < i1;
+}
+__global__ void __launch_bounds__(1024) k_seed_hbins_hist(SeedBufs sb) {
+  __shared__ uint32_t cnt[512];
+  const uint32_t n_ent = min(sb.hpre[sb.nc], sb.cap_hent), nf = 1u << sb.fb, sh = 32u + sb.cb;
+  for (uint32_t e = blockIdx.x; e < n_ent; e += gridDim.x) {
+    uint32_t c, i0, i1;
+    seed_hot_entry(sb, e, c, i0, i1);
+    if (threadIdx.x < 512) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) atomicAdd(&cnt[(uint32_t)(sb.mid[i] >> sh)], 1u);
+    __syncthreads();
+    if (threadIdx.x < nf) sb.hh[(size_t)e * nf + threadIdx.x] = cnt[threadIdx.x];
+    __syncthreads();
+  }
+}
+// one block per coarse bin (the large ones stay): thread f walks the sub-ranges' counts of fine bin f
+__global__ void __launch_bounds__(1024) k_seed_hbins_scan(SeedBufs sb) {
+  __shared__ uint32_t tot[512], fbase[512], s_part[16];
+  const uint32_t c = blockIdx.x, e0 = sb.hpre[c], e1 = min(sb.hpre[c + 1], sb.cap_hent);
+  if (e0 >= e1) return;
+  const uint32_t nf = 1u << sb.fb, f = threadIdx.x, lo = sb.cbase[c];
+  if (f < 512) tot[f] = 0;
+  if (f < nf) {
+    uint32_t run = 0;
+    for (uint32_t e = e0; e < e1; e++) { const size_t o = (size_t)e * nf + f; const uint32_t v = sb.hh[o]; sb.hh[o] = run; run += v; }
+    tot[f] = run;
+  }
+  __syncthreads();
+  block_excl_scan(tot, fbase, nf, s_part);
+  if (f < nf) {
+    const uint32_t b = lo + fbase[f];
+    for (uint32_t e = e0; e < e1; e++) sb.hh[(size_t)e * nf + f] += b;
+    if (sb.hot_min && tot[f] >= seed_hot_key(sb)) seed_push_pieces(sb, b, tot[f]);
+  }
+}
+__global__ void __launch_bounds__(1024) k_seed_hbins_move(SeedBufs sb) {
+  __shared__ uint32_t cur[512], pc0[512], pst[512], s_part[16];
+  SMR_DYN_LDS(uint32_t, lds);
+  SeedTup* stage = reinterpret_cast<SeedTup*>(lds);
+  const uint32_t n_ent = min(sb.hpre[sb.nc], sb.cap_hent), nf = 1u << sb.fb, sh = 32u + sb.cb;
+  for (uint32_t e = blockIdx.x; e < n_ent; e += gridDim.x) {
+    uint32_t c, i0, i1;
+    seed_hot_entry(sb, e, c, i0, i1);
+    if (threadIdx.x < nf) cur[threadIdx.x] = sb.hh[(size_t)e * nf + threadIdx.x];
+    __syncthreads();
+    staged_move(sb.mid, i0, i1, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
+  }
+}
+
+// Repeated seeds.  The two half-seed searches of a window depend on nothing but the window's 18 letters (key + automaton chars = the tuple without
+// its slot), and real samples repeat them: the reference's amplicon fixture has 664 145 first-pass windows per 100 000 reads and 17 948 different
+// ones, the most frequent 35 186 times.  After the sort the tuples of a key lie together (in slot order, repeats interleaved with the key's other
+// seeds); a block takes a piece of the tuples of ONE key with many tuples (sb.pieces) and enters their chars into a hash table in LDS: the first
+// tuple with given chars stays what it was -- the REPRESENTATIVE, searched by k_seed_pg --, a later one is rewritten in place as {slot,
+// representative's slot, SEED_TUP_DUP}.  No search looks at it; k_seed_prop<DIR> hands its window the representative's segment after the
+// launch of its direction (forward before the reverse launch: that one asks for the window's zero bit).  Which of several equal tuples becomes
+// the representative is a race the results do not depend on.  A piece with more different seeds than the table takes leaves the rest as they are.
+__global__ void __launch_bounds__(256) k_seed_dedup(SeedBufs sb) {
+  __shared__ unsigned long long tab[SEED_DD_TAB];
+  const uint32_t n_p = min(sb.sn[SN_PIECES], sb.cap_pieces);
+  for (uint32_t p = blockIdx.x; p < n_p; p += gridDim.x) {
+    const uint2 pc = sb.pieces[p];
+    for (uint32_t q = threadIdx.x; q < SEED_DD_TAB; q += blockDim.x) tab[q] = 0ull;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < pc.y; i += blockDim.x) {
+      const SeedTup t = sb.srt[pc.x + i];
+      const uint32_t v = (uint32_t)(t >> 32) + 1u, slot = (uint32_t)t;        // chars | fine bits (the same for the whole piece), never 0
+      uint32_t h = (v * 2654435761u) >> 20;                                   // 12 bits
+      for (int probe = 0; probe < 8; probe++, h = (h + 1u) & (SEED_DD_TAB - 1u)) {
+        const unsigned long long old = atomicCAS(&tab[h], 0ull, ((unsigned long long)v << 32) | slot);
+        if (old == 0ull) break;                                               // the first of its kind
+        if ((uint32_t)(old >> 32) == v) { sb.srt[pc.x + i] = (unsigned long long)slot | ((unsigned long long)(uint32_t)old << 32) | SEED_TUP_DUP; break; }
+      }
+    }
+    __syncthreads();
+  }
+}
+// the windows of the repeated seeds of direction DIR get their representatives' hit segments (the pool segment itself is shared: k_seed_finish only reads it)
+template <int DIR>
+__global__ void __launch_bounds__(256) k_seed_prop(SeedBufs sb, unsigned long long* __restrict__ ctr) {
+  const uint32_t n_p = min(sb.sn[SN_PIECES], sb.cap_pieces);
+  const uint32_t n_fwd = min(sb.sn[SN_FWD], sb.cap_tuples);
+  unsigned long long moved = 0;
+  for (uint32_t p = blockIdx.x; p < n_p; p += gridDim.x) {
+    const uint2 pc = sb.pieces[p];
+    if ((pc.x >= n_fwd) != (DIR == 1)) continue;           // (a key is forward or reverse: so is a piece)
+    for (uint32_t i = threadIdx.x; i < pc.y; i += blockDim.x) {
+      const SeedTup t = sb.srt[pc.x + i];
+      if (!(t & SEED_TUP_DUP)) continue;
+      const uint32_t slot = (uint32_t)t, rep = (uint32_t)(t >> 32) & 0x7FFFFFFFu;
+      moved += 9u;                                         // the tuple, the representative's bit
+      if (wseg_has(sb, DIR, rep)) { const uint32_t v = sb.wseg[DIR][rep]; wseg_put(sb, DIR, slot, v, (v & SEED_ZERO_BIT) != 0); moved += 8u; }
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) moved += __shfl_down(moved, d, 64);
+  if (lane_id() == 0 && moved) ctr_add(ctr, DIR ? C_B_PG1 : C_B_PG0, moved);
 }
 
 struct SeedLane {           // per-lane search result
@@ -727,11 +881,14 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     if ((pos >= min(sb.sn[SN_FWD], n_tup)) != (DIR == 1)) mine = false;      // the forward tuples lie in front
     else {
       const SeedKey tk = seed_decode(sb, pos);
+      if (tk.dup) mine = false;                            // a repeated seed: its window gets the representative's segment (k_seed_prop)
+      else {
       counted = true;
       const Lookup lk = ix.lookup[tk.key - (DIR ? sb.nkh : 0u)];
       root = DIR == 0 ? lk.rootF : lk.rootR;
       chars = tk.chars; slot = tk.slot;
-      if (DIR == 1 && wseg_has(sb, 0, slot)) {             // the window's list so far = the forward search's hits
+      }
+      if (mine && DIR == 1 && wseg_has(sb, 0, slot)) {     // the window's list so far = the forward search's hits
         const uint32_t seg = sb.wseg[0][slot];
         if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
         else {

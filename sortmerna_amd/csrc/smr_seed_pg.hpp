@@ -212,12 +212,20 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   // ---- the wave's 64 searches ----
   const uint32_t pos = vb * 64u + lane;
   bool mine = DIR ? (pos >= n_fwd && pos < n_tup) : pos < n_fwd;
-  const bool counted = mine;
   uint32_t nh = 0, P9 = 0, slot = 0;
   uint2 rt = make_uint2(NONE, 0);
+  uint32_t n_rep = 0;                                      // tuples of this launch in the chunk that repeat another one's seed (k_seed_dedup): read, not searched
   {
     const bool hit = pf && pf_vb == vb;
     const SeedTup t = hit ? pf_t : (pos < n_tup ? sb.srt[pos] : 0ull);
+    const bool rep = mine && (t & SEED_TUP_DUP);
+    n_rep = (uint32_t)__popcll(__ballot(rep));
+    if (rep) mine = false;
+    if (!__any(mine)) {                                    // (whole chunks of a hot key: nothing but repeats)
+      pf = false; pf_bounds = false;
+      if (lane == 0) acc[2] += 8ull * n_rep + 2u;
+      continue;
+    }
     uint32_t c = hit ? pf_c : (uint32_t)sb.wbin[vb];
     uint32_t nx = (hit && pf_bounds) ? pf_nx : sb.cbase[c + 1];
     pf = false; pf_bounds = false;
@@ -229,6 +237,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
       P9 = tk.chars; slot = tk.slot;
     }
   }
+  const bool counted = mine;
   if (mine) {
     if (DIR == 1 && ((sb.gflag[slot >> 11] >> ((slot >> 6) & 31u)) & 1u) && ((sb.zbits[slot >> 5] >> (slot & 31u)) & 1u)) mine = false;   // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
   }
@@ -373,7 +382,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   // to it; the chunk's coarse bin; DIR 1: the window's group bit (what does not come out of the scans above is summed per lane: < 2^32 per wave)
   unsigned long long w_bytes = (uint32_t)__popcll(__ballot(counted)) * ((uint32_t)sizeof(SeedTup) + 8u + (DIR ? 1u : 0u))
                              + 32u * (uint32_t)__popcll(__ballot(srch && cA)) + 4u * (uint32_t)__popcll(__ballot(wr));
-  w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + 2u;
+  w_bytes += 4ull * wtot + 4ull * total + 8ull * min(s_ncand, ccap) + 2u + 8ull * n_rep;
   if (lane == 0) { acc[0] += w_node; acc[1] += w_entry; acc[2] += w_bytes; }
 #ifdef SMR_SEED_PHASES
   GPH(5)

@@ -464,6 +464,42 @@ def test_batch_dominated_by_one_sequence(engine, tmp_path):
     assert recs_g[500] == recs_g[502] and recs_g[501] == recs_g[503]
 
 
+SKEW_VARIANTS = [{"SMR_SEED_HOT_BIN": "64", "SMR_SEED_HOT_SUB": "200", "SMR_SEED_DEDUP": "2"},      # large coarse bins in sub-ranges of 200 tuples + every repeated seed searched once
+                 {"SMR_SEED_HOT_BIN": "64", "SMR_SEED_HOT_SUB": "8192", "SMR_SEED_DEDUP": "0"},     # ... one sub-range per large bin, no search for repeats
+                 {"SMR_SEED_DEDUP": "16", "SMR_PG_CAND_CAP": "8"}]                                   # repeats + waves that overflow their candidate pool (the DFS kernel meets rewritten tuples)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["pg", "dfs"])
+@pytest.mark.parametrize("env", SKEW_VARIANTS, ids=lambda e: ",".join("%s=%s" % (k.replace("SMR_SEED_", ""), v) for k, v in e.items()))
+def test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed(tmp_path, monkeypatch, env, mode):
+    """The batch of test_batch_dominated_by_one_sequence with the thresholds of the two skew paths lowered to its size: coarse bins far larger
+    than the average are sorted by k_seed_hbins_* (several blocks per bin), and k_seed_dedup / k_seed_prop search a seed that thousands of
+    windows share once (mode 1, the exact-counter DFS kernel, searches every tuple: only the sort differs).  Records, counters and the seed
+    hits of every (strand, pass) equal the oracle's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    w = Workload(str(tmp_path), db_nt=200_000, n_reads=3500, seed=77, frac_db=0.6)
+    hot = [w.seqs[20], w.seqs[41], w.seqs[7][:60] + w.seqs[20][60:]]          # the third shares most windows with the first
+    for i in range(500, 3500):
+        w.seqs[i] = hot[i % 3]
+    w.reads = smr.Reads.from_seqs(w.seqs)
+    lam, K = GUMBEL_UNIFORM
+    w.minimal_score = smr.minimal_score(lam, K, w.parts[0].info(), len(w.seqs), sum(map(len, w.seqs)))
+    e = smr.Engine(0)
+    try:
+        e.set_seed_mode(mode)
+        test_seed_scan_matches_oracle(e, w)
+        recs_o, ctr_o = w.oracle_records()
+        recs_g, ctr_g = w.gpu_records(e)
+        _compare(recs_g, recs_o, "skewed batch %s" % env)
+        assert ctr_g["num_aligned"] == ctr_o["num_aligned"] > 1000
+        if mode == 0 and env.get("SMR_SEED_DEDUP") != "0":
+            tuples, _, meta = e.seed_tuples()
+            assert sum(1 for t in tuples if int(t) >> 63) > meta["n"] // 2       # most tuples of the last launch repeat another one's seed
+    finally:
+        e.close()
+
+
 def _dense_neighbourhood_workload(tmp):
     """A DB that holds, for ONE 18-mer A+B which it does not contain itself, every string within one error of it that a half-seed search can
     accept: under the key A the 255 ten-letter continuations lev1_entry accepts for B (all but the four exact ones), and in front of the key B
@@ -585,11 +621,16 @@ def _host_recount_of_the_search(pg, root3, tuples, cbase, meta, direction, zero_
         chunks = ((n_all + 63) >> 6) - (n_fwd >> 6)
     total = 2 * chunks + (hi - lo) * (8 + 8 + direction)
     zeros = set()
+    segs, repeats = set(), []
     import bisect
     cb_list = [int(x) for x in cbase]
     for i in range(lo, hi):
         t = int(tuples[i])
         slot, chars = t & 0xFFFFFFFF, (t >> 32) & ((1 << cb) - 1)
+        if t >> 63:                                                # a repeated seed (k_seed_dedup): the search only reads the tuple; k_seed_prop reads it again
+            repeats.append((slot, (t >> 32) & 0x7FFFFFFF))         # + the representative's bit, and where that has a segment the slot word is read and written
+            total += 9 - (8 + direction)
+            continue
         c = bisect.bisect_right(cb_list, i) - 1                     # the coarse bin tuple i lies in (empty bins begin where the next one does)
         key = (c << fb) | (t >> (32 + cb))
         if direction == 1 and slot in zero_slots:
@@ -645,17 +686,26 @@ def _host_recount_of_the_search(pg, root3, tuples, cbase, meta, direction, zero_
                 hl.append(idc)
         if hl:
             total += 4 * (1 + len(hl)) + 4
+            segs.add(slot)
         if zero_end:
+            zeros.add(slot)
+    for slot, rep in repeats:
+        if rep in segs:
+            total += 8
+        if rep in zeros:
             zeros.add(slot)
     return total, zeros
 
 
-@pytest.mark.parametrize("strand,pass_", [(0, 0), (1, 2)])
-def test_pigeonhole_search_bytes_equal_a_host_recount(wl, strand, pass_):
+@pytest.mark.parametrize("strand,pass_,dedup", [(0, 0, None), (1, 2, None), (0, 0, "2"), (1, 2, "2")], ids=["s0p0", "s1p2", "s0p0-dedup", "s1p2-dedup"])
+def test_pigeonhole_search_bytes_equal_a_host_recount(wl, monkeypatch, strand, pass_, dedup):
     """The roofline numerator of the dominant seed kernel is counted by the kernel itself (C_B_PG0 / C_B_PG1).  Here the same quantity is
     recomputed on the HOST -- from the pigeonhole layout the host transform builds (smr_build_pigeonhole) and the launch's sorted tuples, walking
     the four exact-key ranges of every search, the closed-form automaton, the duplicate rule and the reference's list rules in Python -- and
-    must equal the device's counters exactly, for the forward and for the reverse launch."""
+    must equal the device's counters exactly, for the forward and for the reverse launch.  The `dedup` cases search every repeated seed once
+    (SMR_SEED_DEDUP=2: every key with two tuples counts as hot) and count what the repeats cost instead."""
+    if dedup:
+        monkeypatch.setenv("SMR_SEED_DEDUP", dedup)
     e = smr.Engine(0)
     try:
         e.upload_reads(wl.reads, 1)
@@ -671,6 +721,7 @@ def test_pigeonhole_search_bytes_equal_a_host_recount(wl, strand, pass_):
         exp0, zeros = _host_recount_of_the_search(pg, root3, tuples, cbase, meta, 0, set(), 9)
         exp1, _ = _host_recount_of_the_search(pg, root3, tuples, cbase, meta, 1, zeros, 9)
         assert len(zeros) > 10                                    # the workload has exact seed matches: the reverse launch really skips searches
+        assert (sum(1 for t in tuples if int(t) >> 63) > 20) == bool(dedup)
         assert int(kp["k_seed_pg<0>"]["bytes"]) == exp0, (int(kp["k_seed_pg<0>"]["bytes"]), exp0)
         assert int(kp["k_seed_pg<1>"]["bytes"]) == exp1, (int(kp["k_seed_pg<1>"]["bytes"]), exp1)
     finally:
