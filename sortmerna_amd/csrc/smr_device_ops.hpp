@@ -39,6 +39,21 @@ template <class T> __device__ __forceinline__ T uni_words(const T& v) {      // 
   __builtin_memcpy(&o, w, sizeof(T));
   return o;
 }
+// inclusive prefix sum over the 64 lanes in six v_add_u32_dpp: row_shr:1/2/4/8 inside the rows of 16 (a lane without a source adds 0), then
+// row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.  Written out because the compiler turns the same steps, given as
+// x += update_dpp(0, x, ...), into a zeroed register + v_mov_b32_dpp + v_add_u32 each: 18 vector instructions instead of 6, three scans per
+// chunk of the seed search.  (s_nop 1: two wait states between a VALU write and a DPP read of the same register.)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+               : "+v"(x));
+  return x;
+}
 // n / d for n = k * d, k < 2^16: one reciprocal and a multiply (the error of v_rcp_f32 is far below the 0.5 that is added)
 __device__ __forceinline__ uint32_t div_multiple(uint32_t n, uint32_t d) { return (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d) + 0.5f); }
 

@@ -274,6 +274,7 @@ int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
     if ((rc = dev_alloc(c, &c->sb.chist, (size_t)4096 + 1))) return rc;
     if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 2))) return rc;
     if ((rc = dev_alloc(c, &c->sb.hpre, (size_t)4096 + 2))) return rc;
+    if ((rc = dev_alloc(c, &c->sb.hlist, (size_t)4096 + 2))) return rc;
     if (!c->sb.rows && (rc = dev_alloc(c, &c->sb.rows, (size_t)SEED_KEY_BLOCKS * 4096))) return rc;
     if (!c->sb.bcnt && (rc = dev_alloc(c, &c->sb.bcnt, (size_t)SEED_KEY_BLOCKS))) return rc;
     if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
@@ -394,12 +395,12 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   ev_mark(c, KP_BINS);
   hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
   // the coarse bins that are far larger than the others, several blocks each (none on evenly spread keys: three empty launches)
-  const uint32_t gh = std::min<uint32_t>(sb.cap_hent, (uint32_t)c->n_cu * 8u);
+  const uint32_t gh = std::min<uint32_t>(sb.cap_hent, (uint32_t)c->n_cu * 2u);       // (grids that loop: an empty launch should cost a launch, not 2 000 blocks)
   hipLaunchKernelGGL(k_seed_hbins_hist, dim3(gh), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_hbins_scan, dim3(sb.nc), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_hbins_scan, dim3(std::min<uint32_t>(sb.nc, 128u)), dim3(1024), 0, c->stream, sb);
   hipLaunchKernelGGL(k_seed_hbins_move, dim3(gh), dim3(1024), lds_bins, c->stream, sb);
   if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
-  const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 16u);
+  const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
   if (sb.hot_min) hipLaunchKernelGGL(k_seed_dedup, dim3(gd), dim3(256), 0, c->stream, sb);
   const uint32_t* no_redo = nullptr;
   if (c->seed_exact) {
@@ -1036,7 +1037,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   for (int q = 0; q < 2; q++) { dev_free(&c->d_wlist[q]); dev_free(&c->d_wstate[q]); dev_free(&c->d_wtask[q]); dev_free(&c->d_wres[q]); }
   dev_free(&c->d_wtidx); dev_free(&c->d_wslow); dev_free(&c->d_wctr);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
-  dev_free(&c->sb.srt); dev_free(&c->sb.hpre); dev_free(&c->sb.hh); dev_free(&c->sb.pieces); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
+  dev_free(&c->sb.srt); dev_free(&c->sb.hpre); dev_free(&c->sb.hlist); dev_free(&c->sb.hh); dev_free(&c->sb.pieces); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
   for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);

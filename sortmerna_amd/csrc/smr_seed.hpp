@@ -134,7 +134,7 @@ __device__ __forceinline__ bool lev1_alive(uint32_t P, uint32_t T, uint32_t m) {
 #define SEED_ZERO_BIT 0x80000000u
 
 enum { CK_PLAIN = 0, CK_UNCOND = 1, CK_COND = 2 };
-enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_PIECES = 3, SN_COUNT = 4 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples, pieces of hot keys
+enum { SN_TUPLES = 0, SN_REDO = 1, SN_FWD = 2, SN_PIECES = 3, SN_HOTBINS = 4, SN_COUNT = 8 };      // device counters of the seed stage (u32): tuples, redo waves, forward tuples, pieces of hot keys, large coarse bins
 
 // The tuples of the seed stage are 8 bytes (round 3: 12).  A tuple = one half-seed search of one window: its 9-mer key (direction in the top
 // bit: forward keys [0, nkh), reverse keys [nkh, 2 nkh)), the pw chars that feed the automaton, and the window's SLOT = read * maxwin +
@@ -182,11 +182,12 @@ struct SeedBufs {
   uint32_t g_shift;          // k_seed_keys: log2 of the lanes per read (0: a lane walks all windows of its read; 6: one read per wave)
   // skewed batches (amplicons, a sample dominated by one organism's rRNA: thousands of windows share a key, and most of them the whole seed)
   uint32_t* hpre;            // [nc + 1] coarse bins far larger than the average are sorted by several blocks: exclusive prefix of their numbers of sub-ranges (0 for the others)
+  uint32_t* hlist;           // [nc] the large coarse bins (sn[SN_HOTBINS] of them, in no particular order)
   uint32_t* hh;              // [cap_hent][2^fb] per sub-range of a large coarse bin: its histogram of the fine bits, then where its first tuple of every fine bin goes
   uint2* pieces;             // {first tuple, tuples <= SEED_DD_PIECE} of the keys with at least hot_min tuples (and four times the average): where k_seed_dedup looks for repeated seeds
   uint32_t cap_hent, cap_pieces;
   uint32_t hot_min;          // 0: no search for repeated seeds
-  uint32_t hbin_min, hsub;   // a coarse bin is "large" from 4 x the average size and at least hbin_min tuples (SEED_HOT_BIN_MIN); tuples per sub-range (SEED_HOT_SUB)
+  uint32_t hbin_min, hsub;   // a coarse bin is "large" from twice the average size and at least hbin_min tuples (SEED_HOT_BIN_MIN); tuples per sub-range (SEED_HOT_SUB)
 };
 __device__ __forceinline__ bool wseg_has(const SeedBufs& sb, int d, uint32_t slot) { return (sb.fbits[d][slot >> 5] >> (slot & 31u)) & 1u; }
 __device__ __forceinline__ void wseg_put(const SeedBufs& sb, int d, uint32_t slot, uint32_t v, bool zero) {
@@ -381,10 +382,10 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
 // + which coarse bins are far larger than the average (a key that thousands of windows share): k_seed_bins leaves those to the k_seed_hbins_*
 // kernels, which sort one bin with several blocks -- hpre[c] = the sub-ranges of SEED_HOT_SUB tuples of the large bins in front of c
 #define SEED_HOT_SUB 65536u                               // tuples of a large coarse bin that one block of k_seed_hbins_* takes   (SeedBufs::hsub; SMR_SEED_HOT_SUB: the tests' small batches)
-#define SEED_HOT_BIN_MIN 262144u                          // a coarse bin is "large" from 4 x the average size and at least this many tuples   (SeedBufs::hbin_min; SMR_SEED_HOT_BIN)
+#define SEED_HOT_BIN_MIN 262144u                          // a coarse bin is "large" from twice the average size and at least this many tuples   (SeedBufs::hbin_min; SMR_SEED_HOT_BIN)
 #define SEED_DD_PIECE 16384u                              // tuples of one key that a block of k_seed_dedup looks at together
 #define SEED_DD_TAB 4096u                                 // ... slots of its hash table in LDS (8 bytes each)
-__device__ __forceinline__ uint32_t seed_hot_bin(const SeedBufs& sb, uint32_t n_tup) { return max(sb.hbin_min, 4u * (n_tup / sb.nc)); }
+__device__ __forceinline__ uint32_t seed_hot_bin(const SeedBufs& sb, uint32_t n_tup) { return max(sb.hbin_min, 2u * (n_tup / sb.nc)); }
 __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long long* __restrict__ ctr) {
   __shared__ uint32_t s_part[16], s_part2[16];
   // <= 4096 bins: 4 consecutive bins per thread
@@ -411,6 +412,7 @@ __global__ void __launch_bounds__(1024) k_seed_cscan(SeedBufs sb, unsigned long 
     const uint32_t c = 4 * t + q;
     if (c < sb.nc) {
       sb.cbase[c] = pre; sb.hpre[c] = npre;
+      if (ns[q]) sb.hlist[atomicAdd(&sb.sn[SN_HOTBINS], 1u)] = c;
       if (c == (sb.nkh >> sb.fb)) { sb.sn[SN_FWD] = pre; if (pre) ctr_add(ctr, C_TUP_F, pre); }   // the forward tuples lie in front of coarse bin nkh >> fb
     }
     pre += v[q]; npre += ns[q];
@@ -578,24 +580,35 @@ __global__ void __launch_bounds__(1024) k_seed_hbins_hist(SeedBufs sb) {
     __syncthreads();
   }
 }
-// one block per coarse bin (the large ones stay): thread f walks the sub-ranges' counts of fine bin f
+// a block per large coarse bin: per fine bin the running sum over the bin's sub-ranges (like k_seed_colscan: lane = fine bin, the 16 waves take a
+// sixteenth of the sub-ranges each), then the fine bins' places in the coarse bin
 __global__ void __launch_bounds__(1024) k_seed_hbins_scan(SeedBufs sb) {
-  __shared__ uint32_t tot[512], fbase[512], s_part[16];
-  const uint32_t c = blockIdx.x, e0 = sb.hpre[c], e1 = min(sb.hpre[c + 1], sb.cap_hent);
-  if (e0 >= e1) return;
-  const uint32_t nf = 1u << sb.fb, f = threadIdx.x, lo = sb.cbase[c];
-  if (f < 512) tot[f] = 0;
-  if (f < nf) {
-    uint32_t run = 0;
-    for (uint32_t e = e0; e < e1; e++) { const size_t o = (size_t)e * nf + f; const uint32_t v = sb.hh[o]; sb.hh[o] = run; run += v; }
-    tot[f] = run;
-  }
-  __syncthreads();
-  block_excl_scan(tot, fbase, nf, s_part);
-  if (f < nf) {
-    const uint32_t b = lo + fbase[f];
-    for (uint32_t e = e0; e < e1; e++) sb.hh[(size_t)e * nf + f] += b;
-    if (sb.hot_min && tot[f] >= seed_hot_key(sb)) seed_push_pieces(sb, b, tot[f]);
+  __shared__ uint32_t tot[512], fbase[512], s_part[16], s_sum[16][64];
+  const uint32_t n_hot = min(sb.sn[SN_HOTBINS], sb.nc), nf = 1u << sb.fb;
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t k = blockIdx.x; k < n_hot; k += gridDim.x) {
+    const uint32_t c = sb.hlist[k], e0 = sb.hpre[c], e1 = min(sb.hpre[c + 1], sb.cap_hent), lo = sb.cbase[c];
+    const uint32_t nsub = e1 > e0 ? e1 - e0 : 0u, per = (nsub + 15u) / 16u, r0 = e0 + min(wv * per, nsub), r1 = e0 + min(wv * per + per, nsub);
+    if (threadIdx.x < 512) tot[threadIdx.x] = 0;
+    for (uint32_t g = 0; g < nf; g += 64) {
+      const uint32_t f = g + lane;
+      uint32_t sum = 0;
+      if (f < nf) for (uint32_t e = r0; e < r1; e++) sum += sb.hh[(size_t)e * nf + f];
+      s_sum[wv][lane] = sum;
+      __syncthreads();
+      uint32_t run = 0;
+      for (uint32_t q = 0; q < wv; q++) run += s_sum[q][lane];
+      if (wv == 15 && f < nf) tot[f] = run + sum;
+      if (f < nf) for (uint32_t e = r0; e < r1; e++) { const size_t o = (size_t)e * nf + f; const uint32_t v = sb.hh[o]; sb.hh[o] = run; run += v; }
+      __syncthreads();
+    }
+    block_excl_scan(tot, fbase, nf, s_part);
+    for (uint32_t g = 0; g < nf; g += 64) {
+      const uint32_t f = g + lane;
+      if (f < nf) { const uint32_t b = lo + fbase[f]; for (uint32_t e = r0; e < r1; e++) sb.hh[(size_t)e * nf + f] += b; }
+    }
+    if (threadIdx.x < nf && sb.hot_min && tot[threadIdx.x] >= seed_hot_key(sb)) seed_push_pieces(sb, lo + fbase[threadIdx.x], tot[threadIdx.x]);
+    __syncthreads();
   }
 }
 __global__ void __launch_bounds__(1024) k_seed_hbins_move(SeedBufs sb) {

@@ -32,6 +32,15 @@ inline uint32_t perm_b32(uint32_t s0, uint32_t s1, uint32_t sel) {          // v
   return r;
 }
 inline uint32_t div_multiple(uint32_t n, uint32_t d) { return n / d; }
+inline uint32_t wave_scan_add(uint32_t x) {                 // the product's six v_add_u32_dpp, step by step through the emulator's DPP
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+  return x;
+}
 // uni(): v_readfirstlane_b32 of a value the kernel claims to be wave-uniform -- here the claim is CHECKED: every active lane must hold the
 // value of the first one
 inline uint32_t uni(uint32_t v) {
