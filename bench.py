@@ -182,7 +182,8 @@ def cpu_baseline(args, dbs, parts_per_db, sample, smr, eng, idx_slots):
 # workloads (BASELINE.json configs[2], [3], [4]; SURVEY.md 8d "Configs restated as concrete inputs")
 # ---------------------------------------------------------------------------------------------------------------------------------------
 WORKLOADS = {
-    "illumina150": {"batch_reads": 8_000_000, "cpu_sample_reads": 200_000, "ref_opts": ["-fastx"],
+    # (cpu_sample_reads: 2 M reads = ~45 s of the reference's 64 threads on this workload -- round 5 timed 200 000 reads in 4.6 s, and a ratio should not rest on start-up)
+    "illumina150": {"batch_reads": 8_000_000, "cpu_sample_reads": 2_000_000, "ref_opts": ["-fastx"],
                     "options": "default options (--fastx, best 1)"},
     "refs8": {"batch_reads": 8_000_000, "cpu_sample_reads": 100_000, "ref_opts": ["-fastx"],
               "options": "default options (--fastx, best 1), 8 --ref"},
@@ -606,9 +607,10 @@ def main():
             w = tj["workload"]
             if (w["read_len"], w["db_nt"], w["batch_reads"]) == (args.read_len, args.db_nt, args.batch_reads) and tj.get("kernel_src_sha") == pmc_traffic.kernel_src_sha():
                 traffic_all = tj["per_launch_bytes"]
-                traffic_note = tj["note"]
+                traffic_note = "REPLAYED from profiles/hbm_traffic.json (a PMC pass of these kernel sources on this workload, not measured in this run): " + tj["note"]
         except Exception:
             pass
+        sw16_pmc = None
         counters_all, counters_note = None, "no counter pass for these kernel sources and this workload (profiles/sq_counters.json)"
         try:
             import pmc_traffic
@@ -616,7 +618,8 @@ def main():
             w = sj["workload"]
             if (w["read_len"], w["db_nt"], w["batch_reads"]) == (args.read_len, args.db_nt, args.batch_reads) and sj.get("kernel_src_sha") == pmc_traffic.kernel_src_sha():
                 counters_all = sj["per_kernel"]
-                counters_note = sj["source"]
+                counters_note = "REPLAYED from profiles/sq_counters.json (counter passes of these kernel sources on this workload, not measured in this run): " + sj["source"]
+                sw16_pmc = sj.get("k_sw16")
         except Exception:
             pass
         seed_k = [k for k in kp if k.startswith("k_seed")]
@@ -668,7 +671,7 @@ def main():
         sw4_peak_gcups = 4 * m_sw * n_sw / (instr4 / 6.144e11) / 1e9 if m_sw <= 256 else None
         # the sixteen-problem kernel of the split walk (k_sw16, smr_walk.hpp): 8 virtual lanes per problem, R = 13 / 19 / 32 rows each (by the longest
         # read of the batch), n + 7 steps of 13 R + 33 instructions (end cells; 10 R + 28 where only the score is asked) for SIXTEEN problems
-        r16 = 13 if max_len <= 104 else (19 if max_len <= 152 else 32)
+        r16 = 13 if max_len <= 104 else (19 if max_len <= 152 else (26 if max_len <= 208 else 32))      # (the instantiations k_sw16<13|19|26|32> the host picks from)
         sw16_peak_gcups = 16 * m_sw * n_sw / ((n_sw + 7) * (13 * r16 + 33) / 6.144e11) / 1e9 if max_len <= 256 else None
         out = {
             "metric": {"illumina150": "reads/sec (150 bp vs smr_v4.3_default_db-sized DB)", "refs8": "reads/sec (150 bp vs the 8-ref rRNA set)",
@@ -704,7 +707,7 @@ def main():
             "roofline": roof,
             "kernels": {"k_seed": {"ms": seed_ms / args.gpus, "launches": seed_l / args.gpus},
                         "k_chain": {"ms": chain_ms / args.gpus, "launches": chain_l / args.gpus,
-                                    "sw_fwd": prof[12], "sw_rev": prof[13], "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6,
+                                    "sw_fwd": prof[12], "sw_rev": prof[13], "sw_cells": prof[14], "k_sw16_valu_per_cell_pair_pmc": sw16_pmc, "gcups": prof[14] / max(chain_ms / args.gpus, 1e-9) / 1e6,
                                     "valu_model_peak_gcups": sw_peak_gcups * args.gpus,
                                     "valu_model_x4_peak_gcups": sw4_peak_gcups * args.gpus if sw4_peak_gcups else None,
                                     "valu_model_x16_peak_gcups": sw16_peak_gcups * args.gpus if sw16_peak_gcups else None,

@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
     } else die("unknown option " + a);
   }
   if (dbs.empty() || reads_paths.empty()) die("--ref and --reads are required (see --help)");
+  if (const char* why = smr_params_refused(&base)) die(std::string("these options are outside what libsmr_hip aligns (the reference accepts them): ") + why);
   // minimal_score (which reads count as aligned) and the e-values / bit scores of the BLAST report depend on the Gumbel parameters of the
   // (scoring scheme, DB background) pair.  The reference computes them per DB with its vendored NCBI ALP library (refstats.cpp:194-233),
   // which is outside this library: they must be given -- from the reference's log ("Gumbel lambda = ..", "Gumbel K = ..") for the same DB

@@ -157,6 +157,7 @@ int main(int argc, char** argv) {
     else die("unknown option " + a);
   }
   if (dbs.empty() || reads_path.empty()) die("--ref and --reads are required");
+  if (const char* why = smr_params_refused(&base)) die(std::string("these options are outside what libsmr_hip aligns (the reference accepts them): ") + why);
   for (auto& d : dbs) if (!d.has_gumbel) die("--gumbel LAMBDA K is required for every --ref (the reference computes them with its vendored ALP library, refstats.cpp:194-233; minimal_score depends on them)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) die("no HIP device (libsmr_hip has no CPU fallback)");

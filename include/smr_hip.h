@@ -81,6 +81,10 @@ typedef struct {
 } smr_params;
 
 void smr_params_default(smr_params* p);
+/* NULL when smr_align_part takes these options; otherwise the reason it will answer SMR_ERR_ARG (a scoring scheme under which ssw.c's striped
+ * kernels leave the affine recurrence -- ssw.c:267,496-507 --, a positive N score, --edges outside 1..10: INTEGRATION.md "known limits").  For a
+ * host's option parser: the reference CLI accepts such options (options.cpp:380-500, 659-681), so a driver should say so before it loads anything. */
+const char* smr_params_refused(const smr_params* p);
 
 /* ------------------------------------------------------------------------------------------------
  * Index (host side).  An smr_index is one (index, part): 9-mer lookup, mini burst tries in a compact

@@ -85,6 +85,7 @@ void align(Readfeed& readfeed, Readstats& readstats, Index& index, KeyValueDatab
 			p.minimal_score = refstats.minimal_score[idx_num];   // derived from the GLOBAL read totals           refstats.cpp:261-265
 			p.index_num = (uint32_t)idx_num;  p.part = part;
 			p.is_last_index_part = (idx_num == opts.indexfiles.size() - 1 && part == refstats.num_index_parts[idx_num] - 1);
+			if (const char* why = smr_params_refused(&p)) { ERR(std::string("options outside what libsmr_hip aligns: ") + why); exit(EXIT_FAILURE); }   // (said before any read is fed)
 			parts.push_back(P);
 		}
 	// the engine keeps up to 64 parts resident on a GPU; a run with more (a small -m, many -ref) streams them through slot 0 per chunk instead

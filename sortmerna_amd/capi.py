@@ -58,7 +58,7 @@ class Kprof(C.Structure):
 
 
 EXPORTS = [
-    "smr_params_default", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_save", "smr_index_load_flat", "smr_index_selfcheck", "smr_index_free",
+    "smr_params_default", "smr_params_refused", "smr_index_load_files", "smr_index_build", "smr_index_build_gpu", "smr_index_write_files", "smr_index_save", "smr_index_load_flat", "smr_index_selfcheck", "smr_index_free",
     "smr_index_get_info", "smr_minimal_score", "smr_minimal_score_split", "smr_refstats_corrected_split", "smr_reads_pack", "smr_reads_load_fastx", "smr_reads_load_fastx_mt", "smr_reads_load_fastx_text", "smr_reads_is_fastq", "smr_reads_record_text", "smr_reads_free", "smr_reads_slice",
     "smr_reads_digest", "smr_reads_count", "smr_reads_total_len", "smr_reads_min_len", "smr_reads_max_len", "smr_create", "smr_device_count", "smr_destroy",
     "smr_last_error", "smr_index_upload", "smr_index_check_device", "smr_index_pigeonhole", "smr_seed_tuples_fetch", "smr_index_unload", "smr_batch_select", "smr_set_seed_mode", "smr_reads_upload", "smr_reads_upload_batch", "smr_state_reset", "smr_align_part",
@@ -201,6 +201,10 @@ def bind(L):
     L.smr_prof_kernels.restype = i32
     L.smr_prof_kernels.argtypes = [vp, C.POINTER(Kprof), u32, C.POINTER(u32)]
     L.smr_refstats_corrected.argtypes = [C.c_double, C.POINTER(C.c_double), u64, u64, u64, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.smr_refstats_corrected_split.argtypes = [C.c_double, C.POINTER(C.c_double), u64, u64, u64, u64, C.c_uint32, C.POINTER(u64), C.POINTER(u64)]
+    L.smr_refstats_corrected_split.restype = None
+    L.smr_params_refused.argtypes = [C.c_void_p]
+    L.smr_params_refused.restype = C.c_char_p
     L.smr_report_open.restype = i32
     L.smr_report_open.argtypes = [cp, C.POINTER(ReportOpts), i32, C.POINTER(vp), cp, C.c_size_t]
     L.smr_report_set_db.restype = i32

@@ -46,6 +46,7 @@ struct Batch {
   bool used = false;
   uint32_t n = 0, max_len = 0, slots = 1;
   uint32_t min_ge[7] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};     // the shortest read of at least 8, 10, ... 20 letters (~0: none): what `--edges N%` is smallest for
+  bool min_ge_known = false;               // (computed when a call with is_as_percent asks for it: one pass over the lengths, which the default options never need)
   uint32_t* d_words = nullptr; uint64_t* d_rec_off = nullptr; uint32_t* d_len = nullptr;
   RState* d_saved = nullptr; RState* d_work = nullptr; RWork* d_rw = nullptr;
   uint8_t* d_marks = nullptr;              // per read: k_chain has to walk it in this (strand, pass) (k_cand)
@@ -1035,6 +1036,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   }
   dev_free(&c->d_bound); dev_free(&c->d_rdq); dev_free(&c->d_mrec); dev_free(&c->d_mpool);
   for (int q = 0; q < 2; q++) { dev_free(&c->d_wlist[q]); dev_free(&c->d_wstate[q]); dev_free(&c->d_wtask[q]); dev_free(&c->d_wres[q]); }
+  dev_free(&c->d_wstat);
   dev_free(&c->d_wtidx); dev_free(&c->d_wslow); dev_free(&c->d_wctr);
   dev_free(&c->sb.chist); dev_free(&c->sb.cbase); dev_free(&c->sb.rows); dev_free(&c->sb.bcnt); dev_free(&c->sb.tmp); dev_free(&c->sb.mid);
   dev_free(&c->sb.srt); dev_free(&c->sb.hpre); dev_free(&c->sb.hlist); dev_free(&c->sb.hh); dev_free(&c->sb.pieces); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
@@ -1227,8 +1229,8 @@ int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipS
   }
   B.n = r->n; B.max_len = r->max_len; B.slots = max_aln; B.used = true;
   for (int k = 0; k < 7; k++) B.min_ge[k] = ~0u;
-  if (r->n && r->min_len >= 100) { for (int k = 0; k < 7; k++) B.min_ge[k] = r->min_len; }      // (1 % of 100 letters is a margin already: nothing to look for)
-  else for (uint32_t i = 0; i < r->n; i++) { const uint32_t l = r->len[i]; for (int k = 0; k < 7; k++) if (l >= 8u + 2u * (uint32_t)k && l < B.min_ge[k]) B.min_ge[k] = l; }
+  B.min_ge_known = false;
+  if (r->n && r->min_len >= 100) { for (int k = 0; k < 7; k++) B.min_ge[k] = r->min_len; B.min_ge_known = true; }      // (1 % of 100 letters is a margin already: nothing to look for)
   HIPCHK(c, hipMemcpyAsync(B.d_words, r->words.data(), r->words.size() * 4, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(B.d_rec_off, r->rec_off.data(), r->rec_off.size() * 8, hipMemcpyHostToDevice, st));
   if (r->n) HIPCHK(c, hipMemcpyAsync(B.d_len, r->len.data(), r->len.size() * 4, hipMemcpyHostToDevice, st));
@@ -1238,6 +1240,13 @@ int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipS
   return reset_batch(c, B, st);
 }
 }  // namespace
+
+extern "C" const char* smr_params_refused(const smr_params* p) {
+  if (!p) return "null params";
+  if (const char* why = scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext)) return why;
+  if (p->edges < 1 || p->edges > 10) return "edges must be 1..10 (nucleotides or percent), like the reference's --edges";
+  return nullptr;
+}
 
 extern "C" int smr_state_reset(smr_ctx* c) {
   if (!c || !c->b->d_saved) return SMR_ERR_STATE;
@@ -1291,6 +1300,12 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   // (alignment.cpp:320,345), so such a read is aligned against the whole rest of its reference sequence.  Not built here (the windows of the
   // Smith-Waterman kernels are sized read + 2 x edges): said before anything runs, not as a capacity error of some kernel.
   if (p->is_as_percent) {
+    if (!c->b->min_ge_known) {                                // the shortest searchable read of the batch, per seed length: from the lengths on the device, once per batch
+      std::vector<uint32_t> len(c->b->n);
+      if (c->b->n) { HIPCHK(c, hipMemcpyAsync(len.data(), c->b->d_len, (size_t)c->b->n * 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+      for (uint32_t l : len) for (int k = 0; k < 7; k++) if (l >= 8u + 2u * (uint32_t)k && l < c->b->min_ge[k]) c->b->min_ge[k] = l;
+      c->b->min_ge_known = true;
+    }
     const uint32_t lmin = c->b->min_ge[(std::min<uint32_t>(std::max<uint32_t>(di.lnwin, 8u), 20u) - 8u) / 2u];
     if (lmin != ~0u && (uint32_t)((p->edges / 100.0) * (double)lmin) == 0) {
       set_err(c, "edges as a percentage: the batch has a searchable read so short that the percentage rounds to 0 letters; the reference then aligns it against the whole rest of the reference sequence (alignment.cpp:320,345), which is not supported -- use an absolute --edges");
@@ -1310,7 +1325,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   const int single = (p->is_forward != 0) ^ (p->is_reverse != 0);
   const int num_strands = single ? 1 : 2;
-  for (int attempt = 0; attempt < 8; attempt++) {
+  for (int attempt = 0; attempt < 16; attempt++) {            // (the hit-list ladder of the DFS kernel alone has seven steps: grow_hcap)
     if ((rc = ensure_chain_scratch(c, di))) return rc;
     const KpSave kp0 = kp_save(c);
     c->wstat_n = 0;
@@ -1781,7 +1796,7 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
   ev_drop(c);
   const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
   std::vector<unsigned long long> h;
-  for (int attempt = 0; attempt < 8; attempt++) {
+  for (int attempt = 0; attempt < 16; attempt++) {
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_HITCAP], 0, 16, c->stream));          // HITCAP, POOL
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * C_PCUR_STRIDE * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_HIT], 0, 8, c->stream));

@@ -82,27 +82,34 @@ __device__ __forceinline__ SMR_GLOBAL_U32* pg_ptr(uint32_t lo, uint32_t hi) { re
 // prefix maximum spreads it to the strings behind (the searches are in the order of their first strings; one without strings starts where
 // the next one does and loses against it); carry = 1 + the last search that starts before the row.
 __device__ __forceinline__ void pg_row_fetch(PgRow& R, uint32_t g0, uint32_t wtot, int lane, uint32_t* own, const PgOwn& O, uint32_t& carry, const uint32_t* pg) {
-  // (called with g0 < wtot only.  Every field is written on one path: values that come out of a branch cost the wave a register copy each --
-  // round 5's version, which cleared the row first and filled it under `g < wtot`, spent ten of its ninety vector instructions per row on them)
-  const uint32_t g = g0 + (uint32_t)lane;
-  own[lane] = 0;
-  __builtin_amdgcn_wave_barrier();
-  if (O.exm - g0 < 64u) own[O.exm - g0] = (uint32_t)lane + 1u;
-  __builtin_amdgcn_wave_barrier();
-  const uint32_t ow = max(pg_scan_max(own[lane]), carry);
-  carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
-  const int s = (int)ow - 1;
-  const uint32_t oP = __shfl(O.P9, s, 64), om = __shfl(O.mab, s, 64), olo = __shfl(O.blo, s, 64), ohi = __shfl(O.bhi, s, 64);
-  const uint32_t t1 = __shfl(O.t1, s, 64), t2 = __shfl(O.t2, s, 64), t3 = __shfl(O.t3, s, 64);
-  const uint32_t d0 = __shfl(O.d0, s, 64), d1 = __shfl(O.d1, s, 64), d2 = __shfl(O.d2, s, 64), d3 = __shfl(O.d3, s, 64);
-  const bool have = g < wtot;
-  const bool p1 = g >= t1, p2 = g >= t2, p3 = g >= t3;
-  // exactly ONE load per call whatever the lane (a lane without a string reads word 0 of the layout): only then can the compiler let the
+  // (A row past the last string only issues its load.  What a row's lane knows about its string is written on ONE path and otherwise left as it
+  // was -- nobody looks at it when `have` is false --: values that come out of both sides of a branch cost the wave a register copy each, and
+  // round 5's version, which cleared the row first and filled it under `g < wtot`, spent ten of its ninety vector instructions per row on them.)
+  uint32_t u = 0;
+  SMR_GLOBAL_U32* tt = (SMR_GLOBAL_U32*)pg;
+  bool have = false;
+  if (g0 < wtot) {
+    const uint32_t g = g0 + (uint32_t)lane;
+    own[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (O.exm - g0 < 64u) own[O.exm - g0] = (uint32_t)lane + 1u;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t ow = max(pg_scan_max(own[lane]), carry);
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)ow, 63);
+    const int s = (int)ow - 1;
+    const uint32_t oP = __shfl(O.P9, s, 64), om = __shfl(O.mab, s, 64), olo = __shfl(O.blo, s, 64), ohi = __shfl(O.bhi, s, 64);
+    const uint32_t t1 = __shfl(O.t1, s, 64), t2 = __shfl(O.t2, s, 64), t3 = __shfl(O.t3, s, 64);
+    const uint32_t d0 = __shfl(O.d0, s, 64), d1 = __shfl(O.d1, s, 64), d2 = __shfl(O.d2, s, 64), d3 = __shfl(O.d3, s, 64);
+    have = g < wtot;
+    const bool p1 = g >= t1, p2 = g >= t2, p3 = g >= t3;
+    u = have ? g + (p3 ? d3 : p2 ? d2 : p1 ? d1 : d0) : 0u;
+    tt = have ? pg_ptr(olo, ohi) : (SMR_GLOBAL_U32*)pg;
+    R.P = oP; R.m = om; R.w = p3 ? 3u : p2 ? 2u : p1 ? 1u : 0u; R.s = s;
+  }
+  // exactly ONE load per call whatever the path (a lane without a string reads word 0 of the layout): only then can the compiler let the
   // wave wait for the older of two loads in flight (s_waitcnt vmcnt(1)) instead of for all of them
-  R.u = have ? g + (p3 ? d3 : p2 ? d2 : p1 ? d1 : d0) : 0u;
-  R.tt = have ? pg_ptr(olo, ohi) : (SMR_GLOBAL_U32*)pg;
-  R.T = R.tt[R.u];
-  R.P = oP; R.m = om; R.w = p3 ? 3u : p2 ? 2u : p1 ? 1u : 0u; R.s = s; R.have = have;
+  R.u = u; R.tt = tt; R.have = have;
+  R.T = tt[u];
 }
 // The automaton over the strings of a row; an accepted one becomes a candidate record of its search.
 __device__ __forceinline__ void pg_row_apply(const PgRow& R, uint32_t pw, uint32_t h, bool full, uint32_t ccap, uint32_t* s_ncand,
@@ -288,13 +295,12 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   PgRow A, B;
   A.T = A.P = A.m = A.u = A.w = 0; A.s = 0; A.tt = (SMR_GLOBAL_U32*)ix.pg; A.have = false;
   B = A;
-  if (wtot) pg_row_fetch(A, 0u, wtot, lane, own, O, carry, ix.pg);
-  for (uint32_t g0 = 0; g0 < wtot; g0 += 128) {
-    if (g0 + 64u < wtot) pg_row_fetch(B, g0 + 64u, wtot, lane, own, O, carry, ix.pg); else B.have = false;
+  for (uint32_t g0 = 0; g0 < wtot + 64u; g0 += 128) {
+    pg_row_fetch(B, g0, wtot, lane, own, O, carry, ix.pg);
     GPH(2)
     pg_row_apply(A, pw, h, full, ccap, &s_ncand, cdk, cdv, cdn, hd);
     GPH(3)
-    if (g0 + 128u < wtot) pg_row_fetch(A, g0 + 128u, wtot, lane, own, O, carry, ix.pg); else A.have = false;
+    pg_row_fetch(A, g0 + 64u, wtot, lane, own, O, carry, ix.pg);
     GPH(2)
     pg_row_apply(B, pw, h, full, ccap, &s_ncand, cdk, cdv, cdn, hd);
     GPH(3)

@@ -6,10 +6,11 @@ from . import capi
 from .engine import SmrError
 
 
-def corrected_sizes(K, info, all_reads_count, all_reads_len):
-    """Refstats::full_ref / full_read after the length correction (refstats.cpp:238-257)"""
+def corrected_sizes(K, info, all_reads_count, all_reads_len, full_read_scale=1):
+    """Refstats::full_ref / full_read after the length correction (refstats.cpp:238-257); full_read_scale: the number of processing threads of a
+    reference run with -score_split (refstats.cpp:247), which the e-value of its BLAST report then carries too"""
     a, b = C.c_uint64(), C.c_uint64()
-    capi.load().smr_refstats_corrected(K, info.bg, info.full_len, info.numseq, all_reads_count, all_reads_len, C.byref(a), C.byref(b))
+    capi.load().smr_refstats_corrected_split(K, info.bg, info.full_len, info.numseq, all_reads_count, all_reads_len, int(full_read_scale), C.byref(a), C.byref(b))
     return a.value, b.value
 
 

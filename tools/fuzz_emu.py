@@ -131,6 +131,7 @@ def main():
                             e.close()
                             continue
                         raise
+                    assert len(recs_g) == len(recs_o), (len(recs_g), len(recs_o))
                     diff = [i for i, (a, b) in enumerate(zip(recs_g, recs_o)) if a != b]
                     same_ctr = ctr_g["num_aligned"] == ctr_o["num_aligned"] and list(ctr_g["reads_matched_per_db"][:len(ws)]) == ctr_o["per_db"] and ctr_g["num_short"] == ctr_o["num_short"]
                     ok = not diff and same_ctr

@@ -34,6 +34,17 @@ pmcmb)
     find $OUT/pmc_$N -name "*counter_collection.csv" -exec python tools/pmc_dispatches.py {} k_walk \; > $OUT/pmcmb_${N}_k_walk_dispatches.txt 2>&1
     rm -rf $OUT/pmc_$N
   done ;;
+pmcalt=*)
+  # pmcalt=LIB   the instruction / cycle counters of the seed kernels on the mini bench with the alternative build sortmerna_amd/lib/LIB.so
+  LIBN=${W#pmcalt=}
+  cp sortmerna_amd/lib/libsmr_hip.so /tmp/libsmr_hip.keep && cp sortmerna_amd/lib/$LIBN.so sortmerna_amd/lib/libsmr_hip.so
+  for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT"; do N=$(echo $SET | cut -d' ' -f2)
+    ( cd /tmp && MB_STEPS=1 timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_$N -o pmc -- python $ROOT/tools/hw_minibench_r5.py base > $ROOT/$OUT/pmcalt_${LIBN}_$N.log 2> $ROOT/$OUT/pmcalt_${LIBN}_$N.err )
+    find $OUT/pmc_$N -name "*counter_collection.csv" -exec python tools/pmc_summary.py {} \; > $OUT/pmcalt_${LIBN}_$N.txt 2>&1
+    grep -E "k_seed" $OUT/pmcalt_${LIBN}_$N.txt | cut -c1-420
+    rm -rf $OUT/pmc_$N
+  done
+  cp /tmp/libsmr_hip.keep sortmerna_amd/lib/libsmr_hip.so ;;
 alt=*)
   # alt=LIB[:ENV=v,...]  the mini bench on an alternative build sortmerna_amd/lib/LIB.so (made in the container), e.g. the -DSMR_WALK_PHASES one
   A=${W#alt=}; LIBN=${A%%:*}; ENVS=""; [ "$A" != "$LIBN" ] && ENVS=${A#*:}
@@ -67,12 +78,16 @@ pmc)
   python tools/pmc_traffic.py $F $W2 8000000 150 140000000 $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt 2>&1; cat $OUT/hbm_traffic.txt | head -40
   rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE ;;
 sq)
+  # derived issue-side metrics per kernel family, every dispatch weighted by its duration (tools/pmc_sq.py), + SQ_INSTS_VALU of k_sw16 per cell pair
   FILES=""
-  for SET in "VALUBusy SALUBusy LDSBankConflict" "MemUnitStalled VALUUtilization"; do N=$(echo $SET | cut -c1-8)
-    ( cd /tmp && timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > /dev/null 2> $ROOT/$OUT/pmc_sq_$N.err )
-    FILES="$FILES $(find $OUT/pmc_sq_$N -name "*counter_collection.csv" | head -1)"
+  for SET in "VALUBusy SALUBusy LDSBankConflict" "MemUnitStalled VALUUtilization" "SQ_INSTS_VALU SQ_WAVES"; do N=$(echo $SET | cut -c1-8)
+    ( cd /tmp && timeout 500 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sq_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_sq_$N.json 2> $ROOT/$OUT/pmc_sq_$N.err )
+    FILES="$FILES $(find $OUT/pmc_sq_$N -name "*counter_collection.csv" | head -1) $(find $OUT/pmc_sq_$N -name "*kernel_trace.csv" | head -1)"
   done
-  ( cd tools && python pmc_sq.py $ROOT/$OUT/sq_counters.json 8000000 150 140000000 $(for F in $FILES; do echo $ROOT/$F; done) ) > $OUT/sq_counters.txt 2>&1; cat $OUT/sq_counters.txt
+  CELLS=$(python -c "
+import json
+o=json.loads([l for l in open('$OUT/pmc_sq_SQ_INSTS.json') if l.startswith('{')][-1]); print(o['kernels']['k_chain']['sw_cells'])")
+  ( cd tools && python pmc_sq.py $ROOT/$OUT/sq_counters.json 8000000 150 140000000 $(for F in $FILES; do echo $ROOT/$F; done) --sw-cells $CELLS ) > $OUT/sq_counters.txt 2>&1; cat $OUT/sq_counters.txt
   rm -rf $OUT/pmc_sq_* ;;
 sqi)
   ( cd /tmp && timeout 500 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d $ROOT/$OUT/pmc_sqi -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --resident-batches 2 --profile-run > $ROOT/$OUT/pmc_sqi.json 2> $ROOT/$OUT/pmc_sqi.err )
