@@ -270,6 +270,8 @@ typedef struct {
   uint64_t n_sw_spec, n_sw_spec_used;          /* forward passes scored ahead of the walk in four-problem batches, and how many of them the walk then asked for */
   uint64_t n_seed_redo;                        /* waves (64 searches) of the fast seed kernel whose candidate pool overflowed and that the per-lane DFS kernel searched again */
   uint64_t hit_list_cap;                       /* entries of the per-search hit lists in use: 4, doubled on demand up to 128, then 31 L/2 - 20 (twice that for the DFS kernel) = what a search can accept at most */
+  uint64_t n_seed_shared;                      /* seed stages since smr_prof_reset whose searches walked the batch's SHARED sorted arrays (one sort for several index parts / --ref) */
+  uint64_t n_seed_shared_builds;               /* ... and how often those six arrays were built */
 } smr_prof;
 /* smr_index_build with the per-occurrence work (sorting all (L+1)-mers, ids, position lists, mini-trie layout) done
  * on the device: same arguments (threads does not apply), same smr_index objects, byte-identical index files

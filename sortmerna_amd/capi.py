@@ -50,6 +50,7 @@ class Prof(C.Structure):
         ("trace_ms", C.c_double), ("trace_launches", C.c_uint64), ("n_windows", C.c_uint64), ("n_lookup", C.c_uint64),
         ("n_node", C.c_uint64), ("n_entry", C.c_uint64), ("n_hit", C.c_uint64), ("n_read_bytes", C.c_uint64),
         ("n_sw_fwd", C.c_uint64), ("n_sw_rev", C.c_uint64), ("n_sw_cells", C.c_uint64), ("n_sw_spec", C.c_uint64), ("n_sw_spec_used", C.c_uint64), ("n_seed_redo", C.c_uint64), ("hit_list_cap", C.c_uint64),
+        ("n_seed_shared", C.c_uint64), ("n_seed_shared_builds", C.c_uint64),
     ]
 
 

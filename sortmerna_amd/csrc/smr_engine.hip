@@ -46,6 +46,7 @@ struct Batch {
   bool used = false;
   uint32_t n = 0, max_len = 0, slots = 1;
   uint32_t min_ge[7] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};     // the shortest read of at least 8, 10, ... 20 letters (~0: none): what `--edges N%` is smallest for
+  uint64_t gen = 0;                        // counts the uploads and state resets of this batch (what a shared seed sort was built for)
   bool min_ge_known = false;               // (computed when a call with is_as_percent asks for it: one pass over the lengths, which the default options never need)
   uint32_t* d_words = nullptr; uint64_t* d_rec_off = nullptr; uint32_t* d_len = nullptr;
   RState* d_saved = nullptr; RState* d_work = nullptr; RWork* d_rw = nullptr;
@@ -61,6 +62,16 @@ struct Batch {
   bool fetched = false;
   // capacities of the device arrays above (grow-only: a re-upload into the same batch allocates nothing unless it is larger)
   size_t cap_words = 0, cap_reads = 0, cap_aln = 0;
+};
+
+// (one seed sort for the index parts of a batch: see ensure_shared_sort)
+struct SharedSet { SeedTup* srt = nullptr; uint16_t* wbin = nullptr; uint32_t* cbase = nullptr; uint32_t* sn = nullptr; uint32_t maxwin = 0; bool built = false; };
+struct SharedSort {
+  SharedSet set[2][3];
+  const void* batch = nullptr; uint64_t gen = 0; uint32_t lnwin = 0, skip[3] = {0, 0, 0}, n = 0, max_len = 0;
+  uint64_t cap[3] = {0, 0, 0};
+  bool usable = false;
+  uint32_t* abits = nullptr; size_t abits_words = 0;
 };
 
 struct smr_ctx {
@@ -82,6 +93,10 @@ struct smr_ctx {
   uint32_t cand_bloom = 128;
   // repeated seeds (k_seed_dedup): keys with at least this many tuples in a launch (and four times the average) are searched once per different seed; 0: off
   uint32_t hot_min = getenv("SMR_SEED_DEDUP") ? (uint32_t)std::max(0, atoi(getenv("SMR_SEED_DEDUP"))) : 1024u;
+  // one seed sort for the index parts of a batch (SharedSort below): 0 off, 1 when the part in hand is not the batch's last, 2 always (tests)
+  int seed_shared = getenv("SMR_SEED_SHARED") ? atoi(getenv("SMR_SEED_SHARED")) : 1;
+  SharedSort* shared = nullptr;
+  uint64_t n_seed_shared = 0, n_seed_shared_builds = 0;      // smr_prof
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
   // k_seed_pg: waves of the launch (0: one per wave chunk the batch can have; else a wave walks chunks it, it + grid, ...), XCD-aware chunk order
   uint32_t pg_grid = getenv("SMR_PG_GRID") ? (uint32_t)atoi(getenv("SMR_PG_GRID")) : 262144u;
@@ -326,18 +341,18 @@ bool grow_hcap(smr_ctx* c, uint32_t pw) {
   return true;
 }
 
-// the seed stage of one (strand, pass): the forward and reverse half-seed searches of all windows (smr_seed.hpp)
-int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
-  int rc = ensure_seed_bufs(c, P); if (rc) return rc;
-  if (c->b->max_len > 0xFFFFu) { set_err(c, "seed stage limit: reads <= 65535 nt"); return SMR_ERR_CAPACITY; }
-  if (di.n_ids >= 0x7FFFFFFFu) { set_err(c, "seed stage limit: < 2^31 - 1 distinct seeds per index part"); return SMR_ERR_CAPACITY; }
-  SeedBufs sb = c->sb;
-  sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
-  const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
-  sb.cap_tuples = (uint32_t)(2 * slots);
-  sb.n = c->b->n;
-  sb.cap_redo = SEED_REDO_CAP;
-  // k_seed_keys: reads per wave trip (a power of two; their packed records must fit the wave's LDS stage) and lanes per read; reads per block
+// One sort for several index parts (BASELINE configs[3]: eight --ref; any index cut into parts by -m).  The reference loops (index, part) over the same
+// reads (processor.cpp:219-277), and the tuples of a (strand, pass) are the same for every part -- but for the reads that are in the pass (per-part state:
+// seed_read_active), the keys the part's lookup table has (a missing mini-trie ends a search before it starts) and the value an ambiguous letter reads as,
+// which depends on the read's history in the part (Read::flip34, read.cpp:379-401: the reads with such letters keep a small sort of their own per part).  So
+// the first part of a batch that is not its last builds SIX sorted arrays (2 strands x 3 passes: every read long enough, every window, both directions)
+// and the searches of every part walk them: keys + two sort passes, 4.1 of a stage's 9.2 ms on the eight-reference workload, once instead of eight times.
+// Not with minoccur > 0 (that emit filter needs the part's counts), not in the exact-counter mode, not when a shared array has hot keys (k_seed_dedup
+// rewrites tuples in place, and which of several equal tuples can stand for the others depends on the part's active reads): the per-part sort runs then.
+// k_seed_keys for this batch (reads per wave trip, lanes per read, reads per block) into sb; returns the instantiation
+typedef void (*seed_keys_fn)(DReads, DParams, int, SeedBufs, const RWork*, unsigned long long*, int);
+seed_keys_fn seed_keys_setup(smr_ctx* c, SeedBufs& sb, size_t& lds_keys) {
+  // reads per wave trip (a power of two; their packed records must fit the wave's LDS stage) and lanes per read; reads per block
   const uint32_t rec_words = (c->b->max_len + 15) / 16 + (c->b->max_len + 31) / 32;
   const bool staged = rec_words <= SEED_STAGE_WORDS;
   uint32_t rwr = 64;
@@ -349,9 +364,128 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   const uint32_t trips = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)sb.n + (uint64_t)per_trip * SEED_KEY_BLOCKS - 1) / ((uint64_t)per_trip * SEED_KEY_BLOCKS)));
   sb.rpb = trips * per_trip;
   sb.kb = std::max<uint32_t>(1u, (sb.n + sb.rpb - 1) / sb.rpb);
-  if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
   const bool mapped = (sb.nkh / 16) * 4 <= 64 * 1024;
-  const size_t lds_keys = (size_t)4 * (((sb.nc + 3u) & ~3u) + (mapped ? sb.nkh / 16 : 0u) + (staged ? SEED_WAVES * (SEED_STAGE_WORDS + 8u) : 0u));
+  lds_keys = (size_t)4 * (((sb.nc + 3u) & ~3u) + (mapped ? sb.nkh / 16 : 0u) + (staged ? SEED_WAVES * (SEED_STAGE_WORDS + 8u) : 0u));
+  seed_keys_fn kf;
+  if (gsh == 0) kf = mapped ? k_seed_keys<true, true, true> : k_seed_keys<true, true, false>;
+  else if (staged) kf = mapped ? k_seed_keys<false, true, true> : k_seed_keys<false, true, false>;
+  else kf = mapped ? k_seed_keys<false, false, true> : k_seed_keys<false, false, false>;
+  if (lds_keys > 64 * 1024) (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys);
+  return kf;
+}
+
+// tuples of one (strand, pass) -> key order: k_seed_keys (mode: smr_seed.hpp) + the two-level sort, into sb.srt / sb.wbin / sb.cbase / sb.sn
+int seed_sort(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, SeedBufs& sb, int mode) {
+  if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
+  const uint64_t slots = (uint64_t)sb.n * sb.maxwin;
+  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
+  const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
+  if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_hbins_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
+  if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
+    c->split_lds_attr = lds_split;
+  }
+  size_t lds_keys;
+  const seed_keys_fn kf = seed_keys_setup(c, sb, lds_keys);
+  ev_mark(c, KP_KEYS);
+  HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
+  if ((mode & 15) != SEED_KEYS_SHARED) hipLaunchKernelGGL(k_seed_emap, dim3((sb.nkh / 16 + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)di.lkc, sb.nkh, P.minoccur, sb.emap);
+  hipLaunchKernelGGL(kf, dim3(sb.kb), dim3(64 * SEED_WAVES), lds_keys, c->stream, dreads(c), P, pass, sb, (const RWork*)c->b->d_rw, c->b->d_ctr, mode);
+  // the two-level sort of the stage's forward and reverse tuples (smr_seed.hpp)
+  ev_mark(c, KP_SPLIT);                                    // (with the scans of the block histograms in front of it)
+  hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
+  hipLaunchKernelGGL(k_seed_wbin, dim3((gw + 255) / 256), dim3(256), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
+  ev_mark(c, KP_BINS);
+  hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
+  // the coarse bins that are far larger than the others, several blocks each (none on evenly spread keys: three empty launches)
+  const uint32_t gh = std::min<uint32_t>(sb.cap_hent, (uint32_t)c->n_cu * 2u);       // (grids that loop: an empty launch should cost a launch, not 2 000 blocks)
+  hipLaunchKernelGGL(k_seed_hbins_hist, dim3(gh), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_hbins_scan, dim3(std::min<uint32_t>(sb.nc, 128u)), dim3(1024), 0, c->stream, sb);
+  hipLaunchKernelGGL(k_seed_hbins_move, dim3(gh), dim3(1024), lds_bins, c->stream, sb);
+  return SMR_OK;
+}
+
+// the searches of one sorted array: forward (dir 0) or reverse launch, the overflow redo, the repeated seeds' windows
+int seed_search(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, const SeedBufs& sb, int dir, uint32_t pool_words, size_t lds, size_t lds_pg) {
+  const uint64_t slots = (uint64_t)sb.n * sb.maxwin;
+  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));
+  const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
+  const uint32_t gp = c->pg_grid ? std::min<uint32_t>((gw + 7u) & ~7u, c->pg_grid) : ((gw + 7u) & ~7u);
+  const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
+  HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
+  if (dir == 0) {
+    hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
+    hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
+    if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<0>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
+  } else {
+    hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
+    hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
+    if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<1>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
+  }
+  return SMR_OK;
+}
+
+// the six shared arrays of the selected batch (see SharedSort); usable = false when a condition above does not hold
+int ensure_shared_sort(smr_ctx* c, const DevIndex& di, const DParams& P) {
+  SharedSort& S = *c->shared;
+  const bool same = S.batch == c->b && S.gen == c->b->gen && S.lnwin == P.lnwin && S.skip[0] == P.skip[0] && S.skip[1] == P.skip[1] && S.skip[2] == P.skip[2] && S.n == c->b->n;
+  if (same) return SMR_OK;
+  S.batch = c->b; S.gen = c->b->gen; S.lnwin = P.lnwin; S.n = c->b->n; S.max_len = c->b->max_len;
+  for (int q = 0; q < 3; q++) S.skip[q] = P.skip[q];
+  S.usable = false;
+  for (int s = 0; s < 2; s++) for (int p = 0; p < 3; p++) S.set[s][p].built = false;
+  const size_t aw = ((size_t)c->b->n + 255) / 256 * 8 + 4;
+  if (S.abits_words < aw) { int rc = dev_alloc(c, &S.abits, aw); if (rc) return rc; S.abits_words = aw; }
+  DParams Q = P; Q.minoccur = 0;
+  for (int p = 0; p < 3; p++) {
+    if (p > 0 && P.skip[p] == P.skip[p - 1]) continue;
+    const uint32_t mw = num_windows(c->b->max_len, P.lnwin, P.skip[p]);
+    const uint64_t cap = 2ull * std::max(c->b->n, 1u) * mw;
+    for (int s = 0; s < 2; s++) {
+      SharedSet& T = S.set[s][p];
+      int rc;
+      if (S.cap[p] < cap || !T.srt) {
+        if ((rc = dev_alloc(c, &T.srt, (size_t)cap)) || (rc = dev_alloc(c, &T.wbin, (size_t)(cap / 64 + 2)))) return rc;
+        if (!T.cbase && ((rc = dev_alloc(c, &T.cbase, (size_t)4096 + 2)) || (rc = dev_alloc(c, &T.sn, (size_t)SN_COUNT)))) return rc;
+      }
+      SeedBufs sb = c->sb;
+      sb.maxwin = T.maxwin = mw; sb.cap_tuples = (uint32_t)cap; sb.n = c->b->n; sb.cap_redo = SEED_REDO_CAP;
+      sb.srt = T.srt; sb.wbin = T.wbin; sb.cbase = T.cbase; sb.sn = T.sn; sb.abits = nullptr;
+      if ((rc = seed_sort(c, di, Q, p, sb, SEED_KEYS_SHARED | (s << 4)))) return rc;
+      T.built = true;
+    }
+    S.cap[p] = std::max(S.cap[p], cap);
+  }
+  ev_stop(c);
+  // a shared array with hot keys: the per-part sort (with k_seed_dedup) serves such a batch better
+  uint32_t hot = 0;
+  for (int s = 0; s < 2; s++) for (int p = 0; p < 3; p++) if (S.set[s][p].built) {
+    uint32_t v = 0;
+    HIPCHK(c, hipMemcpyAsync(&v, S.set[s][p].sn + SN_PIECES, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hot += v;
+  }
+  S.usable = hot == 0 || c->seed_shared >= 2;
+  c->n_seed_shared_builds++;
+  if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: one seed sort for the parts of this batch: built (%u pieces of hot keys: %s)\n", hot, S.usable ? "in use" : "not used, every part sorts for itself");
+  return SMR_OK;
+}
+
+// the seed stage of one (strand, pass): the forward and reverse half-seed searches of all windows (smr_seed.hpp)
+int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool more_parts = false, int strand = -1) {
+  int rc = ensure_seed_bufs(c, P); if (rc) return rc;
+  if (c->b->max_len > 0xFFFFu) { set_err(c, "seed stage limit: reads <= 65535 nt"); return SMR_ERR_CAPACITY; }
+  if (di.n_ids >= 0x7FFFFFFFu) { set_err(c, "seed stage limit: < 2^31 - 1 distinct seeds per index part"); return SMR_ERR_CAPACITY; }
+  SeedBufs sb = c->sb;
+  sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
+  const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
+  sb.cap_tuples = (uint32_t)(2 * slots);
+  sb.n = c->b->n;
+  sb.cap_redo = SEED_REDO_CAP;
+  sb.abits = nullptr; sb.inv_maxwin = 1.0 / (double)sb.maxwin;
+  if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->ccap) * 4;
   const size_t lds_pg = lds_pg1 + (getenv("SMR_PG_LDS_PAD") ? (size_t)atoi(getenv("SMR_PG_LDS_PAD")) : 0);      // (the variable: occupancy experiments)
   // lists of more than 128 hits per search (a crafted neighbourhood: SEED_HCAP_MAX) take more than the default 64 KB of dynamic LDS
@@ -367,42 +501,27 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
   }
   const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
-  const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
-  if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_hbins_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
-  if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
-    c->split_lds_attr = lds_split;
+  // one sort for several parts?  (strand < 0: smr_seed_scan, the test seam of one (strand, pass) -- always the part's own sort)
+  bool shared = false;
+  if (strand >= 0 && c->seed_shared && !c->seed_exact && P.minoccur == 0 && (more_parts || c->seed_shared >= 2 || (c->shared->usable && c->shared->batch == c->b && c->shared->gen == c->b->gen))) {
+    if ((rc = ensure_shared_sort(c, di, P))) return rc;
+    shared = c->shared->usable && c->shared->set[strand][pass].built;
   }
-  // the instantiation of k_seed_keys for this batch
-  typedef void (*keys_fn)(DReads, DParams, int, SeedBufs, const RWork*, unsigned long long*);
-  keys_fn kf;
-  if (gsh == 0) kf = mapped ? k_seed_keys<true, true, true> : k_seed_keys<true, true, false>;
-  else if (staged) kf = mapped ? k_seed_keys<false, true, true> : k_seed_keys<false, true, false>;
-  else kf = mapped ? k_seed_keys<false, false, true> : k_seed_keys<false, false, false>;
-  if (lds_keys > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys));
-  ev_mark(c, KP_KEYS);
-  HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
   for (int d = 0; d < 2; d++) HIPCHK(c, hipMemsetAsync(sb.fbits[d], 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
   HIPCHK(c, hipMemsetAsync(sb.zbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.gflag, 0, (size_t)(slots / 2048 + 2) * 4, c->stream));
-  hipLaunchKernelGGL(k_seed_emap, dim3((sb.nkh / 16 + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)di.lkc, sb.nkh, P.minoccur, sb.emap);
-  hipLaunchKernelGGL(kf, dim3(sb.kb), dim3(64 * SEED_WAVES), lds_keys, c->stream, dreads(c), P, pass, sb, (const RWork*)c->b->d_rw, c->b->d_ctr);
-  // the two-level sort of the stage's forward and reverse tuples (smr_seed.hpp)
-  ev_mark(c, KP_SPLIT);                                    // (with the scans of the block histograms in front of it)
-  hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
-  hipLaunchKernelGGL(k_seed_wbin, dim3((gw + 255) / 256), dim3(256), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
-  ev_mark(c, KP_BINS);
-  hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
-  // the coarse bins that are far larger than the others, several blocks each (none on evenly spread keys: three empty launches)
-  const uint32_t gh = std::min<uint32_t>(sb.cap_hent, (uint32_t)c->n_cu * 2u);       // (grids that loop: an empty launch should cost a launch, not 2 000 blocks)
-  hipLaunchKernelGGL(k_seed_hbins_hist, dim3(gh), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_hbins_scan, dim3(std::min<uint32_t>(sb.nc, 128u)), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_hbins_move, dim3(gh), dim3(1024), lds_bins, c->stream, sb);
-  if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
+  // the part's own sort: every read of the (strand, pass) -- or, beside the shared arrays, the reads with ambiguous letters
+  if ((rc = seed_sort(c, di, P, pass, sb, shared ? SEED_KEYS_AMB : SEED_KEYS_ALL))) return rc;
   const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
   if (sb.hot_min) hipLaunchKernelGGL(k_seed_dedup, dim3(gd), dim3(256), 0, c->stream, sb);
+  SeedBufs sh = sb;                                          // the shared array of this (strand, pass), filtered by the reads that are in the launch
+  if (shared) {
+    const SharedSet& T = c->shared->set[strand][pass];
+    sh.srt = T.srt; sh.wbin = T.wbin; sh.cbase = T.cbase; sh.sn = T.sn; sh.cap_tuples = (uint32_t)std::min<uint64_t>(c->shared->cap[pass], 0xFFFFFFFFull);
+    sh.abits = c->shared->abits; sh.hot_min = 0;
+    c->n_seed_shared++;
+    hipLaunchKernelGGL(k_seed_active, dim3((c->b->n + 255u) / 256u), dim3(256), 0, c->stream, c->b->n, pass, (const RWork*)c->b->d_rw, c->shared->abits);
+  }
   const uint32_t* no_redo = nullptr;
   if (c->seed_exact) {
     ev_mark(c, KP_PG0);
@@ -411,28 +530,20 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass) {
     hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
   } else {
     // pigeonhole search; the (rare) waves whose candidate pool overflowed are searched again by the DFS kernel
-    const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
-    const uint32_t gp = c->pg_grid ? std::min<uint32_t>((gw + 7u) & ~7u, c->pg_grid) : ((gw + 7u) & ~7u);
     for (int dir = 0; dir < 2; dir++) {
-      HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
       ev_mark(c, dir ? KP_PG1 : KP_PG0);
-      if (dir == 0) {
-        hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
-        hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
-        if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<0>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
-      } else {
-        hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
-        hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
-        if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<1>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
-      }
+      if (shared && (rc = seed_search(c, di, P, pass, sh, dir, pool_words, lds, lds_pg))) return rc;
+      if ((rc = seed_search(c, di, P, pass, sb, dir, pool_words, lds, lds_pg))) return rc;
     }
   }
   if (getenv("SMR_SEED_DEBUG")) {                            // (debug aid: synchronises)
-    uint32_t sn[SN_COUNT], hent = 0;
+    uint32_t sn[SN_COUNT], hent = 0, sn2[SN_COUNT] = {0};
     HIPCHK(c, hipMemcpyAsync(sn, sb.sn, sizeof sn, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&hent, sb.hpre + sb.nc, 4, hipMemcpyDeviceToHost, c->stream));
+    if (shared) HIPCHK(c, hipMemcpyAsync(sn2, sh.sn, sizeof sn2, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "libsmr_hip: seed stage pass %d: %u tuples (%u forward), %u sub-ranges of large coarse bins, %u pieces of hot keys (from %u tuples per key), %u redo waves\n", pass, sn[SN_TUPLES], sn[SN_FWD], hent, sn[SN_PIECES], sb.hot_min, sn[SN_REDO]);
+    fprintf(stderr, "libsmr_hip: seed stage pass %d: %u tuples (%u forward), %u sub-ranges of large coarse bins, %u pieces of hot keys (from %u tuples per key), %u redo waves; shared sort %s (%u tuples)\n",
+            pass, sn[SN_TUPLES], sn[SN_FWD], hent, sn[SN_PIECES], sb.hot_min, sn[SN_REDO], shared ? "in use" : "no", sn2[SN_TUPLES]);
   }
   ev_mark(c, KP_FINISH);
   hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, pool_words, c->b->d_ctr);
@@ -995,11 +1106,12 @@ extern "C" int smr_create(int device, smr_ctx** out, char* err, size_t errcap) {
   }
   if (device < 0 || device >= ndev) { if (err && errcap) snprintf(err, errcap, "device %d out of range (%d devices)", device, ndev); return SMR_ERR_ARG; }
   auto c = new smr_ctx();
+  c->shared = new SharedSort();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->upload_stream) != hipSuccess ||
       hipMalloc((void**)&c->d_ctr_snap, C_TOTAL * 8) != hipSuccess) {
     if (err && errcap) snprintf(err, errcap, "cannot initialise device %d", device);
-    delete c; return SMR_ERR_DEVICE;
+    delete c->shared; delete c; return SMR_ERR_DEVICE;
   }
   if (const char* e = getenv("SMR_SEED_EXACT")) c->seed_exact = atoi(e) != 0;
   if (const char* e = getenv("SMR_CAND_BLOOM")) { uint32_t b = 64; while (b < CAND_BLOOM_WORDS && b < (uint32_t)atoi(e)) b <<= 1; c->cand_bloom = b; }      // measurement aid
@@ -1043,6 +1155,11 @@ extern "C" void smr_destroy(smr_ctx* c) {
   for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
   dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
+  if (c->shared) {
+    for (int s = 0; s < 2; s++) for (int p = 0; p < 3; p++) { SharedSet& T = c->shared->set[s][p]; dev_free(&T.srt); dev_free(&T.wbin); dev_free(&T.cbase); dev_free(&T.sn); }
+    dev_free(&c->shared->abits);
+    delete c->shared;
+  }
   for (auto& m : c->events) (void)hipEventDestroy(m.e);
   for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
   dev_free(&c->d_ctr_snap); dev_free(&c->d_fidx); dev_free(&c->d_fstate); dev_free(&c->d_faln);
@@ -1189,6 +1306,7 @@ extern "C" int smr_set_seed_mode(smr_ctx* c, int exact_counters) {
 
 namespace {
 int reset_batch(smr_ctx* c, Batch& B, hipStream_t st) {
+  B.gen++;
   HIPCHK(c, hipMemsetAsync(B.d_saved, 0, (size_t)B.n * sizeof(RState), st));
   HIPCHK(c, hipMemsetAsync(B.d_saved_aln, 0, (size_t)B.n * B.slots * sizeof(AlignRec), st));
   // the Readstats counters, error flags and cursors start over; the profiling work counters (windows .. SW cells, scored-ahead counts and
@@ -1337,7 +1455,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
       HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_PCUR], 0, C_NSHARD * C_PCUR_STRIDE * 8, c->stream));
       for (int pass = 0; pass < 3; pass++) {
         if (pass > 0 && P.skip[pass] == P.skip[pass - 1]) continue;     // equal strides are skipped (paralleltraversal.cpp:269-272)
-        if ((rc = launch_seed(c, di, P, pass))) return rc;
+        if ((rc = launch_seed(c, di, P, pass, !p->is_last_index_part, ((single && p->is_reverse) || count == 1) ? 1 : 0))) return rc;
         if ((rc = launch_chain(c, di, P, pass, single || count == 1))) return rc;
       }
     }
@@ -1862,6 +1980,7 @@ extern "C" int smr_prof_reset(smr_ctx* c) {
   if (!c) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   for (int k = 0; k < KP_COUNT; k++) { c->kp_ms[k] = 0; c->kp_l[k] = 0; }
+  c->n_seed_shared = c->n_seed_shared_builds = 0;
   for (int k = 0; k < SMR_MAX_BATCHES; k++)
     if (c->bt[k].d_ctr) {
       HIPCHK(c, hipMemsetAsync(&c->bt[k].d_ctr[C_WINDOWS], 0, 9 * 8, c->stream));
@@ -1895,6 +2014,7 @@ extern "C" int smr_prof_get(smr_ctx* c, smr_prof* o) {
   o->n_windows = h[C_WINDOWS]; o->n_lookup = h[C_LOOKUP]; o->n_node = h[C_NODE]; o->n_entry = h[C_ENTRY]; o->n_hit = h[C_HIT]; o->n_read_bytes = h[C_READ_BYTES];
   o->n_sw_fwd = h[C_SW_FWD]; o->n_sw_rev = h[C_SW_REV]; o->n_sw_cells = h[C_SW_CELLS];
   o->n_sw_spec = h[C_SW_SPEC]; o->n_sw_spec_used = h[C_SW_SPEC_USED]; o->n_seed_redo = h[C_SEED_REDO]; o->hit_list_cap = c->hcap;
+  o->n_seed_shared = c->n_seed_shared; o->n_seed_shared_builds = c->n_seed_shared_builds;
   return SMR_OK;
 }
 

@@ -186,6 +186,10 @@ struct SeedBufs {
   uint32_t* hh;              // [cap_hent][2^fb] per sub-range of a large coarse bin: its histogram of the fine bits, then where its first tuple of every fine bin goes
   uint2* pieces;             // {first tuple, tuples <= SEED_DD_PIECE} of the keys with at least hot_min tuples (and four times the average): where k_seed_dedup looks for repeated seeds
   uint32_t cap_hent, cap_pieces;
+  // one sort for several index parts (launch_seed in smr_engine.hip): the searches of a part walk sorted arrays that hold the tuples of EVERY read and skip the
+  // tuples of the reads that are not in this (part, strand, pass)
+  const uint32_t* abits;     // bit per read: it is searched in this launch (nullptr: every tuple is)
+  double inv_maxwin;         // 1 / maxwin: a tuple's read = slot / maxwin
   uint32_t hot_min;          // 0: no search for repeated seeds
   uint32_t hbin_min, hsub;   // a coarse bin is "large" from twice the average size and at least hbin_min tuples (SEED_HOT_BIN_MIN); tuples per sub-range (SEED_HOT_SUB)
 };
@@ -193,6 +197,12 @@ __device__ __forceinline__ bool wseg_has(const SeedBufs& sb, int d, uint32_t slo
 __device__ __forceinline__ void wseg_put(const SeedBufs& sb, int d, uint32_t slot, uint32_t v, bool zero) {
   sb.wseg[d][slot] = v; atomicOr(&sb.fbits[d][slot >> 5], 1u << (slot & 31u));
   if (d == 0 && zero) { atomicOr(&sb.zbits[slot >> 5], 1u << (slot & 31u)); atomicOr(&sb.gflag[slot >> 11], 1u << ((slot >> 6) & 31u)); }
+}
+// is the read of window slot `slot` searched in this launch?  (slot / maxwin through a double: exact for slots < 2^31 and maxwin < 2^16)
+__device__ __forceinline__ bool seed_read_active(const SeedBufs& sb, uint32_t slot) {
+  if (!sb.abits) return true;
+  const uint32_t r = (uint32_t)(((double)slot + 0.5) * sb.inv_maxwin);
+  return (sb.abits[r >> 5] >> (r & 31u)) & 1u;
 }
 // tuple i of srt: its fields, the key completed from the position (wave chunk -> first coarse bin, then the bin boundaries)
 __device__ __forceinline__ SeedKey seed_decode(const SeedBufs& sb, uint32_t i) {
@@ -275,10 +285,15 @@ __global__ void k_seed_emap(const uint32_t* __restrict__ lkc, uint32_t nkh, uint
 // window extraction from LDS, both 9-mer keys, both emit bits from the block's LDS copy of emap (MAPPED) -- no global load depends on another
 // after the first three.  The tuples of a block go compactly into ITS region of tmp (a wave reserves its slots with one LDS atomic per window
 // round), counted per COARSE bin (key >> fb) in LDS; that histogram is the block's row of sb.rows: the first sort pass needs no counting pass.
+// `mode` (one sort for several index parts): SEED_KEYS_ALL = the tuples of every read of the part's (strand, pass), as described; SEED_KEYS_SHARED (| strand << 4) =
+// the tuples of EVERY read long enough to have a window and free of ambiguous letters, for strand and pass as given, whatever state the reads are in and whether or not
+// a part's lookup table has the key (the searches of a part skip what is not theirs: seed_read_active, a missing mini-trie); SEED_KEYS_AMB = like ALL, but only
+// the reads WITH ambiguous letters -- what such a letter reads as depends on the read's history in the part (Read::flip34), so their tuples are made per part.
+enum { SEED_KEYS_ALL = 0, SEED_KEYS_SHARED = 1, SEED_KEYS_AMB = 2 };
 template <bool ONE, bool STAGED, bool MAPPED>
-__global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParams P, int pass, SeedBufs sb, const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr) {
+__global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParams P, int pass, SeedBufs sb, const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, int mode) {
   SMR_DYN_LDS(uint32_t, lds);                             // lh [nc rounded to 4] | emap copy [nkh / 16] (MAPPED) | per wave SEED_STAGE_WORDS + 8 (STAGED)
-  __shared__ uint32_t s_cur, s_win;
+  __shared__ uint32_t s_cur;
   uint32_t* const lh = lds;
   const uint32_t lh_words = (sb.nc + 3u) & ~3u, map_words = MAPPED ? sb.nkh >> 4 : 0u;
   uint32_t* const map = lds + lh_words;
@@ -286,7 +301,7 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
   uint32_t* const stage = lds + lh_words + map_words + wv * (SEED_STAGE_WORDS + 8u);
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) lh[c] = 0;
   if (MAPPED) for (uint32_t c = threadIdx.x; c < map_words; c += blockDim.x) map[c] = sb.emap[c];
-  if (threadIdx.x == 0) { s_cur = 0; s_win = 0; }
+  if (threadIdx.x == 0) s_cur = 0;
   __syncthreads();
   const int lane = lane_id();
   const uint32_t pw = P.partialwin, L = P.lnwin;
@@ -303,7 +318,9 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
     RWork w; w.strand_active = 0; w.search = 0; w.pass_n = 0; w.is04 = 0; w.aval = 0; w.reversed = 0;
     uint32_t len = 0; uint64_t off = 0;
     if (have) { w = rw[r]; len = rd.len[r]; off = rd.rec_off[r]; }       // (asked for together: one round trip)
-    const bool active = have && w.strand_active && w.search && w.pass_n == (uint32_t)pass;
+    bool active = have && w.strand_active && w.search && w.pass_n == (uint32_t)pass;
+    if ((mode & 15) == SEED_KEYS_SHARED) { active = have && len >= L && !w.has_amb; w.reversed = (uint8_t)(mode >> 4); w.is04 = 0; w.aval = 0; }
+    else if ((mode & 15) == SEED_KEYS_AMB) active = active && w.has_amb;
     if (!__any(active)) continue;
     const uint32_t numwin = active ? (len - L + stride) / stride : 0u;     // paralleltraversal.cpp:118-120
     const uint32_t* const grec = rd.words + off;
@@ -338,6 +355,7 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
         const uint32_t wa = MAPPED ? map[ra >> 4] : sb.emap[ra >> 4], wb_ = MAPPED ? map[rb >> 4] : sb.emap[rb >> 4];
         e0 = (wa >> (2u * (ra & 15u))) & 1u;
         e1 = (wb_ >> (2u * (rb & 15u) + 1u)) & 1u;
+        if ((mode & 15) == SEED_KEYS_SHARED) e0 = e1 = true;
       }
       const unsigned long long em0 = __ballot(e0), em1 = __ballot(e1);
       nwin += (uint32_t)__popcll(__ballot(mine));
@@ -358,14 +376,14 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
       }
     }
   }
-  if (lane == 0 && nwin) atomicAdd(&s_win, nwin);
+  (void)nwin;                                              // (the windows are counted by k_seed_finish: a shared sort is not a part's work)
   __syncthreads();
   uint32_t* const row = sb.rows + (size_t)blockIdx.x * sb.nc;
   for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) row[c] = lh[c];       // (the bins' totals are k_seed_colscan's column sums: no atomics here)
   if (threadIdx.x == 0) {
     sb.bcnt[blockIdx.x] = s_cur;
-    if (s_win) { ctr_add(ctr, C_WINDOWS, s_win); ctr_add(ctr, C_LOOKUP, s_win); }     // the forward lookups; the reverse ones are counted by k_seed_finish
   }
+  (void)ctr;
 }
 
 // The tuples are brought into key order by a two-level counting sort.  No pass writes a tuple with a store of its own lane's choosing
@@ -894,12 +912,13 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
     if ((pos >= min(sb.sn[SN_FWD], n_tup)) != (DIR == 1)) mine = false;      // the forward tuples lie in front
     else {
       const SeedKey tk = seed_decode(sb, pos);
-      if (tk.dup) mine = false;                            // a repeated seed: its window gets the representative's segment (k_seed_prop)
+      if (tk.dup || !seed_read_active(sb, tk.slot)) mine = false;      // a repeated seed: its window gets the representative's segment (k_seed_prop); a read that is not in this launch
       else {
       counted = true;
       const Lookup lk = ix.lookup[tk.key - (DIR ? sb.nkh : 0u)];
       root = DIR == 0 ? lk.rootF : lk.rootR;
       chars = tk.chars; slot = tk.slot;
+      if (root == NONE) mine = false;                      // (a shared sort holds the tuples of every key; a part without the mini-trie has nothing to search)
       }
       if (mine && DIR == 1 && wseg_has(sb, 0, slot)) {     // the window's list so far = the forward search's hits
         const uint32_t seg = sb.wseg[0][slot];
@@ -965,6 +984,15 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 // the forward search ended with a 0-error match (:188); else the reverse search's candidates in its DFS order -- one already present is
 // skipped, a 0-error candidate (SEED_CAND_COND) that is not present REPLACES the list and ends the window, any other is appended.  A reverse
 // segment marked SEED_SEG_MERGED (k_seed_search<1>) is that final list already.
+// bit per read: its windows are searched in this launch through the shared sort (one sort for several index parts: SeedBufs::abits)
+__global__ void __launch_bounds__(256) k_seed_active(uint32_t n, int pass, const RWork* __restrict__ rw, uint32_t* __restrict__ abits) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  bool a = false;
+  if (r < n) { const RWork w = rw[r]; a = w.strand_active && w.search && w.pass_n == (uint32_t)pass && !w.has_amb; }
+  const unsigned long long m = __ballot(a);
+  if ((threadIdx.x & 63u) == 0) { abits[r >> 5] = (uint32_t)m; abits[(r >> 5) + 1u] = (uint32_t)(m >> 32); }      // (abits has room for the grid's last wave)
+}
+
 #define FIN_KEEP 8u                                       // segments per read and pass whose place k_seed_finish remembers (20 KB of LDS per block; a read from the DB has one per window of the first pass)
 __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int pass, SeedBufs sb, RState* __restrict__ work,
                                                      RWork* __restrict__ rw, uint32_t* __restrict__ pool, uint32_t pool_words,
@@ -972,10 +1000,10 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   __shared__ uint32_t s_sf[FIN_KEEP][256], s_sr[FIN_KEEP][256];     // the first windows with segments a thread met: forward / reverse segment (NONE: none),
   __shared__ uint16_t s_k[FIN_KEEP][256];                           // ... window (reads <= 65 535 letters; 16 bits: 20.5 KB per block = 7 blocks per CU, with 32 bits 24.6 KB = 6)
-  __shared__ unsigned long long s_st[5];
-  if (threadIdx.x < 5) s_st[threadIdx.x] = 0;
+  __shared__ unsigned long long s_st[6];
+  if (threadIdx.x < 6) s_st[threadIdx.x] = 0;
   __syncthreads();
-  unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
+  unsigned long long hits = 0, bytes = 0, looks = 0, moved = 0, kin = 0, wins = 0;      // moved: algorithmic bytes of this read (C_B_FIN); kin: what k_seed_keys read for it (C_B_KEYS)
   if (r < rd.n) {
     RWork w = rw[r];
     const uint32_t len = rd.len[r];                        // (asked for with the state, not after it)
@@ -1039,7 +1067,8 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
           seeds++; upper += cf + cr;
         }
       }
-      looks = rlook;
+      looks = rlook + nsearched;                             // the forward lookup of every window of this pass + the reverse ones that happened
+      wins = nsearched;
       kin += 4u * (((len + 15) >> 4) + ((len + 31) >> 5));      // ... and of an active read its packed record
       uint32_t base = 0, total = 0;
       if (upper) {                                           // room for the longest the merged lists can be; blk_cnt is what they are
@@ -1076,12 +1105,12 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       hits = total; bytes = (len + 3) / 4;
     }
   }
-  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); moved += __shfl_down(moved, d, 64); kin += __shfl_down(kin, d, 64); }
-  // the block's five sums leave with one atomic each (not one per wave)
-  if (lane_id() == 0) { atomicAdd(&s_st[0], hits); atomicAdd(&s_st[1], bytes); atomicAdd(&s_st[2], looks); atomicAdd(&s_st[3], moved); atomicAdd(&s_st[4], kin); }
+  for (int d = 32; d > 0; d >>= 1) { hits += __shfl_down(hits, d, 64); bytes += __shfl_down(bytes, d, 64); looks += __shfl_down(looks, d, 64); moved += __shfl_down(moved, d, 64); kin += __shfl_down(kin, d, 64); wins += __shfl_down(wins, d, 64); }
+  // the block's six sums leave with one atomic each (not one per wave)
+  if (lane_id() == 0) { atomicAdd(&s_st[0], hits); atomicAdd(&s_st[1], bytes); atomicAdd(&s_st[2], looks); atomicAdd(&s_st[3], moved); atomicAdd(&s_st[4], kin); atomicAdd(&s_st[5], wins); }
   __syncthreads();
-  if (threadIdx.x < 5 && s_st[threadIdx.x]) {
-    const int which = threadIdx.x == 0 ? C_HIT : threadIdx.x == 1 ? C_READ_BYTES : threadIdx.x == 2 ? C_LOOKUP : threadIdx.x == 3 ? C_B_FIN : C_B_KEYS;
+  if (threadIdx.x < 6 && s_st[threadIdx.x]) {
+    const int which = threadIdx.x == 0 ? C_HIT : threadIdx.x == 1 ? C_READ_BYTES : threadIdx.x == 2 ? C_LOOKUP : threadIdx.x == 3 ? C_B_FIN : threadIdx.x == 4 ? C_B_KEYS : C_WINDOWS;
     ctr_add(ctr, which, s_st[threadIdx.x]);
   }
 }

@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   {
     const bool hit = pf && pf_vb == vb;
     const SeedTup t = hit ? pf_t : (pos < n_tup ? sb.srt[pos] : 0ull);
-    const bool rep = mine && (t & SEED_TUP_DUP);
+    const bool rep = mine && ((t & SEED_TUP_DUP) || !seed_read_active(sb, (uint32_t)t));      // (or the tuple of a read that is not in this launch: one sort for several parts)
     n_rep = (uint32_t)__popcll(__ballot(rep));
     if (rep) mine = false;
     if (!__any(mine)) {                                    // (whole chunks of a hot key: nothing but repeats)

@@ -15,7 +15,7 @@ from helpers import emu
 from helpers.workload import Workload
 
 from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_index, test_longer_reads, test_empty_batch,  # noqa: F401
-                             test_seed_work_counters_match_oracle, test_batch_dominated_by_one_sequence, test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed, test_pigeonhole_seed_kernel_equals_the_dfs_kernel, test_small_candidate_pool_is_redone_and_grows,
+                             test_seed_work_counters_match_oracle, test_batch_dominated_by_one_sequence, test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed, test_one_seed_sort_for_the_parts_and_references_of_a_batch, test_pigeonhole_seed_kernel_equals_the_dfs_kernel, test_small_candidate_pool_is_redone_and_grows,
                              test_percent_edges_on_kilobase_reads, test_mixed_read_lengths, test_reads_sharing_seeds_with_thousands_of_references,
                              test_optional_paths_of_the_candidate_stage_give_the_oracle_records, test_pigeonhole_search_bytes_equal_a_host_recount,
                              test_a_window_with_hundreds_of_hits, test_rounds_adapt_from_part_to_part_without_changing_a_record,

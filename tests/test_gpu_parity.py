@@ -500,6 +500,60 @@ def test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed(tmp_pa
         e.close()
 
 
+@pytest.mark.parametrize("mode", ["1", "0"], ids=["shared", "per-part"])
+def test_one_seed_sort_for_the_parts_and_references_of_a_batch(tmp_path, monkeypatch, mode):
+    """Two --ref, the first cut into several index parts (processor.cpp:219-277 loops (index, part) over the same reads): from the first part on
+    the searches of every part walk SIX sorted arrays built once for the batch (every read, every window; SMR_SEED_SHARED=1, the default) and
+    skip the tuples of the reads that are not in the part's (strand, pass); reads with ambiguous letters keep a sort per part.  Same records and
+    counters as the oracle and as the per-part sort (SMR_SEED_SHARED=0); a second alignment of the same batch after a state reset builds again."""
+    monkeypatch.setenv("SMR_SEED_SHARED", mode)
+    os.makedirs(str(tmp_path / "a"))
+    w1 = Workload(str(tmp_path / "a"), db_nt=260_000, n_reads=1800, seed=91, frac_db=0.5, n_rate=0.004, max_mb=0.5)
+    assert w1.stats.nparts >= 3
+    os.makedirs(str(tmp_path / "b"))
+    # the second DB: a third of the first one's sequences, every 50th letter changed -- reads align to both
+    out, keep, k = [], True, 0
+    for line in open(w1.db):
+        if line.startswith(">"):
+            k += 1
+            keep = k % 3 == 0
+            if keep:
+                out.append(line)
+        elif keep:
+            a = list(line.rstrip("\n"))
+            for i in range(7, len(a), 50):
+                a[i] = "ACGT"[("ACGT".index(a[i]) + 1) & 3] if a[i] in "ACGT" else a[i]
+            out.append("".join(a) + "\n")
+    db2 = str(tmp_path / "b" / "second.fasta")
+    open(db2, "w").write("".join(out))
+    w2 = Workload(str(tmp_path / "b"), db_fasta=db2, seqs=w1.seqs)
+    ws = [w1, w2]
+    run = orc.Run(w1.seqs)
+    for k, x in enumerate(ws):
+        for part in range(x.stats.nparts):
+            po = orc.default_params(minimal_score=x.minimal_score, num_alignments=2)
+            po.index_num, po.part, po.is_last_index_part = k, part, int(k == 1 and part == x.stats.nparts - 1)
+            run.align_part(x.prefix, x.db, x.stats, part, po)
+    recs_o = run.records()
+    n_al = run.counters.num_aligned
+    run.close()
+    e = smr.Engine(0)
+    try:
+        ps = [smr.default_params(minimal_score=x.minimal_score, num_alignments=2) for x in ws]
+        for rep in range(2):
+            e.prof_reset()
+            smr.align(e, w1.reads, [x.parts for x in ws], ps)
+            _compare(e.records(), recs_o, "two references, %d + %d parts, SMR_SEED_SHARED=%s" % (w1.stats.nparts, w2.stats.nparts, mode))
+            assert e.counters(2)["num_aligned"] == n_al > 300
+            pr = e.prof()
+            if mode == "1":
+                assert pr.n_seed_shared_builds == 1 and pr.n_seed_shared == 6 * (w1.stats.nparts + w2.stats.nparts), (pr.n_seed_shared_builds, pr.n_seed_shared)
+            else:
+                assert pr.n_seed_shared_builds == 0 and pr.n_seed_shared == 0
+    finally:
+        e.close()
+
+
 def _dense_neighbourhood_workload(tmp):
     """A DB that holds, for ONE 18-mer A+B which it does not contain itself, every string within one error of it that a half-seed search can
     accept: under the key A the 255 ten-letter continuations lev1_entry accepts for B (all but the four exact ones), and in front of the key B
