@@ -510,17 +510,20 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool
   for (int d = 0; d < 2; d++) HIPCHK(c, hipMemsetAsync(sb.fbits[d], 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
   HIPCHK(c, hipMemsetAsync(sb.zbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(sb.gflag, 0, (size_t)(slots / 2048 + 2) * 4, c->stream));
-  // the part's own sort: every read of the (strand, pass) -- or, beside the shared arrays, the reads with ambiguous letters
-  if ((rc = seed_sort(c, di, P, pass, sb, shared ? SEED_KEYS_AMB : SEED_KEYS_ALL))) return rc;
-  const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
-  if (sb.hot_min) hipLaunchKernelGGL(k_seed_dedup, dim3(gd), dim3(256), 0, c->stream, sb);
+  // the part's own sort: every read of the (strand, pass) -- or, beside the shared arrays, the reads with ambiguous letters on the reverse strand
+  const bool own = !shared || strand == 1;
+  if (own) {
+    if ((rc = seed_sort(c, di, P, pass, sb, shared ? SEED_KEYS_AMB : SEED_KEYS_ALL))) return rc;
+    const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
+    if (sb.hot_min) hipLaunchKernelGGL(k_seed_dedup, dim3(gd), dim3(256), 0, c->stream, sb);
+  }
   SeedBufs sh = sb;                                          // the shared array of this (strand, pass), filtered by the reads that are in the launch
   if (shared) {
     const SharedSet& T = c->shared->set[strand][pass];
     sh.srt = T.srt; sh.wbin = T.wbin; sh.cbase = T.cbase; sh.sn = T.sn; sh.cap_tuples = (uint32_t)std::min<uint64_t>(c->shared->cap[pass], 0xFFFFFFFFull);
     sh.abits = c->shared->abits; sh.hot_min = 0;
     c->n_seed_shared++;
-    hipLaunchKernelGGL(k_seed_active, dim3((c->b->n + 255u) / 256u), dim3(256), 0, c->stream, c->b->n, pass, (const RWork*)c->b->d_rw, c->shared->abits);
+    hipLaunchKernelGGL(k_seed_active, dim3((c->b->n + 255u) / 256u), dim3(256), 0, c->stream, c->b->n, pass, strand == 0 ? 1 : 0, (const RWork*)c->b->d_rw, c->shared->abits);
   }
   const uint32_t* no_redo = nullptr;
   if (c->seed_exact) {
@@ -533,7 +536,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool
     for (int dir = 0; dir < 2; dir++) {
       ev_mark(c, dir ? KP_PG1 : KP_PG0);
       if (shared && (rc = seed_search(c, di, P, pass, sh, dir, pool_words, lds, lds_pg))) return rc;
-      if ((rc = seed_search(c, di, P, pass, sb, dir, pool_words, lds, lds_pg))) return rc;
+      if (own && (rc = seed_search(c, di, P, pass, sb, dir, pool_words, lds, lds_pg))) return rc;
     }
   }
   if (getenv("SMR_SEED_DEBUG")) {                            // (debug aid: synchronises)

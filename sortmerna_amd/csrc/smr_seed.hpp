@@ -286,9 +286,9 @@ __global__ void k_seed_emap(const uint32_t* __restrict__ lkc, uint32_t nkh, uint
 // after the first three.  The tuples of a block go compactly into ITS region of tmp (a wave reserves its slots with one LDS atomic per window
 // round), counted per COARSE bin (key >> fb) in LDS; that histogram is the block's row of sb.rows: the first sort pass needs no counting pass.
 // `mode` (one sort for several index parts): SEED_KEYS_ALL = the tuples of every read of the part's (strand, pass), as described; SEED_KEYS_SHARED (| strand << 4) =
-// the tuples of EVERY read long enough to have a window and free of ambiguous letters, for strand and pass as given, whatever state the reads are in and whether or not
+// the tuples of EVERY read long enough to have a window (reverse strand: and free of ambiguous letters), for strand and pass as given, whatever state the reads are in and whether or not
 // a part's lookup table has the key (the searches of a part skip what is not theirs: seed_read_active, a missing mini-trie); SEED_KEYS_AMB = like ALL, but only
-// the reads WITH ambiguous letters -- what such a letter reads as depends on the read's history in the part (Read::flip34), so their tuples are made per part.
+// the reads WITH ambiguous letters -- on the reverse strand what such a letter reads as depends on the read's history in the part (Read::flip34), so their tuples are made per part.
 enum { SEED_KEYS_ALL = 0, SEED_KEYS_SHARED = 1, SEED_KEYS_AMB = 2 };
 template <bool ONE, bool STAGED, bool MAPPED>
 __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParams P, int pass, SeedBufs sb, const RWork* __restrict__ rw, unsigned long long* __restrict__ ctr, int mode) {
@@ -319,7 +319,8 @@ __global__ void __launch_bounds__(64 * SEED_WAVES) k_seed_keys(DReads rd, DParam
     uint32_t len = 0; uint64_t off = 0;
     if (have) { w = rw[r]; len = rd.len[r]; off = rd.rec_off[r]; }       // (asked for together: one round trip)
     bool active = have && w.strand_active && w.search && w.pass_n == (uint32_t)pass;
-    if ((mode & 15) == SEED_KEYS_SHARED) { active = have && len >= L && !w.has_amb; w.reversed = (uint8_t)(mode >> 4); w.is04 = 0; w.aval = 0; }
+    // (forward strand: an ambiguous letter always reads 0 -- after Smith-Waterman is04 is set, and k_seed_finish puts 0 back --, so those reads share too)
+    if ((mode & 15) == SEED_KEYS_SHARED) { active = have && len >= L && (!w.has_amb || (mode >> 4) == 0); w.reversed = (uint8_t)(mode >> 4); w.is04 = 0; w.aval = 0; }
     else if ((mode & 15) == SEED_KEYS_AMB) active = active && w.has_amb;
     if (!__any(active)) continue;
     const uint32_t numwin = active ? (len - L + stride) / stride : 0u;     // paralleltraversal.cpp:118-120
@@ -985,10 +986,10 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
 // skipped, a 0-error candidate (SEED_CAND_COND) that is not present REPLACES the list and ends the window, any other is appended.  A reverse
 // segment marked SEED_SEG_MERGED (k_seed_search<1>) is that final list already.
 // bit per read: its windows are searched in this launch through the shared sort (one sort for several index parts: SeedBufs::abits)
-__global__ void __launch_bounds__(256) k_seed_active(uint32_t n, int pass, const RWork* __restrict__ rw, uint32_t* __restrict__ abits) {
+__global__ void __launch_bounds__(256) k_seed_active(uint32_t n, int pass, int with_amb, const RWork* __restrict__ rw, uint32_t* __restrict__ abits) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   bool a = false;
-  if (r < n) { const RWork w = rw[r]; a = w.strand_active && w.search && w.pass_n == (uint32_t)pass && !w.has_amb; }
+  if (r < n) { const RWork w = rw[r]; a = w.strand_active && w.search && w.pass_n == (uint32_t)pass && (with_amb || !w.has_amb); }
   const unsigned long long m = __ballot(a);
   if ((threadIdx.x & 63u) == 0) { abits[r >> 5] = (uint32_t)m; abits[(r >> 5) + 1u] = (uint32_t)(m >> 32); }      // (abits has room for the grid's last wave)
 }
