@@ -392,6 +392,8 @@ def main():
         sys.exit(self_launch(args.gpus))          # `python bench.py --gpus N` as typed: this process becomes the launcher of N ranks
     if world != args.gpus:
         args.gpus = world
+    if world > 1:                                            # the ranks of one job share this host: every rank's loaders / builders / packers get cores / N threads
+        os.environ.setdefault("SMR_HOST_THREADS", str(max(1, (os.cpu_count() or 8) // world)))
     args.steps = max(args.steps, 1)
     args.warmup = max(args.warmup, 0)
     W = WORKLOADS[args.workload]
@@ -546,6 +548,18 @@ def main():
             exact[k] += int(v) * uses[b]
         exact_aligned += eng_counters_aligned(eng, b) * uses[b]
     eng.set_seed_mode(0)
+    # N > 1, weak scaling: the N = 1 configuration of THIS run -- rank 0 alone, its GPU, its batches, the same timed steps, while the other ranks wait --
+    # so that the line carries efficiency_vs_n1 = value / (N x that) from one process tree and one DB cache (the driver computes its own from its N = 1 run)
+    n1_value = None
+    if world > 1 and args.scaling == "weak" and not args.profile_run:
+        barrier()
+        if rank == 0:
+            t1 = time.perf_counter()
+            for b in timed:
+                step(b)
+            torch.cuda.synchronize()
+            n1_value = args.steps * args.batch_reads / (time.perf_counter() - t1)
+            log("N = 1 configuration (rank 0 alone): %.3g reads/s" % n1_value)
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -724,6 +738,9 @@ def main():
         }
         if args.scaling == "strong" and args.n1_value > 0:
             out["efficiency_vs_n1"] = out["value"] / (args.gpus * args.n1_value)
+        if n1_value:
+            out["n1_value_rank0_alone"] = n1_value
+            out["efficiency_vs_n1"] = out["value"] / (args.gpus * n1_value)
         if args.gpus == 1 and not args.no_cpu_baseline and not args.profile_run:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, dbs, parts_per_db, sample0, smr, eng, idx_slots)

@@ -4,12 +4,17 @@
 #include <cstdlib>
 #include <memory>
 #include <string>
+#include <thread>
 #include <mutex>
 #include <vector>
 
 #include "../../include/smr_hip.h"
 
 namespace smr {
+
+// host threads of the loaders / builders / parsers: the machine's cores, or fewer when SMR_HOST_THREADS says so (several ranks of one job share a
+// host: bench.py --gpus N gives every rank cores / N, so that eight ranks setting up at once do not run 8 x 256 threads)
+uint32_t host_threads();
 
 // 9-mer lookup entry.  Replaces struct kmer {trie_F, trie_R, count}  (include/indexdb.hpp:98-103):
 // pointers become word offsets of the mini-trie root node in the trie arena (NONE if absent).

@@ -34,6 +34,14 @@
 
 using namespace smr;
 
+namespace smr {
+uint32_t host_threads() {
+  uint32_t t = std::max(1u, std::thread::hardware_concurrency());
+  if (const char* e = getenv("SMR_HOST_THREADS")) t = std::min<uint32_t>(t, (uint32_t)std::max(1, atoi(e)));
+  return t;
+}
+}  // namespace smr
+
 namespace {
 
 void set_err(char* err, size_t cap, const std::string& m) {
@@ -315,7 +323,7 @@ extern "C" int smr_index_load_files(const char* prefix, uint32_t part, const cha
       !pb.open(std::string(prefix) + ".pos_" + p + ".dat")) {
     delete ix; set_err(err, errcap, "cannot read index part files"); return SMR_ERR_IO;
   }
-  uint32_t threads = std::min<uint32_t>(64, std::max(1u, std::thread::hardware_concurrency()));
+  uint32_t threads = std::min<uint32_t>(64, smr::host_threads());
   if (const char* e = getenv("SMR_LOAD_THREADS")) threads = std::min<uint32_t>(256, std::max(1, atoi(e)));      // test aid: many loader threads on a small machine
   // the reference sequences and the position lists load in threads of their own while the tries are parsed
   bool refs_ok = false;
@@ -681,7 +689,7 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
   StageTimer tm;
   const size_t nk = ix.lookup.size();
   const uint32_t pw = ix.lnwin / 2, h = pw / 2;
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  if (threads == 0) threads = smr::host_threads();
   threads = std::min<uint32_t>(threads, 64);
   // pass 1: entries per mini-trie -> block sizes -> block offsets
   std::vector<uint32_t> cnt(2 * nk, 0);
@@ -958,7 +966,7 @@ int smr_index_build_with(const char* ref_fasta, uint32_t L, double max_mb, uint3
                          smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
   if (!ref_fasta || !parts_out || !n_parts_out || !fn) return SMR_ERR_ARG;
   if (L < 8 || L > 18 || (L & 1)) { set_err(err, errcap, "builder supports even seed lengths 8..18"); return SMR_ERR_ARG; }
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  if (threads == 0) threads = smr::host_threads();
   std::vector<uint8_t> file;
   if (!slurp(ref_fasta, file)) { set_err(err, errcap, std::string("cannot read ") + ref_fasta); return SMR_ERR_IO; }
   StageTimer tmd;
@@ -1184,7 +1192,7 @@ extern "C" int smr_index_save(const smr_index* ix, const char* path, uint64_t st
   void* m = ok ? mmap(nullptr, o, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
   ok = ok && m != MAP_FAILED;
   if (ok) {
-    const uint32_t threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const uint32_t threads = std::min(32u, smr::host_threads());
     memcpy(m, &H, sizeof H);
     for (int q = 0; q < 9; q++) par_copy((char*)m + H.off[q], src[q], bytes[q], threads);
     munmap(m, o);
@@ -1241,7 +1249,7 @@ extern "C" int smr_index_load_flat(const char* path, uint64_t stamp, smr_index**
     if (failed) { set_err(err, errcap, std::string(path) + ": the arrays of the flat index could not be sized (out of memory?)"); return SMR_ERR_IO; }
   } catch (const std::exception& e) { set_err(err, errcap, std::string("smr_index_load_flat: ") + e.what()); return SMR_ERR_IO; }
   tm.lap("load flat: arrays sized");
-  const uint32_t threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+  const uint32_t threads = std::min(64u, smr::host_threads());
   void* dst[8] = {ix->lookup.data(), ix->trie.data(), ix->pos_off.data(), ix->pos_arr.data(), ix->ref_seq.data(), ix->ref_off.data(), ix->lkc.data(), ix->parts.data()};
   for (int q = 0; q < 8; q++) par_copy(dst[q], base + H.off[q], bytes[q], threads);
   const char* sp = base + H.off[8]; const char* se = sp + bytes[8];

@@ -218,7 +218,7 @@ int load_fastx_impl(const char* path, uint32_t threads, bool keep_text, smr_read
   Bytes& b = *bp; std::string w0;
   if (!slurp(path, b, w0)) return fail(w0);
   const char* p = b.p; const size_t n = b.n;
-  if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+  if (threads == 0) threads = smr::host_threads();
   size_t first = 0;
   while (first < n && (p[first] == '\n' || p[first] == '\r')) first++;
   const bool fastq = first < n && p[first] == '@';

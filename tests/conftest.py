@@ -9,3 +9,4 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multigpu: needs at least two MI355X in the node (skips itself on one): `python -m pytest tests -m multigpu -q -rs`")

@@ -82,6 +82,8 @@ def test_unwrapped_multi_rank_command(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["counters"]["reads"] == 2 * 2 * 1200 and out["cpu_baseline"] is None
     assert out["config"]["nranks"] == 2
+    # the N = 1 configuration timed by rank 0 alone in the same run (round 6): efficiency from one process tree
+    assert out["n1_value_rank0_alone"] > 0 and abs(out["efficiency_vs_n1"] - out["value"] / (2 * out["n1_value_rank0_alone"])) < 1e-9
     r = out["roofline"]
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
 
@@ -113,7 +115,7 @@ def test_strong_scaling_splits_one_job_over_the_ranks(tmp_path, ranks):
 def test_the_traffic_file_belongs_to_the_seed_kernels_in_the_tree():
     """bench.py fills roofline.traffic from profiles/hbm_traffic.json only when the file's hash of the seed-stage sources is the tree's
     (tools/pmc_traffic.py).  A stale file is not an error of the code -- the bench then prints traffic: null with a note -- so this only
-    warns: re-run `tools/gpu_session_r3.sh <tag> pmc` on the GPU box and copy <tag>/hbm_traffic.json into profiles/."""
+    warns: re-run `tools/gpu_session_r6.sh <tag> pmc` on the GPU box and copy <tag>/hbm_traffic.json into profiles/."""
     import json
     import sys
     import warnings

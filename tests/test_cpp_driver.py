@@ -211,6 +211,7 @@ def _device_count():
     return int(capi.load().smr_device_count())
 
 
+@pytest.mark.multigpu
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,chunk", [("syn_default", 0), ("syn_all", 40), ("two_db_default", 64)])
 def test_mgpu_host_all_devices_rccl(case, chunk, tmp_path):

@@ -81,6 +81,7 @@ def test_reads_stream_through_the_gpu_in_chunks(case, chunk, tmp_path):
     compare(REF_GPU, case, tmp_path, {"SMR_DROPIN_CHUNK": str(chunk)}, min_chunks=4)
 
 
+@pytest.mark.multigpu
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,chunk", [("real_two_db", 50), ("paired", 32)])
 def test_dropin_spreads_chunks_over_all_devices(case, chunk, tmp_path):
