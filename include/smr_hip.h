@@ -29,9 +29,10 @@
  *   seed hits             no limit: the lane-local hit lists grow to what a half-seed search can accept at most (31 L/2 - 20 strings, smr_prof.hit_list_cap)
  *   candidate references  <= 49 152 references sharing seeds with ONE read on one strand (the per-block global table of k_chain<EXT>)
  *   alignments per read   max_alignments_per_read given to smr_reads_upload (the reference's -num_alignments, or 256 for "all")
- *   scoring               match <= 127, mismatch >= -127, -127 <= score_N <= 0, gaps <= 255, 2 * gap_open, 2 * gap_ext >= |mismatch| and gap_open > gap_ext
- *                         (under these conditions the affine recurrence here equals the reference's striped kernels cell for cell; outside them ssw.c's
- *                         scores depend on its SIMD stripe geometry: ssw.c:267,496 and its 16-bit lazy-F loop :496-507)
+ *   scoring               match <= 127, |mismatch|, |score_N| <= 127, gaps <= 255.  With 2 * gap_open, 2 * gap_ext >= |mismatch|, gap_open > gap_ext and score_N <= 0 the
+ *                         affine recurrence of the fast kernels equals the reference's striped kernels cell for cell; outside those conditions ssw.c's scores
+ *                         depend on its SIMD stripe geometry (ssw.c:267,496 and its 16-bit lazy-F loop :496-507), and smr_align_part scores through a slow
+ *                         path that reproduces that geometry (csrc/smr_sw_striped.hpp; about ten times slower; rounds 1 - 5 refused such schemes)
  *   edges                 1..10 letters or percent like the reference's --edges; a percentage must not round to 0 letters for any searchable read of the batch
  *   pools                 seed-hit pool <= 8 GiB, CIGAR pool < 2^32 words, pigeonhole arena < 2^34 words per part (all grown on demand)
  */
@@ -81,9 +82,9 @@ typedef struct {
 } smr_params;
 
 void smr_params_default(smr_params* p);
-/* NULL when smr_align_part takes these options; otherwise the reason it will answer SMR_ERR_ARG (a scoring scheme under which ssw.c's striped
- * kernels leave the affine recurrence -- ssw.c:267,496-507 --, a positive N score, --edges outside 1..10: INTEGRATION.md "known limits").  For a
- * host's option parser: the reference CLI accepts such options (options.cpp:380-500, 659-681), so a driver should say so before it loads anything. */
+/* NULL when smr_align_part takes these options; otherwise the reason it will answer SMR_ERR_ARG (--edges outside 1..10: INTEGRATION.md "known
+ * limits").  For a host's option parser, so that a driver says so before it loads anything.  (Scoring schemes under which ssw.c's striped kernels
+ * leave the affine recurrence are no longer among them: round 6 scores them through the slow path of csrc/smr_sw_striped.hpp.) */
 const char* smr_params_refused(const smr_params* p);
 
 /* ------------------------------------------------------------------------------------------------
@@ -291,7 +292,8 @@ int smr_sw_mode(smr_ctx*, int set_to);
 int smr_walk_rounds(const smr_ctx*, uint32_t out[3]);
 /* The SW kernels at the ssw.h seam: for n independent pairs (read / reference window in the 0..4 alphabet, pair i = bytes [off[i], off[i+1])),
  * what ssw_align(prof, ref, refLen, gapO, gapE, flag = 2, filters, 0, 0) returns without the CIGAR (ssw.h:118-140, ssw.c:834-941):
- * out[5 i ..] = {score1, ref_begin1, ref_end1, read_begin1, read_end1}, begins = -1 when score1 < filters.  mode 0 / 1 / 2 = 32-bit / packed / packed wave_ror kernel. */
+ * out[5 i ..] = {score1, ref_begin1, ref_end1, read_begin1, read_end1}, begins = -1 when score1 < filters.  mode 0 / 1 / 2 = 32-bit / packed / packed wave_ror kernel, 3 = four pairs per wave (the fast kernels: only under the
+ * schemes whose answers they share with ssw.c, SMR_ERR_ARG otherwise); mode 4 = the slow path that reproduces ssw.c's stripe geometry, any scheme. */
 int smr_ssw_batch(smr_ctx*, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                   int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out);   /* set_to 0 / 1: use the 32-bit / the packed kernel; other values: query; returns the mode in use */
 /* The traceback kernels at the same seam: for n independent triples (read window, reference window -- both exactly the aligned spans

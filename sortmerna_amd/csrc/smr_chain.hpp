@@ -44,7 +44,7 @@ __device__ void wave_sort_u64(unsigned long long* keys, uint32_t n) {
 
 __device__ __forceinline__ uint32_t pow2_floor(uint32_t v) { return v ? 1u << (31 - __clz((int)v)) : 0u; }
 
-struct SwRes { int score, end_ref, end_read; };
+struct SwRes { int score, end_ref, end_read, word; };      // word: set by the striped slow path only (smr_sw_striped.hpp: the 16-bit kernel produced the result)
 
 // Smith-Waterman score + end cell as an anti-diagonal systolic array over the wave.  Lane i owns R consecutive read
 // rows (R = ceil(m/64) <= 4: a 150-nt read is ONE strip of 64 x 3 rows; longer reads take several strips with an LDS
@@ -175,10 +175,19 @@ __device__ __forceinline__ SwRes sw_wave_long(const uint8_t* rdq, int m, int rd0
   return sw_wave_long8(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, hn);
 }
 
+}  // namespace smr
+#include "smr_sw_striped.hpp"
+namespace smr {
+
 // mode 1 / 2: the packed 16-bit kernel (smr_sw_pk.hpp; 2 = its wave_ror variant) where its preconditions hold; mode 0: always the 32-bit kernel
-__device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
-                                         int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
+// mode < 0: the scheme is one under which ssw.c's striped kernels leave the affine recurrence -- the slow path that reproduces their stripe geometry
+// (smr_sw_striped.hpp; terminate / word_in: the forward score and kernel, for the reverse pass; scr: the wave's scratch row)
+// (STRIPED is a template parameter of the kernels that can take that path: the function needs 130 vector registers, which the fast instantiations must not carry)
+template <bool STRIPED>
+__device__ __attribute__((noinline)) SwRes sw_wave_t(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                         int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode, int terminate = 0, int word_in = 0, uint16_t* scr = nullptr) {
 #define SW_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge
+  if (STRIPED) { int w = word_in; SwRes r = sw_wave_striped(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, match, mismatch, scoreN, go, ge, terminate, w, scr); r.word = w; return r; }
   if (mode >= 1 && (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255) {
     bool hasn = false;
     for (int q = lane_id(); q < n; q += 64) hasn |= rfq[rf0 + rfstep * q] == 4;
@@ -206,17 +215,22 @@ __device__ __attribute__((noinline)) SwRes sw_wave(const uint8_t* rdq, int m, in
   return sw_wave_r<4, false>(SW_ARGS);
 #undef SW_ARGS
 }
+__device__ __forceinline__ SwRes sw_wave(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                         int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
+  return sw_wave_t<false>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, mode);
+}
 
 // a read of more than 512 letters through the 8-row strips where the packed kernel applies (the caller knows that its batch has such reads:
 // the instantiations that never see one do not carry the call)
-__device__ __forceinline__ SwRes sw_wave_any(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
-                                             int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode) {
+template <bool STRIPED>
+__device__ __forceinline__ SwRes sw_wave_any_t(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+                                             int* bound, int match, int mismatch, int scoreN, int go, int ge, int mode, int terminate = 0, int word_in = 0, uint16_t* scr = nullptr) {
   if (mode == 2 && m > 512 && (long long)m * match + 255 < 32768 && n + 128 <= 8191 && go + mismatch >= 0 && go + scoreN >= 0 && match + go <= 255 && scoreN + go <= 255) {
     bool hasn = false;
     for (int q = lane_id(); q < n; q += 64) hasn |= rfq[rf0 + rfstep * q] == 4;
     return sw_wave_long(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, __any(hasn));
   }
-  return sw_wave(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, mode);
+  return sw_wave_t<STRIPED>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, mode, terminate, word_in, scr);
 }
 
 #define CH_EXT_CAP 65536u          // slots of the global candidate-set table of a block (tuples carry the slot in 16 bits)
@@ -593,7 +607,7 @@ struct SwTask { uint32_t max_ref; uint64_t rf_start, align_ref_start, head, alig
 #ifndef SMR_CHAIN_WAVES_PER_SIMD
 #define SMR_CHAIN_WAVES_PER_SIMD 3
 #endif
-template <bool EXT, bool LONG>
+template <bool EXT, bool LONG, bool STRIPED = false>
 __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand,
                                               RState* __restrict__ work, AlignRec* __restrict__ work_aln, RWork* __restrict__ rw,
                                               const uint32_t* __restrict__ pool, unsigned long long* __restrict__ ctr,
@@ -693,7 +707,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         const SwRes r4 = sw_wave_x4(rdq + (size_t)lds_mq + (size_t)g * lds_mq, gm, gq, 1, wslot(4 + g), gn, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, q_hasn);
         if ((lane & 15) == 0 && mine) { q_score[g] = r4.score; q_eref[g] = r4.end_ref; q_eread[g] = r4.end_read; }
       } else {
-        const SwRes r1 = sw_wave(rdq + lds_mq, (int)q_m[0], (int)q_aq[0], 1, wslot(4), (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+        const SwRes r1 = sw_wave_t<STRIPED>(rdq + lds_mq, (int)q_m[0], (int)q_aq[0], 1, wslot(4), (int)q_nref[0], 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode, 0, 0, sw_scr(P));
         if (lane == 0) { q_score[0] = r1.score; q_eref[0] = r1.end_ref; q_eread[0] = r1.end_read; }
       }
       __syncthreads();
@@ -1096,8 +1110,8 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
                 }
                 if (n_cached > 1) n_spec += (unsigned long long)(n_cached - 1);
               } else {
-                if (LONG) cfw[0] = sw_wave_any(RD, m, (int)tk.align_que_start, 1, long_rd ? ix.ref_seq + tk.rf_start : rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
-                else cfw[0] = sw_wave(rdq, m, (int)tk.align_que_start, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+                if (LONG) cfw[0] = sw_wave_any_t<STRIPED>(RD, m, (int)tk.align_que_start, 1, long_rd ? ix.ref_seq + tk.rf_start : rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode, 0, 0, sw_scr(P));
+                else cfw[0] = sw_wave_t<STRIPED>(rdq, m, (int)tk.align_que_start, 1, rfq, nref, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode, 0, 0, sw_scr(P));
               }
               __syncthreads();
               TPH(6)
@@ -1125,7 +1139,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
             al.readlen = len; al.ref_num = max_ref;
             al.index_num = (uint16_t)P.index_num; al.part = (uint16_t)P.part;
             al.strand = (uint8_t)!w.reversed; al.score1 = (uint16_t)score1;
-            al.has_cigar = 2; al.cigar_off = 0; al.cigar_len = 0;
+            al.has_cigar = 2; al.cigar_off = 0; al.cigar_len = P.sw_mode < 0 ? (uint32_t)fw.word : 0u;
             AlignRec* slots = work_aln + (size_t)r * P.slots;
             if (!st.is_hit) {                                              // :411-416
               st.is_hit = 1;
@@ -1205,8 +1219,8 @@ __global__ void k_begins_collect(uint32_t n, uint32_t slots, const RState* __res
   if (take) tasks[o] = i;
 }
 
-template <bool LONG>
-__global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, AlignRec* __restrict__ work_aln,
+template <bool LONG, bool STRIPED = false>
+__global__ void __launch_bounds__(64, (LONG || STRIPED) ? 3 : 4) k_begins(DReads rd, DIndex ix, DParams P, const uint32_t* __restrict__ tasks, AlignRec* __restrict__ work_aln,
                                                unsigned long long* __restrict__ ctr, uint32_t lds_m, uint32_t lds_n, int x4, int* g_bound, uint8_t* g_rdq) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   __shared__ uint32_t s_t0;
@@ -1263,7 +1277,7 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
         for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
         fw = sw_wave_x4(rdq, mf, 0, 1, rfq, fwd ? n : 0, 0, 1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
       } else {
-        if (LONG) fw = sw_wave_any(rdq, m, 0, 1, rfq, n, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+        if (LONG) fw = sw_wave_any_t<false>(rdq, m, 0, 1, rfq, n, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
         else fw = sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
       }
       if (fwd) {
@@ -1279,13 +1293,14 @@ __global__ void __launch_bounds__(64, LONG ? 3 : 4) k_begins(DReads rd, DIndex i
       for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
       bw = sw_wave_x4(rdq, m, m - 1, -1, rfq, n, n - 1, -1, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, mm, __any(hasn));
     } else {
-      if (LONG) bw = sw_wave_any(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
-      else bw = sw_wave(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode);
+      // (the striped slow path stops where the forward score is reached, in the kernel the forward pass ended with: kept in cigar_len while the begin is pending)
+      if (LONG) bw = sw_wave_any_t<STRIPED>(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode, (int)al.score1, (int)al.cigar_len, sw_scr(P));
+      else bw = sw_wave_t<STRIPED>(rdq, m, m - 1, -1, rfq, n, n - 1, -1, bound, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, P.sw_mode, (int)al.score1, (int)al.cigar_len, sw_scr(P));
     }
     if (have && (x4 ? (lane & 15) == 0 : lane == 0)) {
       al.ref_begin1 = al.ref_end1 - bw.end_ref;
       al.read_begin1 = al.read_end1 - bw.end_read;
-      al.has_cigar = 0;
+      al.has_cigar = 0; al.cigar_len = 0;
       work_aln[slot] = al;
     }
     if (have) { n_rev += (x4 ? (lane & 15) == 0 : lane == 0) ? 1 : 0; n_cells += (x4 ? (lane & 15) == 0 : lane == 0) ? (unsigned long long)m * n : 0; }

@@ -95,6 +95,7 @@ struct smr_ctx {
   uint32_t hot_min = getenv("SMR_SEED_DEDUP") ? (uint32_t)std::max(0, atoi(getenv("SMR_SEED_DEDUP"))) : 1024u;
   // one seed sort for the index parts of a batch (SharedSort below): 0 off, 1 when the part in hand is not the batch's last, 2 always (tests)
   int seed_shared = getenv("SMR_SEED_SHARED") ? atoi(getenv("SMR_SEED_SHARED")) : 1;
+  uint16_t* d_sw_scr = nullptr; uint32_t sw_scr_stride = 0; size_t sw_scr_words = 0;      // scratch rows of the striped Smith-Waterman slow path (smr_sw_striped.hpp), one per block
   SharedSort* shared = nullptr;
   uint64_t n_seed_shared = 0, n_seed_shared_builds = 0;      // smr_prof
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
@@ -170,6 +171,7 @@ template <class T> int dev_alloc(smr_ctx* c, T** p, size_t count) {
 template <class T> void dev_free(T** p) { if (*p) { (void)hipFree(*p); *p = nullptr; } }
 
 
+const char* scheme_unsupported(int mismatch, int score_N, int gap_open, int gap_ext);
 DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) {
   DParams P;
   memset(&P, 0, sizeof P);
@@ -183,11 +185,14 @@ DParams make_dparams(const smr_ctx* c, const DevIndex& di, const smr_params* p) 
   P.is_best = p->is_best; P.is_full_search = p->is_full_search; P.is_forward = p->is_forward; P.is_reverse = p->is_reverse;
   P.minoccur = p->minoccur; P.index_num = p->index_num; P.part = p->part; P.is_last_index_part = p->is_last_index_part;
   P.slots = c->b->slots;
-  P.sw_mode = c->sw_mode;
+  // a scheme under which ssw.c's striped kernels leave the affine recurrence: the slow path that reproduces their stripe geometry (smr_sw_striped.hpp)
+  P.sw_mode = scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext) ? -1 : c->sw_mode;
+  P.sw_scratch = c->d_sw_scr; P.sw_scratch_stride = c->sw_scr_stride;
   return P;
 }
 
-// nullptr when the Smith-Waterman kernels here (the affine recurrence H = max(0, diag + s, E, F)) give ssw.c's results under the scheme, else why not.
+// nullptr when the FAST Smith-Waterman kernels here (the affine recurrence H = max(0, diag + s, E, F)) give ssw.c's results under the scheme, else why not
+// -- such a scheme goes through the slow path that reproduces ssw.c's stripe geometry (smr_sw_striped.hpp; rounds 1 - 5 refused it).
 // (1) The reference's striped kernels store E before the lazy-F loop has raised H (ssw.c:267,496): a gap in one sequence directly after a gap in
 // the other is missed when the second crosses a SIMD stripe.  Under 2 * gap_open >= |mismatch| and 2 * gap_ext >= |mismatch| such paths are never
 // optimal.  (2) Its 16-bit kernel leaves the lazy-F loop as soon as no lane has F - gap_ext > H - gap_open (ssw.c:496-507); with gap_open <= gap_ext
@@ -212,7 +217,6 @@ int check_params(smr_ctx* c, const smr_params* p, bool sw = true) {
   if (p->num_seeds < 1 || p->gap_open < 0 || p->gap_ext < 0 || p->match <= 0 || p->mismatch > 0) { set_err(c, "bad scoring/seed options"); return SMR_ERR_ARG; }
   // the reference's scoring matrix is int8_t (ssw_init, ssw.h:88); the SW kernel keeps a row's scores as 4 signed bytes
   if (p->match > 127 || p->mismatch < -127 || p->score_N > 127 || p->score_N < -127 || p->gap_open > 255 || p->gap_ext > 255) { set_err(c, "scores must fit int8 / gaps uint8 like the reference's"); return SMR_ERR_ARG; }
-  if (sw) if (const char* why = scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
   // --edges: the reference's parser takes 1..10, nucleotides or percent (options.cpp:676); its geometry is not defined outside (0: `tail > edges - 1` is an
   // unsigned compare, alignment.cpp:320,345 -- the whole rest of the reference becomes the window; larger values: more reads whose window length wraps)
   if (sw && (p->edges < 1 || p->edges > 10)) { set_err(c, "edges must be 1..10 (nucleotides or percent), like the reference's --edges"); return SMR_ERR_ARG; }
@@ -612,6 +616,10 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
     HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     c->chain_lds_attr = lds;
   }
   uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
@@ -700,11 +708,20 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
                              c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks, (const uint2*)mrec, (const uint32_t*)c->d_mpool, \
                              (const uint32_t*)(split ? c->d_wslow : nullptr), (const unsigned long long*)n_slow
   // (LONG: the batch has reads of more than one Smith-Waterman strip; the short-read instantiation carries none of their state)
+  const bool striped = P.sw_mode < 0;                        // (the slow path that reproduces ssw.c's stripe geometry: instantiations of its own)
+  if (striped) {
+    if (gb) hipLaunchKernelGGL((k_chain<false, true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
+    else hipLaunchKernelGGL((k_chain<false, false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
+  } else
   if (gb) hipLaunchKernelGGL((k_chain<false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
   else hipLaunchKernelGGL((k_chain<false, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
   if (c->chain_ext) {
     // the reads whose candidate set outgrew the LDS table of the first launch: same walk, set in the block's global table
     HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
+    if (striped) {
+      if (gb) hipLaunchKernelGGL((k_chain<true, true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
+      else hipLaunchKernelGGL((k_chain<true, false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
+    } else
     if (gb) hipLaunchKernelGGL((k_chain<true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
     else hipLaunchKernelGGL((k_chain<true, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
   }
@@ -983,13 +1000,15 @@ extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uin
 // refLen, gapO, gapE, flag = 2, filters, 0, 0) (ssw.c:834-941) without the CIGAR -- for n independent (read, reference window) pairs,
 // one wave per pair.  A unit-test surface for the SW kernels against the reference's own ssw.c (tests/golden/ssw_pairs.json).
 // =================================================================================================
+template <bool STRIPED>
 __global__ void __launch_bounds__(64) k_ssw_batch(uint32_t n_pairs, const uint8_t* __restrict__ reads, const unsigned long long* __restrict__ read_off,
                                                   const uint8_t* __restrict__ refs, const unsigned long long* __restrict__ ref_off, uint32_t lds_m, uint32_t lds_n,
-                                                  int match, int mismatch, int scoreN, int go, int ge, uint32_t filters, int mode, int* __restrict__ out) {
+                                                  int match, int mismatch, int scoreN, int go, int ge, uint32_t filters, int mode, int* __restrict__ out, uint16_t* scr_all, uint32_t scr_stride) {
   SMR_DYN_LDS(unsigned char, lds_raw);
   uint8_t* rdq = lds_raw;
   uint8_t* rfq = rdq + lds_m;
   int* bound = (int*)(rfq + lds_n);
+  uint16_t* scr = scr_all ? scr_all + (size_t)blockIdx.x * scr_stride : nullptr;      // (mode < 0: the striped slow path)
   const int lane = smr::lane_id();
   for (uint32_t pi = blockIdx.x; pi < n_pairs; pi += gridDim.x) {
     const int m = (int)(read_off[pi + 1] - read_off[pi]), n = (int)(ref_off[pi + 1] - ref_off[pi]);
@@ -998,11 +1017,11 @@ __global__ void __launch_bounds__(64) k_ssw_batch(uint32_t n_pairs, const uint8_
     __syncthreads();
     int res[5] = {0, -1, -1, -1, m - 1};          // score1, ref_begin1, ref_end1, read_begin1, read_end1
     if (m > 0 && n > 0) {
-      const smr::SwRes fw = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, mode);
+      const smr::SwRes fw = smr::sw_wave_t<STRIPED>(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, mode, 0, 0, scr);
       __syncthreads();
       res[0] = fw.score > 65535 ? 65535 : fw.score; res[2] = fw.end_ref; res[4] = fw.end_read;
       if ((uint32_t)res[0] >= filters && fw.score > 0) {
-        const smr::SwRes bw = smr::sw_wave(rdq, fw.end_read + 1, fw.end_read, -1, rfq, fw.end_ref + 1, fw.end_ref, -1, bound, match, mismatch, scoreN, go, ge, mode);
+        const smr::SwRes bw = smr::sw_wave_t<STRIPED>(rdq, fw.end_read + 1, fw.end_read, -1, rfq, fw.end_ref + 1, fw.end_ref, -1, bound, match, mismatch, scoreN, go, ge, mode, res[0], fw.word, scr);
         __syncthreads();
         res[1] = fw.end_ref - bw.end_ref; res[3] = fw.end_read - bw.end_read;
       }
@@ -1046,8 +1065,9 @@ __global__ void __launch_bounds__(64) k_ssw_batch_x4(uint32_t n_pairs, const uin
 
 extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
                              int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out) {
-  if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 3) return SMR_ERR_ARG;
-  if (const char* why = scheme_unsupported(mismatch, score_N, gap_open, gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
+  if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 4) return SMR_ERR_ARG;
+  // (modes 0 - 3 are the fast kernels: only under the schemes whose answers they share with ssw.c; mode 4 = the striped slow path, any scheme)
+  if (mode != 4) if (const char* why = scheme_unsupported(mismatch, score_N, gap_open, gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
   if (n_pairs == 0) return SMR_OK;
   (void)hipSetDevice(c->device);
   uint64_t mx_m = 1, mx_n = 1;
@@ -1073,8 +1093,15 @@ extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads,
     hipLaunchKernelGGL(k_ssw_batch_x4, dim3(std::min<uint32_t>((n_pairs + 3) / 4, (uint32_t)c->n_cu * 8u)), dim3(64), (size_t)4 * (lm + ln), c->stream, n_pairs, (const uint8_t*)d_reads,
                        (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, d_out);
   } else
-  hipLaunchKernelGGL(k_ssw_batch, dim3(std::min<uint32_t>(n_pairs, (uint32_t)c->n_cu * 8u)), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
-                     (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, mode, d_out);
+  {
+    const uint32_t gb = std::min<uint32_t>(n_pairs, (uint32_t)c->n_cu * 8u), stride = 5u * 16u * ((uint32_t)(mx_m + 7) / 8u + 1u);
+    uint16_t* d_scr = nullptr;
+    if (mode == 4) { IB_GET(d_scr_, uint16_t, (size_t)gb * stride); d_scr = d_scr_; }
+    if (mode == 4) hipLaunchKernelGGL(k_ssw_batch<true>, dim3(gb), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
+                       (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, -1, d_out, d_scr, stride);
+    else hipLaunchKernelGGL(k_ssw_batch<false>, dim3(gb), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
+                       (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, mode, d_out, d_scr, stride);
+  }
   HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n_pairs * 5 * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SMR_OK;
@@ -1157,7 +1184,7 @@ extern "C" void smr_destroy(smr_ctx* c) {
   dev_free(&c->sb.srt); dev_free(&c->sb.hpre); dev_free(&c->sb.hlist); dev_free(&c->sb.hh); dev_free(&c->sb.pieces); dev_free(&c->sb.redo); dev_free(&c->sb.sn); dev_free(&c->sb.wbin); dev_free(&c->sb.emap); dev_free(&c->sb.zbits); dev_free(&c->sb.gflag);
   for (int d = 0; d < 2; d++) { dev_free(&c->sb.wseg[d]); dev_free(&c->sb.fbits[d]); }
   dev_free(&c->d_pool); dev_free(&c->d_tuples); dev_free(&c->d_tuples2); dev_free(&c->d_stab); dev_free(&c->d_keys); dev_free(&c->d_pairs); dev_free(&c->d_lis); dev_free(&c->d_hits);
-  dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows);
+  dev_free(&c->d_tasks); dev_free(&c->d_trflags); dev_free(&c->d_trrows); dev_free(&c->d_sw_scr);
   if (c->shared) {
     for (int s = 0; s < 2; s++) for (int p = 0; p < 3; p++) { SharedSet& T = c->shared->set[s][p]; dev_free(&T.srt); dev_free(&T.wbin); dev_free(&T.cbase); dev_free(&T.sn); }
     dev_free(&c->shared->abits);
@@ -1364,7 +1391,6 @@ int upload_into(smr_ctx* c, Batch& B, const smr_reads* r, uint32_t max_aln, hipS
 
 extern "C" const char* smr_params_refused(const smr_params* p) {
   if (!p) return "null params";
-  if (const char* why = scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext)) return why;
   if (p->edges < 1 || p->edges > 10) return "edges must be 1..10 (nucleotides or percent), like the reference's --edges";
   return nullptr;
 }
@@ -1440,6 +1466,16 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   ev_drop(c);
   if (c->b->n == 0) return SMR_OK;
   if ((rc = ensure_pool(c))) return rc;
+  if (P.sw_mode < 0) {
+    // the striped slow path: per block of k_chain / k_begins five arrays of 16 x ceil(len / 8) uint16 (smr_sw_striped.hpp)
+    if (c->chain_blocks == 0) c->chain_blocks = (uint32_t)c->n_cu * (getenv("SMR_CHAIN_WPC") ? atoi(getenv("SMR_CHAIN_WPC")) : 12);
+    const uint32_t stride = 5u * 16u * ((c->b->max_len + 7u) / 8u + 1u);
+    const size_t need = (size_t)std::max<uint32_t>(c->chain_blocks, (uint32_t)c->n_cu * 8u) * stride;
+    if (c->sw_scr_words < need || c->sw_scr_stride < stride) { if ((rc = dev_alloc(c, &c->d_sw_scr, need))) return rc; c->sw_scr_words = need; c->sw_scr_stride = stride; }
+    P.sw_scratch = c->d_sw_scr; P.sw_scratch_stride = c->sw_scr_stride;
+    if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: scoring scheme %d/%d/%d (N %d): %s -- Smith-Waterman through the slow path that reproduces ssw.c's stripe geometry\n",
+                                       p->match, p->mismatch, p->gap_open, p->score_N, scheme_unsupported(p->mismatch, p->score_N, p->gap_open, p->gap_ext));
+  }
   std::vector<unsigned long long> h;
   // the counters as they stand now stay on the device; an attempt that has to be redone starts from them again (one read-back per attempt, none before)
   HIPCHK(c, hipMemcpyAsync(c->d_ctr_snap, c->b->d_ctr, C_TOTAL * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1514,6 +1550,8 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
         if (lds_b > 64 * 1024 && lds_b > c->begins_lds_attr) {
           HIPCHK(c, hipFuncSetAttribute((const void*)k_begins<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
           HIPCHK(c, hipFuncSetAttribute((const void*)k_begins<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          HIPCHK(c, hipFuncSetAttribute((const void*)k_begins<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+          HIPCHK(c, hipFuncSetAttribute((const void*)k_begins<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
           c->begins_lds_attr = lds_b;
         }
         HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_BEGIN_N], 0, 16, c->stream));       // C_BEGIN_N, C_BEGIN_NEXT
@@ -1539,6 +1577,9 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
             hipLaunchKernelGGL(k_begins_apply, dim3((uint32_t)c->n_cu * 4u), dim3(256), 0, c->stream, (const uint32_t*)c->d_tasks, (const unsigned long long*)&c->b->d_ctr[C_BEGIN_N], c->b->d_work_aln, stage,
                                (const WTask*)c->d_wtask[0], (const uint2*)c->d_wres[0], c->b->d_ctr);
           }
+        } else if (P.sw_mode < 0) {
+          if (c->b->max_len > SW_X4_MAX_ROWS) hipLaunchKernelGGL((k_begins<true, true>), dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, c->d_bound, c->d_rdq);
+          else hipLaunchKernelGGL((k_begins<false, true>), dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, (int*)nullptr, (uint8_t*)nullptr);
         } else if (c->b->max_len > SW_X4_MAX_ROWS)
           hipLaunchKernelGGL(k_begins<true>, dim3(bg_blocks), dim3(64), lds_b, c->stream, dreads(c), dindex(di), P, (const uint32_t*)c->d_tasks, c->b->d_work_aln, c->b->d_ctr, ml, rf, x4, c->d_bound, c->d_rdq);
         else

@@ -95,8 +95,11 @@ struct DParams {
   uint32_t minoccur, index_num, part;
   int32_t is_last_index_part;
   uint32_t slots;               // alignment slots per read
-  int32_t sw_mode;              // 1: packed 16-bit Smith-Waterman kernel where it applies (smr_sw_pk.hpp), 0: 32-bit kernel only
+  int32_t sw_mode;              // 1 / 2: packed 16-bit Smith-Waterman kernels where they apply (smr_sw_pk.hpp), 0: 32-bit kernel only, < 0: ssw.c's stripe geometry (smr_sw_striped.hpp)
+  uint16_t* sw_scratch;         // sw_mode < 0: scratch rows of the striped slow path, sw_scratch_stride uint16 per block
+  uint32_t sw_scratch_stride;
 };
+__device__ __forceinline__ uint16_t* sw_scr(const DParams& P) { return P.sw_scratch ? P.sw_scratch + (size_t)blockIdx.x * P.sw_scratch_stride : nullptr; }
 
 // global counters (u64 each)
 enum {

@@ -96,10 +96,28 @@ def make_pairs(seed, n_pairs):
 SCHEMES = [dict(match=2, mismatch=-3, score_N=-3, gap_open=5, gap_ext=2, filters=30), dict(match=5, mismatch=-4, score_N=-4, gap_open=5, gap_ext=2, filters=60)]
 
 
+# Schemes under which ssw.c's striped kernels leave the affine recurrence (round 6: the library's slow path reproduces their stripe geometry,
+# smr_sw_striped.hpp): gap_open <= gap_ext (the 16-bit kernel's early exit from its lazy-F loop, ssw.c:496-507), 2 * gap < |mismatch| (E stored
+# before the lazy-F loop has raised H, ssw.c:267), a positive score for N.  -> ssw_pairs_striped.json (make_golden_ssw.py --striped)
+STRIPED_SCHEMES = [dict(match=2, mismatch=-3, score_N=-3, gap_open=3, gap_ext=3, filters=30), dict(match=2, mismatch=-3, score_N=-3, gap_open=2, gap_ext=2, filters=30),
+                   dict(match=2, mismatch=-5, score_N=-5, gap_open=2, gap_ext=1, filters=30), dict(match=1, mismatch=-3, score_N=-3, gap_open=1, gap_ext=1, filters=20),
+                   dict(match=2, mismatch=-3, score_N=1, gap_open=5, gap_ext=2, filters=30), dict(match=2, mismatch=-3, score_N=-3, gap_open=5, gap_ext=2, filters=30)]
+
+
 def main():
     assert os.path.isfile(LIB), "make -C oracle ref  (needs /root/reference)"
     L = ref_lib()
     out = {"alphabet": "ACGTN", "cases": []}
+    if "--striped" in sys.argv:
+        for k, sc in enumerate(STRIPED_SCHEMES):
+            pairs = make_pairs(20261001 + k, 100)
+            exp = [ssw_reference(L, r, f, sc["match"], sc["mismatch"], sc["score_N"], sc["gap_open"], sc["gap_ext"], sc["filters"]) for r, f in pairs]
+            tr = bytes.maketrans(bytes(range(5)), b"ACGTN")
+            out["cases"].append(dict(scoring=sc, reads=[r.translate(tr).decode() for r, _ in pairs], refs=[f.translate(tr).decode() for _, f in pairs], expected=exp))
+            print("scheme", sc, "pairs", len(pairs), "with begin", sum(1 for e in exp if e[1] >= 0), "max score", max(e[0] for e in exp))
+        json.dump(out, open(os.path.join(HERE, "ssw_pairs_striped.json"), "w"))
+        print(os.path.getsize(os.path.join(HERE, "ssw_pairs_striped.json")), "bytes")
+        return 0
     for k, sc in enumerate(SCHEMES):
         pairs = make_pairs(20260926 + k, 160)
         exp = [ssw_reference(L, r, f, sc["match"], sc["mismatch"], sc["score_N"], sc["gap_open"], sc["gap_ext"], sc["filters"]) for r, f in pairs]

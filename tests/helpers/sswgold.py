@@ -10,8 +10,8 @@ from . import paths
 _TR = bytes.maketrans(b"ACGTN", bytes(range(5)))
 
 
-def load():
-    g = json.load(open(os.path.join(paths.REPO, "tests", "golden", "ssw_pairs.json")))
+def load(name="ssw_pairs.json"):
+    g = json.load(open(os.path.join(paths.REPO, "tests", "golden", name)))
     for c in g["cases"]:
         c["reads_b"] = [s.encode().translate(_TR) for s in c["reads"]]
         c["refs_b"] = [s.encode().translate(_TR) for s in c["refs"]]
@@ -49,4 +49,21 @@ def check_x4(engine):
         assert bad.size == 0, "x4 kernel, scoring %s: %d of %d pairs differ from ssw.c; first pair %d (m=%d, n=%d): got %s, ssw.c %s" % (
             sc, bad.size, len(idx), idx[bad[0]], len(c["reads_b"][idx[bad[0]]]), len(c["refs_b"][idx[bad[0]]]), got[bad[0]].tolist(), exp[bad[0]].tolist())
         n += len(idx)
+    return n
+
+
+def check_striped(engine, max_pairs=None):
+    """the slow path that reproduces ssw.c's stripe geometry (smr_ssw_batch mode 4) on the schemes under which the fast kernels' affine recurrence is NOT
+    what ssw.c computes (tests/golden/ssw_pairs_striped.json, answers of the reference's own ssw.c) -- and on the default scheme, where both must agree"""
+    n = 0
+    for c in load("ssw_pairs_striped.json"):
+        sc = c["scoring"]
+        k = len(c["reads_b"]) if max_pairs is None else min(max_pairs, len(c["reads_b"]))
+        got = engine.ssw_batch(c["reads_b"][:k], c["refs_b"][:k], match=sc["match"], mismatch=sc["mismatch"], score_N=sc["score_N"],
+                               gap_open=sc["gap_open"], gap_ext=sc["gap_ext"], filters=sc["filters"], mode=4)
+        exp = c["expected_a"][:k]
+        bad = np.nonzero((got != exp).any(axis=1))[0]
+        assert bad.size == 0, "striped path, scoring %s: %d of %d pairs differ from ssw.c; first pair %d (m=%d, n=%d): got %s, ssw.c %s" % (
+            sc, bad.size, k, bad[0], len(c["reads_b"][bad[0]]), len(c["refs_b"][bad[0]]), got[bad[0]].tolist(), exp[bad[0]].tolist())
+        n += k
     return n

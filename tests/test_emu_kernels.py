@@ -19,7 +19,7 @@ from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_inde
                              test_percent_edges_on_kilobase_reads, test_mixed_read_lengths, test_reads_sharing_seeds_with_thousands_of_references,
                              test_optional_paths_of_the_candidate_stage_give_the_oracle_records, test_pigeonhole_search_bytes_equal_a_host_recount,
                              test_a_window_with_hundreds_of_hits, test_rounds_adapt_from_part_to_part_without_changing_a_record,
-                             test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_are_refused, test_edges_outside_what_the_reference_defines_are_refused)
+                             test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_give_the_oracle_records, test_edges_outside_what_the_reference_defines_are_refused)
 from test_gpu_parity import test_align_records_match_oracle as _align_body
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 
@@ -148,6 +148,16 @@ def test_sw_kernels_equal_the_reference_ssw_c(emulator):
     e = smr.Engine(0)
     assert sswgold.check(e) == 320
     assert sswgold.check_x4(e) > 150
+    e.close()
+
+
+def test_striped_slow_path_equals_the_reference_ssw_c(emulator):
+    """smr_ssw_batch mode 4 (smr_sw_striped.hpp: ssw.c's stripe geometry on a wave) against tests/golden/ssw_pairs_striped.json = the answers of the
+    reference's own ssw.c under six schemes, four of them ones under which the striped kernels leave the affine recurrence (gap_open <= gap_ext,
+    2 gap < |mismatch|) and one with a positive score for N"""
+    from helpers import sswgold
+    e = smr.Engine(0)
+    assert sswgold.check_striped(e, max_pairs=None if FULL else 40) == (600 if FULL else 240)
     e.close()
 
 

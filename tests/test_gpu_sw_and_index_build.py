@@ -26,6 +26,7 @@ def test_sw_kernels_equal_the_reference_ssw_c(engine):
     from helpers import sswgold
     assert sswgold.check(engine) == 320
     assert sswgold.check_x4(engine) > 150          # the four-problems-per-wave kernel that k_chain batches candidate windows with
+    assert sswgold.check_striped(engine) == 600    # the slow path that reproduces ssw.c's stripe geometry, under the schemes that need it
 
 
 def test_traceback_kernels_equal_the_reference_banded_sw(engine):

@@ -21,7 +21,8 @@ import sortmerna_amd as smr  # noqa: E402
 from helpers import emu, orc  # noqa: E402
 from helpers.workload import Workload  # noqa: E402
 
-SCHEMES = [(2, -3, 5, 2), (2, -3, 5, 2), (2, -3, 3, 2), (3, -4, 6, 3), (5, -4, 5, 2), (1, -2, 3, 1), (2, -3, 4, 3), (4, -5, 7, 3), (2, -3, 10, 2), (1, -1, 2, 1)]
+SCHEMES = [(2, -3, 5, 2), (2, -3, 5, 2), (2, -3, 3, 2), (3, -4, 6, 3), (5, -4, 5, 2), (1, -2, 3, 1), (2, -3, 4, 3), (4, -5, 7, 3), (2, -3, 10, 2), (1, -1, 2, 1),
+           (2, -3, 3, 3), (2, -5, 2, 1)]      # the last two (round 6): schemes that go through the striped slow path (smr_sw_striped.hpp)
 
 
 def case(seed, tmp):
@@ -38,7 +39,7 @@ def case(seed, tmp):
         wk["db_kw"]["sub_hi"] = wk["db_kw"]["sub_lo"] + 0.01
     wk["db_kw"]["min_len"] = min(400, wk["mean_len"])
     match, mismatch, go, ge = pick(SCHEMES)
-    score_n = pick([mismatch, mismatch, 0, -1, -min(2 * go, 2 * ge, 127)])
+    score_n = pick([mismatch, mismatch, 0, -1, -min(2 * go, 2 * ge, 127), 1])      # (+1: a positive N score -- the striped slow path since round 6)
     opts = dict(match=match, mismatch=mismatch, gap_open=go, gap_ext=ge, score_N=int(score_n),
                 num_seeds=int(pick([1, 2, 2, 2, 3, 4])), min_lis=int(pick([1, 2, 2, 3, 4])), is_best=int(pick([1, 1, 0])), num_alignments=int(pick([0, 1, 1, 2, 3, 5, 8])),
                 is_full_search=int(pick([0, 0, 1])), minoccur=int(pick([0, 0, 0, 1, 3])))
