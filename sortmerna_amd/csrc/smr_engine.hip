@@ -489,6 +489,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
   sb.abits = nullptr; sb.inv_maxwin = 1.0 / (double)sb.maxwin;
+  sb.seg_inline = (c->pool_words <= (1ull << 30) && di.n_ids < (1u << 30) && !(getenv("SMR_SEG_INLINE") && atoi(getenv("SMR_SEG_INLINE")) == 0)) ? 1u : 0u;
   if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->ccap) * 4;
   const size_t lds_pg = lds_pg1 + (getenv("SMR_PG_LDS_PAD") ? (size_t)atoi(getenv("SMR_PG_LDS_PAD")) : 0);      // (the variable: occupancy experiments)

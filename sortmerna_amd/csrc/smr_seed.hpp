@@ -158,6 +158,12 @@ struct SeedKey { uint32_t slot, chars, key; bool dup; };          // a decoded t
 #endif
 #define SEED_SEG_MERGED 0x80000000u                       // header bit of a reverse segment whose list is final (written by k_seed_search<1>: forward hits included)
 #define SEED_CAND_COND 0x80000000u                        // bit of an id in a reverse segment of k_seed_pg: this candidate is a 0-error match
+// A window whose search leaves ONE hit (most windows of a read sampled from the DB: the 0-error match) needs no segment: its wseg word IS the hit --
+// SEED_SEG_INLINE | id (| SEED_ZERO_BIT forward, | SEED_CAND_COND reverse).  k_seed_pg then writes no pool words for it and k_seed_finish reads none: a
+// 128-byte line per window less in the kernel furthest from its bytes (round 5: 7.8 GB moved for 1.3 GB).  Needs ids and pool offsets below 2^30
+// (SeedBufs::seg_inline; the host checks both).
+#define SEED_SEG_INLINE 0x40000000u
+#define SEED_SEG_ID 0x3FFFFFFFu
 struct SeedBufs {
   uint32_t* chist;           // [nc + 1] tuples per COARSE bin (key >> fb)
   uint32_t* cbase;           // [nc + 1] exclusive scan of chist
@@ -190,6 +196,7 @@ struct SeedBufs {
   // tuples of the reads that are not in this (part, strand, pass)
   const uint32_t* abits;     // bit per read: it is searched in this launch (nullptr: every tuple is)
   double inv_maxwin;         // 1 / maxwin: a tuple's read = slot / maxwin
+  uint32_t seg_inline;       // 1: a one-hit window's hit lies in its wseg word (SEED_SEG_INLINE)
   uint32_t hot_min;          // 0: no search for repeated seeds
   uint32_t hbin_min, hsub;   // a coarse bin is "large" from twice the average size and at least hbin_min tuples (SEED_HOT_BIN_MIN); tuples per sub-range (SEED_HOT_SUB)
 };
@@ -924,6 +931,7 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
       if (mine && DIR == 1 && wseg_has(sb, 0, slot)) {     // the window's list so far = the forward search's hits
         const uint32_t seg = sb.wseg[0][slot];
         if (seg & SEED_ZERO_BIT) mine = false;             // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+        else if (seg & SEED_SEG_INLINE) { n_prev = 1; hl[lane] = seg & SEED_SEG_ID; sl.nh = 1; }
         else {
           const uint32_t o = seg & ~SEED_ZERO_BIT;
           n_prev = pool[o] & 0xFFFFu;
@@ -1026,19 +1034,23 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
       auto merge = [&](uint32_t sf, uint32_t sr, uint32_t win_pos, uint32_t o) -> uint32_t {
         uint32_t n = 0;
         const bool fzero = sf != NONE && (sf & SEED_ZERO_BIT);
+        // (a one-hit window's hit lies in the word itself: SEED_SEG_INLINE -- no pool line is touched for it)
+        const bool fin = sf != NONE && (sf & SEED_SEG_INLINE), rin = sr != NONE && (sr & SEED_SEG_INLINE);
         const uint32_t of = sf & ~SEED_ZERO_BIT, orv = sr & ~SEED_ZERO_BIT;
-        const uint32_t hr = sr != NONE ? pool[orv] : 0u;
-        const uint32_t nf = sf != NONE ? (pool[of] & 0xFFFFu) : 0u, nr = hr & 0xFFFFu;
+        const uint32_t hr = sr == NONE ? 0u : rin ? 1u : pool[orv];
+        const uint32_t nf = sf == NONE ? 0u : fin ? 1u : (pool[of] & 0xFFFFu), nr = hr & 0xFFFFu;
+        auto fwd_id = [&](uint32_t q) -> uint32_t { return fin ? (sf & SEED_SEG_ID) : pool[of + 1 + q]; };
+        auto rev_id = [&](uint32_t q) -> uint32_t { return rin ? (sr & (SEED_SEG_ID | SEED_CAND_COND)) : pool[orv + 1 + q]; };
         if (sr != NONE && (hr & SEED_SEG_MERGED) && !fzero) {
           for (uint32_t q = 0; q < nr; q++) { if (o != NONE) { pool[o + 2 * n] = pool[orv + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
           return n;
         }
-        for (uint32_t q = 0; q < nf; q++) { if (o != NONE) { pool[o + 2 * n] = pool[of + 1 + q]; pool[o + 2 * n + 1] = win_pos; } n++; }
+        for (uint32_t q = 0; q < nf; q++) { if (o != NONE) { pool[o + 2 * n] = fwd_id(q); pool[o + 2 * n + 1] = win_pos; } n++; }
         if (fzero || sr == NONE) return n;
         for (uint32_t q = 0; q < nr; q++) {
-          const uint32_t c = pool[orv + 1 + q], id = c & ~SEED_CAND_COND;
+          const uint32_t c = rev_id(q), id = c & ~SEED_CAND_COND;
           bool present = false;
-          for (uint32_t f = 0; f < nf; f++) if (pool[of + 1 + f] == id) { present = true; break; }
+          for (uint32_t f = 0; f < nf; f++) if (fwd_id(f) == id) { present = true; break; }
           if (present) continue;
           if (c & SEED_CAND_COND) { if (o != NONE) { pool[o] = id; pool[o + 1] = win_pos; } return 1u; }
           if (o != NONE) { pool[o + 2 * n] = id; pool[o + 2 * n + 1] = win_pos; }
@@ -1063,7 +1075,7 @@ __global__ void __launch_bounds__(256) k_seed_finish(DReads rd, DParams P, int p
           const uint32_t j = (uint32_t)__ffs((int)mm) - 1u, k = kb + j;
           const uint32_t sf = ((mf >> j) & 1u) ? sb.wseg[0][slot0 + k] : NONE, sr = ((mr >> j) & 1u) ? sb.wseg[1][slot0 + k] : NONE;
           if (sf != NONE && ((srch >> j) & 1u) && !(sf & SEED_ZERO_BIT)) rlook++;        // ... unless the forward search hit exactly
-          const uint32_t cf = sf != NONE ? (pool[sf & ~SEED_ZERO_BIT] & 0xFFFFu) : 0u, cr = sr != NONE ? (pool[sr & ~SEED_ZERO_BIT] & 0xFFFFu) : 0u;
+          const uint32_t cf = sf == NONE ? 0u : (sf & SEED_SEG_INLINE) ? 1u : (pool[sf & ~SEED_ZERO_BIT] & 0xFFFFu), cr = sr == NONE ? 0u : (sr & SEED_SEG_INLINE) ? 1u : (pool[sr & ~SEED_ZERO_BIT] & 0xFFFFu);
           if (seeds < FIN_KEEP) { s_sf[seeds][threadIdx.x] = sf; s_sr[seeds][threadIdx.x] = sr; s_k[seeds][threadIdx.x] = (uint16_t)k; }
           seeds++; upper += cf + cr;
         }

@@ -357,7 +357,8 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   if (pf) { pf_nx = sb.cbase[pf_c + 1]; pf_bounds = true; }
   // ---- write the windows' hit segments: [count, id x count] ----
   const bool wr = mine && nh > 0;
-  const uint32_t need = wr ? 1 + nh : 0;
+  const bool inl = wr && nh == 1 && sb.seg_inline;          // one hit: it goes into the window's wseg word, no segment (SEED_SEG_INLINE)
+  const uint32_t need = (wr && !inl) ? 1 + nh : 0;
   const uint32_t incl = pg_scan_add(need);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   uint32_t base = 0;
@@ -369,7 +370,8 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
     }
     base = __shfl(base, 0, 64);
   }
-  if (wr && base != NONE) {
+  if (inl) wseg_put(sb, DIR, slot, SEED_SEG_INLINE | (hp[hb] & (SEED_SEG_ID | (DIR ? SEED_CAND_COND : 0u))) | (zero ? SEED_ZERO_BIT : 0u), zero);
+  else if (wr && base != NONE) {
     const uint32_t o = base + incl - need;
     pool[o] = nh;
     for (uint32_t q = 0; q < nh; q++) pool[o + 1 + q] = hp[hb + q];

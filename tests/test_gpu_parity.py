@@ -748,7 +748,7 @@ def _host_recount_of_the_search(pg, root3, tuples, cbase, meta, direction, zero_
             if not present:
                 hl.append(idc)
         if hl:
-            total += 4 * (1 + len(hl)) + 4
+            total += 4 if len(hl) == 1 else 4 * (1 + len(hl)) + 4      # one hit: it lies in the window's slot word (SEED_SEG_INLINE), no segment
             segs.add(slot)
         if zero_end:
             zeros.add(slot)
