@@ -86,7 +86,7 @@ sq)
   done
   CELLS=$(python -c "
 import json
-o=json.loads([l for l in open('$OUT/pmc_sq_SQ_INSTS.json') if l.startswith('{')][-1]); print(o['kernels']['k_chain']['sw_cells'])")
+o=json.loads([l for l in open('$OUT/pmc_sq_SQ_INSTS.json') if l.startswith('{')][-1]); print(2 * o['kernels']['k_chain']['sw_cells'])")      # (the pass counts the warm-up step and the timed step: two steps' cells)
   ( cd tools && python pmc_sq.py $ROOT/$OUT/sq_counters.json 8000000 150 140000000 $(for F in $FILES; do echo $ROOT/$F; done) --sw-cells $CELLS ) > $OUT/sq_counters.txt 2>&1; cat $OUT/sq_counters.txt
   rm -rf $OUT/pmc_sq_* ;;
 sqi)
