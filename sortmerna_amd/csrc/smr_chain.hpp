@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
     hlo[k] = 0; hln[k] = 0;
-    if (hid[k] != NONE) { hlo[k] = ix.pos_off[hid[k]]; hln[k] = ix.pos_off[hid[k] + 1] - hlo[k]; }
+    if (hid[k] != NONE) { hlo[k] = hid[k] + 1u; hln[k] = ix.pos_arr[hid[k]].x; }      // (a hit's id is the place of its list's header word: {positions, -})
   }
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
@@ -794,7 +794,7 @@ __global__ void __launch_bounds__(64, SMR_CHAIN_WAVES_PER_SIMD) k_chain(DReads r
         if (!from_rec) for (uint32_t hb = 0; hb < nh; hb += 64) {
           const uint32_t h = hb + lane;
           uint32_t lo = 0, ln = 0;
-          if (h < nh) { const uint32_t id = hits[h].x; lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo; }
+          if (h < nh) { const uint32_t id = hits[h].x; lo = id + 1u; ln = ix.pos_arr[id].x; }
           uint32_t tot; const uint32_t ex = wave_excl_scan_u32(ln, tot);
           if (h < nh) { hp[h] = npos + ex; hits[h].x = lo; }
           npos += tot;

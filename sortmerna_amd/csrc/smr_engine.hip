@@ -96,6 +96,7 @@ struct smr_ctx {
   // one seed sort for the index parts of a batch (SharedSort below): 0 off, 1 when the part in hand is not the batch's last, 2 always (tests)
   int seed_shared = getenv("SMR_SEED_SHARED") ? atoi(getenv("SMR_SEED_SHARED")) : 1;
   uint16_t* d_sw_scr = nullptr; uint32_t sw_scr_stride = 0; size_t sw_scr_words = 0;      // scratch rows of the striped Smith-Waterman slow path (smr_sw_striped.hpp), one per block
+  int last_seed_slot = -1;                 // index slot of the last smr_seed_scan (smr_seed_hits_fetch translates its ids back)
   SharedSort* shared = nullptr;
   uint64_t n_seed_shared = 0, n_seed_shared_builds = 0;      // smr_prof
   uint32_t ccap = PG_CAND_CAP0;           // candidate records per wave of k_seed_pg; doubles when more than 1/64 of the waves of a part overflow
@@ -481,7 +482,7 @@ int ensure_shared_sort(smr_ctx* c, const DevIndex& di, const DParams& P) {
 int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool more_parts = false, int strand = -1) {
   int rc = ensure_seed_bufs(c, P); if (rc) return rc;
   if (c->b->max_len > 0xFFFFu) { set_err(c, "seed stage limit: reads <= 65535 nt"); return SMR_ERR_CAPACITY; }
-  if (di.n_ids >= 0x7FFFFFFFu) { set_err(c, "seed stage limit: < 2^31 - 1 distinct seeds per index part"); return SMR_ERR_CAPACITY; }
+  if ((uint64_t)di.n_ids + di.n_pos >= 0x7FFFFFF0ull) { set_err(c, "seed stage limit: positions + distinct seeds < 2^31 per index part"); return SMR_ERR_CAPACITY; }
   SeedBufs sb = c->sb;
   sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
   const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
@@ -489,7 +490,7 @@ int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool
   sb.n = c->b->n;
   sb.cap_redo = SEED_REDO_CAP;
   sb.abits = nullptr; sb.inv_maxwin = 1.0 / (double)sb.maxwin;
-  sb.seg_inline = (c->pool_words <= (1ull << 30) && di.n_ids < (1u << 30) && !(getenv("SMR_SEG_INLINE") && atoi(getenv("SMR_SEG_INLINE")) == 0)) ? 1u : 0u;
+  sb.seg_inline = (c->pool_words <= (1ull << 30) && (uint64_t)di.n_ids + di.n_pos < (1ull << 30) && !(getenv("SMR_SEG_INLINE") && atoi(getenv("SMR_SEG_INLINE")) == 0)) ? 1u : 0u;
   if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
   const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->ccap) * 4;
   const size_t lds_pg = lds_pg1 + (getenv("SMR_PG_LDS_PAD") ? (size_t)atoi(getenv("SMR_PG_LDS_PAD")) : 0);      // (the variable: occupancy experiments)
@@ -1208,6 +1209,18 @@ extern "C" const char* smr_last_error(const smr_ctx* c) {
 
 namespace {
 // The pigeonhole layout of the part in slot d (its lookup table and reference-shaped arena are on the device already): smr_pgbuild.hpp
+// The position lists as the kernels read them (round 6): a hit's id IS the place of its list -- id' = pos_off[id] + id --, where a header word
+// {positions, original id} stands in front of the positions {pos, seq}.  k_cand / k_walk / k_chain went hit -> pos_off[id], pos_off[id + 1] ->
+// pos_arr[...]: two random 128-byte lines and two dependent round trips per hit; now the header and (nearly always) the positions share one line.
+__global__ void __launch_bounds__(256) k_pos2_build(const uint32_t* __restrict__ pos_off, const uint2* __restrict__ pos_arr, uint32_t n_ids, uint2* __restrict__ pos2) {
+  const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_ids) return;
+  const uint32_t lo = pos_off[id], n = pos_off[id + 1] - lo;
+  uint2* o = pos2 + (size_t)lo + id;
+  o[0] = make_uint2(n, id);
+  for (uint32_t q = 0; q < n; q++) o[1 + q] = pos_arr[lo + q];
+}
+
 int build_pigeonhole_device(smr_ctx* c, DevIndex& d, uint32_t nk, uint32_t pw) {
   DevPool pool;
   const uint32_t nb = 2 * nk;
@@ -1225,7 +1238,7 @@ int build_pigeonhole_device(smr_ctx* c, DevIndex& d, uint32_t nk, uint32_t pw) {
   IB_GET(estr, uint32_t, E); IB_GET(eid, uint32_t, E); IB_GET(eblk, uint32_t, E);
   IB_GET(k0, smr::u64, E); IB_GET(k1, smr::u64, E); IB_GET(v0, uint32_t, E); IB_GET(v1, uint32_t, E);
   hipLaunchKernelGGL(smr::k_pgb_collect, dim3((nb + 255) / 256), dim3(256), 0, c->stream, (const Lookup*)d.lookup, (const uint32_t*)d.trie, nk, pw,
-                     (const uint32_t*)cnt, (const uint32_t*)eoff, (const smr::u64*)woff, d.root3, d.pg, estr, eid, eblk, derr);
+                     (const uint32_t*)cnt, (const uint32_t*)eoff, (const smr::u64*)woff, d.root3, d.pg, estr, eid, eblk, derr, (const uint32_t*)d.pos_off);
   uint32_t herr = 0;                                       // (a block k_pgb_collect refused has no entries written: nothing below may run on them)
   HIPCHK(c, hipMemcpyAsync(&herr, derr, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1264,6 +1277,19 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   if ((rc = dev_alloc(c, &d.trie, ix->trie.size()))) return rc;
   HIPCHK(c, hipMemcpyAsync(d.lookup, ix->lookup.data(), ix->lookup.size() * sizeof(Lookup), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.trie, ix->trie.data(), ix->trie.size() * 4, hipMemcpyHostToDevice, c->stream));
+  // the position lists: pos_off (which the layout build below and the DFS kernel translate ids with) and pos2 = {header, positions} per seed (k_pos2_build)
+  if ((uint64_t)ix->pos_arr.size() / 2 + ix->n_ids() >= 0x7FFFFFF0ull) { set_err(c, "index part limit: positions + distinct seeds < 2^31"); return SMR_ERR_CAPACITY; }
+  if ((rc = dev_alloc(c, &d.pos_off, ix->pos_off.size()))) return rc;
+  HIPCHK(c, hipMemcpyAsync(d.pos_off, ix->pos_off.data(), ix->pos_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+  {
+    uint2* raw = nullptr;
+    if ((rc = dev_alloc(c, &raw, ix->pos_arr.size() / 2))) return rc;
+    HIPCHK(c, hipMemcpyAsync(raw, ix->pos_arr.data(), ix->pos_arr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = dev_alloc(c, &d.pos_arr, ix->pos_arr.size() / 2 + (size_t)d.n_ids + 1))) { dev_free(&raw); return rc; }
+    if (d.n_ids) hipLaunchKernelGGL(k_pos2_build, dim3((d.n_ids + 255u) / 256u), dim3(256), 0, c->stream, (const uint32_t*)d.pos_off, (const uint2*)raw, d.n_ids, d.pos_arr);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(&raw);
+  }
   // The pigeonhole layout of the tries (what k_seed_pg reads) is built on the device from the arena just uploaded (smr_pgbuild.hpp).  An index
   // that already carries the host-built layout (smr_index_selfcheck, SMR_PG_HOST=1) is uploaded as it is.
   bool host_pg = getenv("SMR_PG_HOST") && atoi(getenv("SMR_PG_HOST"));
@@ -1279,12 +1305,8 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   } else if ((rc = build_pigeonhole_device(c, d, (uint32_t)ix->lookup.size(), ix->lnwin / 2))) return rc;
   if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: index part: tries %.2f GB, pigeonhole arena %.2f GB (%s), positions %.2f GB\n", ix->trie.size() * 4e-9, d.pg_words * 4e-9,
                                      host_pg ? "host-built" : "built on the device", ix->pos_arr.size() * 4e-9);
-  if ((rc = dev_alloc(c, &d.pos_off, ix->pos_off.size()))) return rc;
-  if ((rc = dev_alloc(c, &d.pos_arr, ix->pos_arr.size() / 2))) return rc;
   if ((rc = dev_alloc(c, &d.ref_seq, ix->ref_seq.size() + 64))) return rc;
   if ((rc = dev_alloc(c, &d.ref_off, ix->ref_off.size()))) return rc;
-  HIPCHK(c, hipMemcpyAsync(d.pos_off, ix->pos_off.data(), ix->pos_off.size() * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d.pos_arr, ix->pos_arr.data(), ix->pos_arr.size() * 4, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.ref_seq, ix->ref_seq.data(), ix->ref_seq.size(), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(d.ref_off, ix->ref_off.data(), ix->ref_off.size() * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1955,6 +1977,7 @@ extern "C" int smr_seed_scan(smr_ctx* c, int slot, const smr_params* p, int stra
   int rc = check_params(c, p); if (rc) return rc;
   const DevIndex& di = c->idx[slot];
   DParams P = make_dparams(c, di, p);
+  c->last_seed_slot = slot;
   if ((rc = ensure_pool(c))) return rc;
   ev_drop(c);
   const uint32_t tb = 256, nb = (c->b->n + tb - 1) / tb;
@@ -2007,12 +2030,25 @@ extern "C" int smr_seed_hits_fetch(smr_ctx* c, uint32_t* triples, uint64_t cap_t
   std::vector<RWork> rw(c->b->n);
   if (words) HIPCHK(c, hipMemcpy(pool.data(), c->d_pool, words * 4, hipMemcpyDeviceToHost));
   if (c->b->n) HIPCHK(c, hipMemcpy(rw.data(), c->b->d_rw, (size_t)c->b->n * sizeof(RWork), hipMemcpyDeviceToHost));
+  // (the device's ids are places in its position array, id' = pos_off[id] + id: back to the index's ids for the caller)
+  std::vector<uint32_t> po;
+  if (c->last_seed_slot >= 0 && c->idx[c->last_seed_slot].used) {
+    const DevIndex& di = c->idx[c->last_seed_slot];
+    po.resize((size_t)di.n_ids + 1);
+    HIPCHK(c, hipMemcpy(po.data(), di.pos_off, po.size() * 4, hipMemcpyDeviceToHost));
+  }
+  auto orig = [&](uint32_t idp) -> uint32_t {
+    if (po.size() < 2) return idp;
+    size_t lo = 0, hi = po.size() - 1;                      // the last id with pos_off[id] + id <= idp
+    while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if ((uint64_t)po[mid] + mid <= idp) lo = mid; else hi = mid; }
+    return (uint32_t)lo;
+  };
   uint64_t o = 0;
   for (uint32_t r = 0; r < c->b->n; r++) {
     for (int pp = 0; pp < 3; pp++) {
       const uint32_t cnt = rw[r].blk_cnt[pp], bo = rw[r].blk_off[pp];
       for (uint32_t q = 0; q < cnt && (uint64_t)bo + 2 * q + 1 < words; q++) {
-        if (triples && o < cap_triples) { triples[3 * o] = r; triples[3 * o + 1] = pool[bo + 2 * q]; triples[3 * o + 2] = pool[bo + 2 * q + 1]; }
+        if (triples && o < cap_triples) { triples[3 * o] = r; triples[3 * o + 1] = orig(pool[bo + 2 * q]); triples[3 * o + 2] = pool[bo + 2 * q + 1]; }
         o++;
       }
     }

@@ -727,6 +727,7 @@ bool smr_build_pigeonhole(smr_index& ix, uint32_t threads, std::string& why) {
         if (root == NONE) continue;
         v.clear(); bstart.clear();
         pg_collect_b(ix.trie.data() + root, 0, 0, 0, v, bstart);   // complete strings (char j at bits 2j) in DFS order
+        for (auto& e : v) e.id = ix.pos_off[e.id] + e.id;          // (what the searches hand on: where the seed's position list lies on the device -- behind a header word, k_pos2_build)
         const uint32_t n = (uint32_t)v.size();
         uint32_t cA, cB;
         pg_chars(n, pw, cA, cB);

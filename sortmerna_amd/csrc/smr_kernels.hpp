@@ -38,8 +38,8 @@ struct DIndex {
   const uint32_t* trie;
   const uint32_t* pg;          // pigeonhole arena (smr_host.hpp) and its block table: forward / reverse mini-trie of key k at [2k], [2k+1] = {offset / 4, n | cA << 24 | cB << 28}
   const uint2* root3;
-  const uint32_t* pos_off;
-  const uint2* pos_arr;        // {pos, seq}
+  const uint32_t* pos_off;     // the index's CSR offsets (id -> list start): what a search's id is made of, id' = pos_off[id] + id
+  const uint2* pos_arr;        // per seed, at [id']: a header {positions, the index's id}, then its positions {pos, seq} (k_pos2_build)
   const uint8_t* ref_seq;
   const uint64_t* ref_off;
   uint32_t n_refs, n_ids, lnwin, partialwin;

@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(256) k_pgb_sizes(const Lookup* __restrict__ lo
 __global__ void __launch_bounds__(256) k_pgb_collect(const Lookup* __restrict__ lookup, const uint32_t* __restrict__ trie, uint32_t nk, uint32_t pw,
                                                     const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ eoff, const u64* __restrict__ woff,
                                                     uint32_t* __restrict__ root3, uint32_t* __restrict__ pg,
-                                                    uint32_t* __restrict__ estr, uint32_t* __restrict__ eid, uint32_t* __restrict__ eblk, uint32_t* __restrict__ err) {
+                                                    uint32_t* __restrict__ estr, uint32_t* __restrict__ eid, uint32_t* __restrict__ eblk, uint32_t* __restrict__ err,
+                                                    const uint32_t* __restrict__ pos_off) {
+  // (pos_off: the ids the searches hand on are where a seed's position list lies -- id' = pos_off[id] + id, the list behind a header word: smr_engine.hip k_pos2_build)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * nk) return;
   const Lookup lk = lookup[i >> 1];
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(256) k_pgb_collect(const Lookup* __restrict__ 
   const uint32_t e0 = eoff[i];
   pgb_walk(trie + root, [&](uint32_t path, uint32_t plen, const uint32_t* b, uint32_t ne) {
     for (uint32_t q = 0; q < ne; q++, r++) {
-      const uint32_t str = path | (b[2 * q] << (2 * plen)), id = b[2 * q + 1];
+      const uint32_t str = path | (b[2 * q] << (2 * plen)), id0 = b[2 * q + 1], id = pos_off[id0] + id0;
       estr[e0 + r] = str; eid[e0 + r] = id; eblk[e0 + r] = i;
       if (cA == 0) { blk[r] = str; blk[n + 2 * r] = r; blk[n + 2 * r + 1] = id; }      // a block without directories: one array in DFS order
     }

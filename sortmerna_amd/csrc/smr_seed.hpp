@@ -741,7 +741,7 @@ __device__ __forceinline__ uint32_t node_states(const uint4 nd, uint32_t rtw, ui
 #else
 #define SPH(i)
 #endif
-__device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ arena, uint32_t root, bool mine, uint32_t chars, uint32_t pw, bool full,
+__device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ arena, const uint32_t* __restrict__ pos_off, uint32_t root, bool mine, uint32_t chars, uint32_t pw, bool full,
                                                  const unsigned long long* s_row, const SeedLds L, uint32_t hcap, SeedLane& out
 #ifdef SMR_SEED_PHASES
                                                  , unsigned long long* sph, unsigned long long& slast
@@ -846,12 +846,14 @@ __device__ __forceinline__ void seed_search_wave(const uint32_t* __restrict__ ar
     if (T > 0) fetch(0);
     for (uint32_t base = 0; base < T; base += 64) {
       const bool v = base + lane < T;
-      const uint32_t bk = f_bk, q = f_q, pbv = f_pbv, str = f_str, id = f_id;
+      const uint32_t bk = f_bk, q = f_q, pbv = f_pbv, str = f_str;
+      uint32_t id = f_id;
       if (base + 64 < T) fetch(base + 64);
       const uint32_t olane = bk / SEED_K;
       const uint32_t nchar = pbv >> 24;                      // chars of the trie path in front of the tail
       const uint32_t tstr = (pbv & 0xFFFFFFu) | (str << (2 * nchar));
       const uint32_t r = v ? lev1_entry(L.pat[olane], tstr, pw) : 0u;
+      if (r & 1u) id = pos_off[id] + id;                       // (what the searches hand on is the place of the seed's position list: k_pos2_build; the arena holds the index's ids)
       const uint32_t kind = ((r & 2u) && !full) ? CK_COND : CK_PLAIN;   // a 0-error match is accepted one step before state 9 shows
       // hand the candidates back to their owners, in entry order
       unsigned long long cm = __ballot((r & 1u) != 0);
@@ -945,9 +947,9 @@ __global__ void __launch_bounds__(64) k_seed_search(DIndex ix, DParams P, int pa
   __syncthreads();
 #ifdef SMR_SEED_PHASES
   unsigned long long sph[6] = {0, 0, 0, 0, 0, 0}, slast = clock64();
-  seed_search_wave(ix.trie, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl, sph, slast);
+  seed_search_wave(ix.trie, ix.pos_off, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl, sph, slast);
 #else
-  seed_search_wave(ix.trie, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
+  seed_search_wave(ix.trie, ix.pos_off, root, mine, chars, P.partialwin, P.is_full_search != 0, s_row, L, hcap, sl);
 #endif
   // ---- write the windows' hit segments: [count (| SEED_SEG_MERGED), id x count] ----
   const bool wr = mine && (DIR == 0 ? sl.nh > 0 : (sl.zero || sl.nh > n_prev));

@@ -331,7 +331,7 @@ k_walk(DReads rd, DIndex ix, DParams P, int pass, int is_last_strand, RState* __
             const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
             const uint32_t id = pool[at];
             g_wn[lane] = pool[at + 1];
-            lo = ix.pos_off[id]; ln = ix.pos_off[id + 1] - lo;
+            lo = id + 1u; ln = ix.pos_arr[id].x;               // (the id is the place of the list's header word)
           }
           uint32_t tot;
           const uint32_t ex = wave_excl_scan_u32(ln, tot);
