@@ -154,8 +154,11 @@ struct SeedKey { uint32_t slot, chars, key; bool dup; };          // a decoded t
 #define SEED_WAVES 16u                                    // waves per block of k_seed_keys
 #define SEED_STAGE_WORDS 1280u                            // LDS words in which a wave of k_seed_keys stages the packed records of the reads of one trip (64 reads of <= 208 letters)
 #ifndef SEED_PIECE
-#define SEED_PIECE 8192u                                  // tuples a sort pass stages in LDS at a time
+#define SEED_PIECE 8192u                                  // tuples the second sort pass (512 fine bins) stages in LDS at a time: two blocks per CU
 #endif
+#ifndef SEED_SPLIT_PIECE
+#define SEED_SPLIT_PIECE 12288u                           // ... and the first (1 024 coarse bins: runs of 12 tuples per bin instead of 8; one block per CU).  Measured per 8 M-read
+#endif                                                    // step (profiles/r6s17_*): split 11.0 -> 9.7 ms with 12 288 or 16 384, bins 10.2 -> 10.9 with either: each pass keeps its own
 #define SEED_SEG_MERGED 0x80000000u                       // header bit of a reverse segment whose list is final (written by k_seed_search<1>: forward hits included)
 #define SEED_CAND_COND 0x80000000u                        // bit of an id in a reverse segment of k_seed_pg: this candidate is a 0-error match
 // A window whose search leaves ONE hit (most windows of a read sampled from the DB: the 0-error match) needs no segment: its wseg word IS the hit --
@@ -496,12 +499,12 @@ __device__ __forceinline__ void block_excl_scan(const uint32_t* cnt, uint32_t* o
 // load (each tuple once), take a place in its bin (LDS atomic), put the piece into LDS in bin order, copy it out with consecutive lanes on
 // consecutive staged tuples (lanes of one bin's run write neighbouring addresses), rewritten by `conv` on the way.
 // LDS: cur / pc0 / pst [nb], stage [SEED_PIECE].
-template <class BINOF, class CONV>
+template <uint32_t PIECE, class BINOF, class CONV>
 __device__ __forceinline__ void staged_move(const SeedTup* __restrict__ src, uint32_t i0, uint32_t i1, SeedTup* __restrict__ dst, uint32_t nb,
                                             uint32_t* cur, uint32_t* pc0, uint32_t* pst, SeedTup* stage, uint32_t* s_part, BINOF binof, CONV conv) {
-  constexpr int PER = SEED_PIECE / 1024;
-  for (uint32_t p0 = i0; p0 < i1; p0 += SEED_PIECE) {
-    const uint32_t np = min(SEED_PIECE, i1 - p0);
+  constexpr int PER = PIECE / 1024;
+  for (uint32_t p0 = i0; p0 < i1; p0 += PIECE) {
+    const uint32_t np = min(PIECE, i1 - p0);
     for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pc0[q] = cur[q];
     __syncthreads();
     SeedTup mine[PER]; uint32_t place[PER];
@@ -542,7 +545,7 @@ __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
   __syncthreads();
   const uint32_t fb = sb.fb, kbits = sb.kbits, cb = sb.cb;
   const uint32_t slot0 = blockIdx.x * sb.rpb * sb.maxwin;                  // the block's first slot
-  staged_move(sb.tmp + (size_t)2 * slot0, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part,
+  staged_move<SEED_SPLIT_PIECE>(sb.tmp + (size_t)2 * slot0, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part,
               [fb, kbits](SeedTup t) { return ((uint32_t)t & ((1u << kbits) - 1u)) >> fb; },
               [fb, kbits, cb, slot0](SeedTup t) {
                 const uint32_t key = (uint32_t)t & ((1u << kbits) - 1u), chars = (uint32_t)(t >> kbits) & ((1u << cb) - 1u), rel = (uint32_t)(t >> (kbits + cb));
@@ -576,7 +579,7 @@ __global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
     if (sb.hot_min && pst[t] >= seed_hot_key(sb)) seed_push_pieces(sb, cur[t], pst[t]);
   }
   __syncthreads();
-  staged_move(sb.mid, lo, hi, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
+  staged_move<SEED_PIECE>(sb.mid, lo, hi, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
 }
 
 // A coarse bin far larger than the others (cscan: hpre) would keep ONE block of k_seed_bins busy long after the rest of the launch is over --
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(1024) k_seed_hbins_move(SeedBufs sb) {
     seed_hot_entry(sb, e, c, i0, i1);
     if (threadIdx.x < nf) cur[threadIdx.x] = sb.hh[(size_t)e * nf + threadIdx.x];
     __syncthreads();
-    staged_move(sb.mid, i0, i1, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
+    staged_move<SEED_PIECE>(sb.mid, i0, i1, sb.srt, nf, cur, pc0, pst, stage, s_part, [sh](SeedTup x) { return (uint32_t)(x >> sh); }, [](SeedTup x) { return x; });
   }
 }
 
