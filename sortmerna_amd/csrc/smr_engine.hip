@@ -284,843 +284,17 @@ uint32_t num_windows(uint32_t max_len, uint32_t L, uint32_t stride) {
   return max_len >= L ? (max_len - L + stride) / stride : 1;
 }
 
-int ensure_seed_bufs(smr_ctx* c, const DParams& P) {
-  uint32_t mw = 1;
-  for (int p = 0; p < 3; p++) mw = std::max(mw, num_windows(c->b->max_len, P.lnwin, P.skip[p]));
-  const uint64_t slots = (uint64_t)std::max(c->b->n, 1u) * mw;
-  const uint32_t nk = 2u << P.lnwin;                      // 2 x 4^(L/2) bins: forward and reverse keys
-  if (2 * slots >= 0xFFFFFF00ull) { set_err(c, "batch too large for the seed stage (reads x windows >= 2^31): use smaller batches"); return SMR_ERR_CAPACITY; }
-  int rc;
-  if (c->sb_nk < nk) {
-    if ((rc = dev_alloc(c, &c->sb.chist, (size_t)4096 + 1))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.cbase, (size_t)4096 + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.hpre, (size_t)4096 + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.hlist, (size_t)4096 + 2))) return rc;
-    if (!c->sb.rows && (rc = dev_alloc(c, &c->sb.rows, (size_t)SEED_KEY_BLOCKS * 4096))) return rc;
-    if (!c->sb.bcnt && (rc = dev_alloc(c, &c->sb.bcnt, (size_t)SEED_KEY_BLOCKS))) return rc;
-    if (!c->sb.redo && (rc = dev_alloc(c, &c->sb.redo, SEED_REDO_CAP))) return rc;
-    if (!c->sb.sn && (rc = dev_alloc(c, &c->sb.sn, SN_COUNT))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.emap, (size_t)(nk / 2) / 16 + 1))) return rc;
-    c->sb_nk = nk;
-  }
-  if (c->sb_slots < slots) {
-    // a forward and a reverse tuple per window; tmp is cut into one region per block of k_seed_keys (the slots of its reads)
-    if ((rc = dev_alloc(c, &c->sb.tmp, 2 * slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.mid, 2 * slots))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.srt, 2 * slots))) return rc;
-    for (int d = 0; d < 2; d++) {
-      if ((rc = dev_alloc(c, &c->sb.wseg[d], slots))) return rc;
-      if ((rc = dev_alloc(c, &c->sb.fbits[d], slots / 32 + 2))) return rc;
-    }
-    if ((rc = dev_alloc(c, &c->sb.wbin, 2 * slots / 64 + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.zbits, slots / 32 + 2))) return rc;
-    if ((rc = dev_alloc(c, &c->sb.gflag, slots / 2048 + 2))) return rc;
-    // skewed batches: a coarse bin of at least SEED_HOT_BIN_MIN tuples in sub-ranges of SEED_HOT_SUB (their fine histograms); the pieces of hot keys (>= 1024 tuples each)
-    c->sb.hbin_min = getenv("SMR_SEED_HOT_BIN") ? (uint32_t)std::max(1, atoi(getenv("SMR_SEED_HOT_BIN"))) : SEED_HOT_BIN_MIN;
-    c->sb.hsub = getenv("SMR_SEED_HOT_SUB") ? (uint32_t)std::max(1, atoi(getenv("SMR_SEED_HOT_SUB"))) : SEED_HOT_SUB;
-    c->sb.cap_hent = (uint32_t)(2 * slots / c->sb.hsub + 2 * slots / c->sb.hbin_min + 2);
-    if ((rc = dev_alloc(c, &c->sb.hh, (size_t)c->sb.cap_hent * 512))) return rc;
-    c->sb.cap_pieces = (uint32_t)std::min<uint64_t>(2 * slots / std::max(c->hot_min, 64u) + 2 * slots / SEED_DD_PIECE + 16, 1u << 26);
-    if ((rc = dev_alloc(c, &c->sb.pieces, (size_t)c->sb.cap_pieces))) return rc;
-    c->sb_slots = slots;
-  }
-  c->sb.hot_min = c->hot_min;
-  c->sb.nk = nk; c->sb.nkh = nk / 2;
-  c->sb.fb = std::min<uint32_t>(9, P.lnwin); c->sb.nc = nk >> c->sb.fb;       // L <= 20: at most 4096 coarse bins
-  c->sb.cb = 2 * P.partialwin; c->sb.kbits = P.lnwin + 1;
-  return SMR_OK;
-}
-
-// The longest hit list ONE half-seed search can leave: the strings T of pw + 1 chars that lev1_entry (smr_seed.hpp) accepts for a pattern P number
-// at most 31 pw - 20 (104, 135, 166 for pw = 4, 5, 6 over every P; 197 ... 290 for pw = 7 ... 10 on the patterns that reach the maximum and on
-// sampled ones: tests/test_lev_closed_form.py), each at most one id.  k_seed_pg needs no capacity per search (its lists lie back to back in the
-// wave's candidate budget); k_seed_search -- the DFS kernel: overflow redo, exact-counter mode -- has lane-local lists of hcap entries, and its
-// reverse search starts from the forward list (twice the bound).
-#define SEED_HCAP_BOUND(pw) (31u * (pw) - 20u)
-// A list of k_seed_search overflowed: the next size.  4, 8, ... 128, then the bound, then twice the bound, which no search can exceed -- reaching the
-// error below would mean the bound is wrong, not that the data is unusual.  (2 x 290 entries x 64 lanes = 145 KB of the 160 KB of LDS.)
-bool grow_hcap(smr_ctx* c, uint32_t pw) {
-  const uint32_t bound = SEED_HCAP_BOUND(pw);
-  if (c->hcap >= 2 * bound) { set_err(c, "a seed search accepted more strings than the LEV(1) bound allows (internal error)"); return false; }
-  c->hcap = c->hcap < 128 ? c->hcap * 2 : c->hcap < bound ? bound : 2 * bound;
-  return true;
-}
-
-// One sort for several index parts (BASELINE configs[3]: eight --ref; any index cut into parts by -m).  The reference loops (index, part) over the same
-// reads (processor.cpp:219-277), and the tuples of a (strand, pass) are the same for every part -- but for the reads that are in the pass (per-part state:
-// seed_read_active), the keys the part's lookup table has (a missing mini-trie ends a search before it starts) and the value an ambiguous letter reads as,
-// which depends on the read's history in the part (Read::flip34, read.cpp:379-401: the reads with such letters keep a small sort of their own per part).  So
-// the first part of a batch that is not its last builds SIX sorted arrays (2 strands x 3 passes: every read long enough, every window, both directions)
-// and the searches of every part walk them: keys + two sort passes, 4.1 of a stage's 9.2 ms on the eight-reference workload, once instead of eight times.
-// Not with minoccur > 0 (that emit filter needs the part's counts), not in the exact-counter mode, not when a shared array has hot keys (k_seed_dedup
-// rewrites tuples in place, and which of several equal tuples can stand for the others depends on the part's active reads): the per-part sort runs then.
-// k_seed_keys for this batch (reads per wave trip, lanes per read, reads per block) into sb; returns the instantiation
-typedef void (*seed_keys_fn)(DReads, DParams, int, SeedBufs, const RWork*, unsigned long long*, int);
-seed_keys_fn seed_keys_setup(smr_ctx* c, SeedBufs& sb, size_t& lds_keys) {
-  // reads per wave trip (a power of two; their packed records must fit the wave's LDS stage) and lanes per read; reads per block
-  const uint32_t rec_words = (c->b->max_len + 15) / 16 + (c->b->max_len + 31) / 32;
-  const bool staged = rec_words <= SEED_STAGE_WORDS;
-  uint32_t rwr = 64;
-  while (rwr > 1 && (uint64_t)rwr * rec_words > SEED_STAGE_WORDS) rwr >>= 1;
-  uint32_t gsh = 0;
-  while ((64u >> gsh) > rwr) gsh++;
-  sb.g_shift = gsh;
-  const uint32_t per_trip = SEED_WAVES * rwr;
-  const uint32_t trips = std::max<uint32_t>(1u, (uint32_t)(((uint64_t)sb.n + (uint64_t)per_trip * SEED_KEY_BLOCKS - 1) / ((uint64_t)per_trip * SEED_KEY_BLOCKS)));
-  sb.rpb = trips * per_trip;
-  sb.kb = std::max<uint32_t>(1u, (sb.n + sb.rpb - 1) / sb.rpb);
-  const bool mapped = (sb.nkh / 16) * 4 <= 64 * 1024;
-  lds_keys = (size_t)4 * (((sb.nc + 3u) & ~3u) + (mapped ? sb.nkh / 16 : 0u) + (staged ? SEED_WAVES * (SEED_STAGE_WORDS + 8u) : 0u));
-  seed_keys_fn kf;
-  if (gsh == 0) kf = mapped ? k_seed_keys<true, true, true> : k_seed_keys<true, true, false>;
-  else if (staged) kf = mapped ? k_seed_keys<false, true, true> : k_seed_keys<false, true, false>;
-  else kf = mapped ? k_seed_keys<false, false, true> : k_seed_keys<false, false, false>;
-  if (lds_keys > 64 * 1024) (void)hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_keys);
-  return kf;
-}
-
-// tuples of one (strand, pass) -> key order: k_seed_keys (mode: smr_seed.hpp) + the two-level sort, into sb.srt / sb.wbin / sb.cbase / sb.sn
-int seed_sort(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, SeedBufs& sb, int mode) {
-  if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
-  const uint64_t slots = (uint64_t)sb.n * sb.maxwin;
-  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
-  const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_SPLIT_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
-  if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_hbins_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
-  if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
-    c->split_lds_attr = lds_split;
-  }
-  size_t lds_keys;
-  const seed_keys_fn kf = seed_keys_setup(c, sb, lds_keys);
-  ev_mark(c, KP_KEYS);
-  HIPCHK(c, hipMemsetAsync(sb.sn, 0, SN_COUNT * 4, c->stream));
-  if ((mode & 15) != SEED_KEYS_SHARED) hipLaunchKernelGGL(k_seed_emap, dim3((sb.nkh / 16 + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)di.lkc, sb.nkh, P.minoccur, sb.emap);
-  hipLaunchKernelGGL(kf, dim3(sb.kb), dim3(64 * SEED_WAVES), lds_keys, c->stream, dreads(c), P, pass, sb, (const RWork*)c->b->d_rw, c->b->d_ctr, mode);
-  // the two-level sort of the stage's forward and reverse tuples (smr_seed.hpp)
-  ev_mark(c, KP_SPLIT);                                    // (with the scans of the block histograms in front of it)
-  hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
-  hipLaunchKernelGGL(k_seed_wbin, dim3((gw + 255) / 256), dim3(256), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
-  ev_mark(c, KP_BINS);
-  hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
-  // the coarse bins that are far larger than the others, several blocks each (none on evenly spread keys: three empty launches)
-  const uint32_t gh = std::min<uint32_t>(sb.cap_hent, (uint32_t)c->n_cu * 2u);       // (grids that loop: an empty launch should cost a launch, not 2 000 blocks)
-  hipLaunchKernelGGL(k_seed_hbins_hist, dim3(gh), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_hbins_scan, dim3(std::min<uint32_t>(sb.nc, 128u)), dim3(1024), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_hbins_move, dim3(gh), dim3(1024), lds_bins, c->stream, sb);
-  return SMR_OK;
-}
-
-// the searches of one sorted array: forward (dir 0) or reverse launch, the overflow redo, the repeated seeds' windows
-int seed_search(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, const SeedBufs& sb, int dir, uint32_t pool_words, size_t lds, size_t lds_pg) {
-  const uint64_t slots = (uint64_t)sb.n * sb.maxwin;
-  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));
-  const uint32_t gr = std::min<uint32_t>(gw, SEED_REDO_CAP);
-  const uint32_t gp = c->pg_grid ? std::min<uint32_t>((gw + 7u) & ~7u, c->pg_grid) : ((gw + 7u) & ~7u);
-  const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
-  HIPCHK(c, hipMemsetAsync(&sb.sn[SN_REDO], 0, 4, c->stream));
-  if (dir == 0) {
-    hipLaunchKernelGGL(k_seed_pg<0>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
-    hipLaunchKernelGGL(k_seed_search<0>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
-    if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<0>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
-  } else {
-    hipLaunchKernelGGL(k_seed_pg<1>, dim3(gp), dim3(64), lds_pg, c->stream, dindex(di), P, pass, sb, c->ccap, c->d_pool, pool_words, c->b->d_ctr, c->pg_swz);
-    hipLaunchKernelGGL(k_seed_search<1>, dim3(gr), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, (const uint32_t*)sb.redo);
-    if (sb.hot_min) hipLaunchKernelGGL(k_seed_prop<1>, dim3(gd), dim3(256), 0, c->stream, sb, c->b->d_ctr);
-  }
-  return SMR_OK;
-}
-
-// the six shared arrays of the selected batch (see SharedSort); usable = false when a condition above does not hold
-int ensure_shared_sort(smr_ctx* c, const DevIndex& di, const DParams& P) {
-  SharedSort& S = *c->shared;
-  const bool same = S.batch == c->b && S.gen == c->b->gen && S.lnwin == P.lnwin && S.skip[0] == P.skip[0] && S.skip[1] == P.skip[1] && S.skip[2] == P.skip[2] && S.n == c->b->n;
-  if (same) return SMR_OK;
-  S.batch = c->b; S.gen = c->b->gen; S.lnwin = P.lnwin; S.n = c->b->n; S.max_len = c->b->max_len;
-  for (int q = 0; q < 3; q++) S.skip[q] = P.skip[q];
-  S.usable = false;
-  for (int s = 0; s < 2; s++) for (int p = 0; p < 3; p++) S.set[s][p].built = false;
-  const size_t aw = ((size_t)c->b->n + 255) / 256 * 8 + 4;
-  if (S.abits_words < aw) { int rc = dev_alloc(c, &S.abits, aw); if (rc) return rc; S.abits_words = aw; }
-  DParams Q = P; Q.minoccur = 0;
-  for (int p = 0; p < 3; p++) {
-    if (p > 0 && P.skip[p] == P.skip[p - 1]) continue;
-    const uint32_t mw = num_windows(c->b->max_len, P.lnwin, P.skip[p]);
-    const uint64_t cap = 2ull * std::max(c->b->n, 1u) * mw;
-    for (int s = 0; s < 2; s++) {
-      SharedSet& T = S.set[s][p];
-      int rc;
-      if (S.cap[p] < cap || !T.srt) {
-        if ((rc = dev_alloc(c, &T.srt, (size_t)cap)) || (rc = dev_alloc(c, &T.wbin, (size_t)(cap / 64 + 2)))) return rc;
-        if (!T.cbase && ((rc = dev_alloc(c, &T.cbase, (size_t)4096 + 2)) || (rc = dev_alloc(c, &T.sn, (size_t)SN_COUNT)))) return rc;
-      }
-      SeedBufs sb = c->sb;
-      sb.maxwin = T.maxwin = mw; sb.cap_tuples = (uint32_t)cap; sb.n = c->b->n; sb.cap_redo = SEED_REDO_CAP;
-      sb.srt = T.srt; sb.wbin = T.wbin; sb.cbase = T.cbase; sb.sn = T.sn; sb.abits = nullptr;
-      if ((rc = seed_sort(c, di, Q, p, sb, SEED_KEYS_SHARED | (s << 4)))) return rc;
-      T.built = true;
-    }
-    S.cap[p] = std::max(S.cap[p], cap);
-  }
-  ev_stop(c);
-  // a shared array with hot keys: the per-part sort (with k_seed_dedup) serves such a batch better
-  uint32_t hot = 0;
-  for (int s = 0; s < 2; s++) for (int p = 0; p < 3; p++) if (S.set[s][p].built) {
-    uint32_t v = 0;
-    HIPCHK(c, hipMemcpyAsync(&v, S.set[s][p].sn + SN_PIECES, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    hot += v;
-  }
-  S.usable = hot == 0 || c->seed_shared >= 2;
-  c->n_seed_shared_builds++;
-  if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: one seed sort for the parts of this batch: built (%u pieces of hot keys: %s)\n", hot, S.usable ? "in use" : "not used, every part sorts for itself");
-  return SMR_OK;
-}
-
-// the seed stage of one (strand, pass): the forward and reverse half-seed searches of all windows (smr_seed.hpp)
-int launch_seed(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, bool more_parts = false, int strand = -1) {
-  int rc = ensure_seed_bufs(c, P); if (rc) return rc;
-  if (c->b->max_len > 0xFFFFu) { set_err(c, "seed stage limit: reads <= 65535 nt"); return SMR_ERR_CAPACITY; }
-  if ((uint64_t)di.n_ids + di.n_pos >= 0x7FFFFFF0ull) { set_err(c, "seed stage limit: positions + distinct seeds < 2^31 per index part"); return SMR_ERR_CAPACITY; }
-  SeedBufs sb = c->sb;
-  sb.maxwin = num_windows(c->b->max_len, P.lnwin, P.skip[pass]);
-  const uint64_t slots = (uint64_t)c->b->n * sb.maxwin;
-  sb.cap_tuples = (uint32_t)(2 * slots);
-  sb.n = c->b->n;
-  sb.cap_redo = SEED_REDO_CAP;
-  sb.abits = nullptr; sb.inv_maxwin = 1.0 / (double)sb.maxwin;
-  sb.seg_inline = (c->pool_words <= (1ull << 30) && (uint64_t)di.n_ids + di.n_pos < (1ull << 30) && !(getenv("SMR_SEG_INLINE") && atoi(getenv("SMR_SEG_INLINE")) == 0)) ? 1u : 0u;
-  if (c->seed_exact) sb.hot_min = 0;                         // the exact work counters count every window's search
-  const size_t lds = (size_t)SEED_LDS_WORDS(c->hcap) * 4, lds_pg1 = (size_t)PG_LDS_WORDS(c->ccap) * 4;
-  const size_t lds_pg = lds_pg1 + (getenv("SMR_PG_LDS_PAD") ? (size_t)atoi(getenv("SMR_PG_LDS_PAD")) : 0);      // (the variable: occupancy experiments)
-  // lists of more than 128 hits per search (a crafted neighbourhood: SEED_HCAP_MAX) take more than the default 64 KB of dynamic LDS
-  if (lds_pg > 64 * 1024 && lds_pg > c->pg_lds_attr) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_pg<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pg));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_pg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pg));
-    c->pg_lds_attr = lds_pg;
-  }
-  if (lds > 64 * 1024 && lds > c->search_lds_attr) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_search<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_search<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    c->search_lds_attr = lds;
-  }
-  const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->pool_words, 0x7FFFFFF0ull);
-  const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
-  // one sort for several parts?  (strand < 0: smr_seed_scan, the test seam of one (strand, pass) -- always the part's own sort)
-  bool shared = false;
-  if (strand >= 0 && c->seed_shared && !c->seed_exact && P.minoccur == 0 && (more_parts || c->seed_shared >= 2 || (c->shared->usable && c->shared->batch == c->b && c->shared->gen == c->b->gen))) {
-    if ((rc = ensure_shared_sort(c, di, P))) return rc;
-    shared = c->shared->usable && c->shared->set[strand][pass].built;
-  }
-  for (int d = 0; d < 2; d++) HIPCHK(c, hipMemsetAsync(sb.fbits[d], 0, (size_t)(slots / 32 + 2) * 4, c->stream));         // no window has a hit segment yet
-  HIPCHK(c, hipMemsetAsync(sb.zbits, 0, (size_t)(slots / 32 + 2) * 4, c->stream));
-  HIPCHK(c, hipMemsetAsync(sb.gflag, 0, (size_t)(slots / 2048 + 2) * 4, c->stream));
-  // the part's own sort: every read of the (strand, pass) -- or, beside the shared arrays, the reads with ambiguous letters on the reverse strand
-  const bool own = !shared || strand == 1;
-  if (own) {
-    if ((rc = seed_sort(c, di, P, pass, sb, shared ? SEED_KEYS_AMB : SEED_KEYS_ALL))) return rc;
-    const uint32_t gd = std::min<uint32_t>(sb.cap_pieces, (uint32_t)c->n_cu * 8u);
-    if (sb.hot_min) hipLaunchKernelGGL(k_seed_dedup, dim3(gd), dim3(256), 0, c->stream, sb);
-  }
-  SeedBufs sh = sb;                                          // the shared array of this (strand, pass), filtered by the reads that are in the launch
-  if (shared) {
-    const SharedSet& T = c->shared->set[strand][pass];
-    sh.srt = T.srt; sh.wbin = T.wbin; sh.cbase = T.cbase; sh.sn = T.sn; sh.cap_tuples = (uint32_t)std::min<uint64_t>(c->shared->cap[pass], 0xFFFFFFFFull);
-    sh.abits = c->shared->abits; sh.hot_min = 0;
-    c->n_seed_shared++;
-    hipLaunchKernelGGL(k_seed_active, dim3((c->b->n + 255u) / 256u), dim3(256), 0, c->stream, c->b->n, pass, strand == 0 ? 1 : 0, (const RWork*)c->b->d_rw, c->shared->abits);
-  }
-  const uint32_t* no_redo = nullptr;
-  if (c->seed_exact) {
-    ev_mark(c, KP_PG0);
-    hipLaunchKernelGGL(k_seed_search<0>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
-    ev_mark(c, KP_PG1);
-    hipLaunchKernelGGL(k_seed_search<1>, dim3(gw), dim3(64), lds, c->stream, dindex(di), P, pass, sb, c->hcap, c->d_pool, pool_words, c->b->d_ctr, no_redo);
-  } else {
-    // pigeonhole search; the (rare) waves whose candidate pool overflowed are searched again by the DFS kernel
-    for (int dir = 0; dir < 2; dir++) {
-      ev_mark(c, dir ? KP_PG1 : KP_PG0);
-      if (shared && (rc = seed_search(c, di, P, pass, sh, dir, pool_words, lds, lds_pg))) return rc;
-      if (own && (rc = seed_search(c, di, P, pass, sb, dir, pool_words, lds, lds_pg))) return rc;
-    }
-  }
-  if (getenv("SMR_SEED_DEBUG")) {                            // (debug aid: synchronises)
-    uint32_t sn[SN_COUNT], hent = 0, sn2[SN_COUNT] = {0};
-    HIPCHK(c, hipMemcpyAsync(sn, sb.sn, sizeof sn, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&hent, sb.hpre + sb.nc, 4, hipMemcpyDeviceToHost, c->stream));
-    if (shared) HIPCHK(c, hipMemcpyAsync(sn2, sh.sn, sizeof sn2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "libsmr_hip: seed stage pass %d: %u tuples (%u forward), %u sub-ranges of large coarse bins, %u pieces of hot keys (from %u tuples per key), %u redo waves; shared sort %s (%u tuples)\n",
-            pass, sn[SN_TUPLES], sn[SN_FWD], hent, sn[SN_PIECES], sb.hot_min, sn[SN_REDO], shared ? "in use" : "no", sn2[SN_TUPLES]);
-  }
-  ev_mark(c, KP_FINISH);
-  hipLaunchKernelGGL(k_seed_finish, dim3((c->b->n + 255) / 256), dim3(256), 0, c->stream, dreads(c), P, pass, sb, c->b->d_work, c->b->d_rw, c->d_pool, pool_words, c->b->d_ctr);
-  ev_stop(c);
-  HIPCHK(c, hipGetLastError());
-  return SMR_OK;
-}
-
-uint32_t chain_edges(const DParams& P, uint32_t len) { return P.is_as_percent ? (uint32_t)((P.edges / 100.0) * len) + 1 : (uint32_t)std::max(P.edges, 0); }
-// ml / rf: the longest read / reference window of the batch (rounded to 16); rq: the longest window of a read of <= SW_X4_MAX_ROWS letters
-void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, uint32_t& rq, size_t& bytes) {
-  const uint32_t mq_len = std::min<uint32_t>(c->b->max_len, SW_X4_MAX_ROWS);
-  ml = (c->b->max_len + 15) & ~15u;
-  rf = (c->b->max_len + 2 * chain_edges(P, c->b->max_len) + 16 + 15) & ~15u;
-  rq = std::min(rf, (mq_len + 2 * chain_edges(P, mq_len) + 16 + 15) & ~15u);
-  bytes = 5 * (size_t)std::min<uint32_t>(ml, SW_X4_MAX_ROWS) + (size_t)9 * rq + (size_t)CH_KEYS_LDS * 8 + (size_t)std::max<uint32_t>(4u * CH_PAIRS_LDS, 2u * c->chain_scap) * 4 +
-          (size_t)CH_HITS_LDS * 8 + (size_t)(CH_HITS_LDS + 8) * 4 + (size_t)c->chain_scap * 4;
-}
-void chain_lds(const smr_ctx* c, const DParams& P, uint32_t& ml, uint32_t& rf, size_t& bytes) { uint32_t rq; chain_lds(c, P, ml, rf, rq, bytes); }
-// per block: strip-boundary rows of the Smith-Waterman kernels (2 ints per reference column) and the letters of the read being walked
-// (1 byte each) -- only batches with reads of more than one strip
-int ensure_bound(smr_ctx* c, uint32_t blocks, uint32_t rf) {
-  if (c->b->max_len <= SW_X4_MAX_ROWS) return SMR_OK;
-  const size_t need = (size_t)blocks * 2 * rf, need_rd = (size_t)blocks * ((c->b->max_len + 15) & ~15u);
-  if (c->bound_cap < need) { int rc = dev_alloc(c, &c->d_bound, need); if (rc) return rc; c->bound_cap = need; }
-  if (c->rdq_cap < need_rd) { int rc = dev_alloc(c, &c->d_rdq, need_rd); if (rc) return rc; c->rdq_cap = need_rd; }
-  return SMR_OK;
-}
-
-__global__ void k_wstat(const unsigned long long* __restrict__ wctr, unsigned long long* __restrict__ out, uint32_t rounds) {
-  if (threadIdx.x < 32) out[threadIdx.x] = threadIdx.x < rounds ? wctr[(size_t)threadIdx.x * WC_STRIDE + WC_NLIST] : 0ull;
-}
-// After a part (the stream is idle): how many rounds its (strand, pass) launches needed -- the last round that listed more reads than the
-// closing round takes in its stride, + that closing round; when the closing round itself was that full, two more next time.  Whatever the
-// number, the closing round ends every listed read's pass: the records do not depend on it (WALK_VARIANTS of the parity tests).
-int adapt_walk_rounds(smr_ctx* c) {
-  if (c->walk_rounds_fixed || !c->wstat_n || !c->d_wstat) return SMR_OK;
-  unsigned long long h[8 * 32];
-  HIPCHK(c, hipMemcpyAsync(h, c->d_wstat, (size_t)c->wstat_n * 32 * 8, hipMemcpyDeviceToHost, c->stream));       // (on the context's stream, like read_ctr: no other stream is waited for)
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const unsigned long long few = (unsigned long long)c->n_cu * 8ull;
-  uint32_t need[3] = {0, 0, 0};
-  for (uint32_t e = 0; e < c->wstat_n; e++) {
-    uint32_t want = 2;
-    for (uint32_t r = 0; r < c->wstat_rm[e]; r++) if (h[e * 32 + r] > few) want = r + 2 + (r + 1 == c->wstat_rm[e] ? 2u : 0u);
-    need[c->wstat_pass[e]] = std::max(need[c->wstat_pass[e]], want);
-  }
-  // more rounds at once; fewer by half the difference per part (parts of one run differ: eight databases, batches of a mixed sample)
-  for (int p = 0; p < 3; p++) if (need[p]) {
-    const uint32_t prev = c->walk_need[p] ? c->walk_need[p] : c->walk_rounds;
-    c->walk_need[p] = std::min(c->walk_rounds, need[p] >= prev ? need[p] : prev - std::max(1u, (prev - need[p]) / 2u));
-  }
-  c->wstat_n = 0;
-  return SMR_OK;
-}
-
-int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int is_last_strand) {
-  uint32_t ml, rf, rq; size_t lds;
-  chain_lds(c, P, ml, rf, rq, lds);
-  HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
-  if (lds > 64 * 1024 && lds > c->chain_lds_attr) {     // reads beyond ~5.6 kb: more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_chain<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    c->chain_lds_attr = lds;
-  }
-  uint32_t blocks = std::min<uint32_t>(c->chain_blocks, std::max(c->b->n, 1u));
-  { int rc = ensure_bound(c, c->chain_blocks, rf); if (rc) return rc; }
-  int* const gb = c->b->max_len > SW_X4_MAX_ROWS ? c->d_bound : nullptr;
-  uint8_t* const grd = c->b->max_len > SW_X4_MAX_ROWS ? c->d_rdq : nullptr;
-  if (c->handover) {
-    // CAND_REC_WORDS words per read of the batch, one slice per block of k_cand
-    const size_t want_w = (size_t)((c->b->n + 15u) / 16u) * 16u * CAND_REC_WORDS;
-    if (c->mrec_cap < c->b->n) { int rc = dev_alloc(c, &c->d_mrec, (size_t)c->b->n); if (rc) return rc; c->mrec_cap = c->b->n; }
-    if (c->mpool_words < want_w) { int rc = dev_alloc(c, &c->d_mpool, want_w); if (rc) return rc; c->mpool_words = want_w; }
-  }
-  uint2* const mrec = c->handover ? c->d_mrec : nullptr;
-  // the split path takes the marked reads with a record of k_cand whose Smith-Waterman problems fit the packed kernels
-  const uint32_t wmq = std::min<uint32_t>(c->b->max_len, WK_MAX_ROWS), wml = (wmq + 15) & ~15u;
-  const bool split = c->walk_split && mrec && P.sw_mode >= 1 && sw_pk_fits((int)wmq, (int)rq, P.match, P.mismatch, P.score_N, P.gap_open);
-  const uint32_t RMX = c->walk_rounds, WK = c->walk_k;         // RMX: what d_wctr is laid out for; RM: the rounds of this launch
-  const uint32_t RM = (!c->walk_rounds_fixed && c->walk_need[pass]) ? std::min(RMX, c->walk_need[pass]) : RMX;
-  if (split) {
-    const size_t n = c->b->n;
-    if (c->walk_cap < n || c->walk_kcap < WK) {
-      for (int q = 0; q < 2; q++) {
-        int rc;
-        if ((rc = dev_alloc(c, &c->d_wlist[q], n)) || (rc = dev_alloc(c, &c->d_wstate[q], n)) || (rc = dev_alloc(c, &c->d_wtask[q], n * WK)) || (rc = dev_alloc(c, &c->d_wres[q], n * WK))) return rc;
-      }
-      int rc;
-      if ((rc = dev_alloc(c, &c->d_wtidx, 2 * n * WK)) || (rc = dev_alloc(c, &c->d_wslow, n))) return rc;
-      c->walk_cap = n; c->walk_kcap = WK;
-    }
-    if (c->walk_rcap < RMX) { int rc = dev_alloc(c, &c->d_wctr, (size_t)(RMX + 2) * WC_STRIDE); if (rc) return rc; if ((rc = dev_alloc(c, &c->d_wstat, (size_t)8 * 32))) return rc; c->walk_rcap = RMX; }
-    HIPCHK(c, hipMemsetAsync(c->d_wctr, 0, (size_t)(RMX + 2) * WC_STRIDE * 8, c->stream));
-    const size_t lds_w = (size_t)wml + rq;
-    if (lds_w > 64 * 1024 && lds_w > c->walk_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w)); c->walk_lds_attr = lds_w; }
-  }
-  const size_t n_tix = (size_t)c->walk_cap * c->walk_kcap;     // the second half of d_wtidx: the score-only tasks
-  unsigned long long* const n_slow = split ? c->d_wctr + (size_t)(RMX + 1) * WC_STRIDE : nullptr;
-  ev_mark(c, KP_CAND);
-  // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
-  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
-                     mrec, c->d_mpool, c->mpool_words);
-  if (split) {
-    // rounds of walk -> Smith-Waterman -> next list (smr_walk.hpp); the last round scores in the walk kernel, so every listed read ends its pass here
-    ev_mark(c, KP_WNEXT);
-    hipLaunchKernelGGL(k_wlist, dim3((c->b->n + 1023u) / 1024u), dim3(1024), 0, c->stream, dreads(c), c->b->d_marks, (const uint2*)mrec, (uint32_t)WK_MAX_ROWS, c->d_wlist[0], c->d_wslow, c->d_wctr, n_slow, getenv("SMR_WALK_DEBUG") ? n_slow + 8 : (unsigned long long*)nullptr, (P.num_seeds >= 2 && c->walk_gather) ? 1 : 0);
-    const int swr = wmq <= 104 ? 13 : wmq <= 152 ? 19 : wmq <= 208 ? 26 : 32;
-    const uint32_t walk_blocks = (uint32_t)c->n_cu * 4u * SMR_WALK_WAVES_PER_SIMD, sw_blocks = (uint32_t)c->n_cu * 4u * (uint32_t)SW16_WAVES(swr);
-    for (uint32_t rnd = 0; rnd < RM; rnd++) {
-      const int cur = (int)(rnd & 1u), prv = cur ^ 1;
-      unsigned long long* const wc = c->d_wctr + (size_t)rnd * WC_STRIDE;
-      const bool fin = rnd + 1 == RM;
-      ev_mark(c, KP_WALK);
-#define WALK_ARGS dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->b->d_ctr, (const uint2*)mrec, (const uint32_t*)c->d_mpool, (const uint32_t*)c->d_pool, (const uint2*)c->d_wlist[cur], \
-                  (const WState*)c->d_wstate[prv], (const WTask*)c->d_wtask[prv], (const uint2*)c->d_wres[prv], c->d_wstate[cur], c->d_wtask[cur], c->d_wtidx, c->d_wtidx + n_tix, wc, WK, (unsigned long long)n_tix, (int)rnd, wml, rq, c->walk_assume
-      if (fin) hipLaunchKernelGGL(k_walk<true>, dim3(walk_blocks * 3u / SMR_WALK_WAVES_PER_SIMD), dim3(64), (size_t)wml + rq, c->stream, WALK_ARGS);
-      else {
-        hipLaunchKernelGGL(k_walk<false>, dim3(walk_blocks), dim3(64), 0, c->stream, WALK_ARGS);
-        ev_mark(c, KP_SW16);
-#define SW16_ARGS dreads(c), dindex(di), P, (const WTask*)c->d_wtask[cur], (const uint32_t*)c->d_wtidx, (const uint32_t*)(c->d_wtidx + n_tix), (const unsigned long long*)wc, c->d_wres[cur]
-        if (swr == 13) hipLaunchKernelGGL(k_sw16<13>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
-        else if (swr == 19) hipLaunchKernelGGL(k_sw16<19>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
-        else if (swr == 26) hipLaunchKernelGGL(k_sw16<26>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
-        else hipLaunchKernelGGL(k_sw16<32>, dim3(sw_blocks), dim3(64), 0, c->stream, SW16_ARGS);
-#undef SW16_ARGS
-        ev_mark(c, KP_WNEXT);
-        hipLaunchKernelGGL(k_wnext, dim3((uint32_t)c->n_cu * 2u), dim3(1024), 0, c->stream, P, is_last_strand, c->b->d_work, c->b->d_rw, c->b->d_ctr, (const uint2*)c->d_wlist[cur], (const WState*)c->d_wstate[cur],
-                           (const uint2*)c->d_wres[cur], c->d_wlist[prv], (const unsigned long long*)wc, wc + WC_STRIDE, WK, (unsigned long long)n_tix, (int)rnd);
-      }
-#undef WALK_ARGS
-    }
-    if (!c->walk_rounds_fixed && c->wstat_n < 8) {         // the reads listed per round, kept for adapt_walk_rounds
-      hipLaunchKernelGGL(k_wstat, dim3(1), dim3(32), 0, c->stream, (const unsigned long long*)c->d_wctr, c->d_wstat + (size_t)c->wstat_n * 32, RM);
-      c->wstat_pass[c->wstat_n] = pass; c->wstat_rm[c->wstat_n] = RM; c->wstat_n++;
-    }
-    if (getenv("SMR_WALK_DEBUG")) {                         // measurement aid: reads listed and tasks left per round, reads left to k_chain
-      std::vector<unsigned long long> h((size_t)(RMX + 2) * WC_STRIDE);
-      HIPCHK(c, hipMemcpyAsync(h.data(), c->d_wctr, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      { const unsigned long long* q = &h[(size_t)(RMX + 1) * WC_STRIDE];
-        fprintf(stderr, "libsmr_hip: walk rounds (pass %d): slow %llu (positions <= 64 / 128 / 256 / 512 / more / > 64 hits: %llu %llu %llu %llu %llu %llu);", pass, q[0], q[8], q[9], q[10], q[11], q[12], q[13]); }
-      for (uint32_t rnd = 0; rnd < RM; rnd++) fprintf(stderr, " %llu/%llu+%llu", h[(size_t)rnd * WC_STRIDE + WC_NLIST], h[(size_t)rnd * WC_STRIDE + WC_NTASK], h[(size_t)rnd * WC_STRIDE + WC_NTASK2]);
-      fprintf(stderr, "\n");
-    }
-  }
-  ev_mark(c, KP_CHAIN);
-#define CHAIN_ARGS(stab, t2) dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_work_aln, c->b->d_rw, c->d_pool, c->b->d_ctr, c->d_tuples, c->d_keys, c->d_pairs, \
-                             c->d_lis, c->d_hits, c->keys_cap, c->pairs_cap, c->hits_cap, ml, rf, c->chain_scap, stab, t2, rq, gb, grd, c->b->d_marks, (const uint2*)mrec, (const uint32_t*)c->d_mpool, \
-                             (const uint32_t*)(split ? c->d_wslow : nullptr), (const unsigned long long*)n_slow
-  // (LONG: the batch has reads of more than one Smith-Waterman strip; the short-read instantiation carries none of their state)
-  const bool striped = P.sw_mode < 0;                        // (the slow path that reproduces ssw.c's stripe geometry: instantiations of its own)
-  if (striped) {
-    if (gb) hipLaunchKernelGGL((k_chain<false, true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
-    else hipLaunchKernelGGL((k_chain<false, false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
-  } else
-  if (gb) hipLaunchKernelGGL((k_chain<false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
-  else hipLaunchKernelGGL((k_chain<false, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->chain_ext ? c->d_stab : nullptr, c->chain_ext ? c->d_tuples2 : nullptr));
-  if (c->chain_ext) {
-    // the reads whose candidate set outgrew the LDS table of the first launch: same walk, set in the block's global table
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_WORK_NEXT], 0, 8, c->stream));
-    if (striped) {
-      if (gb) hipLaunchKernelGGL((k_chain<true, true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
-      else hipLaunchKernelGGL((k_chain<true, false, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
-    } else
-    if (gb) hipLaunchKernelGGL((k_chain<true, true>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
-    else hipLaunchKernelGGL((k_chain<true, false>), dim3(blocks), dim3(64), lds, c->stream, CHAIN_ARGS(c->d_stab, c->d_tuples2));
-  }
-#undef CHAIN_ARGS
-  ev_stop(c);
-  HIPCHK(c, hipGetLastError());
-  return SMR_OK;
-}
-
-// fold the sharded work counters into their base slots (and clear the shards, so the vector can be written back);
-// C_POOL_CURSOR becomes the largest shard cursor
-void fold_shards(std::vector<unsigned long long>& h) {
-  for (int s = 0; s < C_NSHARD; s++)
-    for (int k = 0; k < C_SHARD_W; k++) {
-      if (k < C_SHARD_X) h[C_WINDOWS + k] += h[C_SHARDS + C_SHARD_W * s + k];
-      else if (k < C_SHARD_X + C_SHARD_NX) h[C_TUP_F + k - C_SHARD_X] += h[C_SHARDS + C_SHARD_W * s + k];
-      h[C_SHARDS + C_SHARD_W * s + k] = 0;
-    }
-  unsigned long long mx = 0;
-  for (int s = 0; s < C_NSHARD; s++) mx = std::max(mx, h[C_PCUR + s * C_PCUR_STRIDE]);
-  h[C_POOL_CURSOR] = mx;
-}
-
-int read_ctr(smr_ctx* c, std::vector<unsigned long long>& h) {
-  h.resize(C_TOTAL);
-  HIPCHK(c, hipMemcpyAsync(h.data(), c->b->d_ctr, C_TOTAL * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  fold_shards(h);
-  return SMR_OK;
-}
-
+#include "smr_engine_seed.hpp"
+#include "smr_engine_chain.hpp"
 }  // namespace
 
 
 // =================================================================================================
 // Device index build (kernels in smr_ibuild.hpp)
 // =================================================================================================
-namespace {
-struct DevPool {                         // device buffers of one build; freed together
-  std::vector<void*> ptrs;
-  ~DevPool() { for (void* p : ptrs) (void)hipFree(p); }
-  template <class T> T* get(smr_ctx* c, size_t count) {
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) { set_err(c, "hipMalloc failed in the index build"); return nullptr; }
-    ptrs.push_back(p);
-    return (T*)p;
-  }
-};
-#define IB_GET(var, type, count) type* var = pool.get<type>(c, (count)); if (!var) return SMR_ERR_DEVICE
+#include "smr_engine_ibuild.hpp"
 
-template <class T> int dev_scan(smr_ctx* c, DevPool& pool, const T* in, T* out, uint64_t n, T* total) {
-  const uint64_t tiles = (n + 2047) / 2048;
-  if (n == 0) { if (total) *total = 0; return SMR_OK; }
-  IB_GET(sums, T, tiles);
-  hipLaunchKernelGGL(smr::k_scan_tile<T>, dim3((uint32_t)tiles), dim3(256), 0, c->stream, in, out, sums, (smr::u64)n);
-  if (tiles == 1) {
-    if (total) { HIPCHK(c, hipMemcpyAsync(total, sums, sizeof(T), hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
-    return SMR_OK;
-  }
-  IB_GET(pre, T, tiles);
-  int rc = dev_scan<T>(c, pool, sums, pre, tiles, total);
-  if (rc) return rc;
-  hipLaunchKernelGGL(smr::k_scan_add<T>, dim3((uint32_t)tiles), dim3(256), 0, c->stream, out, (const T*)pre, (smr::u64)n);
-  return SMR_OK;
-}
-
-// stable LSD radix sort of bits [lo, hi) ; the sorted data end up in ka / va (the buffers are swapped as needed)
-int dev_radix_sort(smr_ctx* c, DevPool& pool, smr::u64*& ka, smr::u64*& kb, uint32_t*& va, uint32_t*& vb, uint64_t n, int lo, int hi) {
-  if (n == 0) return SMR_OK;
-  const uint32_t tiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-  IB_GET(hist, uint32_t, (size_t)256 * tiles);
-  IB_GET(offs, uint32_t, (size_t)256 * tiles);
-  for (int shift = lo; shift < hi; shift += 8) {
-    hipLaunchKernelGGL(smr::k_rs_hist, dim3(tiles), dim3(64), 0, c->stream, (const smr::u64*)ka, (smr::u64)n, shift, hist, tiles);
-    int rc = dev_scan<uint32_t>(c, pool, hist, offs, (uint64_t)256 * tiles, nullptr);
-    if (rc) return rc;
-    hipLaunchKernelGGL(smr::k_rs_scatter, dim3(tiles), dim3(64), 0, c->stream, (const smr::u64*)ka, (const uint32_t*)va, kb, vb, (smr::u64)n, shift, (const uint32_t*)offs, tiles);
-    std::swap(ka, kb); std::swap(va, vb);
-  }
-  return SMR_OK;
-}
-
-int ib_part_device(void* user, const smr::IBuildInput& in, smr_index& ix, std::string& why) {
-  smr_ctx* c = (smr_ctx*)user;
-  auto fail = [&](int rc) { why = c->err; return rc; };
-  (void)hipSetDevice(c->device);
-  DevPool pool;
-  const uint32_t L = in.L, P = L / 2, W = L + 1, T = P + 1, NK = 1u << L;
-  std::vector<uint64_t> occ_start((size_t)in.n_seqs + 1, 0);
-  for (size_t m = 0; m < in.n_seqs; m++) occ_start[m + 1] = occ_start[m] + (in.seq_off[m + 1] - in.seq_off[m] - W + 1);
-  const uint64_t N = occ_start.back();
-  int occbits = 1; while ((1ull << occbits) < N) occbits++;
-  if ((int)(2 * L) + occbits > 64 || N >= 0xFFFFFFF0ull) { why = "part too large for the builder (reduce -m)"; return SMR_ERR_ARG; }
-  auto run = [&]() -> int {
-    const uint64_t ncodes = in.seq_off[in.n_seqs];
-    IB_GET(d_codes, uint8_t, ncodes + 1);
-    IB_GET(d_seq_off, smr::u64, (size_t)in.n_seqs + 1);
-    IB_GET(d_occ_start, smr::u64, (size_t)in.n_seqs + 1);
-    HIPCHK(c, hipMemcpyAsync(d_codes, in.codes, ncodes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_seq_off, in.seq_off, ((size_t)in.n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_occ_start, occ_start.data(), ((size_t)in.n_seqs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    smr::IBuildDev B; B.codes = d_codes; B.seq_off = d_seq_off; B.occ_start = d_occ_start; B.n_seqs = in.n_seqs;
-    B.L = L; B.P = P; B.W = W; B.T = T; B.occbits = (uint32_t)occbits; B.max_pos = in.max_pos; B.N = N;
-    const uint32_t gN = (uint32_t)((N + 255) / 256);
-    IB_GET(k0, smr::u64, N); IB_GET(k1, smr::u64, N);
-    IB_GET(d_last, uint8_t, N);
-    hipLaunchKernelGGL(smr::k_ib_keys, dim3(gN), dim3(256), 0, c->stream, B, k0, d_last);
-    uint32_t* nov = nullptr; uint32_t* nov2 = nullptr;
-    int rc = dev_radix_sort(c, pool, k0, k1, nov, nov2, N, occbits, occbits + 2 * (int)L);
-    if (rc) return rc;
-    // ids and groups
-    IB_GET(d_flag, uint32_t, N); IB_GET(d_excl, uint32_t, N);
-    hipLaunchKernelGGL(smr::k_ib_flags, dim3(gN), dim3(256), 0, c->stream, (const smr::u64*)k0, (smr::u64)N, (uint32_t)occbits, d_flag);
-    uint32_t n_ids = 0;
-    rc = dev_scan<uint32_t>(c, pool, d_flag, d_excl, N, &n_ids);
-    if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    IB_GET(d_gstart, uint32_t, (size_t)n_ids + 1); IB_GET(d_present, uint32_t, (size_t)n_ids + 1);
-    HIPCHK(c, hipMemsetAsync(d_present, 0, ((size_t)n_ids + 1) * 4, c->stream));
-    const uint32_t N32 = (uint32_t)N;
-    HIPCHK(c, hipMemcpyAsync(d_gstart + n_ids, &N32, 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(smr::k_ib_groups, dim3(gN), dim3(256), 0, c->stream, (const smr::u64*)k0, (const uint8_t*)d_last, (const uint32_t*)d_flag, (const uint32_t*)d_excl,
-                       (smr::u64)N, (uint32_t)occbits, d_gstart, d_present);
-    const uint32_t gI = (n_ids + 255) / 256;
-    IB_GET(d_pcount, uint32_t, (size_t)n_ids + 1); IB_GET(d_ecount, uint32_t, (size_t)n_ids + 1);
-    IB_GET(d_pos_off, uint32_t, (size_t)n_ids + 1); IB_GET(d_ent_off, uint32_t, (size_t)n_ids + 1);
-    HIPCHK(c, hipMemsetAsync(d_pcount + n_ids, 0, 4, c->stream)); HIPCHK(c, hipMemsetAsync(d_ecount + n_ids, 0, 4, c->stream));
-    hipLaunchKernelGGL(smr::k_ib_counts, dim3(gI), dim3(256), 0, c->stream, (const uint32_t*)d_gstart, (const uint32_t*)d_present, n_ids, in.max_pos, d_pcount, d_ecount);
-    uint32_t n_pos = 0, M = 0;
-    rc = dev_scan<uint32_t>(c, pool, d_pcount, d_pos_off, (uint64_t)n_ids + 1, &n_pos); if (rc) return rc;
-    rc = dev_scan<uint32_t>(c, pool, d_ecount, d_ent_off, (uint64_t)n_ids + 1, &M); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    IB_GET(d_pos_arr, uint32_t, (size_t)2 * n_pos);
-    hipLaunchKernelGGL(smr::k_ib_positions, dim3(gN), dim3(256), 0, c->stream, B, (const smr::u64*)k0, (const uint32_t*)d_flag, (const uint32_t*)d_excl,
-                       (const uint32_t*)d_gstart, (const uint32_t*)d_pcount, (const uint32_t*)d_pos_off, d_pos_arr);
-    // entries
-    IB_GET(d_fkey, uint32_t, M); IB_GET(d_ftail, smr::u64, M); IB_GET(d_rtail, smr::u64, M);
-    IB_GET(r0, smr::u64, M); IB_GET(r1, smr::u64, M); IB_GET(rv0, uint32_t, M); IB_GET(rv1, uint32_t, M);
-    hipLaunchKernelGGL(smr::k_ib_entries, dim3(gI), dim3(256), 0, c->stream, B, (const smr::u64*)k0, (const uint32_t*)d_gstart, (const uint32_t*)d_present,
-                       (const uint32_t*)d_ent_off, n_ids, d_fkey, d_ftail, r0, rv0);
-    rc = dev_radix_sort(c, pool, r0, r1, rv0, rv1, M, 0, 2 * (int)(P + T));
-    if (rc) return rc;
-    IB_GET(d_cntF, uint32_t, (size_t)NK + 1); IB_GET(d_cntR, uint32_t, (size_t)NK + 1);
-    IB_GET(d_fstart, uint32_t, (size_t)NK + 1); IB_GET(d_rstart, uint32_t, (size_t)NK + 1);
-    HIPCHK(c, hipMemsetAsync(d_cntF, 0, ((size_t)NK + 1) * 4, c->stream)); HIPCHK(c, hipMemsetAsync(d_cntR, 0, ((size_t)NK + 1) * 4, c->stream));
-    hipLaunchKernelGGL(smr::k_ib_rfinal, dim3((M + 255) / 256), dim3(256), 0, c->stream, (const smr::u64*)r0, (const uint32_t*)rv0, M, 2 * T, d_rtail, d_cntR,
-                       (const uint32_t*)d_fkey, d_cntF);
-    rc = dev_scan<uint32_t>(c, pool, d_cntF, d_fstart, (uint64_t)NK + 1, nullptr); if (rc) return rc;
-    rc = dev_scan<uint32_t>(c, pool, d_cntR, d_rstart, (uint64_t)NK + 1, nullptr); if (rc) return rc;
-    // mini-tries
-    const int burst_depth = (int)(W - P - 3);
-    IB_GET(d_size, smr::u64, (size_t)2 * NK + 1); IB_GET(d_toff, smr::u64, (size_t)2 * NK + 1);
-    IB_GET(d_nodes, uint32_t, (size_t)2 * NK); IB_GET(d_buckets, uint32_t, (size_t)2 * NK); IB_GET(d_status, uint32_t, 1);
-    HIPCHK(c, hipMemsetAsync(d_status, 0, 4, c->stream)); HIPCHK(c, hipMemsetAsync(d_size + 2 * (size_t)NK, 0, 8, c->stream));
-    const uint32_t gT = (2 * NK + 255) / 256;
-    hipLaunchKernelGGL(smr::k_ib_sizes, dim3(gT), dim3(256), 0, c->stream, (const smr::u64*)d_ftail, (const smr::u64*)d_rtail, (const uint32_t*)d_fstart, (const uint32_t*)d_rstart,
-                       NK, (int)T, burst_depth, d_size, d_nodes, d_buckets, d_status);
-    smr::u64 words = 0;
-    rc = dev_scan<smr::u64>(c, pool, d_size, d_toff, (uint64_t)2 * NK + 1, &words); if (rc) return rc;
-    uint32_t status = 0;
-    HIPCHK(c, hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (status != smr::TRIE_OK) { set_err(c, status == smr::TRIE_ERR_BUCKET ? "bucket with more than 255 entries" : "mini-trie larger than 2^22 words"); return SMR_ERR_IO; }
-    if (words > 0xFFFFFFF0ull) { set_err(c, "trie arena exceeds 2^32 words"); return SMR_ERR_IO; }
-    IB_GET(d_trie, uint32_t, words); IB_GET(d_lookup, smr::Lookup, NK);
-    hipLaunchKernelGGL(smr::k_ib_emit, dim3(gT), dim3(256), 0, c->stream, (const smr::u64*)d_ftail, (const smr::u64*)d_rtail, (const uint32_t*)d_fstart, (const uint32_t*)d_rstart,
-                       NK, (int)T, burst_depth, (const smr::u64*)d_toff, d_trie, d_lookup);
-    // back to the host object
-    reserve_huge(ix.trie, words); reserve_huge(ix.pos_arr, (size_t)2 * n_pos);      // (2 MB pages for the two GB-sized arrays that the copies below fill)
-    ix.lookup.resize(NK); ix.trie.resize(words); ix.pos_off.resize((size_t)n_ids + 1); ix.pos_arr.resize((size_t)2 * n_pos);
-    std::vector<uint32_t> hn((size_t)2 * NK), hb((size_t)2 * NK);
-    HIPCHK(c, hipMemcpyAsync(ix.lookup.data(), d_lookup, (size_t)NK * sizeof(smr::Lookup), hipMemcpyDeviceToHost, c->stream));
-    if (words) HIPCHK(c, hipMemcpyAsync(ix.trie.data(), d_trie, (size_t)words * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ix.pos_off.data(), d_pos_off, ((size_t)n_ids + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    if (n_pos) HIPCHK(c, hipMemcpyAsync(ix.pos_arr.data(), d_pos_arr, (size_t)2 * n_pos * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hn.data(), d_nodes, hn.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hb.data(), d_buckets, hb.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i < hn.size(); i++) { ix.n_nodes += hn[i]; ix.n_buckets += hb[i]; }
-    ix.n_entries += 2ull * M;
-    return SMR_OK;
-  };
-  const int rc = run();
-  if (rc != SMR_OK) return fail(rc);
-  return SMR_OK;
-}
-}  // namespace
-
-extern "C" int smr_index_build_gpu(smr_ctx* c, const char* ref_fasta, uint32_t L, double max_mb, uint32_t max_pos,
-                                   smr_index** parts_out, uint32_t cap_parts, uint32_t* n_parts_out, char* err, size_t errcap) {
-  if (!c) return SMR_ERR_ARG;
-  return smr_index_build_with(ref_fasta, L, max_mb, max_pos, 0, ib_part_device, c, parts_out, cap_parts, n_parts_out, err, errcap);
-}
-
-// =================================================================================================
-// Device self-check of the packed Smith-Waterman kernel against the 32-bit one (both on the GPU): one wave per case, seeded
-// pseudo-random read (1..max_m nt, ~1.5 % N) against either a mutated copy of it with substitutions and indels or a random
-// sequence; forward pass and the reverse-direction pass on the prefixes ending in the forward end cell, like k_chain's two calls.
-__device__ __forceinline__ uint32_t sc_hash(uint32_t a, uint32_t b, uint32_t c) {
-  uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (c + 0x165667B1u) * 0xC2B2AE35u;
-  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
-  return h;
-}
-__global__ void __launch_bounds__(64) k_sw_selfcheck(uint32_t n_cases, uint32_t seed, uint32_t max_m, uint32_t lds_m, uint32_t lds_n,
-                                                     int match, int mismatch, int scoreN, int go, int ge, int mode_b, unsigned long long* out) {
-  SMR_DYN_LDS(unsigned char, lds_raw);
-  uint8_t* rdq = lds_raw;
-  uint8_t* rfq = rdq + lds_m;
-  int* bound = (int*)(rfq + lds_n);
-  __shared__ int s_n;
-  const int lane = smr::lane_id();
-  for (uint32_t cs = blockIdx.x; cs < n_cases; cs += gridDim.x) {
-    const uint32_t hm = sc_hash(seed, cs, 1);
-    const int m = 1 + (int)(hm % max_m);
-    for (int q = lane; q < m; q += 64) { const uint32_t h = sc_hash(seed, cs, 100u + (uint32_t)q); rdq[q] = (h & 63u) == 0 ? 4 : (uint8_t)((h >> 8) & 3u); }
-    __syncthreads();
-    if (lane == 0) {
-      int n = 0;
-      const bool homolog = (hm >> 20) & 3u;                       // 3 of 4 cases: a mutated copy (with a random flank), else unrelated
-      const int flank = (int)((hm >> 24) & 15u);
-      for (int q = 0; q < flank; q++) rfq[n++] = (uint8_t)(sc_hash(seed, cs, 5000u + (uint32_t)q) & 3u);
-      for (int q = 0; q < m && n + 2 < (int)lds_n; q++) {
-        const uint32_t h = sc_hash(seed, cs, 9000u + (uint32_t)q);
-        if (!homolog) { rfq[n++] = (uint8_t)(h & 3u); continue; }
-        const uint32_t ev = (h >> 4) & 63u;
-        if (ev == 0) continue;                                      // deletion in the reference
-        if (ev == 1) rfq[n++] = (uint8_t)((h >> 12) & 3u);          // insertion
-        if (ev == 2) { rfq[n++] = 4; continue; }                    // N in the reference
-        rfq[n++] = ev < 6 ? (uint8_t)((h >> 16) & 3u) : (rdq[q] == 4 ? (uint8_t)0 : rdq[q]);
-      }
-      for (int q = 0; q < flank && n + 1 < (int)lds_n; q++) rfq[n++] = (uint8_t)(sc_hash(seed, cs, 7000u + (uint32_t)q) & 3u);
-      s_n = n;
-    }
-    __syncthreads();
-    const int n = s_n;
-    const smr::SwRes a0 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, 0);
-    __syncthreads();
-    const smr::SwRes a1 = smr::sw_wave(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, mode_b);
-    __syncthreads();
-    bool bad = a0.score != a1.score || a0.end_ref != a1.end_ref || a0.end_read != a1.end_read;
-    if (a0.score > 0 && a0.end_ref >= 0) {
-      const smr::SwRes b0 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, 0);
-      __syncthreads();
-      const smr::SwRes b1 = smr::sw_wave(rdq, a0.end_read + 1, a0.end_read, -1, rfq, a0.end_ref + 1, a0.end_ref, -1, bound, match, mismatch, scoreN, go, ge, mode_b);
-      __syncthreads();
-      bad = bad || b0.score != b1.score || b0.end_ref != b1.end_ref || b0.end_read != b1.end_read;
-    }
-    if (lane == 0) { atomicAdd(&out[0], 1ull); if (bad) atomicAdd(&out[1], 1ull); atomicAdd(&out[2], (unsigned long long)a0.score); }
-    __syncthreads();
-  }
-}
-
-extern "C" int smr_sw_selfcheck(smr_ctx* c, uint32_t n_cases, uint32_t seed, uint32_t max_len, uint64_t* n_bad) {
-  if (!c || !n_bad || max_len == 0 || max_len > 4000) return SMR_ERR_ARG;
-  (void)hipSetDevice(c->device);
-  DevPool pool;
-  IB_GET(d, unsigned long long, 3);
-  HIPCHK(c, hipMemsetAsync(d, 0, 3 * 8, c->stream));
-  const uint32_t lm = (max_len + 15) & ~15u, ln = (max_len + max_len / 16 + 64 + 15) & ~15u;
-  const size_t lds = (size_t)lm + ln + (size_t)2 * ln * 4;
-  const int sc[2][3] = {{2, -3, -3}, {5, -4, -4}};
-  for (int k = 0; k < 2 && n_cases; k++)
-    hipLaunchKernelGGL(k_sw_selfcheck, dim3(std::min<uint32_t>(n_cases, (uint32_t)c->n_cu * 8u)), dim3(64), lds, c->stream, n_cases, seed + 7919u * (uint32_t)k, max_len, lm, ln,
-                       sc[k][0], sc[k][1], sc[k][2], 5, 2, std::max(c->sw_mode, 1), d);
-  unsigned long long h[3] = {0, 0, 0};
-  HIPCHK(c, hipMemcpyAsync(h, d, 3 * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (h[0] != 2ull * n_cases) { set_err(c, "SW self-check did not run all cases"); return SMR_ERR_DEVICE; }
-  *n_bad = h[1];
-  return SMR_OK;
-}
-
-
-// =================================================================================================
-// Batched Smith-Waterman at the ssw.h seam (SURVEY.md 8b "existing C ABI"): what k_chain does per candidate -- ssw_align(prof, ref,
-// refLen, gapO, gapE, flag = 2, filters, 0, 0) (ssw.c:834-941) without the CIGAR -- for n independent (read, reference window) pairs,
-// one wave per pair.  A unit-test surface for the SW kernels against the reference's own ssw.c (tests/golden/ssw_pairs.json).
-// =================================================================================================
-template <bool STRIPED>
-__global__ void __launch_bounds__(64) k_ssw_batch(uint32_t n_pairs, const uint8_t* __restrict__ reads, const unsigned long long* __restrict__ read_off,
-                                                  const uint8_t* __restrict__ refs, const unsigned long long* __restrict__ ref_off, uint32_t lds_m, uint32_t lds_n,
-                                                  int match, int mismatch, int scoreN, int go, int ge, uint32_t filters, int mode, int* __restrict__ out, uint16_t* scr_all, uint32_t scr_stride) {
-  SMR_DYN_LDS(unsigned char, lds_raw);
-  uint8_t* rdq = lds_raw;
-  uint8_t* rfq = rdq + lds_m;
-  int* bound = (int*)(rfq + lds_n);
-  uint16_t* scr = scr_all ? scr_all + (size_t)blockIdx.x * scr_stride : nullptr;      // (mode < 0: the striped slow path)
-  const int lane = smr::lane_id();
-  for (uint32_t pi = blockIdx.x; pi < n_pairs; pi += gridDim.x) {
-    const int m = (int)(read_off[pi + 1] - read_off[pi]), n = (int)(ref_off[pi + 1] - ref_off[pi]);
-    for (int q = lane; q < m; q += 64) rdq[q] = reads[read_off[pi] + q];
-    for (int q = lane; q < n; q += 64) rfq[q] = refs[ref_off[pi] + q];
-    __syncthreads();
-    int res[5] = {0, -1, -1, -1, m - 1};          // score1, ref_begin1, ref_end1, read_begin1, read_end1
-    if (m > 0 && n > 0) {
-      const smr::SwRes fw = smr::sw_wave_t<STRIPED>(rdq, m, 0, 1, rfq, n, 0, 1, bound, match, mismatch, scoreN, go, ge, mode, 0, 0, scr);
-      __syncthreads();
-      res[0] = fw.score > 65535 ? 65535 : fw.score; res[2] = fw.end_ref; res[4] = fw.end_read;
-      if ((uint32_t)res[0] >= filters && fw.score > 0) {
-        const smr::SwRes bw = smr::sw_wave_t<STRIPED>(rdq, fw.end_read + 1, fw.end_read, -1, rfq, fw.end_ref + 1, fw.end_ref, -1, bound, match, mismatch, scoreN, go, ge, mode, res[0], fw.word, scr);
-        __syncthreads();
-        res[1] = fw.end_ref - bw.end_ref; res[3] = fw.end_read - bw.end_read;
-      }
-    }
-    if (lane < 5) out[(size_t)pi * 5 + lane] = res[lane];
-    __syncthreads();
-  }
-}
-
-// the same through the four-problems-per-wave kernel (sw_wave_x4): row g of the wave takes pair 4 b + g; forward pass, then the reverse
-// pass of the rows whose score passed the filter (the others idle)
-__global__ void __launch_bounds__(64) k_ssw_batch_x4(uint32_t n_pairs, const uint8_t* __restrict__ reads, const unsigned long long* __restrict__ read_off,
-                                                     const uint8_t* __restrict__ refs, const unsigned long long* __restrict__ ref_off, uint32_t lds_m, uint32_t lds_n,
-                                                     int match, int mismatch, int scoreN, int go, int ge, uint32_t filters, int* __restrict__ out) {
-  SMR_DYN_LDS(unsigned char, lds_raw);
-  const int lane = smr::lane_id(), g = lane >> 4, gl = lane & 15;
-  uint8_t* rdq = lds_raw + (size_t)g * lds_m;
-  uint8_t* rfq = lds_raw + (size_t)4 * lds_m + (size_t)g * lds_n;
-  for (uint32_t p0 = blockIdx.x * 4; p0 < n_pairs; p0 += gridDim.x * 4) {
-    const uint32_t pi = p0 + g;
-    const bool have = pi < n_pairs;
-    int m = have ? (int)(read_off[pi + 1] - read_off[pi]) : 0, n = have ? (int)(ref_off[pi + 1] - ref_off[pi]) : 0;
-    if (n == 0) m = 0;
-    __syncthreads();
-    bool hasn = false;
-    for (int q = gl; q < m; q += 16) rdq[q] = reads[read_off[pi] + q];
-    for (int q = gl; q < n; q += 16) { const uint8_t ch = refs[ref_off[pi] + q]; rfq[q] = ch; hasn |= ch == 4; }
-    __syncthreads();
-    int mm = m;
-    for (int d = 32; d > 0; d >>= 1) mm = max(mm, __shfl_xor(mm, d, 64));
-    const bool hn = __any(hasn);
-    int res[5] = {0, -1, -1, -1, m - 1};
-    const smr::SwRes fw = smr::sw_wave_x4(rdq, m, 0, 1, rfq, n, 0, 1, match, mismatch, scoreN, go, ge, mm, hn);
-    res[0] = fw.score > 65535 ? 65535 : fw.score; res[2] = fw.end_ref; res[4] = fw.end_read;
-    const bool rev = m > 0 && (uint32_t)res[0] >= filters && fw.score > 0;
-    const smr::SwRes bw = smr::sw_wave_x4(rdq, rev ? fw.end_read + 1 : 0, fw.end_read, -1, rfq, rev ? fw.end_ref + 1 : 0, fw.end_ref, -1, match, mismatch, scoreN, go, ge, mm, hn);
-    if (rev) { res[1] = fw.end_ref - bw.end_ref; res[3] = fw.end_read - bw.end_read; }
-    if (have && gl < 5) out[(size_t)pi * 5 + gl] = res[gl];
-  }
-}
-
-extern "C" int smr_ssw_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
-                             int match, int mismatch, int score_N, int gap_open, int gap_ext, uint32_t filters, int mode, int32_t* out) {
-  if (!c || !read_off || !ref_off || !out || mode < 0 || mode > 4) return SMR_ERR_ARG;
-  // (modes 0 - 3 are the fast kernels: only under the schemes whose answers they share with ssw.c; mode 4 = the striped slow path, any scheme)
-  if (mode != 4) if (const char* why = scheme_unsupported(mismatch, score_N, gap_open, gap_ext)) { set_err(c, why); return SMR_ERR_ARG; }
-  if (n_pairs == 0) return SMR_OK;
-  (void)hipSetDevice(c->device);
-  uint64_t mx_m = 1, mx_n = 1;
-  for (uint32_t i = 0; i < n_pairs; i++) { mx_m = std::max(mx_m, read_off[i + 1] - read_off[i]); mx_n = std::max(mx_n, ref_off[i + 1] - ref_off[i]); }
-  const uint32_t lm = (uint32_t)((mx_m + 15) & ~15ull), ln = (uint32_t)((mx_n + 15) & ~15ull);
-  const size_t lds = (size_t)lm + ln + (size_t)2 * ln * 4;
-  if (lds > 60 * 1024) { set_err(c, "smr_ssw_batch: sequences too long for one LDS tile (read + 9 x reference window <= 60 KB)"); return SMR_ERR_CAPACITY; }
-  DevPool pool;
-  IB_GET(d_reads, uint8_t, read_off[n_pairs] + 1); IB_GET(d_refs, uint8_t, ref_off[n_pairs] + 1);
-  IB_GET(d_ro, unsigned long long, (size_t)n_pairs + 1); IB_GET(d_fo, unsigned long long, (size_t)n_pairs + 1);
-  IB_GET(d_out, int, (size_t)n_pairs * 5);
-  if (read_off[n_pairs]) HIPCHK(c, hipMemcpyAsync(d_reads, reads, read_off[n_pairs], hipMemcpyHostToDevice, c->stream));
-  if (ref_off[n_pairs]) HIPCHK(c, hipMemcpyAsync(d_refs, refs, ref_off[n_pairs], hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_ro, read_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(d_fo, ref_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-  if (mode == 3) {          // four pairs per wave (the kernel k_chain batches candidate windows with): spans up to SW_X4_MAX_ROWS, numbers within the packed range
-    for (uint32_t i = 0; i < n_pairs; i++) {
-      const uint64_t m = read_off[i + 1] - read_off[i], n = ref_off[i + 1] - ref_off[i];
-      if (m > SW_X4_MAX_ROWS || !((long long)m * match + 255 < 32768 && n + 128 <= 8191 && gap_open + mismatch >= 0 && gap_open + score_N >= 0 && match + gap_open <= 255 && score_N + gap_open <= 255)) {
-        set_err(c, "smr_ssw_batch mode 3: a pair is outside the range of the four-problem kernel"); return SMR_ERR_ARG;
-      }
-    }
-    hipLaunchKernelGGL(k_ssw_batch_x4, dim3(std::min<uint32_t>((n_pairs + 3) / 4, (uint32_t)c->n_cu * 8u)), dim3(64), (size_t)4 * (lm + ln), c->stream, n_pairs, (const uint8_t*)d_reads,
-                       (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, d_out);
-  } else
-  {
-    const uint32_t gb = std::min<uint32_t>(n_pairs, (uint32_t)c->n_cu * 8u), stride = 5u * 16u * ((uint32_t)(mx_m + 7) / 8u + 1u);
-    uint16_t* d_scr = nullptr;
-    if (mode == 4) { IB_GET(d_scr_, uint16_t, (size_t)gb * stride); d_scr = d_scr_; }
-    if (mode == 4) hipLaunchKernelGGL(k_ssw_batch<true>, dim3(gb), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
-                       (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, -1, d_out, d_scr, stride);
-    else hipLaunchKernelGGL(k_ssw_batch<false>, dim3(gb), dim3(64), lds, c->stream, n_pairs, (const uint8_t*)d_reads,
-                       (const unsigned long long*)d_ro, (const uint8_t*)d_refs, (const unsigned long long*)d_fo, lm, ln, match, mismatch, score_N, gap_open, gap_ext, filters, mode, d_out, d_scr, stride);
-  }
-  HIPCHK(c, hipMemcpyAsync(out, d_out, (size_t)n_pairs * 5 * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return SMR_OK;
-}
-
-extern "C" int smr_sw_mode(smr_ctx* c, int set_to) {      // set_to: 0 / 1 = select, anything else = query only; returns the mode in use
-  if (!c) return SMR_ERR_ARG;
-  if (set_to >= 0 && set_to <= 2) c->sw_mode = set_to;
-  return c->sw_mode;
-}
-
-// rounds the candidate walk of the next part runs per pass (smr_walk.hpp; adapts to what the previous part needed unless SMR_WALK_ROUNDS fixes it)
-extern "C" int smr_walk_rounds(const smr_ctx* c, uint32_t out[3]) {
-  if (!c || !out) return SMR_ERR_ARG;
-  for (int p = 0; p < 3; p++) out[p] = (!c->walk_rounds_fixed && c->walk_need[p]) ? std::min(c->walk_rounds, c->walk_need[p]) : c->walk_rounds;
-  return SMR_OK;
-}
+#include "smr_engine_swseam.hpp"
 
 // =================================================================================================
 extern "C" int smr_device_count(void) {
@@ -1621,219 +795,7 @@ extern "C" int smr_align_part(smr_ctx* c, int slot, const smr_params* p) {
   return SMR_ERR_CAPACITY;
 }
 
-// collect alignments of (index_num, part) that still need a CIGAR
-__global__ void k_trace_collect(uint32_t n, uint32_t slots, const RState* __restrict__ saved, const AlignRec* __restrict__ aln, uint32_t index_num, uint32_t part,
-                                uint32_t* __restrict__ tasks, unsigned long long* __restrict__ ctr) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool take = false;
-  if (i < n * slots) {
-    uint32_t r = i / slots, k = i % slots;
-    if (k < saved[r].n_align) { const AlignRec& a = aln[i]; take = !(a.has_cigar || a.index_num != index_num || a.part != part); }
-  }
-  const uint32_t o = block_append(&ctr[C_TRACE_NEXT], take);
-  if (take) tasks[o] = i;
-}
-
-// CIGARs for every stored alignment of the selected batch that lacks one and belongs to (p->index_num, p->part), whose reference sequences are di's
-static int traceback_core(smr_ctx* c, const DevIndex& di, const smr_params* p) {
-  int rc;
-  ev_drop(c);
-  DParams P = make_dparams(c, di, p);
-  c->b->fetched = false;
-  const uint64_t ntot = (uint64_t)c->b->n * c->b->slots;
-  if (c->tasks_cap < ntot) { if ((rc = dev_alloc(c, &c->d_tasks, 2 * ntot))) return rc; c->tasks_cap = ntot; }     // two lists: in / handed on
-  if (c->b->cigar_words == 0) {
-    c->b->cigar_words = std::max<uint64_t>(ntot * 16, 1u << 20);
-    if (const char* e = getenv("SMR_CIGAR_POOL_WORDS")) c->b->cigar_words = std::max<uint64_t>(strtoull(e, nullptr, 10), 16);   // debugging aid: start small, exercise the regrow
-    if ((rc = dev_alloc(c, &c->b->d_cigar, c->b->cigar_words))) return rc;
-  }
-  uint32_t ml, rf; size_t chain_bytes;
-  chain_lds(c, P, ml, rf, chain_bytes);                    // ml / rf: the longest read / reference window an alignment can span (edges as k_chain takes them)
-  const uint32_t row_pairs = c->b->max_len / 2 + 1;
-  std::vector<unsigned long long> h;
-  uint32_t* t_in = c->d_tasks; uint32_t* t_out = c->d_tasks + ntot;
-  auto before = [&]() -> int {
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_ERR_CIGAR], 0, 16, c->stream));     // C_ERR_CIGAR, C_ERR_TRACE
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_TRACE_DEFER], 0, 8, c->stream));
-    ev_mark(c, KP_TRACE);
-    return SMR_OK;
-  };
-  // after a kernel: 0 = all done, 1 = tasks were handed on (n_tasks updated), 2 = the CIGAR pool was too small (grown; start over), < 0 = error
-  auto after = [&](uint32_t& n_tasks) -> int {
-    ev_stop(c);
-    HIPCHK(c, hipGetLastError());
-    int r2 = read_ctr(c, h); if (r2) return r2;
-    ev_collect(c);
-    if (h[C_ERR_TRACE]) { set_err(c, "banded traceback left the band for some alignments (internal error)"); return SMR_ERR_CAPACITY; }
-    if (h[C_ERR_CIGAR]) {
-      // grow the CIGAR pool, keeping what is already there; the failed claims moved the cursor past the end: back to the old capacity
-      const uint64_t w = c->b->cigar_words * 2; uint32_t* nw = nullptr;
-      if (w > 0xFFFFFFF0ull) { set_err(c, "CIGAR pool exceeds 2^32 words"); return SMR_ERR_CAPACITY; }
-      HIPCHK(c, hipMalloc((void**)&nw, w * 4));
-      HIPCHK(c, hipMemcpy(nw, c->b->d_cigar, c->b->cigar_words * 4, hipMemcpyDeviceToDevice));
-      (void)hipFree(c->b->d_cigar); c->b->d_cigar = nw;
-      const unsigned long long cur = std::min<unsigned long long>(h[C_CIGAR_CURSOR], c->b->cigar_words);
-      c->b->cigar_words = w;
-      HIPCHK(c, hipMemcpy(&c->b->d_ctr[C_CIGAR_CURSOR], &cur, 8, hipMemcpyHostToDevice));
-      return 2;
-    }
-    n_tasks = (uint32_t)h[C_TRACE_DEFER];
-    std::swap(t_in, t_out);
-    return n_tasks ? 1 : 0;
-  };
-  for (int attempt = 0; attempt < 40; attempt++) {
-    t_in = c->d_tasks; t_out = c->d_tasks + ntot;
-    HIPCHK(c, hipMemsetAsync(&c->b->d_ctr[C_TRACE_NEXT], 0, 8, c->stream));
-    hipLaunchKernelGGL(k_trace_collect, dim3((uint32_t)((ntot + 1023) / 1024)), dim3(1024), 0, c->stream, c->b->n, c->b->slots, c->b->d_saved, c->b->d_saved_aln, P.index_num, P.part, t_in, c->b->d_ctr);
-    if ((rc = read_ctr(c, h))) return rc;
-    uint32_t n_tasks = (uint32_t)h[C_TRACE_NEXT];
-    if (n_tasks == 0) return SMR_OK;
-    const uint32_t pool_words = (uint32_t)std::min<uint64_t>(c->b->cigar_words, 0xFFFFFFF0ull);
-    int st = 1;
-    // narrow kernels: 8 then 16 lanes per alignment (bands <= 3, <= 7), everything in LDS
-    for (int G = 8; G <= 16 && st == 1; G *= 2) {
-      const uint32_t ng = 64u / (uint32_t)G;
-      const size_t lds = (size_t)row_pairs * 64 + (size_t)ng * (ml + rf) + (size_t)ng * TR_CIG_STAGE * 4;
-      if (lds > 64 * 1024) break;
-      const uint32_t blocks = std::min<uint32_t>((n_tasks + ng - 1) / ng, (uint32_t)c->n_cu * 16u);
-      if ((rc = before())) return rc;
-      if (G == 8) hipLaunchKernelGGL(k_trace_band<8>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, (const uint32_t*)t_in, n_tasks, c->b->d_saved_aln,
-                                     c->b->d_cigar, pool_words, c->b->d_ctr, t_out, ml, rf, row_pairs);
-      else hipLaunchKernelGGL(k_trace_band<16>, dim3(blocks), dim3(64), lds, c->stream, dreads(c), dindex(di), P, (const uint32_t*)t_in, n_tasks, c->b->d_saved_aln,
-                              c->b->d_cigar, pool_words, c->b->d_ctr, t_out, ml, rf, row_pairs);
-      st = after(n_tasks);
-    }
-    // wide kernel: one wave per alignment, band caps growing level by level up to a band that covers the whole window
-    const uint32_t max_band = 2 * std::max(ml, rf);
-    const uint32_t level_band[4] = {31u, 255u, 2047u, max_band};
-    for (int level = 0; level < 4 && st == 1; level++) {
-      if (level > 0 && level_band[level - 1] >= max_band) break;
-      const uint32_t band = std::min(level_band[level], max_band);
-      const uint32_t wcap = (2 * band + 1 + 63) & ~63u;
-      const bool rows_lds = (size_t)wcap * 8 + TR_CIG_STAGE * 4 <= 64 * 1024 && !getenv("SMR_TRACE_GLOBAL_ROWS");     // (the variable: debugging aid, forces the wide-band variant)
-      const uint64_t flags_cap = (uint64_t)std::max(c->b->max_len, 1u) * (wcap / 2);
-      const uint64_t per_block = flags_cap + (rows_lds ? 0 : (uint64_t)wcap * 8);
-      // (measured on 5 kb reads, k_trace per 50 000-read step: 8 blocks per CU 762 ms; 16: 496; 32: 459: the kernel lives on waves in flight, profiles/r4s10_*)
-      static const int tw_bpc = getenv("SMR_TRACE_BPC") ? atoi(getenv("SMR_TRACE_BPC")) : 32;
-      // (the tiles take at most 16 GiB and at most a quarter of what is free on the device now: with many resident batches and index parts, or on a
-      // smaller device, fewer blocks run instead of the allocation failing)
-      size_t mem_free = 0, mem_total = 0;
-      if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = (size_t)16 << 30;
-      const uint64_t budget = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(c->trflags_bytes, (uint64_t)mem_free / 4));
-      uint32_t blocks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(budget / per_block, 1), (uint64_t)c->n_cu * tw_bpc);
-      blocks = std::min(blocks, n_tasks);
-      const size_t lds_tw = (size_t)TR_CIG_STAGE * 4 + (rows_lds ? (size_t)wcap * 8 : 0);
-      if (c->trflags_bytes < (uint64_t)blocks * flags_cap) { if ((rc = dev_alloc(c, &c->d_trflags, (size_t)blocks * flags_cap))) return rc; c->trflags_bytes = (uint64_t)blocks * flags_cap; }
-      if (!rows_lds && c->trrows_ints < (uint64_t)blocks * 2 * wcap) { if ((rc = dev_alloc(c, &c->d_trrows, (size_t)blocks * 2 * wcap))) return rc; c->trrows_ints = (uint64_t)blocks * 2 * wcap; }
-      if ((rc = before())) return rc;
-      if (rows_lds) hipLaunchKernelGGL(k_trace_wide<true>, dim3(blocks), dim3(64), lds_tw, c->stream, dreads(c), dindex(di), P, (const uint32_t*)t_in, n_tasks,
-                                       c->b->d_saved_aln, c->b->d_cigar, pool_words, c->b->d_ctr, t_out, (int)band, c->d_trflags, (unsigned long long)flags_cap, c->d_trrows, wcap);
-      else hipLaunchKernelGGL(k_trace_wide<false>, dim3(blocks), dim3(64), lds_tw, c->stream, dreads(c), dindex(di), P, (const uint32_t*)t_in, n_tasks,
-                              c->b->d_saved_aln, c->b->d_cigar, pool_words, c->b->d_ctr, t_out, (int)band, c->d_trflags, (unsigned long long)flags_cap, c->d_trrows, wcap);
-      st = after(n_tasks);
-    }
-    if (st < 0) return st;
-    if (st == 0) return SMR_OK;
-    if (st == 1) { set_err(c, "banded traceback did not reach the alignment score within the widest band (internal error)"); return SMR_ERR_CAPACITY; }
-  }
-  set_err(c, "CIGAR pool regrow attempts exhausted");
-  return SMR_ERR_CAPACITY;
-}
-
-extern "C" int smr_traceback(smr_ctx* c, int slot, const smr_params* p) {
-  if (!c || slot < 0 || slot >= 64) return SMR_ERR_ARG;
-  if (!c->idx[slot].used || !c->b->d_saved) { set_err(c, "index slot empty or no reads uploaded"); return SMR_ERR_STATE; }
-  HIPCHK(c, hipSetDevice(c->device));
-  int rc = check_params(c, p); if (rc) return rc;
-  if (c->b->n == 0) return SMR_OK;
-  return traceback_core(c, c->idx[slot], p);
-}
-
-// The traceback kernels at the ssw.h seam: for n independent (read window, reference window, score) triples what banded_sw returns
-// (ssw.c:577-773, called from ssw_align :919-926 with band |refLen - readLen| + 1): a throw-away batch / reference set is put on the
-// device, with one stored alignment per pair spanning both windows, and goes through the same host logic and kernels as smr_traceback.
-extern "C" int smr_cigar_batch(smr_ctx* c, uint32_t n_pairs, const uint8_t* reads, const uint64_t* read_off, const uint8_t* refs, const uint64_t* ref_off,
-                               const uint16_t* scores, int match, int mismatch, int score_N, int gap_open, int gap_ext,
-                               uint32_t* cigar_out, uint64_t cigar_cap, uint64_t* cigar_off_out) {
-  if (!c || !read_off || !ref_off || !scores || !cigar_off_out) return SMR_ERR_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
-  cigar_off_out[0] = 0;
-  if (n_pairs == 0) return SMR_OK;
-  smr_params p; smr_params_default(&p);
-  p.match = match; p.mismatch = mismatch; p.score_N = score_N; p.gap_open = gap_open; p.gap_ext = gap_ext; p.edges = 0;
-  Batch* keep = c->b;
-  Batch tmp;
-  DevIndex di;
-  std::vector<uint32_t> words, lens(n_pairs);
-  std::vector<uint64_t> rec_off((size_t)n_pairs + 1, 0);
-  std::vector<RState> st(n_pairs);
-  std::vector<AlignRec> al(n_pairs);
-  uint32_t max_len = 1; uint64_t max_ref = 1;
-  for (uint32_t i = 0; i < n_pairs; i++) {
-    const uint64_t m = read_off[i + 1] - read_off[i], n = ref_off[i + 1] - ref_off[i];
-    if (m == 0 || n == 0 || m > 0xFFFFu) { set_err(c, "smr_cigar_batch: empty or oversized pair"); return SMR_ERR_ARG; }
-    const uint32_t cw = (uint32_t)((m + 15) >> 4), mw = (uint32_t)((m + 31) >> 5);
-    rec_off[i] = words.size();
-    words.resize(words.size() + cw + mw, 0u);
-    uint32_t* rec = words.data() + rec_off[i];
-    for (uint64_t q = 0; q < m; q++) {
-      const uint8_t ch = reads[read_off[i] + q];
-      if (ch > 3) rec[cw + (q >> 5)] |= 1u << (q & 31); else rec[q >> 4] |= (uint32_t)ch << ((q & 15) * 2);
-    }
-    lens[i] = (uint32_t)m; max_len = std::max(max_len, (uint32_t)m); max_ref = std::max(max_ref, n);
-    memset(&st[i], 0, sizeof(RState)); st[i].n_align = 1; st[i].is_hit = 1;
-    memset(&al[i], 0, sizeof(AlignRec));
-    al[i].ref_num = i; al[i].ref_begin1 = 0; al[i].ref_end1 = (int32_t)n - 1; al[i].read_begin1 = 0; al[i].read_end1 = (int32_t)m - 1;
-    al[i].readlen = (uint32_t)m; al[i].score1 = scores[i]; al[i].strand = 1;
-  }
-  rec_off[n_pairs] = words.size();
-  p.edges = (int32_t)std::min<uint64_t>(max_ref > max_len ? (max_ref - max_len + 1) / 2 : 0, 0x3FFFFFFF);   // so that the LDS window bound covers the longest reference window
-  tmp.n = n_pairs; tmp.max_len = max_len; tmp.slots = 1; tmp.used = true;
-  int rc = SMR_OK;
-  auto run = [&]() -> int {
-    int r2;
-    c->b = &tmp;
-    if ((r2 = dev_alloc(c, &tmp.d_words, words.size() + 4))) return r2;
-    if ((r2 = dev_alloc(c, &tmp.d_rec_off, rec_off.size()))) return r2;
-    if ((r2 = dev_alloc(c, &tmp.d_len, lens.size()))) return r2;
-    if ((r2 = dev_alloc(c, &tmp.d_saved, (size_t)n_pairs))) return r2;
-    if ((r2 = dev_alloc(c, &tmp.d_saved_aln, (size_t)n_pairs))) return r2;
-    if ((r2 = dev_alloc(c, &tmp.d_ctr, (size_t)C_TOTAL))) return r2;
-    if ((r2 = dev_alloc(c, &di.ref_seq, (size_t)ref_off[n_pairs] + 64))) return r2;
-    if ((r2 = dev_alloc(c, &di.ref_off, (size_t)n_pairs + 1))) return r2;
-    HIPCHK(c, hipMemcpyAsync(tmp.d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tmp.d_rec_off, rec_off.data(), rec_off.size() * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tmp.d_len, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tmp.d_saved, st.data(), st.size() * sizeof(RState), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tmp.d_saved_aln, al.data(), al.size() * sizeof(AlignRec), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(tmp.d_ctr, 0, C_TOTAL * 8, c->stream));
-    HIPCHK(c, hipMemcpyAsync(di.ref_seq, refs, (size_t)ref_off[n_pairs], hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(di.ref_off, ref_off, ((size_t)n_pairs + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    di.n_refs = n_pairs; di.lnwin = 18; di.used = true;
-    if ((r2 = check_params(c, &p, false))) return r2;
-    if ((r2 = traceback_core(c, di, &p))) return r2;
-    std::vector<unsigned long long> h;
-    if ((r2 = read_ctr(c, h))) return r2;
-    std::vector<uint32_t> pool((size_t)std::min<uint64_t>(h[C_CIGAR_CURSOR], tmp.cigar_words));
-    HIPCHK(c, hipMemcpyAsync(al.data(), tmp.d_saved_aln, al.size() * sizeof(AlignRec), hipMemcpyDeviceToHost, c->stream));
-    if (!pool.empty()) HIPCHK(c, hipMemcpyAsync(pool.data(), tmp.d_cigar, pool.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint64_t o = 0;
-    for (uint32_t i = 0; i < n_pairs; i++) {
-      if (!al[i].has_cigar) { set_err(c, "smr_cigar_batch: an alignment was left without a CIGAR"); return SMR_ERR_STATE; }
-      for (uint32_t q = 0; q < al[i].cigar_len; q++, o++) if (cigar_out && o < cigar_cap) cigar_out[o] = pool[(size_t)al[i].cigar_off + q];
-      cigar_off_out[i + 1] = o;
-    }
-    return SMR_OK;
-  };
-  rc = run();
-  (void)hipStreamSynchronize(c->stream);
-  c->b = keep;
-  dev_free(&tmp.d_words); dev_free(&tmp.d_rec_off); dev_free(&tmp.d_len); dev_free(&tmp.d_saved); dev_free(&tmp.d_saved_aln); dev_free(&tmp.d_ctr); dev_free(&tmp.d_cigar);
-  dev_free(&di.ref_seq); dev_free(&di.ref_off);
-  return rc;
-}
-
+#include "smr_engine_trace.hpp"
 extern "C" int smr_counters(smr_ctx* c, uint64_t* out, uint32_t n_db) {
   if (!c || !out) return SMR_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->device));

@@ -527,7 +527,7 @@ extern "C" int smr_index_selfcheck(smr_index* ix, char* err, size_t errcap) {
         uint64_t prev = 0;
         for (uint32_t i = 0; i < n; i++) {
           const uint32_t T = Ts[i], r = Rs[2 * i];
-          if (r >= n || seen[r] || a[r].str != T || a[r].id != Rs[2 * i + 1]) { set_err(err, errcap, "pigeonhole layout: entries differ" + at); return SMR_ERR_STATE; }
+          if (r >= n || seen[r] || a[r].str != T || ix->pos_off[a[r].id] + a[r].id != Rs[2 * i + 1]) { set_err(err, errcap, "pigeonhole layout: entries differ" + at); return SMR_ERR_STATE; }      // (the layout's ids are the places of the seeds' position lists: pos_off[id] + id)
           seen[r] = 1;
           if (!cA) { if (r != i) { set_err(err, errcap, "pigeonhole layout: scan block not in DFS order" + at); return SMR_ERR_STATE; } continue; }
           const uint64_t key = o ? pg_key(T, h, pw - h) : pg_key(T, 0, pw + 1);

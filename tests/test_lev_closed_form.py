@@ -214,7 +214,7 @@ def _accepted_per_pattern(Ps, pw):
 
 @pytest.mark.parametrize("pw", [4, 5, 6, 7, 8, 9, 10])
 def test_a_search_accepts_at_most_31_pw_minus_20_strings(pw):
-    """What bounds a search's hit list (SEED_HCAP_BOUND in smr_engine.hip): every accepted string is one entry of the mini-trie = at most one id.
+    """What bounds a search's hit list (SEED_HCAP_BOUND in smr_engine_seed.hpp): every accepted string is one entry of the mini-trie = at most one id.
     Exhaustive over P for pw <= 6; for the longer seeds the patterns without equal neighbours (they reach the maximum) + random ones."""
     import os
     import re
@@ -230,5 +230,5 @@ def test_a_search_accepts_at_most_31_pw_minus_20_strings(pw):
         pats += [int(x) for x in rng.integers(0, 4 ** pw, 6 if pw == 10 else 10)]
         c = np.concatenate([_accepted_per_pattern(pats[i:i + 2], pw) for i in range(0, len(pats), 2)])
         assert int(c.max()) == bound
-    src = open(os.path.join(paths.REPO, "sortmerna_amd", "csrc", "smr_engine.hip")).read()
+    src = open(os.path.join(paths.REPO, "sortmerna_amd", "csrc", "smr_engine_seed.hpp")).read()
     assert re.search(r"#define SEED_HCAP_BOUND\(pw\) \(31u \* \(pw\) - 20u\)", src)
