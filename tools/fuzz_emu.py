@@ -95,7 +95,11 @@ def main():
             env = {}
             for name, vals in (("SMR_WALK_ROUNDS", [None, None, "1", "2", "3"]), ("SMR_WALK_K", [None, None, "1", "2", "8"]), ("SMR_WALK_ASSUME", [None, None, "0", "100"]),
                                ("SMR_WALK_SPLIT", [None, None, None, "0"]), ("SMR_HANDOVER", [None, None, None, "0"]), ("SMR_CAND_BLOOM", [None, None, None, "64"]),
-                               ("SMR_PG_CAND_CAP", [None, None, None, "8"]), ("SMR_WALK_GATHER", [None, None, None, "0"])):
+                               ("SMR_PG_CAND_CAP", [None, None, None, "8"]), ("SMR_WALK_GATHER", [None, None, None, "0"]),
+                               # round 6: repeated seeds searched once / large bins sorted by several blocks at thresholds of a test's size, one seed sort for all parts
+                               # forced or off, single-hit windows with a segment after all
+                               ("SMR_SEED_DEDUP", [None, None, "2", "16", "0"]), ("SMR_SEED_HOT_BIN", [None, None, "64"]), ("SMR_SEED_HOT_SUB", [None, None, "200"]),
+                               ("SMR_SEED_SHARED", [None, None, "2", "0"]), ("SMR_SEG_INLINE", [None, None, None, "0"])):
                 v = vals[int(rng.integers(0, len(vals)))]
                 os.environ.pop(name, None)
                 if v is not None:
