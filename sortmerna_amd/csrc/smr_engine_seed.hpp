@@ -170,8 +170,16 @@ int ensure_shared_sort(smr_ctx* c, const DevIndex& di, const DParams& P) {
       SharedSet& T = S.set[s][p];
       int rc;
       if (S.cap[p] < cap || !T.srt) {
-        if ((rc = dev_alloc(c, &T.srt, (size_t)cap)) || (rc = dev_alloc(c, &T.wbin, (size_t)(cap / 64 + 2)))) return rc;
-        if (!T.cbase && ((rc = dev_alloc(c, &T.cbase, (size_t)4096 + 2)) || (rc = dev_alloc(c, &T.sn, (size_t)SN_COUNT)))) return rc;
+        if ((rc = dev_alloc(c, &T.srt, (size_t)cap)) || (rc = dev_alloc(c, &T.wbin, (size_t)(cap / 64 + 2))) ||
+            (!T.cbase && ((rc = dev_alloc(c, &T.cbase, (size_t)4096 + 2)) || (rc = dev_alloc(c, &T.sn, (size_t)SN_COUNT))))) {
+          // no room for the six arrays (17 GB at 8 M reads; several contexts on one device): every part sorts for itself, as without the option
+          (void)hipGetLastError();
+          for (int s2 = 0; s2 < 2; s2++) for (int p2 = 0; p2 < 3; p2++) { SharedSet& U = S.set[s2][p2]; dev_free(&U.srt); dev_free(&U.wbin); U.built = false; }
+          for (int p2 = 0; p2 < 3; p2++) S.cap[p2] = 0;
+          c->seed_shared = 0;
+          if (getenv("SMR_VERBOSE")) fprintf(stderr, "libsmr_hip: no device memory for the shared seed sort: every index part sorts for itself\n");
+          return SMR_OK;
+        }
       }
       SeedBufs sb = c->sb;
       sb.maxwin = T.maxwin = mw; sb.cap_tuples = (uint32_t)cap; sb.n = c->b->n; sb.cap_redo = SEED_REDO_CAP;
