@@ -15,15 +15,39 @@ from helpers import emu
 from helpers.workload import Workload
 
 from test_gpu_parity import (test_seed_scan_matches_oracle, test_multi_part_index, test_longer_reads, test_empty_batch,  # noqa: F401
-                             test_seed_work_counters_match_oracle, test_batch_dominated_by_one_sequence, test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed, test_one_seed_sort_for_the_parts_and_references_of_a_batch, test_pigeonhole_seed_kernel_equals_the_dfs_kernel, test_small_candidate_pool_is_redone_and_grows,
+                             test_seed_work_counters_match_oracle, test_batch_dominated_by_one_sequence, test_pigeonhole_seed_kernel_equals_the_dfs_kernel, test_small_candidate_pool_is_redone_and_grows,
                              test_percent_edges_on_kilobase_reads, test_mixed_read_lengths, test_reads_sharing_seeds_with_thousands_of_references,
                              test_optional_paths_of_the_candidate_stage_give_the_oracle_records, test_pigeonhole_search_bytes_equal_a_host_recount,
                              test_a_window_with_hundreds_of_hits, test_rounds_adapt_from_part_to_part_without_changing_a_record,
-                             test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_give_the_oracle_records, test_edges_outside_what_the_reference_defines_are_refused)
+                             test_edges_outside_what_the_reference_defines_are_refused)
 from test_gpu_parity import test_align_records_match_oracle as _align_body
 from test_gpu_golden import test_gpu_records_equal_reference_records as _golden_body
 
 FULL = os.environ.get("SMR_EMU_FULL", "0") == "1"
+# round 6's paths: every variant with SMR_EMU_FULL=1 (and in the -m gpu suite), a slice of them by default (the CPU suite has a time budget)
+from test_gpu_parity import (test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed as _skew_body, SKEW_VARIANTS,      # noqa: E402
+                             test_one_seed_sort_for_the_parts_and_references_of_a_batch as _shared_body,
+                             test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_give_the_oracle_records as _striped_body)
+
+
+@pytest.mark.parametrize("env,mode", [(e, m) for e in SKEW_VARIANTS for m in (0, 1)] if FULL else [(SKEW_VARIANTS[0], 0), (SKEW_VARIANTS[2], 0), (SKEW_VARIANTS[1], 1)],
+                         ids=lambda v: ",".join("%s=%s" % (k.replace("SMR_SEED_", ""), x) for k, x in v.items()) if isinstance(v, dict) else ("dfs" if v else "pg"))
+def test_skewed_batch_sorted_by_several_blocks_and_searched_once_per_seed(tmp_path, monkeypatch, env, mode):
+    _skew_body(tmp_path, monkeypatch, env, mode)
+
+
+@pytest.mark.parametrize("mode", ["1", "0"] if FULL else ["1"], ids=lambda m: "shared" if m == "1" else "per-part")
+def test_one_seed_sort_for_the_parts_and_references_of_a_batch(tmp_path, monkeypatch, mode):
+    _shared_body(tmp_path, monkeypatch, mode)
+
+
+@pytest.mark.parametrize("scoring", [{"gap_open": 3, "gap_ext": 3}, {"gap_open": 2, "gap_ext": 2}, {"mismatch": -5, "gap_open": 2, "gap_ext": 1}, {"score_N": 1}, {"gap_open": 3, "gap_ext": 3, "num_alignments": 3}]
+                         if FULL else [{"score_N": 1, "gap_open": 3, "gap_ext": 3}],
+                         ids=lambda d: ",".join("%s=%s" % kv for kv in d.items()))
+def test_schemes_under_which_ssw_c_leaves_the_affine_recurrence_give_the_oracle_records(engine, wl, scoring):
+    _striped_body(engine, wl, scoring)
+
+
 if FULL:
     from test_gpu_parity import (test_align_records_match_oracle, test_other_seed_lengths, test_non_default_strides,  # noqa: F401
                                  test_long_noisy_reads, test_long_reads_with_large_gaps, test_very_long_reads)
@@ -157,7 +181,7 @@ def test_striped_slow_path_equals_the_reference_ssw_c(emulator):
     2 gap < |mismatch|) and one with a positive score for N"""
     from helpers import sswgold
     e = smr.Engine(0)
-    assert sswgold.check_striped(e, max_pairs=None if FULL else 40) == (600 if FULL else 240)
+    assert sswgold.check_striped(e, max_pairs=None if FULL else 25) == (600 if FULL else 150)
     e.close()
 
 

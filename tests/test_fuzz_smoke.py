@@ -21,7 +21,7 @@ import pytest  # noqa: E402
 def test_a_slice_of_the_oracle_against_the_reference_binary():
     """tools/fuzz_ref.py: the same kind of random (workload, option) cases through the UNMODIFIED reference binary and through the oracle -- records
     and counters equal.  (The fuzzer above referees the kernels with the oracle; this pins the referee to the reference over the random option space.)"""
-    out = subprocess.run([sys.executable, os.path.join(paths.REPO, "tools", "fuzz_ref.py"), "9100", "14"], capture_output=True, text=True, timeout=1500)
+    out = subprocess.run([sys.executable, os.path.join(paths.REPO, "tools", "fuzz_ref.py"), "9100", "9"], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert ", 0 differing or failing" in out.stdout
-    assert out.stdout.count(" ok:") >= 12
+    assert out.stdout.count(" ok:") >= 7

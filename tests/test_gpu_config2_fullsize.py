@@ -72,3 +72,46 @@ def test_config2_fullsize_records_equal_the_reference(setup, run, seed_mode):
     pr = e.prof()
     print("config 2 (%s, seed kernel %d): %d reads, %d aligned, %.2f s incl. upload/fetch; seed %.1f ms, chain %.1f ms, traceback %.2f ms (%d launches)" % (
         run, seed_mode, reads.count, ctr["num_aligned"], dt, pr.seed_ms, pr.chain_ms, pr.trace_ms, pr.trace_launches))
+
+
+def test_config2_read_set_twelve_times_over_at_the_shipped_thresholds(setup):
+    """The skew paths at the thresholds they ship with (round 5's verdict, item 1c): the amplicon read set twelve times over in one batch (1.2 M reads, what
+    `bench.py --workload config2` does 80 times) puts coarse key bins far above twice the average and 256 k tuples -- sorted by several blocks
+    (k_seed_hbins_*) -- and makes most tuples repeats of another one's seed (k_seed_dedup / k_seed_prop).  Every copy of a read must get the record the
+    reference gave the read (the per-1000-read digests of the golden run, copy by copy), and the last seed stage's sorted tuples must show the repeats."""
+    g, e, parts, reads = setup
+    r = g["runs"]["default"]
+    seqs = []
+    with gzip.open(os.path.join(C2, g["reads"]), "rt") as f:
+        cur = []
+        for line in f:
+            if line.startswith(">"):
+                if cur:
+                    seqs.append("".join(cur))
+                cur = []
+            else:
+                cur.append(line.strip())
+        if cur:
+            seqs.append("".join(cur))
+    assert len(seqs) == g["n_reads"]
+    copies = 12
+    big = smr.Reads.from_seqs(seqs * copies)
+    # the reference's threshold for the ORIGINAL run: the copies are aligned with it (a larger read total would raise the minimal score)
+    p = smr.default_params(minimal_score=r["minimal_score"], **r["params"])
+    e.set_seed_mode(0)
+    smr.align(e, big, [parts], [p], with_cigar=True)
+    recs = e.records()
+    assert e.counters(1)["num_aligned"] == copies * r["num_aligned"]
+    for k in range(copies):
+        tot, chunks = digests(recs[k * g["n_reads"]:(k + 1) * g["n_reads"]], g["chunk"])
+        assert tot == r["md5_total"], "copy %d of the read set: chunks %s differ" % (k, [i for i, (a, b) in enumerate(zip(chunks, r["md5_chunks"])) if a != b][:5])
+    # the sorted tuples of one seed stage at this size: most are repeats (k_seed_dedup ran at its shipped threshold)
+    e.upload_reads(big, 1)
+    e.upload_index(parts[0], 0)
+    e.reset_state()
+    e.seed_scan(0, p, 0, 0)
+    tuples, _, meta = e.seed_tuples()
+    n_rep = int((tuples >> 63).sum())
+    assert n_rep > meta["n"] // 2, (n_rep, meta["n"])
+    e.unload_index(0)
+    big.free()

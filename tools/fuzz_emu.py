@@ -87,7 +87,9 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     bad = 0
-    with emu.active():
+    import contextlib
+    # FUZZ_ON_GPU=1: the same cases on the real device instead of the emulator (a case that is hours of emulation -- a dense family under the striped slow path -- is seconds there)
+    with (contextlib.nullcontext() if os.environ.get("FUZZ_ON_GPU") == "1" else emu.active()):
         for seed in range(first, first + n):
             t = time.time()
             # the library's own switches (each one a different route to the same records), drawn per case: a context reads them when it is created
