@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SEED_SOURCES = ["smr_seed.hpp", "smr_seed_pg.hpp", "smr_ibuild.hpp", "smr_trie_layout.hpp", "smr_host.hpp"]      # the kernels of the seed stage and the layouts they read
 FAMILY = [("k_seed_keys", "k_seed_keys"), ("k_seed_emap", "k_seed_keys"), ("k_seed_wbin", "k_seed_split"), ("k_seed_cscan", "k_seed_split"), ("k_seed_colscan", "k_seed_split"), ("k_seed_split", "k_seed_split"),
-          ("k_seed_bins", "k_seed_bins"), ("k_seed_pg<0>", "k_seed_pg<0>"), ("k_seed_search<0>", "k_seed_pg<0>"), ("k_seed_pg<1>", "k_seed_pg<1>"),
+          ("k_seed_bins", "k_seed_bins"), ("k_seed_hbins", "k_seed_bins"), ("k_seed_dedup", "k_seed_bins"), ("k_seed_active", "k_seed_bins"),      # (round 6: the skew paths, timed with the second sort pass)
+          ("k_seed_prop<0>", "k_seed_pg<0>"), ("k_seed_prop<1>", "k_seed_pg<1>"), ("k_seed_pg<0>", "k_seed_pg<0>"), ("k_seed_search<0>", "k_seed_pg<0>"), ("k_seed_pg<1>", "k_seed_pg<1>"),
           ("k_seed_search<1>", "k_seed_pg<1>"), ("k_seed_finish", "k_seed_finish"), ("k_cand", "k_cand"), ("k_chain", "k_chain"), ("k_begins", "k_begins"),
           ("k_trace", "k_trace"), ("k_walk", "k_walk"), ("k_sw16", "k_sw16"), ("k_wnext", "k_wnext"), ("k_wlist", "k_wnext")]      # (round 5: the candidate walk in rounds, smr_walk.hpp)
 
