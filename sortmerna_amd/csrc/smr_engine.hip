@@ -26,6 +26,7 @@ struct DevIndex {
   uint32_t* pg = nullptr; uint32_t* root3 = nullptr; uint32_t* lkc = nullptr;
   uint8_t* ref_seq = nullptr; uint64_t* ref_off = nullptr;
   uint32_t n_refs = 0, n_ids = 0, lnwin = 0;
+  uint32_t ref_any_n = 1;     // does any reference hold an ambiguous letter (0 only when the upload looked and found none)
   uint64_t trie_words = 0, n_pos = 0, ref_bytes = 0, pg_words = 0;
 };
 
@@ -227,7 +228,7 @@ int check_params(smr_ctx* c, const smr_params* p, bool sw = true) {
 
 DIndex dindex(const DevIndex& d) {
   DIndex x; x.lookup = d.lookup; x.trie = d.trie; x.pg = d.pg; x.lkc = d.lkc; x.root3 = reinterpret_cast<const uint2*>(d.root3); x.pos_off = d.pos_off; x.pos_arr = d.pos_arr; x.ref_seq = d.ref_seq; x.ref_off = d.ref_off;
-  x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2;
+  x.n_refs = d.n_refs; x.n_ids = d.n_ids; x.lnwin = d.lnwin; x.partialwin = d.lnwin / 2; x.ref_any_n = d.ref_any_n;
   return x;
 }
 DReads dreads(const smr_ctx* c) { DReads r; r.words = c->b->d_words; r.rec_off = c->b->d_rec_off; r.len = c->b->d_len; r.n = c->b->n; r.max_len = c->b->max_len; return r; }
@@ -482,6 +483,7 @@ extern "C" int smr_index_upload(smr_ctx* c, const smr_index* ix, int slot) {
   if ((rc = dev_alloc(c, &d.ref_seq, ix->ref_seq.size() + 64))) return rc;
   if ((rc = dev_alloc(c, &d.ref_off, ix->ref_off.size()))) return rc;
   HIPCHK(c, hipMemcpyAsync(d.ref_seq, ix->ref_seq.data(), ix->ref_seq.size(), hipMemcpyHostToDevice, c->stream));
+  d.ref_any_n = (!ix->ref_seq.empty() && memchr(ix->ref_seq.data(), 4, ix->ref_seq.size())) ? 1u : 0u;      // (k_sw16 asks each window for its ambiguous letters only then)
   HIPCHK(c, hipMemcpyAsync(d.ref_off, ix->ref_off.data(), ix->ref_off.size() * 8, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   d.used = true;

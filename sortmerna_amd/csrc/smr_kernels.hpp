@@ -43,6 +43,7 @@ struct DIndex {
   const uint8_t* ref_seq;
   const uint64_t* ref_off;
   uint32_t n_refs, n_ids, lnwin, partialwin;
+  uint32_t ref_any_n;          // 0: no reference of this index part holds an ambiguous letter (4)
 };
 
 struct DReads {

@@ -154,7 +154,7 @@ struct SeedKey { uint32_t slot, chars, key; bool dup; };          // a decoded t
 #define SEED_WAVES 16u                                    // waves per block of k_seed_keys
 #define SEED_STAGE_WORDS 1280u                            // LDS words in which a wave of k_seed_keys stages the packed records of the reads of one trip (64 reads of <= 208 letters)
 #ifndef SEED_PIECE
-#define SEED_PIECE 8192u                                  // tuples the second sort pass (512 fine bins) stages in LDS at a time: two blocks per CU
+#define SEED_PIECE 8192u                                  // tuples the second sort pass (512 fine bins) stages in LDS at a time (two blocks per CU by LDS; one by registers since a piece's loads are in flight together)
 #endif
 #ifndef SEED_SPLIT_PIECE
 #define SEED_SPLIT_PIECE 12288u                           // ... and the first (1 024 coarse bins: runs of 12 tuples per bin instead of 8; one block per CU).  Measured per 8 M-read
@@ -499,31 +499,67 @@ __device__ __forceinline__ void block_excl_scan(const uint32_t* cnt, uint32_t* o
 // load (each tuple once), take a place in its bin (LDS atomic), put the piece into LDS in bin order, copy it out with consecutive lanes on
 // consecutive staged tuples (lanes of one bin's run write neighbouring addresses), rewritten by `conv` on the way.
 // LDS: cur / pc0 / pst [nb], stage [SEED_PIECE].
+// (Blocks of 1024 threads, and the code says so: `blockDim.x` is a global load from the dispatch packet, and the compiler put one -- with its s_waitcnt
+// vmcnt(0), which on this target also waits for the piece's stores -- in front of every loop that strides by it.  All loads of a piece first and none of
+// them under a branch (a lane past the piece reads the piece's last tuple): with `if (i < np) { load; atomic }` the compiler emitted load, s_waitcnt
+// vmcnt(0), ds_add_rtn PER times over -- twelve round trips to memory one after the other per piece; round 6, profiles/r6s26_*: k_seed_split - 10 %.)
+#ifndef SMR_SORT_PREFETCH
+#define SMR_SORT_PREFETCH 0                               // 1: the next piece's loads are issued before the copy-out of this one (their registers are free by then)
+#endif
+#ifndef SMR_SORT_COPY_UNROLLED
+#define SMR_SORT_COPY_UNROLLED 0                          // 1: the copy-out as PER unrolled steps (the staged tuples of all steps read first)
+#endif
 template <uint32_t PIECE, class BINOF, class CONV>
 __device__ __forceinline__ void staged_move(const SeedTup* __restrict__ src, uint32_t i0, uint32_t i1, SeedTup* __restrict__ dst, uint32_t nb,
                                             uint32_t* cur, uint32_t* pc0, uint32_t* pst, SeedTup* stage, uint32_t* s_part, BINOF binof, CONV conv) {
   constexpr int PER = PIECE / 1024;
+  const uint32_t tid = threadIdx.x;
+  SeedTup mine[PER]; uint32_t place[PER];
+  if (SMR_SORT_PREFETCH && i0 < i1) {
+    const uint32_t np = min(PIECE, i1 - i0);
+#pragma unroll
+    for (int j = 0; j < PER; j++) mine[j] = src[i0 + min((uint32_t)j * 1024u + tid, np - 1u)];
+  }
   for (uint32_t p0 = i0; p0 < i1; p0 += PIECE) {
     const uint32_t np = min(PIECE, i1 - p0);
-    for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pc0[q] = cur[q];
+    for (uint32_t q = tid; q < nb; q += 1024u) pc0[q] = cur[q];
     __syncthreads();
-    SeedTup mine[PER]; uint32_t place[PER];
+    if (!SMR_SORT_PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < PER; j++) mine[j] = src[p0 + min((uint32_t)j * 1024u + tid, np - 1u)];
+    }
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-      const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
-      if (i < np) { mine[j] = src[p0 + i]; place[j] = atomicAdd(&cur[binof(mine[j])], 1u); }
+      const uint32_t i = (uint32_t)j * 1024u + tid;
+      if (i < np) place[j] = atomicAdd(&cur[binof(mine[j])], 1u);
     }
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < nb; q += blockDim.x) pst[q] = cur[q] - pc0[q];      // the piece's tuples per bin ...
+    for (uint32_t q = tid; q < nb; q += 1024u) pst[q] = cur[q] - pc0[q];                   // the piece's tuples per bin ...
     __syncthreads();
     block_excl_scan(pst, pst, nb, s_part);                                                 // ... become where the bin's run starts in the staged piece
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-      const uint32_t i = (uint32_t)j * 1024u + threadIdx.x;
+      const uint32_t i = (uint32_t)j * 1024u + tid;
       if (i < np) { const uint32_t f = binof(mine[j]); stage[pst[f] + (place[j] - pc0[f])] = mine[j]; }
     }
     __syncthreads();
-    for (uint32_t sidx = threadIdx.x; sidx < np; sidx += blockDim.x) {
+    if (SMR_SORT_PREFETCH && p0 + PIECE < i1) {
+      const uint32_t q0 = p0 + PIECE, nq = min(PIECE, i1 - q0);
+#pragma unroll
+      for (int j = 0; j < PER; j++) mine[j] = src[q0 + min((uint32_t)j * 1024u + tid, nq - 1u)];
+    }
+    if (SMR_SORT_COPY_UNROLLED) {
+      SeedTup tq[PER];
+#pragma unroll
+      for (int j = 0; j < PER; j++) tq[j] = stage[min((uint32_t)j * 1024u + tid, np - 1u)];
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        const uint32_t sidx = (uint32_t)j * 1024u + tid;
+        const uint32_t f = binof(tq[j]);
+        if (sidx < np) dst[pc0[f] + (sidx - pst[f])] = conv(tq[j]);
+      }
+    } else
+    for (uint32_t sidx = tid; sidx < np; sidx += 1024u) {
       const SeedTup t = stage[sidx];
       const uint32_t f = binof(t);
       dst[pc0[f] + (sidx - pst[f])] = conv(t);
@@ -541,7 +577,7 @@ __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
   const uint32_t nmine = sb.bcnt[blockIdx.x];
   if (nmine == 0) return;
   const uint32_t* row = sb.rows + (size_t)blockIdx.x * sb.nc;
-  for (uint32_t c = threadIdx.x; c < sb.nc; c += blockDim.x) cur[c] = sb.cbase[c] + row[c];
+  for (uint32_t c = threadIdx.x; c < sb.nc; c += 1024u) cur[c] = sb.cbase[c] + row[c];
   __syncthreads();
   const uint32_t fb = sb.fb, kbits = sb.kbits, cb = sb.cb;
   const uint32_t slot0 = blockIdx.x * sb.rpb * sb.maxwin;                  // the block's first slot
@@ -562,7 +598,10 @@ __device__ __forceinline__ void seed_push_pieces(const SeedBufs& sb, uint32_t st
   for (uint32_t q = 0; q < np && b + q < sb.cap_pieces; q++) sb.pieces[b + q] = make_uint2(start + q * SEED_DD_PIECE, min(SEED_DD_PIECE, cnt - q * SEED_DD_PIECE));
 }
 
-__global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
+#ifndef SMR_BINS_BLOCKS_PER_CU
+#define SMR_BINS_BLOCKS_PER_CU 1                         // (2: 8 waves per SIMD = at most 64 VGPRs)
+#endif
+__global__ void __launch_bounds__(1024, 4 * SMR_BINS_BLOCKS_PER_CU) k_seed_bins(SeedBufs sb) {
   __shared__ uint32_t cur[512], pc0[512], pst[512], s_part[16];
   SMR_DYN_LDS(uint32_t, lds);
   SeedTup* stage = reinterpret_cast<SeedTup*>(lds);
@@ -571,7 +610,7 @@ __global__ void __launch_bounds__(1024) k_seed_bins(SeedBufs sb) {
   const uint32_t t = threadIdx.x, nf = 1u << sb.fb, sh = 32u + sb.cb;
   if (t < 512) pst[t] = 0;
   __syncthreads();
-  for (uint32_t i = lo + t; i < hi; i += blockDim.x) atomicAdd(&pst[(uint32_t)(sb.mid[i] >> sh)], 1u);
+  for (uint32_t i = lo + t; i < hi; i += 1024u) atomicAdd(&pst[(uint32_t)(sb.mid[i] >> sh)], 1u);
   __syncthreads();
   block_excl_scan(pst, cur, nf, s_part);
   if (t < nf) {
@@ -603,7 +642,7 @@ __global__ void __launch_bounds__(1024) k_seed_hbins_hist(SeedBufs sb) {
     seed_hot_entry(sb, e, c, i0, i1);
     if (threadIdx.x < 512) cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) atomicAdd(&cnt[(uint32_t)(sb.mid[i] >> sh)], 1u);
+    for (uint32_t i = i0 + threadIdx.x; i < i1; i += 1024u) atomicAdd(&cnt[(uint32_t)(sb.mid[i] >> sh)], 1u);
     __syncthreads();
     if (threadIdx.x < nf) sb.hh[(size_t)e * nf + threadIdx.x] = cnt[threadIdx.x];
     __syncthreads();

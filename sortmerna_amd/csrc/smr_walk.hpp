@@ -89,6 +89,8 @@ __device__ __forceinline__ unsigned long long quad_max_u64(unsigned long long v)
   return v;
 }
 
+struct __attribute__((aligned(4))) Sw16W3 { uint32_t a, b, c; };       // (4-byte aligned: global_load_dwordx3 / x2 take that)
+struct __attribute__((aligned(4))) Sw16W2 { uint32_t a, b; };
 // KEYS = false: the score only (no running-maximum key per row: ten instead of thirteen instructions per cell pair, R registers less) -- for
 // the tasks of reads that are not expected to align (their result is "score <= minimal_score", nothing else is asked of it; when one aligns
 // after all, its end cell is found by k_begins)
@@ -104,6 +106,25 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
   pk16 hmax = ZERO;
   const uint32_t t_mm = ((uint32_t)(mismatch + go) & 0xFFu) * 0x01010101u, t_x = ((uint32_t)(mismatch + go) ^ (uint32_t)(match + go)) & 0xFFu,
                  t_n = ((uint32_t)(scoreN + go) & 0xFFu) * 0x01010101u;
+  // The letters of a lane's rows are two runs of R consecutive read positions (low half: rows gl R .., high half: rows (gl + 4) R ..): at most three
+  // words of 2-bit codes and two of ambiguity bits per run (R <= 32), and all ten are asked for before the first is looked at -- read_nt per row
+  // was two loads under `if (row < m)` each, which the compiler turned into 2 R waits for memory one after the other.
+  const uint32_t cw = (len + 15u) >> 4, cwm = max(cw, 1u) - 1u, awm = max((len + 31u) >> 5, 1u) - 1u;
+  const int sgn = reversed ? -dir : dir;                  // a row further = this many physical positions further (read.cpp:350-357: the reverse strand is read from the end)
+  uint32_t cwd[2][3], awd[2][2];
+  int pa[2], cw0[2], aw0[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; hf++) {
+    const int row0 = (gl + 4 * hf) * R, nv = max(1, min(R, m - row0));
+    const int k0 = aq + dir * row0;
+    pa[hf] = reversed ? (int)len - 1 - k0 : k0;
+    const int pmin = max(0, min(pa[hf], pa[hf] + sgn * (nv - 1)));      // the lowest position of the run's rows < m (they lie inside the read)
+    cw0[hf] = (int)min((uint32_t)pmin >> 4, cwm); aw0[hf] = (int)min((uint32_t)pmin >> 5, awm);
+    // (one 12-byte and one 8-byte load per run: the words behind a record's last one are the next record's or the slack the upload leaves behind the batch)
+    const Sw16W3 c3 = *reinterpret_cast<const Sw16W3*>(rec + cw0[hf]);
+    const Sw16W2 a2 = *reinterpret_cast<const Sw16W2*>(rec + cw + aw0[hf]);
+    cwd[hf][0] = c3.a; cwd[hf][1] = c3.b; cwd[hf][2] = c3.c; awd[hf][0] = a2.a; awd[hf][1] = a2.b;
+  }
 #pragma unroll
   for (int j = 0; j < R; j++) {
     uint32_t t2[2];
@@ -112,7 +133,13 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
       const int row = (gl + 4 * hf) * R + j;
       uint32_t t = 0;
       if (row < m) {
-        const uint32_t c = read_nt(rec, len, (uint32_t)(aq + dir * row), reversed, 4u);
+        const int ph = pa[hf] + sgn * j;
+        const int wi = (ph >> 4) - cw0[hf], ai = (ph >> 5) - aw0[hf];
+        const uint32_t wd = wi == 0 ? cwd[hf][0] : wi == 1 ? cwd[hf][1] : cwd[hf][2];
+        const uint32_t ad = ai == 0 ? awd[hf][0] : awd[hf][1];
+        uint32_t c = (wd >> ((ph & 15) * 2)) & 3u;
+        if (reversed) c = 3u - c;
+        if ((ad >> (ph & 31)) & 1u) c = 4u;               // (Read::flip34, read.cpp:379-401: ambiguous letters are 4 for Smith-Waterman)
         t = c == 4u ? t_n : t_mm ^ (t_x << (8u * c));
       }
       t2[hf] = t;
@@ -122,6 +149,9 @@ __device__ __forceinline__ SwRes sw_quad16(const uint32_t* __restrict__ rec, uin
   }
   int steps = m > 0 ? n + (m + R - 1) / R - 1 : 0;
   for (int d = 32; d > 0; d >>= 1) steps = max(steps, __shfl_xor(steps, d, 64));
+#ifdef SMR_SW16_NOSTEPS                                   // what-if build: set-up and result only (how much of the kernel is not the step loop)
+  steps = min(steps, 4);
+#endif
   uint32_t lastY = pk_bits(pk_splat(-go)), lastF = 0, selcur = PK_SEL_NONE * 0x00010001u;
   pk16 diag0 = pk_splat(-go);
   const uint32_t in_y = (uint32_t)(-go) & 0xFFFFu;
@@ -213,28 +243,44 @@ __global__ void __launch_bounds__(64, SW16_WAVES(R)) k_sw16(DReads rd, DIndex ix
   // two lists: tidx[0, ntA) = tasks scored with their end cells, tidx2[0, ntB) = tasks of which only the score is asked
   const uint32_t ntA = (uint32_t)wc[WC_NTASK], ntB = (uint32_t)wc[WC_NTASK2];
   const uint32_t npassA = (ntA + 15u) / 16u, npass = npassA + (ntB + 15u) / 16u;
+  // (the slot of a pass's task is asked for one pass ahead: the first of the four dependent loads -- slot, task, read, letters -- in front of a pass's work)
+  auto slot_of = [&](uint32_t p) -> uint32_t {
+    const bool keys = p < npassA;
+    const uint32_t ti = (keys ? p : p - npassA) * 16u + (uint32_t)g;
+    return (p < npass && ti < (keys ? ntA : ntB)) ? (keys ? tidx1 : tidx2)[ti] : NONE;
+  };
+  uint32_t slot_next = slot_of(blockIdx.x);
   for (uint32_t p = blockIdx.x; p < npass; p += gridDim.x) {
     const bool keys = p < npassA;
     const uint32_t ti = (keys ? p : p - npassA) * 16u + (uint32_t)g;
-    const uint32_t nt = keys ? ntA : ntB;
     const uint32_t* const tidx = keys ? tidx1 : tidx2;
-    const bool have = ti < nt;
-    uint32_t slot = 0;
+    const uint32_t slot = slot_next;
+    const bool have = slot != NONE;
     int m = 0, n = 0, aq = 0, dir = 1;
     uint32_t len = 0, reversed = 0;
     const uint32_t* rec = rd.words;
     const uint8_t* ref = ix.ref_seq;
     if (have) {
-      slot = tidx[ti];
       const WTask t = tk[slot];
       m = t.m; n = t.nref; aq = t.aq; reversed = t.flags & 1u; dir = (t.flags & 2u) ? -1 : 1;
       len = rd.len[t.r]; rec = rd.words + rd.rec_off[t.r];
       ref = ix.ref_seq + t.rf_start;
     }
+    slot_next = slot_of(p + gridDim.x);
     int nn = n;
     for (int d = 32; d > 0; d >>= 1) nn = max(nn, __shfl_xor(nn, d, 64));
+    // does the window hold an ambiguous letter?  Only asked of a reference DB that has one at all (DIndex::ref_any_n), eight letters per lane at a time
     bool hn = false;
-    for (int q = gl; q < nn; q += 4) if (q < n) hn |= ref[dir * q] == 4;
+    if (ix.ref_any_n) {
+      const int nm = max(n, 1) - 1;
+      for (int q0 = gl; q0 < nn; q0 += 32) {
+        uint8_t b[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) b[i] = ref[dir * min(q0 + 4 * i, nm)];
+#pragma unroll
+        for (int i = 0; i < 8; i++) hn |= (q0 + 4 * i < n) && b[i] == 4;
+      }
+    }
     SwRes s;
     const bool hasn = __any(hn);
 #define SW16_ARGS rec, len, reversed, m, aq, ref, n, P.match, P.mismatch, P.score_N, P.gap_open, P.gap_ext, dir

@@ -68,7 +68,7 @@ for cfg in sys.argv[1:] or ["base"]:
 
         def step(b):
             eng.select_batch(b); eng.reset_state()
-            smr.align_resident(eng, list(range(len(parts))), [params], with_cigar=True)
+            smr.align_resident(eng, list(range(len(parts))), [params], with_cigar=os.environ.get("MB_CIGAR", "1") != "0")
 
         step(0)
         eng.prof_reset()
