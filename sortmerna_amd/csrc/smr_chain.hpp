@@ -370,25 +370,28 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
   uint32_t npos = 0;
   if (scan) { for (uint32_t q = gl; q < bloom_words; q += 16) bloom[q] = 0; }
   // (all four rows' hit words are asked for, then all list bounds, before anything waits: two round trips per read, not eight)
-  uint32_t hid[CAND_HITS / 16], hlo[CAND_HITS / 16], hln[CAND_HITS / 16];
+  uint32_t hid[CAND_HITS / 16], hlo[CAND_HITS / 16], hln[CAND_HITS / 16], hwn[CAND_HITS / 16];
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
     const uint32_t h = 16u * k + (uint32_t)gl;
-    hid[k] = NONE;
+    hid[k] = NONE; hwn[k] = 0;
     if (scan && h < nh) {
       // the hit blocks of the passes run so far on this strand, concatenated (no loop over the three: an index that the compiler cannot
       // resolve sends the read's state to 12 KB of LDS per block)
       const uint32_t c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
       const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
       const CandPair hw = *reinterpret_cast<const CandPair*>(pool + at);      // (id, win_pos) with one 8-byte load
-      hid[k] = hw.x;
-      if (mrec) wn_[h] = (uint16_t)hw.y;
+      hid[k] = hw.x; hwn[k] = hw.y;                          // (the window position goes to LDS below: storing it here made every one of the four loads wait for itself)
     }
   }
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
     hlo[k] = 0; hln[k] = 0;
     if (hid[k] != NONE) { hlo[k] = hid[k] + 1u; hln[k] = ix.pos_arr[hid[k]].x; }      // (a hit's id is the place of its list's header word: {positions, -})
+  }
+  if (mrec) {
+#pragma unroll
+    for (uint32_t k = 0; k < CAND_HITS / 16; k++) if (hid[k] != NONE) wn_[16u * k + (uint32_t)gl] = (uint16_t)hwn[k];
   }
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
   // ---- the wave's 64 searches ----
   const uint32_t pos = vb * 64u + lane;
   bool mine = DIR ? (pos >= n_fwd && pos < n_tup) : pos < n_fwd;
-  uint32_t nh = 0, P9 = 0, slot = 0;
+  uint32_t nh = 0, P9 = 0, slot = 0, gfl = 0;
   uint2 rt = make_uint2(NONE, 0);
   uint32_t n_rep = 0;                                      // tuples of this launch in the chunk that repeat another one's seed (k_seed_dedup): read, not searched
   {
@@ -232,11 +232,12 @@ __global__ void __launch_bounds__(64 * PG_WAVES, PG_OCC / PG_WAVES) k_seed_pg(DI
       tk.slot = (uint32_t)t; tk.chars = (uint32_t)(t >> 32) & ((1u << sb.cb) - 1u); tk.key = (c << sb.fb) | (uint32_t)(t >> (32u + sb.cb));
       rt = ix.root3[2 * (tk.key - (DIR ? sb.nkh : 0u)) + DIR];
       P9 = tk.chars; slot = tk.slot;
+      if (DIR == 1) gfl = sb.gflag[slot >> 11];              // (asked for with the block table entry, not after it)
     }
   }
   const bool counted = mine;
   if (mine) {
-    if (DIR == 1 && ((sb.gflag[slot >> 11] >> ((slot >> 6) & 31u)) & 1u) && ((sb.zbits[slot >> 5] >> (slot & 31u)) & 1u)) mine = false;   // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
+    if (DIR == 1 && ((gfl >> ((slot >> 6) & 31u)) & 1u) && ((sb.zbits[slot >> 5] >> (slot & 31u)) & 1u)) mine = false;   // accept_zero_kmer: no reverse search (paralleltraversal.cpp:188)
   }
   if (lane == 0) s_ncand = 0;
   __syncthreads();
