@@ -496,16 +496,27 @@ __device__ __forceinline__ bool chain_build_set(const SetArgs& A, uint32_t* bl, 
   __syncthreads();
   // walk 1: Bloom bitmap -> set S of references that may occur more than once
   bool s_over = false;
-  for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
-    const uint32_t p = p0 + lane;
-    if (p < npos) {
-      uint32_t seq;
-      if (A.rec) seq = A.rec[p];
-      else {
-        uint32_t h = 0;
-        for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
-        seq = A.pos_arr[A.hits[h].x + (p - A.hp[h])].y;
+  // (four rows of 64 positions per trip, their loads asked for together: a read with hundreds of positions waited for memory once per row)
+  for (uint32_t p0 = 0; p0 < npos; p0 += 256) {
+    uint32_t sq4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t p = p0 + 64u * u + lane;
+      sq4[u] = 0;
+      if (p < npos) {
+        if (A.rec) sq4[u] = A.rec[p];
+        else {
+          uint32_t h = 0;
+          for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
+          sq4[u] = A.pos_arr[A.hits[h].x + (p - A.hp[h])].y;
+        }
       }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+    const uint32_t p = p0 + 64u * u + lane;
+    if (p < npos) {
+      const uint32_t seq = sq4[u];
       const uint32_t hb = (seq * 2654435761u) >> bshift;
       const uint32_t old = atomicOr(&bl[hb >> 5], 1u << (hb & 31u));
       if (((old >> (hb & 31u)) & 1u) || A.num_seeds < 2) {
@@ -518,22 +529,33 @@ __device__ __forceinline__ bool chain_build_set(const SetArgs& A, uint32_t* bl, 
         }
       }
     }
+    }
   }
   __threadfence_block();
   __syncthreads();
   if (__any(s_over)) return false;
   if (*A.s_ns > 0) {
     // walk 2: exact counts for the members of S, and their (pos, win) tuples
-    for (uint32_t p0 = 0; p0 < npos; p0 += 64) {
-      const uint32_t p = p0 + lane;
-      if (p < npos) {
-        uint2 pa; uint32_t win;
-        if (A.rec) { pa = make_uint2(A.rec[npos + p], A.rec[p]); win = A.rec[2u * npos + p]; }
-        else {
-          uint32_t h = 0;
-          for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
-          pa = A.pos_arr[A.hits[h].x + (p - A.hp[h])]; win = A.hits[h].y;
+    for (uint32_t p0 = 0; p0 < npos; p0 += 256) {
+      uint2 pa4[4]; uint32_t win4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t p = p0 + 64u * u + lane;
+        pa4[u] = make_uint2(0u, 0u); win4[u] = 0;
+        if (p < npos) {
+          if (A.rec) { pa4[u] = make_uint2(A.rec[npos + p], A.rec[p]); win4[u] = A.rec[2u * npos + p]; }
+          else {
+            uint32_t h = 0;
+            for (uint32_t step = pow2_floor(nh); step > 0; step >>= 1) { const uint32_t t = h + step; if (t < nh && A.hp[t] <= p) h = t; }
+            pa4[u] = A.pos_arr[A.hits[h].x + (p - A.hp[h])]; win4[u] = A.hits[h].y;
+          }
         }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+      const uint32_t p = p0 + 64u * u + lane;
+      if (p < npos) {
+        const uint2 pa = pa4[u]; const uint32_t win = win4[u];
         uint32_t sl = (pa.y * 0x9E3779B1u >> 7) & mask;
         for (;;) {
           const uint32_t o = sk[sl];
@@ -546,6 +568,7 @@ __device__ __forceinline__ bool chain_build_set(const SetArgs& A, uint32_t* bl, 
           if (o == 0) break;
           sl = (sl + 1) & mask;
         }
+      }
       }
     }
     __threadfence_block();

@@ -34,7 +34,9 @@ __host__ __device__ __forceinline__ uint32_t walk_tasks_per_read(uint32_t nlist,
 }
 #define WK_MAX_ROWS 256u              // longest read span k_sw16 takes (8 virtual lanes x 32 rows)
 #define WK_MAX_POS 128u               // most positions (seed hits x their occurrences) of a read the round kernels take: two per lane
+#ifndef WK_CLAIM
 #define WK_CLAIM 24u                                      // list entries a wave claims at a time, at most (24 x WK_MAX task slots = 7 424 bytes of LDS for the kernel; with 32 it was 8 160 and the kernel 6 % slower, profiles/r5s33_*: fewer than the 20 waves per CU its registers allow)
+#endif
 // per-round counters (u64 words): every hot one on a 128-byte line of its own
 enum { WC_NLIST = 0, WC_CLAIM = 16, WC_NTASK = 32, WC_NTASK2 = 48, WC_STRIDE = 64 };
 
