@@ -129,3 +129,27 @@ def test_lds_leaves_room_for_the_waves_the_registers_allow():
         assert k["lds"] <= 7680 and k["lds"] * 5 * 4 <= lds_cu and k["vgpr"] <= 96, k        # 5 waves per SIMD; 8 160 bytes measured 6 % slower than 7 424 (profiles/r5s33_*)
     for k in _find(md, "k_seed_finish"):
         assert k["lds"] * 7 <= lds_cu and k["vgpr"] <= 72, k              # 7 blocks of four waves
+
+
+def test_loads_that_belong_together_are_issued_together():
+    """Round 6 ("What the ISA showed"): `if (i < np) { load; atomic }` unrolled twelve times compiled to load, s_waitcnt vmcnt(0), ds_add_rtn twelve
+    times over -- twelve round trips to memory one after the other per piece of the first sort pass, and nothing but the disassembly told; k_sw16 read the
+    letters of its rows with 4 R conditional loads per pass.  The shape of the fixed code is pinned here."""
+    def longest_run(isa, op):
+        best = run = 0
+        for ins in isa:
+            if ins.startswith(op):
+                run += 1; best = max(best, run)
+            elif ins.startswith("s_waitcnt") and "vmcnt" in ins:
+                run = 0
+        return best
+    split = _kernel_isa("k_seed_split")
+    assert longest_run(split, "global_load_dwordx2") >= 12, "the twelve tuple loads of a piece no longer leave together"
+    assert not any(i.startswith("global_load_ushort") for i in split), "a load of blockDim.x (and its wait) is back in k_seed_split"
+    bins = _kernel_isa("k_seed_bins")
+    assert longest_run(bins, "global_load_dwordx2") >= 8
+    sw = _kernel_isa("k_sw16ILi19")
+    n_loads = sum(1 for i in sw if i.startswith("global_load"))
+    assert n_loads <= 120 and any(i.startswith("global_load_dwordx3") for i in sw), n_loads      # (320 loads when every row asked for its letter by itself)
+    cand = _kernel_isa("k_candE")
+    assert longest_run(cand, "global_load_dwordx2") >= 4                                        # the four hit words of a lane
