@@ -671,10 +671,14 @@ def main():
         mean_len = int(round(g_len / max(g_reads, 1)))
         m_sw, n_sw = mean_len, mean_len + 8
         if eng.sw_mode() >= 1:
-            # (reads beyond 512 letters: strips of 128 virtual lanes x 4 rows, n + 127 steps each)
-            r_sw = min((m_sw + 127) // 128, 4)
-            n_strips = (m_sw + 128 * r_sw - 1) // (128 * r_sw)
-            instr = n_strips * (n_sw + (min(m_sw, 128 * r_sw) + r_sw - 1) // r_sw - 1) * (13 * r_sw + 14)
+            if m_sw > 512:
+                # (reads beyond 512 letters: strips of 128 virtual lanes x R rows, R = the cheapest of 8, 10 .. 24 by the step cost counted in the
+                # disassembly, 14 R + 35 instructions, n + 127 steps per strip: sw_long_rows in csrc/smr_chain.hpp)
+                r_sw = min(range(8, 25, 2), key=lambda r: ((m_sw + 128 * r - 1) // (128 * r)) * (14 * r + 35))
+                instr = ((m_sw + 128 * r_sw - 1) // (128 * r_sw)) * (n_sw + 127) * (14 * r_sw + 35)
+            else:
+                r_sw = min((m_sw + 127) // 128, 4)
+                instr = (n_sw + (m_sw + r_sw - 1) // r_sw - 1) * (13 * r_sw + 14)
         else:
             r_sw = (m_sw + 63) // 64
             instr = (n_sw + 63) * (20 * r_sw + 15)

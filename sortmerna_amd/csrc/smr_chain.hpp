@@ -150,29 +150,45 @@ __device__ __forceinline__ SwRes sw_wave_r(const uint8_t* rdq, int m, int rd0, i
 #include "smr_sw_pk.hpp"
 namespace smr {
 
-// reads of more than 512 letters (mode 2): strips of 128 virtual lanes x R rows, R = 8 or 16.  The per-step overhead (hand-over between lanes,
-// inputs of lane 0, the boundary row for the next strip: 78 instructions) is paid per 128 R cells, so more rows per lane are cheaper per cell
-// (9 R + 78 instructions per step) -- as long as the last strip is not mostly empty: a read of m rows takes ceil(m / 128 R) strips of n + 127
-// steps.  5 kb reads: 5 strips x 150 = 750 per column with R = 8, 3 x 222 = 666 with R = 16.  Functions of their own so that their registers
-// (16 rows of state per lane) are not the footprint of every other call of sw_wave
-#ifndef SW_LONG_R2
-#define SW_LONG_R2 16
-#endif
-__device__ __attribute__((noinline)) SwRes sw_wave_long8(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
-                                               int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
-  if (hn) return sw_wave_pk_r<8, true, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
-  return sw_wave_pk_r<8, false, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
-}
-__device__ __attribute__((noinline)) SwRes sw_wave_long16(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
+// reads of more than 512 letters (mode 2): strips of 128 virtual lanes x R rows.  A step of a strip is 14 R + 35 vector instructions (counted in the
+// disassembly: R = 8: 147, R = 16: 259 -- the hand-over between lanes, the inputs of lane 0 and the boundary row for the next strip are paid per
+// 128 R cells), and a read of m rows takes ceil(m / 128 R) strips of n + 127 steps: what a column costs is strips x (14 R + 35), least when the strips
+// are few AND the last one is full.  Rounds 3 - 5 chose between R = 8 and 16 with a cost model from before the kernel was tuned (9 R + 78), which
+// sent 5 kb reads to R = 16 -- three strips, the third 44 % full: 777 per column against 735 with R = 8; with R = 20 it is two strips and 630.  Now the
+// cheapest of seven strip heights by the counted cost (mean over N(5000, 500) reads: 771 -> 661 per column).  Functions of their own so that their
+// registers (up to 20 rows of state per lane) are not the footprint of every other call of sw_wave.
+template <int R>
+__device__ __attribute__((noinline)) SwRes sw_wave_long_r(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                                 int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
-  if (hn) return sw_wave_pk_r<SW_LONG_R2, true, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
-  return sw_wave_pk_r<SW_LONG_R2, false, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  if (hn) return sw_wave_pk_r<R, true, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+  return sw_wave_pk_r<R, false, true>(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge);
+}
+#ifndef SW_LONG_RMAX
+#define SW_LONG_RMAX 24
+#endif
+__host__ __device__ __forceinline__ int sw_long_cost(int m, int R) { return ((m + 128 * R - 1) / (128 * R)) * (14 * R + 35); }
+__host__ __device__ __forceinline__ int sw_long_rows(int m) {       // the strip height a read of m rows is scored with
+  int best = 8, bc = sw_long_cost(m, 8);
+  for (int R = 10; R <= SW_LONG_RMAX; R += 2) { const int c = sw_long_cost(m, R); if (c < bc) { bc = c; best = R; } }
+  return best;
 }
 __device__ __forceinline__ SwRes sw_wave_long(const uint8_t* rdq, int m, int rd0, int rdstep, const uint8_t* rfq, int n, int rf0, int rfstep,
                                               int* bound, int match, int mismatch, int scoreN, int go, int ge, bool hn) {
-  const int c8 = ((m + 1023) / 1024) * (9 * 8 + 78), c16 = ((m + 128 * SW_LONG_R2 - 1) / (128 * SW_LONG_R2)) * (9 * SW_LONG_R2 + 78);
-  if (c16 < c8) return sw_wave_long16(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, hn);
-  return sw_wave_long8(rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, hn);
+#define SW_LONG_ARGS rdq, m, rd0, rdstep, rfq, n, rf0, rfstep, bound, match, mismatch, scoreN, go, ge, hn
+  switch (sw_long_rows(m)) {
+    case 10: return sw_wave_long_r<10>(SW_LONG_ARGS);
+    case 12: return sw_wave_long_r<12>(SW_LONG_ARGS);
+    case 14: return sw_wave_long_r<14>(SW_LONG_ARGS);
+    case 16: return sw_wave_long_r<16>(SW_LONG_ARGS);
+    case 18: return sw_wave_long_r<18>(SW_LONG_ARGS);
+    case 20: return sw_wave_long_r<20>(SW_LONG_ARGS);
+#if SW_LONG_RMAX >= 24
+    case 22: return sw_wave_long_r<22>(SW_LONG_ARGS);
+    case 24: return sw_wave_long_r<24>(SW_LONG_ARGS);
+#endif
+    default: return sw_wave_long_r<8>(SW_LONG_ARGS);
+  }
+#undef SW_LONG_ARGS
 }
 
 }  // namespace smr
