@@ -348,7 +348,8 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 // 18.5 KB with the default 128 Bloom words = 8 blocks per CU, the 8 waves per SIMD the kernel is compiled for (round 5; 20.5 KB = 7 blocks before)
 #define CAND_LDS_BYTES(bw, handover) (16u * (((bw) + 2u * CAND_HITS + 1u) * 4u + ((handover) ? 2u * CAND_HITS : 0u)))
 #define CAND_REC_MAX 64u              // positions of a marked read that k_cand hands over to k_chain as a record (99 % of the marked reads have no more)
-#define CAND_REC_WORDS 32u            // words of mpool per read of the batch (a block of 16 reads shares 512: room for its two or three marked reads)
+#define CAND_REC_WORDS 32u            // words of mpool per read of the batch (a block's reads share their sum: room for its marked reads)
+#define CAND_BLOCK 256u               // reads per block of k_cand (phase 1: a lane each; phase 2: sixteen lanes each, sixteen at a time)
 // The hand-over (mrec != nullptr): k_cand has walked hit -> list bounds -> positions of every read it marks; k_chain would repeat those three
 // dependent gathers one read per wave.  So a marked read with at most CAND_REC_MAX positions leaves a RECORD in mpool -- npos reference
 // numbers | npos reference positions | npos window positions, in the order of the walk -- and {offset, npos} in mrec[r] ({NONE, 0}: none);
@@ -364,21 +365,39 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
   uint32_t* const lo_ = cand_lds + 16u * (bloom_words + CAND_HITS + 1u) + (size_t)g * CAND_HITS;
   uint16_t* const wn_ = reinterpret_cast<uint16_t*>(cand_lds + 16u * (bloom_words + 2u * CAND_HITS + 1u)) + (size_t)g * CAND_HITS;   // window position of every hit
   __shared__ uint32_t s_rec_cur;                            // words of the block's slice of mpool already given out
-  if (threadIdx.x == 0) s_rec_cur = 0;
+  __shared__ uint32_t s_wcnt[4], s_list[CAND_BLOCK];
   const uint32_t bshift = 32u - (5u + (uint32_t)__ffs((int)bloom_words) - 1u);
-  const uint32_t r = blockIdx.x * 16u + (uint32_t)g;
-  bool have = r < rd.n;
-  RWork w; RState st;
-  bool eligible = false;
-  if (have) {
-    w = rw[r];
-    st = work[r];                                           // (asked for with w, not after it)
-    have = w.strand_active && w.search && w.pass_n == (uint32_t)pass;
-    if (have) {
-      eligible = st.hit_seeds >= (uint32_t)P.num_seeds && w.hit_total > 0;
-      if (!eligible) { chain_finish_read<true>(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+  // Phase 1, one LANE per read: the reads of the pass without enough seed hits end it here (pass control + write-back), the others are listed.  (Round 6:
+  // sixteen lanes and a block slot per read for this -- 500 000 blocks of two dependent round trips each per 8 M-read launch -- was 1 ms of the kernel's
+  // 1.7, and all of it on a batch against a reference that few reads hit.)
+  uint32_t n_el;
+  {
+    const uint32_t r1 = blockIdx.x * CAND_BLOCK + threadIdx.x;
+    bool el = false;
+    if (r1 < rd.n) {
+      RWork w1 = rw[r1];
+      RState s1 = work[r1];                                 // (asked for with w1, not after it)
+      const bool act = w1.strand_active && w1.search && w1.pass_n == (uint32_t)pass;
+      el = act && s1.hit_seeds >= (uint32_t)P.num_seeds && w1.hit_total > 0;
+      if (act && !el) chain_finish_read<true>(P, is_last_strand, r1, s1, w1, 1, true, work, rw);
+      if (!el) { marks[r1] = 0; if (mrec) mrec[r1] = make_uint2(NONE, 0xFFFFFFFFu); }
     }
+    const unsigned long long bm = __ballot(el);
+    if (lane == 0) s_wcnt[threadIdx.x >> 6] = (uint32_t)__popcll(bm);
+    if (threadIdx.x == 0) s_rec_cur = 0;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t q = 0; q < (threadIdx.x >> 6); q++) base += s_wcnt[q];
+    if (el) s_list[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = r1;       // (in read order: the block's records lie in mpool in read order)
+    n_el = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
   }
+  // Phase 2, sixteen lanes per listed read, sixteen reads at a time
+  for (uint32_t e0 = 0; e0 < n_el; e0 += 16u) {
+  const bool eligible = e0 + (uint32_t)g < n_el;
+  const uint32_t r = eligible ? s_list[e0 + (uint32_t)g] : 0u;
+  RWork w;
+  if (eligible) w = rw[r];
   const uint32_t nh = eligible ? w.hit_total : 0u;
   bool mark = eligible && (nh > CAND_HITS || P.num_seeds < 2);
   const bool scan = eligible && !mark;
@@ -390,16 +409,17 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
     const uint32_t h = 16u * k + (uint32_t)gl;
-    hid[k] = NONE; hwn[k] = 0;
-    if (scan && h < nh) {
-      // the hit blocks of the passes run so far on this strand, concatenated (no loop over the three: an index that the compiler cannot
-      // resolve sends the read's state to 12 KB of LDS per block)
-      const uint32_t c0 = w.blk_cnt[0], c1 = w.blk_cnt[1];
-      const uint32_t at = h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
-      const CandPair hw = *reinterpret_cast<const CandPair*>(pool + at);      // (id, win_pos) with one 8-byte load
-      hid[k] = hw.x; hwn[k] = hw.y;                          // (the window position goes to LDS below: storing it here made every one of the four loads wait for itself)
-    }
+    // the hit blocks of the passes run so far on this strand, concatenated (no loop over the three: an index that the compiler cannot
+    // resolve sends the read's state to 12 KB of LDS per block).  The load itself is under no branch (a lane without a hit reads pool word 0):
+    // its value merging with NONE at the end of an `if` made the compiler wait for each of the four loads in turn.
+    const bool ok = scan && h < nh;
+    const uint32_t c0 = ok ? w.blk_cnt[0] : 0u, c1 = ok ? w.blk_cnt[1] : 0u;
+    const uint32_t at = !ok ? 0u : h < c0 ? w.blk_off[0] + 2 * h : h - c0 < c1 ? w.blk_off[1] + 2 * (h - c0) : w.blk_off[2] + 2 * (h - c0 - c1);
+    const CandPair hw = *reinterpret_cast<const CandPair*>(pool + at);        // (id, win_pos) with one 8-byte load
+    hid[k] = hw.x; hwn[k] = hw.y;                            // (the window position goes to LDS below: storing it here made every one of the four loads wait for itself)
   }
+#pragma unroll
+  for (uint32_t k = 0; k < CAND_HITS / 16; k++) if (!(scan && 16u * k + (uint32_t)gl < nh)) { hid[k] = NONE; hwn[k] = 0; }
 #pragma unroll
   for (uint32_t k = 0; k < CAND_HITS / 16; k++) {
     hlo[k] = 0; hln[k] = 0;
@@ -463,10 +483,10 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
   const unsigned long long hm = __ballot(hit);
   if (scan && ((hm >> (lane & 48)) & 0xFFFFull)) mark = true;
   if (eligible) {
-    if (!mark) { chain_finish_read<true>(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }
+    if (!mark) { RState st = work[r]; chain_finish_read<true>(P, is_last_strand, r, st, w, 1, gl == 0, work, rw); }      // (the read's state record only now: carried from the top it cost the kernel three registers it does not have)
   }
   // one byte per read says whether k_chain has to walk it: its waves claim reads by looking at 64 of these bytes, not at 64 per-read states
-  if (r < rd.n && gl == 0) marks[r] = (eligible && mark) ? 1 : 0;
+  if (eligible && gl == 0) marks[r] = mark ? 1 : 0;
   if (mrec) {
     // a block's records go into ITS slice of mpool (CAND_REC_WORDS per read of the block, placed by an LDS cursor: no atomic leaves the CU);
     // a read that does not fit leaves no record
@@ -474,7 +494,7 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
     uint32_t off = NONE;
     if (want && gl == 0) {
       const uint32_t old = atomicAdd(&s_rec_cur, 3u * npos);
-      if (old + 3u * npos <= 16u * CAND_REC_WORDS && (size_t)(blockIdx.x + 1u) * 16u * CAND_REC_WORDS <= mpool_words) off = blockIdx.x * 16u * CAND_REC_WORDS + old;
+      if (old + 3u * npos <= CAND_BLOCK * CAND_REC_WORDS && (size_t)(blockIdx.x + 1u) * CAND_BLOCK * CAND_REC_WORDS <= mpool_words) off = blockIdx.x * CAND_BLOCK * CAND_REC_WORDS + old;
     }
     off = (uint32_t)__shfl((int)off, lane & 48, 64);
     if (want && off != NONE) {
@@ -485,7 +505,9 @@ __global__ void __launch_bounds__(256, 8) k_cand(DReads rd, DIndex ix, DParams P
       if (g0 + 48u < npos) { mpool[off + g0 + 48u] = kp3.y; mpool[off + npos + g0 + 48u] = kp3.x; mpool[off + 2u * npos + g0 + 48u] = wn_[kh3]; }
     }
     // (a marked read without a record: .y says why -- its number of positions, ~0 when its hits outgrew the group (k_wlist's census, SMR_WALK_DEBUG))
-    if (r < rd.n && gl == 0) mrec[r] = (want && off != NONE) ? make_uint2(off, npos) : make_uint2(NONE, scan ? npos : 0xFFFFFFFFu);
+    if (eligible && gl == 0) mrec[r] = (want && off != NONE) ? make_uint2(off, npos) : make_uint2(NONE, scan ? npos : 0xFFFFFFFFu);
+  }
+  __syncthreads();                                          // (the groups' LDS rows are free for the next sixteen reads)
   }
 }
 

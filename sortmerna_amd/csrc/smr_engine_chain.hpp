@@ -71,7 +71,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   uint8_t* const grd = c->b->max_len > SW_X4_MAX_ROWS ? c->d_rdq : nullptr;
   if (c->handover) {
     // CAND_REC_WORDS words per read of the batch, one slice per block of k_cand
-    const size_t want_w = (size_t)((c->b->n + 15u) / 16u) * 16u * CAND_REC_WORDS;
+    const size_t want_w = (size_t)((c->b->n + CAND_BLOCK - 1u) / CAND_BLOCK) * CAND_BLOCK * CAND_REC_WORDS;
     if (c->mrec_cap < c->b->n) { int rc = dev_alloc(c, &c->d_mrec, (size_t)c->b->n); if (rc) return rc; c->mrec_cap = c->b->n; }
     if (c->mpool_words < want_w) { int rc = dev_alloc(c, &c->d_mpool, want_w); if (rc) return rc; c->mpool_words = want_w; }
   }
@@ -101,7 +101,7 @@ int launch_chain(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, int
   unsigned long long* const n_slow = split ? c->d_wctr + (size_t)(RMX + 1) * WC_STRIDE : nullptr;
   ev_mark(c, KP_CAND);
   // the reads without any candidate reference end their pass in k_cand; k_chain walks the ones it marks
-  hipLaunchKernelGGL(k_cand, dim3((c->b->n + 15u) / 16u), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
+  hipLaunchKernelGGL(k_cand, dim3((c->b->n + CAND_BLOCK - 1u) / CAND_BLOCK), dim3(256), CAND_LDS_BYTES(c->cand_bloom, c->handover), c->stream, dreads(c), dindex(di), P, pass, is_last_strand, c->b->d_work, c->b->d_rw, (const uint32_t*)c->d_pool, c->b->d_marks, c->cand_bloom,
                      mrec, c->d_mpool, c->mpool_words);
   if (split) {
     // rounds of walk -> Smith-Waterman -> next list (smr_walk.hpp); the last round scores in the walk kernel, so every listed read ends its pass here
