@@ -336,7 +336,7 @@ __device__ __forceinline__ void chain_finish_read(const DParams& P, int is_last_
 // ------------------------------------------------------------------------------------------------
 // k_cand: the cheap majority first.  Most reads that reach compute_lis_alignment (alignment.cpp:100-148) have no candidate reference
 // at all: no reference sequence occurs twice among the positions of their seed hits.  That is decided here for every read of the
-// (strand, pass), 16 lanes per read and four reads per wave: the position lists of the read's hits are walked with one lane per
+// (strand, pass) that has enough seed hits (phase 2; the others end their pass in phase 1, a lane each), 16 lanes per read and four reads per wave: the position lists of the read's hits are walked with one lane per
 // POSITION and every reference number sets one bit of a Bloom bitmap in LDS (2 KB per read).  No bit set twice -> no reference seen
 // twice -> no candidate (for num_seeds >= 2): the read's pass ends here, exactly as the candidate loop would end it without a single
 // ssw_align (pass control + write-back by one lane).  Anything else -- a collision, more hits than the group holds, num_seeds < 2 --
