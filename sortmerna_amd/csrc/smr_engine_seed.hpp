@@ -102,10 +102,12 @@ int seed_sort(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, SeedBu
   if ((uint64_t)sb.rpb * sb.maxwin >= (1ull << (64 - sb.kbits - sb.cb))) { set_err(c, "seed stage: a block's windows do not fit the tuple format"); return SMR_ERR_CAPACITY; }
   const uint64_t slots = (uint64_t)sb.n * sb.maxwin;
   const uint32_t gw = std::max<uint32_t>(1u, (uint32_t)((2 * slots + 63) / 64));     // wave chunks of 64 tuples the batch can have at most (every kernel checks its range)
-  const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)SEED_SPLIT_PIECE * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
+  const bool many_bins = sb.nc > 2048u;                    // (their three tables take 48 KB of the 160)
+  const size_t lds_split = (size_t)3 * ((sb.nc + 1u) & ~1u) * 4 + (size_t)(many_bins ? SEED_SPLIT_PIECE_MANY_BINS : SEED_SPLIT_PIECE) * sizeof(SeedTup), lds_bins = (size_t)SEED_PIECE * sizeof(SeedTup);
   if (lds_bins > 60 * 1024 && lds_bins > c->bins_lds_attr) { HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_bins, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_hbins_move, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bins)); c->bins_lds_attr = lds_bins; }      // (per context = per device, like split_lds_attr)
   if (lds_split > 64 * 1024 && lds_split > c->split_lds_attr) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split<SEED_SPLIT_PIECE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
+    HIPCHK(c, hipFuncSetAttribute((const void*)k_seed_split<SEED_SPLIT_PIECE_MANY_BINS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_split));
     c->split_lds_attr = lds_split;
   }
   size_t lds_keys;
@@ -119,7 +121,8 @@ int seed_sort(smr_ctx* c, const DevIndex& di, const DParams& P, int pass, SeedBu
   hipLaunchKernelGGL(k_seed_colscan, dim3((sb.nc + 63) / 64), dim3(1024), 0, c->stream, sb);
   hipLaunchKernelGGL(k_seed_cscan, dim3(1), dim3(1024), 0, c->stream, sb, c->b->d_ctr);
   hipLaunchKernelGGL(k_seed_wbin, dim3((gw + 255) / 256), dim3(256), 0, c->stream, sb);
-  hipLaunchKernelGGL(k_seed_split, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
+  if (many_bins) hipLaunchKernelGGL(k_seed_split<SEED_SPLIT_PIECE_MANY_BINS>, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
+  else hipLaunchKernelGGL(k_seed_split<SEED_SPLIT_PIECE>, dim3(sb.kb), dim3(1024), lds_split, c->stream, sb);
   ev_mark(c, KP_BINS);
   hipLaunchKernelGGL(k_seed_bins, dim3(sb.nc), dim3(1024), lds_bins, c->stream, sb);
   // the coarse bins that are far larger than the others, several blocks each (none on evenly spread keys: three empty launches)

@@ -154,11 +154,13 @@ struct SeedKey { uint32_t slot, chars, key; bool dup; };          // a decoded t
 #define SEED_WAVES 16u                                    // waves per block of k_seed_keys
 #define SEED_STAGE_WORDS 1280u                            // LDS words in which a wave of k_seed_keys stages the packed records of the reads of one trip (64 reads of <= 208 letters)
 #ifndef SEED_PIECE
-#define SEED_PIECE 8192u                                  // tuples the second sort pass (512 fine bins) stages in LDS at a time (two blocks per CU by LDS; one by registers since a piece's loads are in flight together)
+#define SEED_PIECE 16384u                                 // tuples the second sort pass (512 fine bins) stages in LDS at a time: 128 KB, one 1024-thread block per CU, sixteen loads per thread in flight
 #endif
 #ifndef SEED_SPLIT_PIECE
-#define SEED_SPLIT_PIECE 12288u                           // ... and the first (1 024 coarse bins: runs of 12 tuples per bin instead of 8; one block per CU).  Measured per 8 M-read
-#endif                                                    // step (profiles/r6s17_*): split 11.0 -> 9.7 ms with 12 288 or 16 384, bins 10.2 -> 10.9 with either: each pass keeps its own
+#define SEED_SPLIT_PIECE 16384u                           // ... and the first (1 024 coarse bins: runs of 16 tuples per bin; 140 KB with its tables).  Measured per 8 M-read step, builds side by side on one box:
+#endif                                                    // round 6 before the loads of a piece left together 8 192 / 12 288 were best (profiles/r6s17_*); since then 12 288 -> 16 384 takes 0.5 ms off the first pass and
+                                                          // 8 192 -> 16 384 0.9 ms off the second (profiles/r6s53_* - r6s55_*: 19.1 -> 17.6 ms for both), 18 432 no more and the second pass spills
+#define SEED_SPLIT_PIECE_MANY_BINS 12288u                 // ... with more than 2 048 coarse bins (seed length 20: 4 096 bins = 48 KB of tables): 144 KB
 #define SEED_SEG_MERGED 0x80000000u                       // header bit of a reverse segment whose list is final (written by k_seed_search<1>: forward hits included)
 #define SEED_CAND_COND 0x80000000u                        // bit of an id in a reverse segment of k_seed_pg: this candidate is a 0-error match
 // A window whose search leaves ONE hit (most windows of a read sampled from the DB: the 0-error match) needs no segment: its wseg word IS the hit --
@@ -568,6 +570,7 @@ __device__ __forceinline__ void staged_move(const SeedTup* __restrict__ src, uin
   }
 }
 
+template <uint32_t PIECE>                                   // (SEED_SPLIT_PIECE, or SEED_SPLIT_PIECE_MANY_BINS when the tables of 4 096 coarse bins leave less room)
 __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
   SMR_DYN_LDS(uint32_t, lds);                             // cur | pc0 | pst [nc each, rounded to an even number of words] | stage
   __shared__ uint32_t s_part[16];
@@ -581,7 +584,7 @@ __global__ void __launch_bounds__(1024) k_seed_split(SeedBufs sb) {
   __syncthreads();
   const uint32_t fb = sb.fb, kbits = sb.kbits, cb = sb.cb;
   const uint32_t slot0 = blockIdx.x * sb.rpb * sb.maxwin;                  // the block's first slot
-  staged_move<SEED_SPLIT_PIECE>(sb.tmp + (size_t)2 * slot0, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part,
+  staged_move<PIECE>(sb.tmp + (size_t)2 * slot0, 0u, nmine, sb.mid, sb.nc, cur, pc0, pst, stage, s_part,
               [fb, kbits](SeedTup t) { return ((uint32_t)t & ((1u << kbits) - 1u)) >> fb; },
               [fb, kbits, cb, slot0](SeedTup t) {
                 const uint32_t key = (uint32_t)t & ((1u << kbits) - 1u), chars = (uint32_t)(t >> kbits) & ((1u << cb) - 1u), rel = (uint32_t)(t >> (kbits + cb));
